@@ -1,0 +1,344 @@
+"""
+CPU ORACLE -- python side (ctypes binding of oracle/bfg_oracle.c + numpy glue).
+
+THIS MODULE IS TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import it, and only as the checker.  The product
+package (baryonforge_amd) never imports it.
+
+It restates, for the shell paint / baryonify hot path:
+  * the reference runner loops      /root/reference/BaryonForge/Runners/HealpixRunner.py:252-373, :390-483
+  * the table read-outs              utils/Tabulate.py:279-327, :598-650 ; Profiles/BaryonCorrection.py:331-419
+  * the per-halo scalars             HealpixRunner.py:297-299 (D_A spline), :320 (R_delta)
+and the third-party arithmetic underneath them (healpy -> HEALPix RING,
+pyccl -> flat wCDM background), neither of which is installed here:
+see the header of bfg_oracle.c for the parity status.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libbfg_oracle.so")
+
+_i64 = C.c_int64
+_dbl = C.c_double
+_pd = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_pi = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    """gcc-build the C restatement next to its source."""
+    src = os.path.join(_HERE, "bfg_oracle.c")
+    if force or (not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libbfg_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.orc_ring_above.restype = _i64
+        L.orc_ring_above.argtypes = [_i64, _dbl]
+        L.orc_ang2vec_lonlat.argtypes = [_i64, _pd, _pd, _pd]
+        L.orc_pix2vec_ring.argtypes = [_i64, _i64, _pi, _pd]
+        L.orc_query_disc_ring.restype = _i64
+        L.orc_query_disc_ring.argtypes = [_i64, _pd, _dbl, C.c_void_p, _i64]
+        L.orc_get_interp_weights_lonlat.argtypes = [_i64, _i64, _pd, _pd, _pi, _pd]
+        L.orc_get_interp_weights_thetaphi.argtypes = [_i64, _i64, _pd, _pd, _pi, _pd]
+        L.orc_vec2ang_lonlat.argtypes = [_i64, _pd, _pd, _pd]
+        L.orc_interp_linear.argtypes = [C.c_int, _pi, _pd, _pd, _i64, _pd, _pd]
+        L.orc_paint_shell.restype = _i64
+        L.orc_paint_shell.argtypes = [_i64, _i64, _pd, _pd, _pd, _pd, _pd, _pd, C.c_void_p,
+                                      C.c_int, _dbl, C.c_int, C.c_int, _pi, _pd, _pd, _pd]
+        L.orc_paint_shell_splitjoin.restype = _i64
+        L.orc_paint_shell_splitjoin.argtypes = [C.c_int, _i64, _i64, _pd, _pd, _pd, _pd, _pd, _pd,
+                                                C.c_void_p, C.c_int, _dbl, C.c_int, _pi, _pd,
+                                                _pd, _pd]
+        L.orc_baryonify_offsets.restype = _i64
+        L.orc_baryonify_offsets.argtypes = [_i64, _i64, _pd, _pd, _pd, _pd, _pd, _pd, _pd,
+                                            C.c_void_p, C.c_int, _dbl, _dbl, C.c_int, C.c_int,
+                                            _pi, _pd, _pd, _pd]
+        L.orc_regrid_shell.argtypes = [_i64, _pd, _pd, _pd]
+        L.orc_regrid_pixels_hpix.argtypes = [_pd, _i64, _pd, _pi, _pd]
+        _lib = L
+    return _lib
+
+
+def _f(x):
+    return np.ascontiguousarray(x, dtype=np.float64)
+
+
+# --------------------------------------------------------------------------
+# healpy-shaped wrappers (same call signatures as the healpy functions the
+# reference calls, HealpixRunner.py:327,330,334,336,357,358,361,426; io.py:353)
+# --------------------------------------------------------------------------
+def nside2npix(nside):
+    return 12 * int(nside) ** 2
+
+
+def npix2nside(npix):
+    nside = int(round(np.sqrt(npix / 12.0)))
+    if 12 * nside * nside != npix:
+        raise ValueError("Wrong pixel number (it is not 12*nside**2)")
+    return nside
+
+
+def nside2pixarea(nside, degrees=False):
+    area = 4.0 * np.pi / nside2npix(nside)
+    return area * (180.0 / np.pi) ** 2 if degrees else area
+
+
+def nside2resol(nside, arcmin=False):
+    r = np.sqrt(nside2pixarea(nside))
+    return np.degrees(r) * 60 if arcmin else r
+
+
+def ang2vec(theta, phi, lonlat=False):
+    scalar = np.ndim(theta) == 0 and np.ndim(phi) == 0
+    theta, phi = np.broadcast_arrays(_f(np.atleast_1d(theta)), _f(np.atleast_1d(phi)))
+    if not lonlat:  # convert to the lon/lat the C routine expects, exactly invertible enough for tests
+        lon, lat = np.degrees(phi), 90.0 - np.degrees(theta)
+    else:
+        lon, lat = theta, phi
+    lon, lat = _f(lon), _f(lat)
+    out = np.empty((lon.size, 3))
+    lib().orc_ang2vec_lonlat(lon.size, lon, lat, out)
+    return out[0] if scalar else out
+
+
+def pix2vec(nside, ipix, nest=False):
+    assert not nest
+    scalar = np.ndim(ipix) == 0
+    ipix = np.ascontiguousarray(np.atleast_1d(ipix), dtype=np.int64)
+    out = np.empty((ipix.size, 3))
+    lib().orc_pix2vec_ring(int(nside), ipix.size, ipix, out)
+    if scalar:
+        return out[0, 0], out[0, 1], out[0, 2]
+    return out[:, 0].copy(), out[:, 1].copy(), out[:, 2].copy()
+
+
+def query_disc(nside, vec, radius, inclusive=False, fact=4, nest=False):
+    assert (not inclusive) and (not nest)
+    vec = _f(vec)
+    n = lib().orc_query_disc_ring(int(nside), vec, float(radius), None, 0)
+    out = np.empty(n, dtype=np.int64)
+    if n:
+        lib().orc_query_disc_ring(int(nside), vec, float(radius), out.ctypes.data, n)
+    return out
+
+
+def get_interp_weights(nside, theta, phi=None, nest=False, lonlat=False):
+    assert not nest and phi is not None
+    scalar = np.ndim(theta) == 0 and np.ndim(phi) == 0
+    theta, phi = np.broadcast_arrays(_f(np.atleast_1d(theta)), _f(np.atleast_1d(phi)))
+    theta, phi = _f(theta), _f(phi)
+    pix = np.empty((theta.size, 4), dtype=np.int64)
+    wgt = np.empty((theta.size, 4))
+    if lonlat:
+        lib().orc_get_interp_weights_lonlat(int(nside), theta.size, theta, phi, pix, wgt)
+    else:
+        lib().orc_get_interp_weights_thetaphi(int(nside), theta.size, theta, phi, pix, wgt)
+    if scalar:
+        return pix[0].copy(), wgt[0].copy()
+    return pix.T.copy(), wgt.T.copy()  # healpy returns shape (4, n)
+
+
+def vec2ang(vectors, lonlat=False):
+    v = _f(vectors).reshape(-1, 3)
+    lon = np.empty(v.shape[0])
+    lat = np.empty(v.shape[0])
+    lib().orc_vec2ang_lonlat(v.shape[0], v, lon, lat)
+    if lonlat:
+        return lon, lat
+    return np.radians(90.0 - lat), np.radians(lon)
+
+
+# --------------------------------------------------------------------------
+# N-linear read-out (scipy RegularGridInterpolator, linear, nan fill)
+# --------------------------------------------------------------------------
+def _table_args(axes, values):
+    values = _f(values)
+    shape = np.ascontiguousarray(values.shape, dtype=np.int64)
+    assert len(axes) == values.ndim and all(len(a) == s for a, s in zip(axes, values.shape))
+    axes_concat = _f(np.concatenate([np.asarray(a, dtype=np.float64) for a in axes]))
+    return values.ndim, shape, axes_concat, values
+
+
+def interp_linear(axes, values, coords):
+    """coords: [npts, ndim] -> [npts]"""
+    ndim, shape, axes_concat, values = _table_args(axes, values)
+    coords = _f(coords).reshape(-1, ndim)
+    out = np.empty(coords.shape[0])
+    lib().orc_interp_linear(ndim, shape, axes_concat, values, coords.shape[0], coords, out)
+    return out
+
+
+# --------------------------------------------------------------------------
+# Background cosmology: what ccl.Cosmology(Omega_c, Omega_b, h, sigma8, n_s, w0)
+# gives with its defaults (flat, T_CMB = 2.7255 K, N_eff = 3.044 massless,
+# T_ncdm = 0.71611) for the three calls on the path:
+#   ccl.angular_diameter_distance   HealpixRunner.py:299, :431
+#   mass_def.get_radius             HealpixRunner.py:320, :454 ; BaryonCorrection.py:399
+# --------------------------------------------------------------------------
+CLIGHT = 299792458.0
+GNEWT = 6.67430e-11
+MPC_TO_METER = 3.085677581491367e22
+GM_SUN = 1.3271244e20
+SOLAR_MASS = GM_SUN / GNEWT
+STBOLTZ = 5.670374419e-8
+T_CMB = 2.7255
+N_EFF = 3.044
+T_NCDM = 0.71611
+# 3 (100 km/s/Mpc)^2 / (8 pi G) in Msun / Mpc^3  (= 2.775366e11)
+RHO_CRITICAL = (3.0 * 100.0 * 100.0) / (8.0 * np.pi * GNEWT) * (1000.0 * 1000.0 * MPC_TO_METER / SOLAR_MASS)
+
+
+def _omegas(cosmo):
+    h = cosmo["h"]
+    rho_crit_si = RHO_CRITICAL * SOLAR_MASS / MPC_TO_METER ** 3 * h * h
+    rho_g = 4.0 * STBOLTZ / CLIGHT ** 3 * T_CMB ** 4
+    Om_g = rho_g / rho_crit_si
+    Om_nu = N_EFF * 7.0 / 8.0 * T_NCDM ** 4 * Om_g
+    Om_m = cosmo["Omega_m"]
+    Om_l = 1.0 - Om_m - Om_g - Om_nu
+    return Om_m, Om_l, Om_g + Om_nu
+
+
+def E2(cosmo, a):
+    a = np.asarray(a, dtype=np.float64)
+    Om_m, Om_l, Om_r = _omegas(cosmo)
+    w0 = cosmo.get("w0", -1.0)
+    return Om_m / a ** 3 + Om_l * a ** (-3.0 * (1.0 + w0)) + Om_r / a ** 4
+
+
+_GL_X, _GL_W = np.polynomial.legendre.leggauss(96)
+
+
+def comoving_radial_distance(cosmo, a):
+    """chi(a) = c/H0 int_a^1 da' / (a'^2 E(a'))   [Mpc]"""
+    a = np.atleast_1d(np.asarray(a, dtype=np.float64))
+    half = 0.5 * (1.0 - a)[:, None]
+    mid = 0.5 * (1.0 + a)[:, None]
+    x = mid + half * _GL_X[None, :]
+    integrand = 1.0 / (x * x * np.sqrt(E2(cosmo, x)))
+    return (CLIGHT / 1000.0 / 100.0 / cosmo["h"]) * np.sum(integrand * _GL_W[None, :], axis=1) * half[:, 0]
+
+
+def angular_diameter_distance(cosmo, a):
+    a = np.asarray(a, dtype=np.float64)
+    return (np.atleast_1d(a) * comoving_radial_distance(cosmo, a)).reshape(a.shape)
+
+
+def rho_x(cosmo, a, rho_type="critical"):
+    """physical density in Msun/Mpc^3"""
+    a = np.asarray(a, dtype=np.float64)
+    h = cosmo["h"]
+    if rho_type == "critical":
+        return RHO_CRITICAL * h * h * E2(cosmo, a)
+    if rho_type == "matter":
+        return RHO_CRITICAL * h * h * cosmo["Omega_m"] / a ** 3
+    raise ValueError(rho_type)
+
+
+def get_radius(cosmo, M, a, Delta=200, rho_type="critical"):
+    """ccl MassDef(Delta, rho_type).get_radius: physical Mpc"""
+    return (np.asarray(M, dtype=np.float64) / (4.18879020479 * Delta * rho_x(cosmo, a, rho_type))) ** (1.0 / 3.0)
+
+
+def halo_scalars(cosmo, M, z, Delta=200, rho_type="critical"):
+    """a_j, R_j, D_j exactly as the runner loops form them
+    (HealpixRunner.py:297-299, :317-321)."""
+    from scipy import interpolate
+    M = _f(M)
+    z = _f(z)
+    z_m = np.max(z)
+    z_t = np.linspace(0, z_m + 0.1, 1000)
+    D_a = interpolate.CubicSpline(z_t, angular_diameter_distance(cosmo, 1 / (1 + z_t)))
+    a = 1 / (1 + z)
+    R = get_radius(cosmo, M, a, Delta, rho_type)
+    D = D_a(z)
+    return _f(a), _f(R), _f(D)
+
+
+# --------------------------------------------------------------------------
+# Runner loops
+# --------------------------------------------------------------------------
+def _extra_ptr(extra, n):
+    if extra is None or np.size(extra) == 0:
+        return None, 0, None
+    extra = _f(extra).reshape(n, -1)
+    return extra.ctypes.data, extra.shape[1], extra
+
+
+def paint_shell(nside, ra, dec, M, a, D, R, axes, values_log, eps_run,
+                include_pixel_size=False, extra=None, njobs=None):
+    """PaintProfilesShell.process loop (HealpixRunner.py:449-481) on a zero map.
+    values_log is the table the interpolator holds, i.e. np.log(raw_input_2D)
+    (Tabulate.py:271).  Returns (map, P_tot).  njobs: SplitJoinParallel analogue."""
+    ra, dec, M, a, D, R = map(_f, (ra, dec, M, a, D, R))
+    n = ra.size
+    ndim, shape, axes_concat, values = _table_args(axes, values_log)
+    eptr, n_extra, _keep = _extra_ptr(extra, n)
+    assert ndim == 3 + n_extra
+    out = np.zeros(nside2npix(nside))
+    if njobs is None:
+        ptot = lib().orc_paint_shell(nside, n, ra, dec, M, a, D, R, eptr, n_extra, float(eps_run),
+                                     int(bool(include_pixel_size)), ndim, shape, axes_concat,
+                                     values, out)
+    else:
+        assert not include_pixel_size  # Parallelize.py:271 does not forward it
+        ptot = lib().orc_paint_shell_splitjoin(int(njobs), nside, n, ra, dec, M, a, D, R, eptr,
+                                               n_extra, float(eps_run), ndim, shape, axes_concat,
+                                               values, out)
+    return out, int(ptot)
+
+
+def baryonify_offsets(nside, ra, dec, M, a, D, R, R_model_com, axes, values, eps_run,
+                      eps_model, rdelta_sampling=False, extra=None):
+    """BaryonifyShell.process halo loop (HealpixRunner.py:315-355). Returns (offsets[npix,3], P_tot)."""
+    ra, dec, M, a, D, R, R_model_com = map(_f, (ra, dec, M, a, D, R, R_model_com))
+    n = ra.size
+    ndim, shape, axes_concat, values = _table_args(axes, values)
+    eptr, n_extra, _keep = _extra_ptr(extra, n)
+    assert ndim == 3 + n_extra
+    off = np.zeros((nside2npix(nside), 3))
+    ptot = lib().orc_baryonify_offsets(nside, n, ra, dec, M, a, D, R, R_model_com, eptr, n_extra,
+                                       float(eps_run), float(eps_model), int(bool(rdelta_sampling)),
+                                       ndim, shape, axes_concat, values, off)
+    return off, int(ptot)
+
+
+def regrid_shell(nside, pix_offsets, orig_map):
+    """HealpixRunner.py:357-365"""
+    out = np.zeros(nside2npix(nside))
+    lib().orc_regrid_shell(nside, _f(pix_offsets), _f(orig_map), out)
+    return out
+
+
+def regrid_pixels_hpix(hmap, parent_pix_vals, child_pix, child_weights):
+    """HealpixRunner.py:17-71 (child arrays [N,4])"""
+    hmap = _f(hmap)
+    lib().orc_regrid_pixels_hpix(hmap, len(parent_pix_vals), _f(parent_pix_vals),
+                                 np.ascontiguousarray(child_pix, dtype=np.int64), _f(child_weights))
+    return hmap
+
+
+def baryonify_shell(nside, orig_map, ra, dec, M, a, D, R, R_model_com, axes, values, eps_run,
+                    eps_model, rdelta_sampling=False, extra=None):
+    """BaryonifyShell.process (HealpixRunner.py:252-373) given per-halo scalars."""
+    orig_map = _f(orig_map)
+    if np.allclose(orig_map, 0):  # :293-294
+        return orig_map
+    off, _ = baryonify_offsets(nside, ra, dec, M, a, D, R, R_model_com, axes, values, eps_run,
+                               eps_model, rdelta_sampling, extra)
+    new_map = regrid_shell(nside, off, orig_map)
+    assert np.isclose(np.sum(new_map), np.sum(orig_map))  # :368-370
+    return new_map

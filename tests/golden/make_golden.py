@@ -1,0 +1,398 @@
+#!/usr/bin/env python3
+"""
+Generate the golden vectors under tests/golden/ by EXECUTING THE REFERENCE'S OWN
+MODULES (imported from /root/reference, never copied) on small seeded inputs.
+
+Runs only in the build container (needs /root/reference).  The reference
+cannot be imported as shipped: pyccl, healpy and numba are not installed and
+there is no network.  Its hot-path modules do load under thin
+stand-ins for those three third-party packages:
+
+  * numba.njit       -> identity decorator (semantics = the plain python loop)
+  * healpy           -> oracle/oracle.py's HEALPix RING functions (same call
+                        signatures).  So these vectors pin the reference's LOOP
+                        GLUE (order of a-factors, chord distance, NaN->0,
+                        epsilon handling, include_pixel_size, <4-pixel
+                        fallback, regrid, mass conservation) and its table
+                        READ-OUT, not healpy's geometry itself.
+  * pyccl            -> Cosmology / angular_diameter_distance / MassDef.get_radius
+                        backed by oracle/oracle.py's flat-wCDM background; the
+                        HaloProfile base class with projected()->_projected().
+
+What is executed verbatim from the reference:
+  utils/Tabulate.py         TabulatedProfile.projected/real, ParamTabulatedProfile.projected
+  Profiles/BaryonCorrection.py  BaryonificationClass.displacement,
+                                Baryonification2D.get_masses / setup_interpolator
+  utils/io.py               HaloLightConeCatalog, LightconeShell
+  Runners/HealpixRunner.py  PaintProfilesShell.process, BaryonifyShell.process,
+                            regrid_pixels_hpix
+
+Usage:  python tests/golden/make_golden.py      (writes tests/golden/*.npz)
+"""
+import importlib.util
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/BaryonForge"
+sys.path.insert(0, REPO)
+
+from oracle import oracle as orc  # noqa: E402
+from scipy import interpolate  # noqa: E402
+
+COSMO = {"Omega_m": 0.30, "Omega_b": 0.04, "h": 0.7, "sigma8": 0.8, "n_s": 0.96, "w0": -1.0}
+
+
+# ------------------------------------------------------------------ stubs
+def install_stubs():
+    # numba
+    numba = types.ModuleType("numba")
+    numba.njit = lambda f: f
+    sys.modules["numba"] = numba
+
+    # healpy <- oracle HEALPix
+    hp = types.ModuleType("healpy")
+    for name in ("ang2vec", "pix2vec", "query_disc", "get_interp_weights", "vec2ang",
+                 "nside2pixarea", "npix2nside", "nside2npix", "nside2resol"):
+        setattr(hp, name, getattr(orc, name))
+    sys.modules["healpy"] = hp
+
+    # pyccl
+    ccl = types.ModuleType("pyccl")
+    halos = types.ModuleType("pyccl.halos")
+    massdef = types.ModuleType("pyccl.halos.massdef")
+    profiles = types.ModuleType("pyccl.halos.profiles")
+
+    class Cosmology(object):
+        def __init__(self, Omega_c, Omega_b, h, sigma8=None, n_s=None, w0=-1.0, **kw):
+            self.d = {"Omega_m": Omega_c + Omega_b, "Omega_b": Omega_b, "h": h, "sigma8": sigma8,
+                      "n_s": n_s, "w0": w0}
+            self._pk_lin, self._pk_nl = {}, {}
+
+        def compute_sigma(self):
+            pass
+
+    def angular_diameter_distance(cosmo, a):
+        return orc.angular_diameter_distance(cosmo.d, a)
+
+    class MassDef(object):
+        def __init__(self, Delta, rho_type):
+            self.Delta, self.rho_type = Delta, rho_type
+
+        def get_radius(self, cosmo, M, a):
+            return orc.get_radius(cosmo.d, M, a, self.Delta, self.rho_type)
+
+    class _Prec(object):
+        def to_dict(self):
+            return {}
+
+    class HaloProfile(object):
+        def __init__(self, mass_def=None):
+            self.mass_def = mass_def
+            self.precision_fftlog = _Prec()
+
+        def update_precision_fftlog(self, **kw):
+            pass
+
+        def projected(self, cosmo, r, M, a, **kw):
+            return self._projected(cosmo, r, M, a, **kw)
+
+        def real(self, cosmo, r, M, a, **kw):
+            return self._real(cosmo, r, M, a, **kw)
+
+    ccl.Cosmology = Cosmology
+    ccl.angular_diameter_distance = angular_diameter_distance
+    massdef.MassDef = MassDef
+    profiles.HaloProfile = HaloProfile
+    halos.massdef, halos.profiles = massdef, profiles
+    ccl.halos = halos
+    sys.modules.update({"pyccl": ccl, "pyccl.halos": halos, "pyccl.halos.massdef": massdef,
+                        "pyccl.halos.profiles": profiles})
+
+    # package shells so relative imports resolve without running the star-import __init__ files
+    for pkg, sub in (("BaryonForge", ""), ("BaryonForge.utils", "utils"),
+                     ("BaryonForge.Profiles", "Profiles"), ("BaryonForge.Runners", "Runners")):
+        m = types.ModuleType(pkg)
+        m.__path__ = [os.path.join(REF, sub)]
+        sys.modules[pkg] = m
+    return ccl
+
+
+def load(modname, relpath):
+    spec = importlib.util.spec_from_file_location(modname, os.path.join(REF, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[modname] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_reference():
+    ccl = install_stubs()
+    load("BaryonForge.utils.misc", "utils/misc.py")
+    tab = load("BaryonForge.utils.Tabulate", "utils/Tabulate.py")
+    sys.modules["BaryonForge.utils"].ParamTabulatedProfile = tab.ParamTabulatedProfile
+    bc = load("BaryonForge.Profiles.BaryonCorrection", "Profiles/BaryonCorrection.py")
+    io = load("BaryonForge.utils.io", "utils/io.py")
+    run = load("BaryonForge.Runners.HealpixRunner", "Runners/HealpixRunner.py")
+    return ccl, tab, bc, io, run
+
+
+# ------------------------------------------------------------------ synthetic inputs
+def r200c_com(M, z):
+    a = 1 / (1 + z)
+    return orc.get_radius(COSMO, M, a) / a
+
+
+def paint_table(nz=6, nM=9, nr=40, bad_block=False, extra=None):
+    """GNFW-like projected pressure, times a (Tabulate.py:259)."""
+    z = np.geomspace(0.01, 1.0, nz)
+    M = np.geomspace(1e12, 1e16, nM)
+    r = np.geomspace(1e-3, 1e2, nr)
+    Z, MM, RR = np.meshgrid(z, M, r, indexing="ij")
+    rc = 0.2 * r200c_com(MM, Z)
+    T = 1e-6 * (MM / 1e14) ** (5 / 3) * (1 + Z) ** (8 / 3) * (1 + (RR / rc) ** 2) ** -1.5
+    T = T / (1 + Z)
+    if extra is not None:  # extra axis: multiplicative amplitude-like parameter
+        T = T[..., None] * (1.0 + 0.3 * extra[None, None, None, :] ** 2)
+    if bad_block:
+        T = T.copy()
+        T[1:3, 2:4, 5:9] = 0.0       # ln -> -inf
+        T[3, 5, 20:23] = -1.0        # ln -> nan
+        T[4, 6, 30] = np.nan
+    return np.log(1 + z), np.log(M), np.log(r), T
+
+
+def disp_table(nz=6, nM=9, nr=40, rdelta=False, extra=None):
+    """signed displacement d(r|M,z) in comoving Mpc."""
+    z = np.geomspace(0.01, 1.0, nz)
+    M = np.geomspace(1e12, 1e16, nM)
+    if rdelta:
+        rax = np.geomspace(1e-3, 10, nr)   # r / R_delta axis
+    else:
+        rax = np.geomspace(1e-3, 1e2, nr)
+    Z, MM, RR = np.meshgrid(z, M, rax, indexing="ij")
+    x = RR if rdelta else RR / r200c_com(MM, Z)
+    d = 0.1 * (MM / 1e14) ** (1 / 3) * x * (1 - x / 4) * np.exp(-x)
+    if extra is not None:
+        d = d[..., None] * (1.0 + 0.5 * extra[None, None, None, :])
+    return np.log(1 + z), np.log(M), np.log(rax), d
+
+
+def catalog(n, seed, logM=(13.0, 15.5), zr=(0.05, 0.4), specials=True):
+    rng = np.random.default_rng(seed)
+    ra = np.degrees(rng.uniform(0, 2 * np.pi, n))
+    dec = np.degrees(np.arcsin(rng.uniform(-1, 1, n)))
+    M = 10 ** rng.uniform(*logM, n)
+    z = rng.uniform(*zr, n)
+    if specials and n >= 12:
+        dec[0], dec[1] = 89.6, -89.7            # polar caps / pole inside disc
+        M[0], M[1], z[0], z[1] = 3e15, 2e15, 0.06, 0.07
+        ra[2], ra[3] = 0.02, 359.97             # phi wrap
+        M[2], M[3] = 2e15, 2.5e15
+        dec[4], M[4], z[4] = 41.8103, 1e15, 0.08   # cap/belt transition (z = 2/3)
+        dec[5], M[5], z[5] = -41.8103, 1e15, 0.08
+        M[6], z[6] = 1e12, 0.4                  # tiny disc: empty / 4-neighbour fallback
+        M[7], z[7] = 3e12, 0.39
+        dec[8], ra[8], M[8], z[8] = 0.0, 180.0, 8e14, 0.1
+        M[9], z[9] = 9.9e15, 0.055              # near the table's upper mass edge
+        M[10] = 5e16                            # outside the table hull in M -> NaN -> 0
+        z[11] = 0.004                           # outside the hull in z
+        M[11] = 1e14
+    return ra, dec, M, z
+
+
+def rgi(axes, values, **kw):
+    return interpolate.RegularGridInterpolator(tuple(axes), values, bounds_error=False, **kw)
+
+
+def main():
+    ccl, tab, bc, io, run = load_reference()
+    warnings.simplefilter("ignore")
+    np.seterr(all="ignore")
+    cosmo_obj = ccl.Cosmology(Omega_c=COSMO["Omega_m"] - COSMO["Omega_b"], Omega_b=COSMO["Omega_b"],
+                              h=COSMO["h"], sigma8=COSMO["sigma8"], n_s=COSMO["n_s"], w0=COSMO["w0"])
+    mdef = ccl.halos.massdef.MassDef(200, "critical")
+
+    def make_tabulated(zax, Max, rax, T2D, T3D=None):
+        obj = tab.TabulatedProfile.__new__(tab.TabulatedProfile)
+        ccl.halos.profiles.HaloProfile.__init__(obj, mass_def=mdef)
+        T3D = T2D if T3D is None else T3D
+        obj.raw_input_2D, obj.raw_input_3D = T2D, T3D
+        obj.raw_input_z_range, obj.raw_input_M_range, obj.raw_input_r_range = zax, Max, rax
+        obj.interp2D = rgi((zax, Max, rax), np.log(T2D))     # Tabulate.py:270-271
+        obj.interp3D = rgi((zax, Max, rax), np.log(T3D))
+        return obj
+
+    def make_param_tabulated(zax, Max, rax, pax, T2D):
+        obj = tab.ParamTabulatedProfile.__new__(tab.ParamTabulatedProfile)
+        obj.p_keys = ["cdelta"]
+        obj.raw_input_2D = obj.raw_input_3D = T2D
+        obj.raw_input_z_range, obj.raw_input_M_range, obj.raw_input_r_range = zax, Max, rax
+        obj.raw_input_cdelta_range = pax
+        obj.interp2D = rgi((zax, Max, rax, pax), np.log(T2D))  # Tabulate.py:589-590
+        obj.interp3D = obj.interp2D
+        return obj
+
+    def make_disp(zax, Max, rax, d, rdelta=False, eps=20, pax=None):
+        obj = bc.Baryonification2D.__new__(bc.Baryonification2D)
+        obj.cosmo, obj.mass_def, obj.epsilon_max = cosmo_obj, mdef, eps
+        obj.p_keys = [] if pax is None else ["cdelta"]
+        obj.raw_input_d = d
+        obj.raw_input_z_range, obj.raw_input_M_range, obj.raw_input_r_range = zax, Max, rax
+        axes = (zax, Max, rax) if pax is None else (zax, Max, rax, pax)
+        if pax is not None:
+            obj.raw_input_cdelta_range = pax
+        obj.interp_d = rgi(axes, d, fill_value=np.nan)        # BaryonCorrection.py:322
+        obj.Rdelta_sampling = rdelta
+        return obj
+
+    # ---------------------------------------------------------------- 1. read-outs
+    out = {}
+    rng = np.random.default_rng(11)
+    zax, Max, rax, T = paint_table(bad_block=True)
+    prof = make_tabulated(zax, Max, rax, T, T3D=T * 2.0)
+    r_q = np.concatenate([np.geomspace(5e-4, 2e2, 60), np.exp(rax[[0, 7, -1]]), [0.0]])
+    cases_M = np.array([1e12, 3.3e13, 1e14, np.exp(Max[4]), 9.99e15, 1e16, 2e16, 5e11])
+    cases_a = 1 / (1 + np.array([0.01, 0.0173, 0.2, 0.5, 0.999, 1.0, 1.2, 0.005]))
+    proj = np.array([[prof.projected(None, r_q, M, a) for a in cases_a] for M in cases_M])
+    real = np.array([[prof.real(None, r_q, M, a) for a in cases_a] for M in cases_M])
+    out.update(ro_zax=zax, ro_Max=Max, ro_rax=rax, ro_T2D=T, ro_r=r_q, ro_M=cases_M, ro_a=cases_a,
+               ro_projected=proj, ro_real=real)
+
+    pax = np.array([2.0, 4.0, 7.0, 11.0])
+    zax4, Max4, rax4, T4 = paint_table(nz=4, nM=5, nr=20, extra=pax)
+    pprof = make_param_tabulated(zax4, Max4, rax4, pax, T4)
+    cd_q = np.array([2.0, 3.1, 7.0, 10.9, 11.0, 11.5, 1.0])
+    pproj = np.array([[pprof.projected(None, r_q, M, 1 / 1.25, cdelta=c) for c in cd_q]
+                      for M in cases_M[:5]])
+    out.update(rp_zax=zax4, rp_Max=Max4, rp_rax=rax4, rp_pax=pax, rp_T2D=T4, rp_cd=cd_q,
+               rp_M=cases_M[:5], rp_a=np.array(1 / 1.25), rp_projected=pproj)
+
+    for tag, rdelta in (("rd0", False), ("rd1", True)):
+        zd, Md, rd, d = disp_table(rdelta=rdelta)
+        d = d.copy()
+        d[2, 3, 10:12] = np.nan
+        disp = make_disp(zd, Md, rd, d, rdelta=rdelta, eps=20 if not rdelta else 4)
+        vals = np.array([[disp.displacement(r_q, M, a) for a in cases_a] for M in cases_M])
+        Rm = np.array([[mdef.get_radius(cosmo_obj, M, a) / a for a in cases_a] for M in cases_M])
+        out.update({f"rb_{tag}_zax": zd, f"rb_{tag}_Max": Md, f"rb_{tag}_rax": rd, f"rb_{tag}_d": d,
+                    f"rb_{tag}_eps": np.array(disp.epsilon_max), f"rb_{tag}_disp": vals,
+                    f"rb_{tag}_Rcom": Rm})
+    np.savez_compressed(os.path.join(HERE, "readout.npz"), **out)
+    print("readout.npz", {k: np.shape(v) for k, v in out.items() if "proj" in k or "disp" in k})
+
+    # ---------------------------------------------------------------- 2. PaintProfilesShell.process
+    out = {}
+    for tag, nside, n, seed, eps, ips, bad in (("a", 32, 120, 42, 10, False, False),
+                                               ("b", 64, 200, 43, 10, True, True),
+                                               ("c", 64, 60, 44, 20, False, True)):
+        ra, dec, M, z = catalog(n, seed)
+        zax, Max, rax, T = paint_table(bad_block=bad)
+        prof = make_tabulated(zax, Max, rax, T)
+        Cat = io.HaloLightConeCatalog(ra, dec, M, z, COSMO)
+        Shell = io.LightconeShell(map=np.zeros(orc.nside2npix(nside)), cosmo=COSMO)
+        R = run.PaintProfilesShell(Cat, Shell, epsilon_max=eps, model=prof, mass_def=mdef,
+                                   include_pixel_size=ips, verbose=False)
+        res = R.process()
+        out.update({f"{tag}_nside": np.array(nside), f"{tag}_ra": ra, f"{tag}_dec": dec, f"{tag}_M": M,
+                    f"{tag}_z": z, f"{tag}_eps": np.array(eps), f"{tag}_ips": np.array(ips),
+                    f"{tag}_zax": zax, f"{tag}_Max": Max, f"{tag}_rax": rax, f"{tag}_T2D": T,
+                    f"{tag}_map": res})
+        print("paint", tag, "sum", res.sum(), "nonzero", np.count_nonzero(res))
+    # with an extra per-halo table coordinate (p_keys) through ParamTabulatedProfile
+    ra, dec, M, z = catalog(80, 45)
+    cd = np.random.default_rng(5).uniform(2.0, 11.0, 80)
+    cd[20] = 12.0  # outside hull -> contributes nothing
+    pprof = make_param_tabulated(zax4, Max4, rax4, pax, T4)
+    Cat = io.HaloLightConeCatalog(ra, dec, M, z, COSMO, cdelta=cd)
+    Shell = io.LightconeShell(map=np.zeros(orc.nside2npix(32)), cosmo=COSMO)
+    res = run.PaintProfilesShell(Cat, Shell, epsilon_max=10, model=pprof, mass_def=mdef,
+                                 verbose=False).process()
+    out.update(p_nside=np.array(32), p_ra=ra, p_dec=dec, p_M=M, p_z=z, p_cdelta=cd, p_eps=np.array(10),
+               p_zax=zax4, p_Max=Max4, p_rax=rax4, p_pax=pax, p_T2D=T4, p_map=res)
+    print("paint p", "sum", res.sum(), "nonzero", np.count_nonzero(res))
+    np.savez_compressed(os.path.join(HERE, "paint_shell.npz"), **out)
+
+    # ---------------------------------------------------------------- 3. BaryonifyShell.process
+    out = {}
+    for tag, nside, n, seed, eps, rdelta, emod in (("a", 32, 120, 52, 10, False, 20),
+                                                   ("b", 64, 150, 53, 10, True, 4),
+                                                   ("c", 64, 60, 54, 20, False, 6)):
+        ra, dec, M, z = catalog(n, seed)
+        zd, Md, rd, d = disp_table(rdelta=rdelta)
+        if tag == "c":
+            d = d.copy()
+            d[1:3, 4:6, 12:15] = np.nan
+        disp = make_disp(zd, Md, rd, d, rdelta=rdelta, eps=emod)
+        m_in = np.random.default_rng(7).uniform(0, 10, orc.nside2npix(nside))
+        m_in[np.random.default_rng(8).uniform(size=m_in.size) < 0.15] = 0.0
+        Cat = io.HaloLightConeCatalog(ra, dec, M, z, COSMO)
+        Shell = io.LightconeShell(map=m_in, cosmo=COSMO)
+        res = run.BaryonifyShell(Cat, Shell, epsilon_max=eps, model=disp, mass_def=mdef,
+                                 verbose=False).process()
+        out.update({f"{tag}_nside": np.array(nside), f"{tag}_ra": ra, f"{tag}_dec": dec, f"{tag}_M": M,
+                    f"{tag}_z": z, f"{tag}_eps": np.array(eps), f"{tag}_eps_model": np.array(emod),
+                    f"{tag}_rdelta": np.array(rdelta), f"{tag}_zax": zd, f"{tag}_Max": Md,
+                    f"{tag}_rax": rd, f"{tag}_d": d, f"{tag}_map_in": m_in, f"{tag}_map_out": res})
+        print("baryonify", tag, "sum in/out", m_in.sum(), res.sum(), "changed px",
+              np.count_nonzero(~np.isclose(res, m_in)))
+    np.savez_compressed(os.path.join(HERE, "baryonify_shell.npz"), **out)
+
+    # ---------------------------------------------------------------- 4. regrid_pixels_hpix
+    rng = np.random.default_rng(3)
+    N, npix = 5000, 3072
+    vals = rng.uniform(0, 5, N)
+    cpix = rng.integers(0, npix, (N, 4))
+    cw = rng.dirichlet(np.ones(4), N)
+    hm = run.regrid_pixels_hpix(np.zeros(npix), vals, cpix, cw)
+    np.savez_compressed(os.path.join(HERE, "regrid.npz"), vals=vals, child_pix=cpix,
+                        child_weights=cw, hmap=hm)
+
+    # ---------------------------------------------------------------- 5. Baryonification2D table builder (a6)
+    class Sigma(ccl.halos.profiles.HaloProfile):
+        """analytic projected-density stand-in for the (out-of-scope) profile zoo"""
+        def __init__(self, core, slope, amp=1.0):
+            super().__init__(mass_def=mdef)
+            self.core, self.slope, self.amp, self.cutoff = core, slope, amp, None
+
+        def set_parameter(self, k, v):
+            setattr(self, k, v)
+
+        def _projected(self, cosmo, r, M, a):
+            M = np.atleast_1d(M)
+            R = r200c_com(M, 1 / a - 1)[:, None]
+            x = np.atleast_1d(r)[None, :] / (self.core * R)
+            S = self.amp * M[:, None] / (2 * np.pi * (self.core * R) ** 2) * (1 + x * x) ** (-self.slope)
+            return S * np.exp(-np.atleast_1d(r)[None, :] / (30 * R))
+
+    DMO, DMB = Sigma(0.25, 1.6), Sigma(0.45, 1.6)
+    B2 = bc.Baryonification2D(DMO, DMB, cosmo_obj, epsilon_max=20, mass_def=mdef, N_int=500)
+    r_t = np.geomspace(1e-3, 1e2, 50)
+    M_t = np.geomspace(1e12, 1e16, 5)
+    a_t = 1 / 1.3
+    S_r = np.geomspace(min(r_t.min(), 1e-6) / 1.2, max(r_t.max(), 1000) * 1.2, 500)
+    out = dict(tb_r=r_t, tb_M=M_t, tb_a=np.array(a_t), tb_rint=S_r,
+               tb_Sigma_DMO=DMO._projected(None, S_r, M_t, a_t) * a_t,
+               tb_Sigma_DMB=DMB._projected(None, S_r, M_t, a_t) * a_t,
+               tb_M_DMO=B2.get_masses(DMO, r_t, M_t, a_t), tb_M_DMB=B2.get_masses(DMB, r_t, M_t, a_t))
+    B2.setup_interpolator(z_min=0.1, z_max=0.5, N_samples_z=3, M_min=1e12, M_max=1e16,
+                          N_samples_Mass=5, R_min=1e-3, R_max=1e2, N_samples_R=50, verbose=False)
+    zs = np.exp(B2.raw_input_z_range) - 1
+    out.update(tb_z_tab=zs, tb_d_interp=B2.raw_input_d,
+               tb_Sigma_DMO_z=np.array([DMO._projected(None, S_r, M_t, 1 / (1 + zz)) / (1 + zz) for zz in zs]),
+               tb_Sigma_DMB_z=np.array([DMB._projected(None, S_r, M_t, 1 / (1 + zz)) / (1 + zz) for zz in zs]))
+    np.savez_compressed(os.path.join(HERE, "table_builder.npz"), **out)
+    print("table_builder d range", np.nanmin(B2.raw_input_d), np.nanmax(B2.raw_input_d))
+
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,140 @@
+"""
+Pins the CPU oracle (oracle/) against the golden vectors that
+tests/golden/make_golden.py captured by executing the reference's own modules
+(Tabulate.py, BaryonCorrection.py, io.py, HealpixRunner.py).
+Tolerances: the read-out and the loops restate the same IEEE sequence, so the
+bar is 1e-12 relative (libm exp/log of numpy vs glibc may differ in the last ulp).
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+
+RT = 1e-12
+
+
+def _eq(a, b, rtol=RT, atol=0.0):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    m = ~np.isnan(a)
+    np.testing.assert_allclose(a[m], b[m], rtol=rtol, atol=atol)
+
+
+def _readout(axes, vals, r, M, a, extra=None):
+    n = r.size
+    cols = [np.full(n, np.log(1 / a)), np.full(n, np.log(M)), np.log(r)]
+    if extra is not None:
+        cols.append(np.full(n, extra))
+    with np.errstate(all="ignore"):
+        return o.interp_linear(axes, vals, np.stack(cols, 1))
+
+
+def test_tabulated_readout(golden):
+    g = golden("readout.npz")
+    axes = (g["ro_zax"], g["ro_Max"], g["ro_rax"])
+    with np.errstate(all="ignore"):
+        lnT = np.log(g["ro_T2D"])
+        for i, M in enumerate(g["ro_M"]):
+            for j, a in enumerate(g["ro_a"]):
+                _eq(np.exp(_readout(axes, lnT, g["ro_r"], M, a)), g["ro_projected"][i, j])
+                _eq(np.exp(_readout(axes, np.log(g["ro_T2D"] * 2.0), g["ro_r"], M, a)), g["ro_real"][i, j])
+    assert np.isnan(g["ro_projected"]).any() and (g["ro_projected"] == 0).any()
+
+
+def test_param_tabulated_readout(golden):
+    g = golden("readout.npz")
+    axes = (g["rp_zax"], g["rp_Max"], g["rp_rax"], g["rp_pax"])
+    lnT = np.log(g["rp_T2D"])
+    for i, M in enumerate(g["rp_M"]):
+        for j, c in enumerate(g["rp_cd"]):
+            with np.errstate(all="ignore"):
+                _eq(np.exp(_readout(axes, lnT, g["ro_r"], M, float(g["rp_a"]), extra=c)), g["rp_projected"][i, j])
+
+
+@pytest.mark.parametrize("tag", ["rd0", "rd1"])
+def test_displacement_readout(golden, tag):
+    g = golden("readout.npz")
+    axes = (g[f"rb_{tag}_zax"], g[f"rb_{tag}_Max"], g[f"rb_{tag}_rax"])
+    d, eps = g[f"rb_{tag}_d"], float(g[f"rb_{tag}_eps"])
+    r = g["ro_r"]
+    for i, M in enumerate(g["ro_M"]):
+        for j, a in enumerate(g["ro_a"]):
+            R = g[f"rb_{tag}_Rcom"][i, j]
+            assert R == pytest.approx(o.get_radius({"Omega_m": 0.3, "h": 0.7, "w0": -1.0}, M, a) / a, rel=1e-14)
+            with np.errstate(all="ignore"):
+                rr = r / R if tag == "rd1" else r
+                n = r.size
+                pts = np.stack([np.full(n, np.log(1 / a)), np.full(n, np.log(M)), np.log(rr) if tag == "rd0"
+                                else np.log(r) - np.log(R)], 1)
+                v = o.interp_linear(axes, d, pts)
+            v = np.where(r < eps * R, v, 0)
+            _eq(v, g[f"rb_{tag}_disp"][i, j], atol=1e-300)
+
+
+def _scalars(g, tag, cosmo):
+    return o.halo_scalars(cosmo, g[f"{tag}_M"], g[f"{tag}_z"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_paint_shell_loop(golden, cosmo, tag):
+    g = golden("paint_shell.npz")
+    a, R, D = _scalars(g, tag, cosmo)
+    with np.errstate(all="ignore"):
+        lnT = np.log(g[f"{tag}_T2D"])
+    m, ptot = o.paint_shell(int(g[f"{tag}_nside"]), g[f"{tag}_ra"], g[f"{tag}_dec"], g[f"{tag}_M"], a, D, R,
+                            (g[f"{tag}_zax"], g[f"{tag}_Max"], g[f"{tag}_rax"]), lnT, float(g[f"{tag}_eps"]),
+                            include_pixel_size=bool(g[f"{tag}_ips"]))
+    ref = g[f"{tag}_map"]
+    assert np.array_equal(m != 0, ref != 0)
+    np.testing.assert_allclose(m, ref, rtol=RT, atol=0)
+    assert ptot >= np.count_nonzero(ref)
+
+
+def test_paint_shell_loop_param(golden, cosmo):
+    g = golden("paint_shell.npz")
+    a, R, D = _scalars(g, "p", cosmo)
+    m, _ = o.paint_shell(int(g["p_nside"]), g["p_ra"], g["p_dec"], g["p_M"], a, D, R,
+                         (g["p_zax"], g["p_Max"], g["p_rax"], g["p_pax"]), np.log(g["p_T2D"]),
+                         float(g["p_eps"]), extra=g["p_cdelta"])
+    np.testing.assert_allclose(m, g["p_map"], rtol=RT, atol=0)
+
+
+def test_paint_splitjoin_equals_serial(golden, cosmo):
+    g = golden("paint_shell.npz")
+    a, R, D = _scalars(g, "a", cosmo)
+    args = (int(g["a_nside"]), g["a_ra"], g["a_dec"], g["a_M"], a, D, R,
+            (g["a_zax"], g["a_Max"], g["a_rax"]), np.log(g["a_T2D"]), float(g["a_eps"]))
+    m1, p1 = o.paint_shell(*args)
+    m3, p3 = o.paint_shell(*args, njobs=3)
+    assert p1 == p3
+    np.testing.assert_allclose(m3, m1, rtol=1e-13, atol=0)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_baryonify_shell_loop(golden, cosmo, tag):
+    g = golden("baryonify_shell.npz")
+    a, R, D = _scalars(g, tag, cosmo)
+    Rm = R / a  # model cosmology == runner cosmology in the fixtures
+    res = o.baryonify_shell(int(g[f"{tag}_nside"]), g[f"{tag}_map_in"], g[f"{tag}_ra"], g[f"{tag}_dec"],
+                            g[f"{tag}_M"], a, D, R, Rm, (g[f"{tag}_zax"], g[f"{tag}_Max"], g[f"{tag}_rax"]),
+                            g[f"{tag}_d"], float(g[f"{tag}_eps"]), float(g[f"{tag}_eps_model"]),
+                            rdelta_sampling=bool(g[f"{tag}_rdelta"]))
+    ref = g[f"{tag}_map_out"]
+    # weights like (1 - 1e-16) are rounding-sensitive: absolute floor at 1e-13 of the map scale
+    np.testing.assert_allclose(res, ref, rtol=1e-11, atol=1e-12)
+    assert np.count_nonzero(~np.isclose(ref, g[f"{tag}_map_in"])) > 100
+
+
+def test_zero_map_early_return(golden, cosmo):
+    z = np.zeros(o.nside2npix(4))
+    out = o.baryonify_shell(4, z, [1.0], [2.0], [1e14], [0.8], [500.0], [1.0], [1.2],
+                            (np.array([0., 1.]), np.array([30., 35.]), np.array([-5., 5.])),
+                            np.zeros((2, 2, 2)), 10, 20)
+    assert out is not None and np.all(out == 0)
+
+
+def test_regrid_pixels_hpix(golden):
+    g = golden("regrid.npz")
+    hm = o.regrid_pixels_hpix(np.zeros(g["hmap"].size), g["vals"], g["child_pix"], g["child_weights"])
+    np.testing.assert_allclose(hm, g["hmap"], rtol=1e-15, atol=0)
