@@ -1,0 +1,142 @@
+"""
+ctypes binding of libbfg_mi355.so (include/bfg_mi355.h).
+
+There is NO CPU fallback: if the HIP library cannot be loaded, or no GPU is
+visible, every product entry point raises.  (The CPU oracle under oracle/ is
+test infrastructure and is never imported from here.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+_i64 = C.c_int64
+_dbl = C.c_double
+_vp = C.c_void_p
+
+BFG_OK = 0
+BFG_MAX_DIM = 6
+BFG_MAX_EXTRA = 3
+BFG_TABLE_LOG_VALUES = 1
+
+VARIANT_AUTO, VARIANT_SCATTER_WAVE, VARIANT_SCATTER_QUARTER, VARIANT_TILE_LDS = 0, 1, 2, 3
+VARIANTS = {"auto": VARIANT_AUTO, "scatter_wave": VARIANT_SCATTER_WAVE,
+            "scatter_quarter": VARIANT_SCATTER_QUARTER, "tile_lds": VARIANT_TILE_LDS}
+
+WARN_Z_RANGE, WARN_M_RANGE, WARN_R_RANGE = 1, 2, 4
+
+# every symbol include/bfg_mi355.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    "bfg_abi_version", "bfg_status_string", "bfg_last_error", "bfg_device_count",
+    "bfg_ctx_create", "bfg_ctx_destroy", "bfg_ctx_synchronize", "bfg_ctx_device_info",
+    "bfg_dev_malloc", "bfg_dev_free", "bfg_memcpy_h2d", "bfg_memcpy_d2h", "bfg_dev_memset_zero",
+    "bfg_table_create", "bfg_table_destroy", "bfg_table_eval",
+    "bfg_spline_create", "bfg_spline_destroy",
+    "bfg_paint_shell", "bfg_baryonify_offsets", "bfg_regrid_shell", "bfg_reduce_absmax_sum",
+    "bfg_stats_reset", "bfg_stats_read", "bfg_timing_enable", "bfg_timing_read",
+]
+
+
+class MassDefStruct(C.Structure):
+    _fields_ = [("Omega_m", _dbl), ("Omega_l", _dbl), ("Omega_r", _dbl), ("w0", _dbl), ("h", _dbl),
+                ("rho_crit0_h2", _dbl), ("Delta", _dbl), ("rho_type", C.c_int32), ("reserved", C.c_int32)]
+
+
+class ShellArgs(C.Structure):
+    _fields_ = [("nside", _i64), ("n_halo", _i64), ("d_catalog", _vp), ("cat_stride", C.c_int32),
+                ("n_extra", C.c_int32), ("epsilon_max", _dbl), ("runner_md", MassDefStruct),
+                ("model_md", MassDefStruct), ("model_epsilon_max", _dbl),
+                ("rdelta_sampling", C.c_int32), ("include_pixel_size", C.c_int32),
+                ("variant", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("pixel_updates", C.c_uint64), ("halos_out_of_table", C.c_uint64),
+                ("pixels_out_of_table", C.c_uint64), ("halos_fallback4", C.c_uint64),
+                ("warn_mask", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class BFGError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def so_path():
+    return _build.SO
+
+
+def load(build_if_missing=True):
+    """Load the shared library (building it with hipcc first if it is missing or stale)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_missing:
+        try:
+            _build.build()
+        except Exception as exc:  # no hipcc on this box: fall through to the prebuilt .so if present
+            if not os.path.exists(_build.SO):
+                raise BFGError(f"libbfg_mi355.so is missing and could not be built: {exc}") from exc
+    if not os.path.exists(_build.SO):
+        raise BFGError("libbfg_mi355.so not found; run `python -m baryonforge_amd._build`")
+    # PyTorch-ROCm bundles its own libamdhip64.so.7.  Import torch FIRST so that this library
+    # binds to the same HIP runtime instance (one runtime per process: torch's streams and
+    # allocations are then valid handles inside libbfg_mi355.so).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(_build.SO)
+    L.bfg_abi_version.restype = C.c_int
+    L.bfg_status_string.restype = C.c_char_p
+    L.bfg_status_string.argtypes = [C.c_int]
+    L.bfg_last_error.restype = C.c_char_p
+    L.bfg_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.bfg_ctx_create.argtypes = [C.c_int, _vp, C.POINTER(_vp)]
+    L.bfg_ctx_destroy.argtypes = [_vp]
+    L.bfg_ctx_synchronize.argtypes = [_vp]
+    L.bfg_ctx_device_info.argtypes = [_vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.POINTER(_i64)]
+    L.bfg_dev_malloc.argtypes = [_vp, C.c_size_t, C.POINTER(_vp)]
+    L.bfg_dev_free.argtypes = [_vp, _vp]
+    L.bfg_memcpy_h2d.argtypes = [_vp, _vp, _vp, C.c_size_t]
+    L.bfg_memcpy_d2h.argtypes = [_vp, _vp, _vp, C.c_size_t]
+    L.bfg_dev_memset_zero.argtypes = [_vp, _vp, C.c_size_t]
+    L.bfg_table_create.argtypes = [_vp, C.c_int, C.POINTER(_i64), C.POINTER(C.POINTER(_dbl)),
+                                   C.POINTER(_dbl), C.c_uint32, C.POINTER(_vp)]
+    L.bfg_table_destroy.argtypes = [_vp, _vp]
+    L.bfg_table_eval.argtypes = [_vp, _vp, _i64, C.POINTER(_dbl), C.POINTER(_dbl)]
+    L.bfg_spline_create.argtypes = [_vp, C.c_int, C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_vp)]
+    L.bfg_spline_destroy.argtypes = [_vp, _vp]
+    L.bfg_paint_shell.argtypes = [_vp, C.POINTER(ShellArgs), _vp, _vp, _vp]
+    L.bfg_baryonify_offsets.argtypes = [_vp, C.POINTER(ShellArgs), _vp, _vp, _vp]
+    L.bfg_regrid_shell.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp]
+    L.bfg_reduce_absmax_sum.argtypes = [_vp, _i64, _vp, C.POINTER(_dbl), C.POINTER(_dbl)]
+    L.bfg_stats_reset.argtypes = [_vp]
+    L.bfg_stats_read.argtypes = [_vp, C.POINTER(Stats)]
+    L.bfg_timing_enable.argtypes = [_vp, C.c_int]
+    L.bfg_timing_read.argtypes = [_vp, C.c_int, C.POINTER(_dbl), C.POINTER(_i64)]
+    for name in SYMBOLS:
+        if name not in ("bfg_status_string", "bfg_last_error"):
+            getattr(L, name).restype = C.c_int
+    if L.bfg_abi_version() != 1:
+        raise BFGError("libbfg_mi355.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(status, what=""):
+    if status != BFG_OK:
+        L = load()
+        msg = L.bfg_status_string(status).decode()
+        detail = L.bfg_last_error().decode() if status == -2 else ""
+        raise BFGError(f"{what}: {msg} ({status}) {detail}".strip())
+
+
+def dptr(arr):
+    """ctypes double* view of a C-contiguous float64 numpy array"""
+    assert arr.dtype == np.float64 and arr.flags["C_CONTIGUOUS"]
+    return arr.ctypes.data_as(C.POINTER(_dbl))

@@ -1,0 +1,1089 @@
+// bfg_mi355.hip -- libbfg_mi355.so: hand-written gfx950 (CDNA4, wave64) kernels
+// and the C-ABI of include/bfg_mi355.h for BaryonForge's shell paint / baryonify
+// hot path (Runners/HealpixRunner.py:252-483 of the reference).
+//
+// Kernels (all float64, HBM/atomic/ALU bound -- there is no dense contraction
+// on this path, so no MFMA):
+//   halo_prep_kernel      catalog record -> per-halo scalars (a, R_delta, D_A,
+//                         unit vector, disc ring range, (z, M, extras) table cell)
+//   shell_scatter_kernel  one G-lane group per halo: ring windows of the disc
+//                         (query_disc arithmetic) -> prefix scan over rings ->
+//                         flattened pixel loop -> LDS-staged blended profile row
+//                         -> global f64 atomic scatter-add (paint: 1, baryonify: 3)
+//   regrid_kernel         one thread per pixel: displaced direction -> 4 bilinear
+//                         neighbours -> 4 f64 atomics
+//   reduce kernels        sum / absmax
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bfg_mi355.h"
+#include "bfg_device.hpp"
+
+using namespace bfg;
+
+// ------------------------------------------------------------------------------------
+// host-side bookkeeping
+// ------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            g_last_error = std::string(#expr) + ": " + hipGetErrorString(e_);               \
+            return BFG_ERR_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+
+enum { F_X0 = 0, F_Y0, F_Z0, F_PTHETA, F_PPHI, F_D, F_A, F_R, F_RM, F_RADIUS, F_LNM, F_LNZ, F_NF };
+enum { I_RFIRST = 0, I_RLAST, I_IRMIN, I_IRMAX, I_FLAGS, I_NI };
+#define HF_OOB 1        // (z, M, extras) outside the table hull, or NaN
+#define HF_SKIP 2       // nothing to do for this halo (NaN radius etc.)
+
+struct DevTable {
+    int ndim;                       // 3 + n_extra
+    int nouter;                     // ndim - 1 : (z, M, extras...)
+    int nr;                         // r-axis length
+    int oshape[BFG_MAX_DIM];        // outer axis lengths
+    int64_t ostride[BFG_MAX_DIM];   // outer strides in doubles (r is fastest)
+    const double *oaxis[BFG_MAX_DIM];
+    const double *raxis;
+    const double *values;           // permuted to [z][M][extras...][r]
+    int log_values;
+    int r_uniform;                  // ln r axis is a linspace to rounding
+    double r0, inv_dr;
+};
+
+struct bfg_table {
+    DevTable dev;
+    double *d_blob;                 // one allocation: axes + values
+    std::vector<std::vector<double>> h_axes;  // original order (z, M, r, extras...)
+    std::vector<double> h_values;   // original C order, for bfg_table_eval's bookkeeping
+    std::vector<int64_t> shape;
+};
+
+struct bfg_spline {
+    int n;
+    double *d_knots;  // [n]
+    double *d_coef;   // [4][n-1]
+};
+
+struct bfg_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    int n_cu;
+    int lds_per_cu;
+    size_t max_dyn_lds;
+    // per-halo workspace
+    int64_t cap_halo;
+    double *d_rec;      // [F_NF][cap]
+    int32_t *d_irec;    // [I_NI][cap]
+    int32_t *d_cidx;    // [BFG_MAX_DIM-1][cap]
+    double *d_cw;       // [BFG_MAX_DIM-1][cap]
+    bfg_stats *d_stats;
+    double *d_red;      // scratch for reductions [4]
+    // timing: a growing pool of event pairs per kernel class, resolved lazily in bfg_timing_read
+    bool timing;
+    std::vector<hipEvent_t> *ev_a[3], *ev_b[3];
+    size_t ev_used[3];
+    double t_ms[3];
+    int64_t t_n[3];
+};
+
+struct ShellParams {
+    Hpx hpx;
+    int64_t n_halo;
+    int64_t cap;             // stride of the SoA workspace
+    const double *rec;
+    const int32_t *irec;
+    const int32_t *cidx;
+    const double *cw;
+    const double *cat;       // catalog (for ra/dec of the fallback)
+    int cat_stride;
+    DevTable tab;
+    int win_nodes;           // LDS window length in r nodes
+    double eps_model;
+    int rdelta;
+    double pixfac_area;      // pixarea if include_pixel_size else 0
+    double *out;             // map [npix] or offsets [npix][3]
+    bfg_stats *stats;
+};
+
+// ------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------
+struct PrepParams {
+    Hpx hpx;
+    int64_t n_halo, cap;
+    const double *cat;
+    int cat_stride, n_extra;
+    double eps_run;
+    bfg_massdef md_run, md_model;
+    int spl_n;
+    const double *spl_knots, *spl_coef;
+    DevTable tab;
+    double *rec;
+    int32_t *irec;
+    int32_t *cidx;
+    double *cw;
+    bfg_stats *stats;
+    int want_model_radius;
+};
+
+__device__ inline double massdef_radius(const bfg_massdef &md, double M, double a)
+{
+    double rho;
+    if (md.rho_type == 0) {
+        double E2 = md.Omega_m / (a * a * a) + md.Omega_l * pow(a, -3.0 * (1.0 + md.w0)) +
+                    md.Omega_r / (a * a * a * a);
+        rho = md.rho_crit0_h2 * md.h * md.h * E2;
+    } else {
+        rho = md.rho_crit0_h2 * md.h * md.h * md.Omega_m / (a * a * a);
+    }
+    return cbrt(M / (4.18879020479 * md.Delta * rho));
+}
+
+// scipy PPoly evaluation of the not-a-knot CubicSpline of HealpixRunner.py:299 (extrapolates)
+__device__ inline double spline_eval(int n, const double *__restrict__ x, const double *__restrict__ c, double v)
+{
+    int i = find_interval(x, n, v);
+    double s = v - x[i];
+    int m = n - 1;
+    return ((c[i] * s + c[m + i]) * s + c[2 * m + i]) * s + c[3 * m + i];
+}
+
+__global__ __launch_bounds__(256) void halo_prep_kernel(const PrepParams P)
+{
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P.n_halo) return;
+    const double *c = P.cat + j * (int64_t)P.cat_stride;
+    const double M = c[0], zred = c[1], ra = c[2], dec = c[3];
+    const double a = 1.0 / (1.0 + zred);                                   // HealpixRunner.py:319/:453
+    const double R = massdef_radius(P.md_run, M, a);                        // :320/:454
+    const double D = spline_eval(P.spl_n, P.spl_knots, P.spl_coef, zred);   // :321/:455
+    // hp.ang2vec(ra, dec, lonlat=True)                                      // :327/:460
+    const double theta = kHalfPi - dec * kDeg2Rad, phi = ra * kDeg2Rad;
+    double st, ct, sp, cp;
+    sincos(theta, &st, &ct);
+    sincos(phi, &sp, &cp);
+    const double x0 = st * cp, y0 = st * sp, z0v = ct;
+    // pointing(vec3) inside query_disc
+    double ptheta = atan2(sqrt(x0 * x0 + y0 * y0), z0v);
+    double pphi = (x0 == 0.0 && y0 == 0.0) ? 0.0 : atan2(y0, x0);
+    if (pphi < 0.0) pphi += kTwoPi;
+    const double radius = R * P.eps_run / D;                                 // :329/:462
+
+    double *rec = P.rec + j;
+    const int64_t cap = P.cap;
+    rec[F_X0 * cap] = x0; rec[F_Y0 * cap] = y0; rec[F_Z0 * cap] = z0v;
+    rec[F_PTHETA * cap] = ptheta; rec[F_PPHI * cap] = pphi;
+    rec[F_D * cap] = D; rec[F_A * cap] = a; rec[F_R * cap] = R;
+    rec[F_RM * cap] = P.want_model_radius ? massdef_radius(P.md_model, M, a) / a : 0.0;  // BaryonCorrection.py:399
+    rec[F_RADIUS * cap] = radius;
+    const double lnM = log(M), lnz = log(1.0 / a);                           // Tabulate.py:308,312
+    rec[F_LNM * cap] = lnM; rec[F_LNZ * cap] = lnz;
+
+    // disc ring range (query_disc_internal, fact = 0)
+    int32_t flags = 0, rfirst = 1, rlast = 0, irmin = 1, irmax = 0;
+    const int64_t nl4 = 4 * P.hpx.nside;
+    if (!(radius >= 0.0) || !isfinite(ptheta)) {
+        flags |= HF_SKIP;   // NaN radius: every healpy comparison is false -> empty disc
+    } else if (radius >= kPi) {
+        rfirst = 1; rlast = (int32_t)(nl4 - 1); irmin = (int32_t)nl4; irmax = (int32_t)nl4;  // every ring complete
+    } else {
+        const double rlat1 = ptheta - radius;
+        const double zmax = cos(rlat1);
+        int64_t imin = ring_above(P.hpx, zmax) + 1;
+        const double rlat2 = ptheta + radius;
+        const double zmin = cos(rlat2);
+        int64_t imax = ring_above(P.hpx, zmin);
+        bool north = (rlat1 <= 0) && (imin > 1);
+        bool south = (rlat2 >= kPi) && (imax + 1 < nl4);
+        irmin = (int32_t)imin; irmax = (int32_t)imax;
+        rfirst = north ? 1 : irmin;
+        rlast = south ? (int32_t)(nl4 - 1) : irmax;
+    }
+    int32_t *irec = P.irec + j;
+    // table cell of the halo in the outer (non-radial) dimensions
+    bool oob = false;
+    uint32_t warn = 0;
+    for (int k = 0; k < P.tab.nouter; ++k) {
+        double x = (k == 0) ? lnz : (k == 1) ? lnM : c[4 + (k - 2)];
+        const double *g = P.tab.oaxis[k];
+        int n = P.tab.oshape[k];
+        if (!(x >= g[0]) || !(x <= g[n - 1])) {
+            oob = true;
+            if (k == 0) warn |= BFG_WARN_Z_RANGE;
+            if (k == 1) warn |= BFG_WARN_M_RANGE;
+        }
+        int i = find_interval(g, n, x);
+        P.cidx[k * cap + j] = i;
+        P.cw[k * cap + j] = (x - g[i]) / (g[i + 1] - g[i]);
+    }
+    if (oob) {
+        flags |= HF_OOB;
+        atomicAdd((unsigned long long *)&P.stats->halos_out_of_table, 1ull);
+        atomicOr(&P.stats->warn_mask, warn);
+    }
+    irec[I_RFIRST * cap] = rfirst; irec[I_RLAST * cap] = rlast;
+    irec[I_IRMIN * cap] = irmin; irec[I_IRMAX * cap] = irmax;
+    irec[I_FLAGS * cap] = flags;
+}
+
+#define MODE_PAINT 0
+#define MODE_BARYONIFY 1
+
+// per-group LDS layout (G entries each), followed by the (axis, value) window
+constexpr int kMaxCorner = 1 << (BFG_MAX_DIM - 1);
+template <int G>
+struct RingLds {
+    int32_t cum[G];
+    int32_t nr[G];
+    int32_t iplo[G];
+    int32_t pad[G];
+    int64_t start[G];
+    double z[G], sth[G], phistep[G], phioff[G];
+    double cwgt[kMaxCorner];      // weights / row offsets of the halo's outer-cell corners
+    int64_t coff[kMaxCorner];
+};
+
+template <int G, int MODE>
+__global__ __launch_bounds__(256) void shell_scatter_kernel(const ShellParams P)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    constexpr int GPB = 256 / G;
+    const int lane = threadIdx.x % G;
+    const int grp = threadIdx.x / G;
+    RingLds<G> *rl = reinterpret_cast<RingLds<G> *>(smem_raw) + grp;
+    double2 *win = reinterpret_cast<double2 *>(smem_raw + sizeof(RingLds<G>) * GPB) + (size_t)grp * P.win_nodes;
+
+    const int64_t j = (int64_t)blockIdx.x * GPB + grp;
+    if (j >= P.n_halo) return;
+    const int64_t cap = P.cap;
+    const int32_t flags = P.irec[I_FLAGS * cap + j];
+    if (flags & HF_SKIP) return;
+    // paint: a halo outside the table hull paints NaN -> 0 everywhere (HealpixRunner.py:473);
+    // baryonify: offset NaN -> 0 (:347) -- but its pixels still count toward P_tot.
+    const bool halo_oob = (flags & HF_OOB) != 0;
+
+    const double *rec = P.rec + j;
+    const double x0 = rec[F_X0 * cap], y0 = rec[F_Y0 * cap], z0v = rec[F_Z0 * cap];
+    const double ptheta = rec[F_PTHETA * cap], pphi = rec[F_PPHI * cap];
+    const double D = rec[F_D * cap], a = rec[F_A * cap];
+    const double radius = rec[F_RADIUS * cap];
+    const double Rm = rec[F_RM * cap];
+    const int32_t rfirst = P.irec[I_RFIRST * cap + j], rlast = P.irec[I_RLAST * cap + j];
+    const int32_t irmin = P.irec[I_IRMIN * cap + j], irmax = P.irec[I_IRMAX * cap + j];
+    const Hpx &hp = P.hpx;
+    const DevTable &T = P.tab;
+
+    // ---- outer-cell corners ------------------------------------------------------
+    const int ncorner = 1 << T.nouter;
+    for (int c = lane; c < ncorner; c += G) {
+        double w = 1.0;
+        int64_t off = 0;
+        for (int k = 0; k < T.nouter; ++k) {
+            int bit = (c >> (T.nouter - 1 - k)) & 1;
+            double y = P.cw[k * cap + j];
+            int i = P.cidx[k * cap + j];
+            w = w * (bit ? y : 1.0 - y);
+            off += (int64_t)(i + bit) * T.ostride[k];
+        }
+        rl->cwgt[c] = w; rl->coff[c] = off;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double *cwgt = rl->cwgt;
+    const int64_t *coff = rl->coff;
+    const double r_lo = T.raxis[0], r_hi = T.raxis[T.nr - 1];
+
+    // ---- stage the blended radial row window in LDS --------------------------------
+    // largest radius any disc pixel can have -> top node of the window
+    const double q_rdelta = (MODE == MODE_BARYONIFY && P.rdelta) ? log(Rm) : 0.0;
+    int win_lo = 0;
+    if (!halo_oob) {
+        double rmax_com = 2.0 * D * sin(0.5 * fmin(radius, kPi)) / a;
+        double rho_max = log(rmax_com) - q_rdelta;
+        int itop = find_interval(T.raxis, T.nr, rho_max) + 1;          // top node that can be touched
+        win_lo = itop - (P.win_nodes - 1);
+        if (win_lo > T.nr - P.win_nodes) win_lo = T.nr - P.win_nodes;
+        if (win_lo < 0) win_lo = 0;
+        for (int e = lane; e < P.win_nodes; e += G) {
+            int ir = win_lo + e;
+            double acc = 0.0;
+            for (int c = 0; c < ncorner; ++c) acc = acc + T.values[coff[c] + ir] * cwgt[c];
+            win[e] = make_double2(T.raxis[ir], acc);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- per-pixel work --------------------------------------------------------------
+    const double cosrbig = cos(radius);
+    const double z0 = cos(ptheta);
+    const double xa = 1.0 / sqrt((1.0 - z0) * (1.0 + z0));
+    const double pixfac = (MODE == MODE_PAINT && P.pixfac_area != 0.0) ? P.pixfac_area * (D * D) : 1.0;
+    const double posj0 = x0 * D, posj1 = y0 * D, posj2 = z0v * D;
+    unsigned long long n_r_oob = 0;
+
+    auto process_pixel = [&](int64_t pix, double z, double sth, double phi) {
+        double sphi, cphi;
+        sincos(phi, &sphi, &cphi);
+        const double vx = sth * cphi, vy = sth * sphi, vz = z;
+        const double p0 = vx * D, p1 = vy * D, p2 = vz * D;            // pos = vec * D_j
+        const double d0 = p0 - posj0, d1 = p1 - posj1, d2 = p2 - posj2;
+        const double r_sep = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+        const double r_com = r_sep / a;
+        double val = NAN;   // interpolant (ln T for paint, d for baryonify); NaN = outside hull
+        if (!halo_oob) {
+            const double rho = log(r_com) - q_rdelta;
+            if (rho >= r_lo && rho <= r_hi) {
+                bool done = false;
+                if (T.r_uniform) {
+                    int i = (int)((rho - T.r0) * T.inv_dr);
+                    i = i < 0 ? 0 : (i > T.nr - 2 ? T.nr - 2 : i);
+                    int e = i - win_lo;
+                    if (e >= 0 && e + 1 < P.win_nodes) {
+                        double2 a0 = win[e], a1 = win[e + 1];
+                        if (rho >= a0.x && (rho < a1.x || i == T.nr - 2)) {
+                            double w = (rho - a0.x) / (a1.x - a0.x);
+                            val = a0.y * (1.0 - w) + a1.y * w;
+                            done = true;
+                        }
+                    }
+                }
+                if (!done) {   // generic path: exact cell by bisection, corners from L2
+                    int i = find_interval(T.raxis, T.nr, rho);
+                    double g0 = T.raxis[i], g1 = T.raxis[i + 1];
+                    double v0 = 0.0, v1 = 0.0;
+                    for (int c = 0; c < ncorner; ++c) {
+                        v0 = v0 + T.values[coff[c] + i] * cwgt[c];
+                        v1 = v1 + T.values[coff[c] + i + 1] * cwgt[c];
+                    }
+                    double w = (rho - g0) / (g1 - g0);
+                    val = v0 * (1.0 - w) + v1 * w;
+                }
+            } else {
+                ++n_r_oob;
+            }
+        }
+        if (MODE == MODE_PAINT) {
+            double v = exp(val);                                       // Tabulate.py:315
+            if (!isfinite(v)) v = 0.0;                                 // HealpixRunner.py:473
+            v = v * pixfac;                                            // :478
+            if (v != 0.0) unsafeAtomicAdd(P.out + pix, v);             // :481
+        } else {
+            double d = val;
+            if (!(r_com < P.eps_model * Rm)) d = 0.0;                  // BaryonCorrection.py:410-411
+            d = d * a;                                                 // HealpixRunner.py:345
+            double o0 = d * (d0 / r_sep), o1 = d * (d1 / r_sep), o2 = d * (d2 / r_sep);   // :346
+            if (!isfinite(o0)) o0 = 0.0;                               // :347
+            if (!isfinite(o1)) o1 = 0.0;
+            if (!isfinite(o2)) o2 = 0.0;
+            const double n0 = p0 + o0, n1 = p1 + o1, n2 = p2 + o2;     // :350
+            const double nn = sqrt(n0 * n0 + n1 * n1 + n2 * n2);       // :351
+            const double f0 = n0 / nn - vx, f1 = n1 / nn - vy, f2 = n2 / nn - vz;   // :352
+            if (o0 != 0.0 || o1 != 0.0 || o2 != 0.0) {                 // zero offsets add exactly 0
+                double *o = P.out + 3 * pix;
+                unsafeAtomicAdd(o + 0, f0);                            // :355
+                unsafeAtomicAdd(o + 1, f1);
+                unsafeAtomicAdd(o + 2, f2);
+            }
+        }
+    };
+
+    unsigned long long my_pixels = 0;
+    const int nrings = rlast - rfirst + 1;
+    for (int ring0 = rfirst; ring0 <= rlast || ring0 == rfirst; ring0 += G) {
+        // phase A: one lane per ring -> phi window of the disc on that ring
+        const int ring = ring0 + lane;
+        int cnt = 0, iplo = 0;
+        RingGeom g;
+        g.start = 0; g.nr = 1; g.z = 0; g.sth = 0; g.phistep = 0; g.phioff = 0;
+        if (ring <= rlast) {
+            g = ring_geom(hp, ring);
+            if (ring < irmin || ring > irmax) {
+                cnt = g.nr;              // ring completely inside the disc (pole in disc)
+                iplo = 0;
+            } else {
+                const double z = ring2z(hp, ring);
+                const double x = (cosrbig - z * z0) * xa;
+                const double ysq = 1.0 - z * z - x * x;
+                const double dphi = (ysq <= 0.0) ? 0.0 : atan2(sqrt(ysq), x);
+                if (dphi > 0.0) {
+                    const double shift = (g.phioff != 0.0) ? 0.5 : 0.0;
+                    int64_t lo = (int64_t)floor((double)g.nr * kInvTwoPi * (pphi - dphi) - shift) + 1;
+                    int64_t hi = (int64_t)floor((double)g.nr * kInvTwoPi * (pphi + dphi) - shift);
+                    int64_t c = hi - lo + 1;
+                    if (c > g.nr) c = g.nr;   // the two healpy ranges overlap -> whole ring once
+                    if (c > 0) { cnt = (int)c; iplo = (int)lo; }
+                }
+            }
+        }
+        const int cum = group_inclusive_scan<G>(cnt, lane);
+        const int total = __shfl(cum, G - 1, G);
+        rl->cum[lane] = cum; rl->nr[lane] = g.nr; rl->iplo[lane] = iplo; rl->start[lane] = g.start;
+        rl->z[lane] = g.z; rl->sth[lane] = g.sth; rl->phistep[lane] = g.phistep; rl->phioff[lane] = g.phioff;
+        __builtin_amdgcn_wave_barrier();
+
+        if (MODE == MODE_BARYONIFY && nrings <= G && total < 4) {
+            // fewer than 4 pixels: use the 4 bilinear neighbours of the halo centre  (:333-334)
+            if (lane < 4) {
+                const double *c = P.cat + j * (int64_t)P.cat_stride;
+                int64_t fp[4]; double fw[4];
+                get_interpol(hp, kHalfPi - c[3] * kDeg2Rad, c[2] * kDeg2Rad, fp, fw);
+                int64_t pix = fp[lane], fring, fip;
+                pix2ring(hp, pix, fring, fip);
+                RingGeom fg = ring_geom(hp, fring);
+                process_pixel(pix, fg.z, fg.sth, ((double)fip + fg.phioff) * fg.phistep);
+            }
+            if (lane == 0) { my_pixels += 4; atomicAdd((unsigned long long *)&P.stats->halos_fallback4, 1ull); }
+            break;
+        }
+
+        // phase B: flattened loop over the pixels of these rings
+        for (int t = lane; t < total; t += G) {
+            int lo = 0, hi = G - 1;        // smallest jr with cum[jr] > t
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if (rl->cum[mid] > t) hi = mid; else lo = mid + 1;
+            }
+            const int jr = lo;
+            const int before = (jr == 0) ? 0 : rl->cum[jr - 1];
+            const int nr = rl->nr[jr];
+            int ip = rl->iplo[jr] + (t - before);
+            if (ip < 0) ip += nr;
+            if (ip >= nr) ip -= nr;
+            if (ip >= nr) ip -= nr;
+            const int64_t pix = rl->start[jr] + ip;
+            process_pixel(pix, rl->z[jr], rl->sth[jr], ((double)ip + rl->phioff[jr]) * rl->phistep[jr]);
+        }
+        if (lane == 0) my_pixels += (unsigned long long)total;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0 && my_pixels) atomicAdd((unsigned long long *)&P.stats->pixel_updates, my_pixels);
+    if (n_r_oob) {
+        atomicAdd((unsigned long long *)&P.stats->pixels_out_of_table, n_r_oob);
+        atomicOr(&P.stats->warn_mask, BFG_WARN_R_RANGE);
+    }
+}
+
+// Final regrid, HealpixRunner.py:357-365: one thread per pixel.
+__global__ __launch_bounds__(256) void regrid_kernel(Hpx hp, const double *__restrict__ off,
+                                                     const double *__restrict__ in_map,
+                                                     double *__restrict__ out_map, double *sums)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double v_in = 0.0, v_dep = 0.0;
+    if (p < hp.npix) {
+        const double val = in_map[p];
+        if (val != 0.0) {                                              // :359
+            int64_t ring, ip;
+            pix2ring(hp, p, ring, ip);
+            RingGeom g = ring_geom(hp, ring);
+            double sphi, cphi;
+            sincos(((double)ip + g.phioff) * g.phistep, &sphi, &cphi);
+            const double vx = g.sth * cphi + off[3 * p + 0];           // :357
+            const double vy = g.sth * sphi + off[3 * p + 1];
+            const double vz = g.z + off[3 * p + 2];
+            const double dnorm = sqrt(vx * vx + vy * vy + vz * vz);    // hp.vec2ang :358
+            const double theta = acos(vz / dnorm);
+            double phi = atan2(vy, vx);
+            if (phi < 0) phi += kTwoPi;
+            int64_t cp[4]; double cw[4];
+            get_interpol(hp, theta, phi, cp, cw);                      // :361
+            for (int k = 0; k < 4; ++k) {
+                const double d = cw[k] * val;                          // :64-68
+                if (d != 0.0) unsafeAtomicAdd(out_map + cp[k], d);
+                v_dep += d;
+            }
+        }
+        v_in = val;
+    }
+    if (sums) {
+        for (int o = 32; o > 0; o >>= 1) { v_in += __shfl_down(v_in, o, 64); v_dep += __shfl_down(v_dep, o, 64); }
+        __shared__ double s_in[4], s_dep[4];
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { s_in[w] = v_in; s_dep[w] = v_dep; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsafeAtomicAdd(sums + 0, s_in[0] + s_in[1] + s_in[2] + s_in[3]);
+            unsafeAtomicAdd(sums + 1, s_dep[0] + s_dep[1] + s_dep[2] + s_dep[3]);
+        }
+    }
+}
+
+__device__ inline double nanmax(double a, double b)
+{
+    if (a != a) return a;
+    if (b != b) return b;
+    return a > b ? a : b;
+}
+
+__global__ __launch_bounds__(256) void reduce_absmax_sum_kernel(int64_t n, const double *__restrict__ x, double *red)
+{
+    double s = 0.0, m = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double v = x[i];
+        s += v;
+        m = nanmax(m, fabs(v));     // NaN is sticky, like np.allclose failing on it
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_down(s, o, 64);
+        m = nanmax(m, __shfl_down(m, o, 64));
+    }
+    __shared__ double ss[4], sm[4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { ss[w] = s; sm[w] = m; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double S = ss[0] + ss[1] + ss[2] + ss[3];
+        double Mx = sm[0];
+        for (int k = 1; k < 4; ++k) Mx = nanmax(Mx, sm[k]);
+        unsafeAtomicAdd(red + 0, S);
+        // absmax: values are >= 0 or NaN -> integer max on the bit pattern is order preserving
+        atomicMax((unsigned long long *)(red + 1), (unsigned long long)__double_as_longlong(Mx));
+    }
+}
+
+__global__ void table_eval_kernel(DevTable T, int64_t npts, const double *__restrict__ coords, double *__restrict__ out)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npts) return;
+    const double *x = coords + p * (int64_t)T.ndim;   // (z, M, r, extras...)
+    bool oob = false;
+    int idx[BFG_MAX_DIM]; double y[BFG_MAX_DIM];
+    for (int k = 0; k < T.nouter; ++k) {
+        double xv = (k < 2) ? x[k] : x[k + 1];
+        const double *g = T.oaxis[k]; int n = T.oshape[k];
+        if (!(xv >= g[0]) || !(xv <= g[n - 1])) oob = true;
+        idx[k] = find_interval(g, n, xv);
+        y[k] = (xv - g[idx[k]]) / (g[idx[k] + 1] - g[idx[k]]);
+    }
+    const double rho = x[2];
+    if (!(rho >= T.raxis[0]) || !(rho <= T.raxis[T.nr - 1])) oob = true;
+    const int ir = find_interval(T.raxis, T.nr, rho);
+    const double wr = (rho - T.raxis[ir]) / (T.raxis[ir + 1] - T.raxis[ir]);
+    double v0 = 0.0, v1 = 0.0;
+    const int ncorner = 1 << T.nouter;
+    for (int c = 0; c < ncorner; ++c) {
+        double w = 1.0; int64_t off = 0;
+        for (int k = 0; k < T.nouter; ++k) {
+            int bit = (c >> (T.nouter - 1 - k)) & 1;
+            w = w * (bit ? y[k] : 1.0 - y[k]);
+            off += (int64_t)(idx[k] + bit) * T.ostride[k];
+        }
+        v0 = v0 + T.values[off + ir] * w;
+        v1 = v1 + T.values[off + ir + 1] * w;
+    }
+    double v = v0 * (1.0 - wr) + v1 * wr;
+    if (oob) v = NAN;
+    out[p] = T.log_values ? exp(v) : v;
+}
+
+// ------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------
+extern "C" {
+
+int bfg_abi_version(void) { return BFG_ABI_VERSION; }
+
+const char *bfg_status_string(int s)
+{
+    switch (s) {
+    case BFG_OK: return "ok";
+    case BFG_ERR_INVALID: return "invalid argument";
+    case BFG_ERR_HIP: return "HIP runtime error";
+    case BFG_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case BFG_ERR_UNSUPPORTED: return "unsupported configuration";
+    case BFG_ERR_NOMEM: return "out of memory";
+    default: return "unknown status";
+    }
+}
+
+const char *bfg_last_error(void) { return g_last_error.c_str(); }
+
+int bfg_device_count(int *count)
+{
+    if (!count) return BFG_ERR_INVALID;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *count = n;
+    return BFG_OK;
+}
+
+int bfg_ctx_create(int device_id, void *stream, bfg_ctx **out)
+{
+    if (!out) return BFG_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        g_last_error = "hipGetDeviceCount found no device";
+        return BFG_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n) return BFG_ERR_INVALID;
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    bfg_ctx *c = new bfg_ctx();
+    std::memset((void *)c, 0, sizeof(*c));
+    c->device = device_id;
+    c->n_cu = prop.multiProcessorCount;
+    c->lds_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+    c->max_dyn_lds = prop.sharedMemPerBlock;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    HIP_TRY(hipMalloc((void **)&c->d_stats, sizeof(bfg_stats)));
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(bfg_stats), c->stream));
+    HIP_TRY(hipMalloc((void **)&c->d_red, 4 * sizeof(double)));
+    for (int k = 0; k < 3; ++k) { c->ev_a[k] = new std::vector<hipEvent_t>(); c->ev_b[k] = new std::vector<hipEvent_t>(); }
+    *out = c;
+    return BFG_OK;
+}
+
+static int ctx_enter(bfg_ctx *c)
+{
+    if (!c) return BFG_ERR_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    return BFG_OK;
+}
+
+int bfg_ctx_destroy(bfg_ctx *c)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    (void)hipStreamSynchronize(c->stream);
+    if (c->d_rec) (void)hipFree(c->d_rec);
+    if (c->d_irec) (void)hipFree(c->d_irec);
+    if (c->d_cidx) (void)hipFree(c->d_cidx);
+    if (c->d_cw) (void)hipFree(c->d_cw);
+    (void)hipFree(c->d_stats);
+    (void)hipFree(c->d_red);
+    for (int k = 0; k < 3; ++k) {
+        for (hipEvent_t e : *c->ev_a[k]) (void)hipEventDestroy(e);
+        for (hipEvent_t e : *c->ev_b[k]) (void)hipEventDestroy(e);
+        delete c->ev_a[k]; delete c->ev_b[k];
+    }
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return BFG_OK;
+}
+
+int bfg_ctx_synchronize(bfg_ctx *c)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BFG_OK;
+}
+
+int bfg_ctx_device_info(bfg_ctx *c, char *name, int name_len, int *n_cu, int *lds, int64_t *hbm)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    if (name && name_len > 0) { std::snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName); }
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (lds) *lds = (int)prop.maxSharedMemoryPerMultiProcessor;
+    if (hbm) *hbm = (int64_t)prop.totalGlobalMem;
+    return BFG_OK;
+}
+
+int bfg_dev_malloc(bfg_ctx *c, size_t bytes, void **d_ptr)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    if (!d_ptr) return BFG_ERR_INVALID;
+    HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 8));
+    return BFG_OK;
+}
+
+int bfg_dev_free(bfg_ctx *c, void *d_ptr)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(d_ptr));
+    return BFG_OK;
+}
+
+int bfg_memcpy_h2d(bfg_ctx *c, void *d_dst, const void *src, size_t bytes)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BFG_OK;
+}
+
+int bfg_memcpy_d2h(bfg_ctx *c, void *dst, const void *d_src, size_t bytes)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BFG_OK;
+}
+
+int bfg_dev_memset_zero(bfg_ctx *c, void *d_ptr, size_t bytes)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(d_ptr, 0, bytes, c->stream));
+    return BFG_OK;
+}
+
+// ---- tables -------------------------------------------------------------------------
+int bfg_table_create(bfg_ctx *c, int ndim, const int64_t *shape, const double *const *axes,
+                     const double *values, uint32_t flags, bfg_table **out)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    if (!shape || !axes || !values || !out) return BFG_ERR_INVALID;
+    if (ndim < 3) return BFG_ERR_INVALID;
+    if (ndim > BFG_MAX_DIM) return BFG_ERR_UNSUPPORTED;
+    int64_t total = 1;
+    for (int d = 0; d < ndim; ++d) {
+        if (shape[d] < 2 || shape[d] > (1 << 24)) return BFG_ERR_INVALID;
+        for (int64_t i = 1; i < shape[d]; ++i)
+            if (!(axes[d][i] > axes[d][i - 1])) return BFG_ERR_INVALID;   // strictly ascending, no NaN
+        total *= shape[d];
+    }
+    bfg_table *t = new bfg_table();
+    t->shape.assign(shape, shape + ndim);
+    t->h_axes.resize(ndim);
+    for (int d = 0; d < ndim; ++d) t->h_axes[d].assign(axes[d], axes[d] + shape[d]);
+    // permute values so that r (dim 2) is the fastest axis: [z][M][extras...][r]
+    const int nouter = ndim - 1;
+    std::vector<int> odim(nouter);   // outer k -> original dim
+    odim[0] = 0; odim[1] = 1;
+    for (int k = 2; k < nouter; ++k) odim[k] = k + 1;
+    const int64_t NR = shape[2];
+    std::vector<int64_t> src_stride(ndim);
+    { int64_t s = 1; for (int d = ndim - 1; d >= 0; --d) { src_stride[d] = s; s *= shape[d]; } }
+    std::vector<double> perm((size_t)total);
+    std::vector<int64_t> ostride(nouter);
+    { int64_t s = NR; for (int k = nouter - 1; k >= 0; --k) { ostride[k] = s; s *= shape[odim[k]]; } }
+    const int64_t nrows = total / NR;
+    for (int64_t row = 0; row < nrows; ++row) {
+        int64_t rem = row, src = 0;
+        for (int k = nouter - 1; k >= 0; --k) {
+            int64_t n = shape[odim[k]];
+            int64_t i = rem % n; rem /= n;
+            src += i * src_stride[odim[k]];
+        }
+        for (int64_t ir = 0; ir < NR; ++ir) perm[(size_t)(row * NR + ir)] = values[src + ir * src_stride[2]];
+    }
+    // one device blob: [outer axes...][r axis][values]
+    size_t n_axes = 0;
+    for (int d = 0; d < ndim; ++d) n_axes += (size_t)shape[d];
+    std::vector<double> blob(n_axes + (size_t)total);
+    DevTable &D = t->dev;
+    std::memset(&D, 0, sizeof(D));
+    D.ndim = ndim; D.nouter = nouter; D.nr = (int)NR;
+    D.log_values = (flags & BFG_TABLE_LOG_VALUES) ? 1 : 0;
+    if (hipMalloc((void **)&t->d_blob, blob.size() * sizeof(double)) != hipSuccess) {
+        (void)hipGetLastError(); delete t; return BFG_ERR_NOMEM;
+    }
+    size_t pos = 0;
+    for (int k = 0; k < nouter; ++k) {
+        int d = odim[k];
+        std::copy(axes[d], axes[d] + shape[d], blob.begin() + pos);
+        D.oaxis[k] = t->d_blob + pos; D.oshape[k] = (int)shape[d]; D.ostride[k] = ostride[k];
+        pos += (size_t)shape[d];
+    }
+    std::copy(axes[2], axes[2] + NR, blob.begin() + pos);
+    D.raxis = t->d_blob + pos; pos += (size_t)NR;
+    std::copy(perm.begin(), perm.end(), blob.begin() + pos);
+    D.values = t->d_blob + pos;
+    // is the radial axis a linspace (geomspace in r) to rounding?
+    const double *r = axes[2];
+    double dr = (r[NR - 1] - r[0]) / (double)(NR - 1);
+    bool uni = dr > 0;
+    for (int64_t i = 0; i < NR && uni; ++i)
+        if (std::fabs(r[i] - (r[0] + dr * (double)i)) > 1e-6 * dr) uni = false;
+    D.r_uniform = uni ? 1 : 0; D.r0 = r[0]; D.inv_dr = uni ? 1.0 / dr : 0.0;
+    HIP_TRY(hipMemcpyAsync(t->d_blob, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *out = t;
+    return BFG_OK;
+}
+
+int bfg_table_destroy(bfg_ctx *c, bfg_table *t)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    if (!t) return BFG_ERR_INVALID;
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(t->d_blob);
+    delete t;
+    return BFG_OK;
+}
+
+int bfg_table_eval(bfg_ctx *c, const bfg_table *t, int64_t npts, const double *coords, double *out)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    if (!t || !coords || !out || npts < 0) return BFG_ERR_INVALID;
+    if (npts == 0) return BFG_OK;
+    double *d_c = nullptr, *d_o = nullptr;
+    size_t nb = (size_t)npts * t->dev.ndim * sizeof(double);
+    HIP_TRY(hipMalloc((void **)&d_c, nb));
+    HIP_TRY(hipMalloc((void **)&d_o, (size_t)npts * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(d_c, coords, nb, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(table_eval_kernel, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, c->stream,
+                       t->dev, npts, d_c, d_o);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d_o, (size_t)npts * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(d_c); (void)hipFree(d_o);
+    return BFG_OK;
+}
+
+// ---- spline ----------------------------------------------------------------------------
+int bfg_spline_create(bfg_ctx *c, int n, const double *knots, const double *coef, bfg_spline **out)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    if (n < 2 || !knots || !coef || !out) return BFG_ERR_INVALID;
+    for (int i = 1; i < n; ++i) if (!(knots[i] > knots[i - 1])) return BFG_ERR_INVALID;
+    bfg_spline *s = new bfg_spline();
+    s->n = n;
+    HIP_TRY(hipMalloc((void **)&s->d_knots, (size_t)n * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&s->d_coef, (size_t)4 * (n - 1) * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(s->d_knots, knots, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(s->d_coef, coef, (size_t)4 * (n - 1) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *out = s;
+    return BFG_OK;
+}
+
+int bfg_spline_destroy(bfg_ctx *c, bfg_spline *s)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    if (!s) return BFG_ERR_INVALID;
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(s->d_knots); (void)hipFree(s->d_coef);
+    delete s;
+    return BFG_OK;
+}
+
+// ---- hot path ----------------------------------------------------------------------------
+static int ensure_workspace(bfg_ctx *c, int64_t n)
+{
+    if (n <= c->cap_halo) return BFG_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_rec) { (void)hipFree(c->d_rec); (void)hipFree(c->d_irec); (void)hipFree(c->d_cidx); (void)hipFree(c->d_cw); }
+    c->d_rec = nullptr; c->cap_halo = 0;
+    int64_t cap = (n + 1023) / 1024 * 1024;
+    HIP_TRY(hipMalloc((void **)&c->d_rec, (size_t)cap * F_NF * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&c->d_irec, (size_t)cap * I_NI * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void **)&c->d_cidx, (size_t)cap * (BFG_MAX_DIM - 1) * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void **)&c->d_cw, (size_t)cap * (BFG_MAX_DIM - 1) * sizeof(double)));
+    c->cap_halo = cap;
+    return BFG_OK;
+}
+
+static void timing_fold(bfg_ctx *c, int which)
+{
+    for (size_t i = 0; i < c->ev_used[which]; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize((*c->ev_b[which])[i]) == hipSuccess &&
+            hipEventElapsedTime(&ms, (*c->ev_a[which])[i], (*c->ev_b[which])[i]) == hipSuccess) {
+            c->t_ms[which] += ms; c->t_n[which] += 1;
+        }
+    }
+    c->ev_used[which] = 0;
+}
+
+static void timing_begin(bfg_ctx *c, int which)
+{
+    if (!c->timing) return;
+    if (c->ev_used[which] >= 4096) timing_fold(c, which);
+    if (c->ev_used[which] >= c->ev_a[which]->size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { c->timing = false; return; }
+        c->ev_a[which]->push_back(a); c->ev_b[which]->push_back(b);
+    }
+    (void)hipEventRecord((*c->ev_a[which])[c->ev_used[which]], c->stream);
+}
+
+static void timing_end(bfg_ctx *c, int which)
+{
+    if (!c->timing) return;
+    (void)hipEventRecord((*c->ev_b[which])[c->ev_used[which]], c->stream);
+    c->ev_used[which] += 1;
+}
+
+static int check_args(const bfg_shell_args *a, const bfg_table *t, const bfg_spline *s, const void *d_out)
+{
+    if (!a || !t || !s || !d_out) return BFG_ERR_INVALID;
+    if (a->nside < 1 || a->nside > (1 << 20)) return BFG_ERR_INVALID;
+    if (a->n_halo < 0) return BFG_ERR_INVALID;
+    if (a->n_halo > 0 && !a->d_catalog) return BFG_ERR_INVALID;
+    if (a->n_extra < 0 || a->n_extra > BFG_MAX_EXTRA) return BFG_ERR_UNSUPPORTED;
+    if (a->cat_stride < 4 + a->n_extra) return BFG_ERR_INVALID;
+    if (t->dev.ndim != 3 + a->n_extra) return BFG_ERR_INVALID;
+    if (!(a->epsilon_max >= 0)) return BFG_ERR_INVALID;
+    return BFG_OK;
+}
+
+static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, const bfg_spline *s,
+                     double *d_out, int mode)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    rc = check_args(a, t, s, d_out);
+    if (rc) return rc;
+    if (mode == MODE_PAINT && !t->dev.log_values) return BFG_ERR_INVALID;
+    if (mode == MODE_BARYONIFY && t->dev.log_values) return BFG_ERR_INVALID;
+    if (a->n_halo == 0) return BFG_OK;
+    rc = ensure_workspace(c, a->n_halo);
+    if (rc) return rc;
+
+    PrepParams pp;
+    std::memset(&pp, 0, sizeof(pp));
+    pp.hpx = make_hpx(a->nside);
+    pp.n_halo = a->n_halo; pp.cap = c->cap_halo;
+    pp.cat = a->d_catalog; pp.cat_stride = a->cat_stride; pp.n_extra = a->n_extra;
+    pp.eps_run = a->epsilon_max;
+    pp.md_run = a->runner_md; pp.md_model = a->model_md;
+    pp.spl_n = s->n; pp.spl_knots = s->d_knots; pp.spl_coef = s->d_coef;
+    pp.tab = t->dev;
+    pp.rec = c->d_rec; pp.irec = c->d_irec; pp.cidx = c->d_cidx; pp.cw = c->d_cw;
+    pp.stats = c->d_stats;
+    pp.want_model_radius = (mode == MODE_BARYONIFY);
+    timing_begin(c, 0);
+    hipLaunchKernelGGL(halo_prep_kernel, dim3((unsigned)((a->n_halo + 255) / 256)), dim3(256), 0, c->stream, pp);
+    HIP_TRY(hipGetLastError());
+    timing_end(c, 0);
+
+    ShellParams sp;
+    std::memset(&sp, 0, sizeof(sp));
+    sp.hpx = pp.hpx; sp.n_halo = a->n_halo; sp.cap = c->cap_halo;
+    sp.rec = c->d_rec; sp.irec = c->d_irec; sp.cidx = c->d_cidx; sp.cw = c->d_cw;
+    sp.cat = a->d_catalog; sp.cat_stride = a->cat_stride;
+    sp.tab = t->dev;
+    sp.eps_model = a->model_epsilon_max; sp.rdelta = a->rdelta_sampling;
+    sp.pixfac_area = a->include_pixel_size ? 4.0 * kPi / (double)pp.hpx.npix : 0.0;
+    sp.out = d_out; sp.stats = c->d_stats;
+
+    int variant = a->variant;
+    if (variant == BFG_VARIANT_AUTO || variant == BFG_VARIANT_TILE_LDS) variant = BFG_VARIANT_SCATTER_QUARTER;
+    const int G = (variant == BFG_VARIANT_SCATTER_WAVE) ? 64 : 16;
+    const int gpb = 256 / G;
+    // LDS: ring records + per-group (axis, value) window; keep a block at or under 64 KiB
+    const size_t ring_bytes = (G == 64 ? sizeof(RingLds<64>) : sizeof(RingLds<16>)) * (size_t)gpb;
+    size_t budget = 64 * 1024 - ring_bytes;
+    int win = (int)std::min<int64_t>(t->dev.nr, (int64_t)(budget / (sizeof(double2) * (size_t)gpb)));
+    if (win < 2) return BFG_ERR_UNSUPPORTED;
+    sp.win_nodes = win;
+    const size_t lds = ring_bytes + (size_t)win * sizeof(double2) * (size_t)gpb;
+    const unsigned grid = (unsigned)((a->n_halo + gpb - 1) / gpb);
+    timing_begin(c, 1);
+    if (mode == MODE_PAINT) {
+        if (G == 64) hipLaunchKernelGGL((shell_scatter_kernel<64, MODE_PAINT>), dim3(grid), dim3(256), lds, c->stream, sp);
+        else hipLaunchKernelGGL((shell_scatter_kernel<16, MODE_PAINT>), dim3(grid), dim3(256), lds, c->stream, sp);
+    } else {
+        if (G == 64) hipLaunchKernelGGL((shell_scatter_kernel<64, MODE_BARYONIFY>), dim3(grid), dim3(256), lds, c->stream, sp);
+        else hipLaunchKernelGGL((shell_scatter_kernel<16, MODE_BARYONIFY>), dim3(grid), dim3(256), lds, c->stream, sp);
+    }
+    HIP_TRY(hipGetLastError());
+    timing_end(c, 1);
+    return BFG_OK;
+}
+
+int bfg_paint_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, const bfg_spline *s, double *d_map)
+{
+    return run_shell(c, a, t, s, d_map, MODE_PAINT);
+}
+
+int bfg_baryonify_offsets(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, const bfg_spline *s,
+                          double *d_offsets)
+{
+    return run_shell(c, a, t, s, d_offsets, MODE_BARYONIFY);
+}
+
+int bfg_regrid_shell(bfg_ctx *c, int64_t nside, const double *d_offsets, const double *d_in_map,
+                     double *d_out_map, double *d_sums)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    if (nside < 1 || nside > (1 << 20) || !d_offsets || !d_in_map || !d_out_map) return BFG_ERR_INVALID;
+    Hpx hp = make_hpx(nside);
+    if (d_sums) HIP_TRY(hipMemsetAsync(d_sums, 0, 2 * sizeof(double), c->stream));
+    timing_begin(c, 2);
+    hipLaunchKernelGGL(regrid_kernel, dim3((unsigned)((hp.npix + 255) / 256)), dim3(256), 0, c->stream, hp,
+                       d_offsets, d_in_map, d_out_map, d_sums);
+    HIP_TRY(hipGetLastError());
+    timing_end(c, 2);
+    return BFG_OK;
+}
+
+int bfg_reduce_absmax_sum(bfg_ctx *c, int64_t n, const double *d_x, double *absmax, double *sum)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && !d_x)) return BFG_ERR_INVALID;
+    double h[2] = {0.0, 0.0};
+    if (n > 0) {
+        HIP_TRY(hipMemsetAsync(c->d_red, 0, 2 * sizeof(double), c->stream));
+        unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+        hipLaunchKernelGGL(reduce_absmax_sum_kernel, dim3(grid), dim3(256), 0, c->stream, n, d_x, c->d_red);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h, c->d_red, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    if (sum) *sum = h[0];
+    if (absmax) *absmax = h[1];
+    return BFG_OK;
+}
+
+int bfg_stats_reset(bfg_ctx *c)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(bfg_stats), c->stream));
+    return BFG_OK;
+}
+
+int bfg_stats_read(bfg_ctx *c, bfg_stats *out)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    if (!out) return BFG_ERR_INVALID;
+    HIP_TRY(hipMemcpyAsync(out, c->d_stats, sizeof(bfg_stats), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BFG_OK;
+}
+
+int bfg_timing_enable(bfg_ctx *c, int enable)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->timing = enable != 0;
+    for (int k = 0; k < 3; ++k) { c->t_ms[k] = 0; c->t_n[k] = 0; c->ev_used[k] = 0; }
+    return BFG_OK;
+}
+
+int bfg_timing_read(bfg_ctx *c, int which, double *ms_total, int64_t *launches)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    if (which < 0 || which > 2) return BFG_ERR_INVALID;
+    timing_fold(c, which);
+    if (ms_total) *ms_total = c->t_ms[which];
+    if (launches) *launches = c->t_n[which];
+    return BFG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,244 @@
+"""
+Device engine: owns one libbfg_mi355 context per GPU and turns the Python-level
+objects of the reference API (catalog, shell, tabulated model) into the
+device-resident inputs of the C-ABI (include/bfg_mi355.h).
+
+PyTorch is used for plumbing only: HBM allocations (torch tensors), the HIP
+stream (torch's current stream is handed to the library) and, for multi-GPU
+runs, torch.distributed (RCCL).  All arithmetic of the hot path runs in the
+hand-written HIP kernels; there is no CPU or eager-PyTorch fallback.
+"""
+import ctypes as C
+import threading
+import warnings
+
+import numpy as np
+
+from . import _lib
+from .background import Background, RHO_CRITICAL, massdef_params
+
+_contexts = {}
+_lock = threading.Lock()
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def require_gpu():
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise _lib.BFGError("baryonforge_amd needs an AMD MI355X (gfx950) GPU: torch.cuda.is_available() is False. "
+                            "There is no CPU fallback for the shell paint / baryonify path.")
+    return torch
+
+
+class Table(object):
+    """An interpolation table resident in HBM (bfg_table)."""
+
+    def __init__(self, ctx, axes, values, log_values):
+        self.ctx = ctx
+        axes = [np.ascontiguousarray(a, dtype=np.float64) for a in axes]
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        if values.ndim != len(axes) or any(a.ndim != 1 or a.size != s for a, s in zip(axes, values.shape)):
+            raise ValueError("table axes do not match the shape of the table values")
+        if values.ndim > _lib.BFG_MAX_DIM:
+            raise NotImplementedError(f"tables with more than {_lib.BFG_MAX_EXTRA} extra (p_keys) dimensions "
+                                      "are not supported on the MI355X path")
+        self.ndim = values.ndim
+        self.shape = values.shape
+        shape = (C.c_int64 * self.ndim)(*values.shape)
+        ax_ptrs = (C.POINTER(C.c_double) * self.ndim)(*[_lib.dptr(a) for a in axes])
+        handle = C.c_void_p()
+        flags = _lib.BFG_TABLE_LOG_VALUES if log_values else 0
+        _lib.check(ctx.lib.bfg_table_create(ctx.handle, self.ndim, shape, ax_ptrs, _lib.dptr(values), flags,
+                                            C.byref(handle)), "bfg_table_create")
+        self.handle = handle
+        self.log_values = bool(log_values)
+
+    def eval(self, coords):
+        """stand-alone read-out at coords [npts, ndim] = (ln(1+z), ln M, ln r, extras...)"""
+        coords = np.ascontiguousarray(coords, dtype=np.float64).reshape(-1, self.ndim)
+        out = np.empty(coords.shape[0])
+        _lib.check(self.ctx.lib.bfg_table_eval(self.ctx.handle, self.handle, coords.shape[0], _lib.dptr(coords),
+                                               _lib.dptr(out)), "bfg_table_eval")
+        return out
+
+    def __del__(self):
+        try:
+            if self.handle and self.ctx.handle:
+                self.ctx.lib.bfg_table_destroy(self.ctx.handle, self.handle)
+        except Exception:
+            pass
+
+
+class Spline(object):
+    """D_A(z) cubic spline resident in HBM (bfg_spline); HealpixRunner.py:297-299."""
+
+    def __init__(self, ctx, knots, coef):
+        knots = np.ascontiguousarray(knots, dtype=np.float64)
+        coef = np.ascontiguousarray(coef, dtype=np.float64)
+        assert coef.shape == (4, knots.size - 1)
+        self.ctx = ctx
+        handle = C.c_void_p()
+        _lib.check(ctx.lib.bfg_spline_create(ctx.handle, knots.size, _lib.dptr(knots), _lib.dptr(coef),
+                                             C.byref(handle)), "bfg_spline_create")
+        self.handle = handle
+
+    def __del__(self):
+        try:
+            if self.handle and self.ctx.handle:
+                self.ctx.lib.bfg_spline_destroy(self.ctx.handle, self.handle)
+        except Exception:
+            pass
+
+
+class Context(object):
+    """One bfg_ctx bound to a GPU and to torch's current stream on it."""
+
+    def __init__(self, device_index):
+        torch = require_gpu()
+        self.lib = _lib.load()
+        self.device_index = int(device_index)
+        self.device = torch.device("cuda", self.device_index)
+        with torch.cuda.device(self.device):
+            self.stream = torch.cuda.current_stream(self.device)
+            handle = C.c_void_p()
+            _lib.check(self.lib.bfg_ctx_create(self.device_index, C.c_void_p(self.stream.cuda_stream),
+                                               C.byref(handle)), "bfg_ctx_create")
+        self.handle = handle
+        self._table_cache = {}
+
+    # ---- device info -------------------------------------------------------------
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        ncu, lds, hbm = C.c_int(), C.c_int(), C.c_int64()
+        _lib.check(self.lib.bfg_ctx_device_info(self.handle, name, 256, C.byref(ncu), C.byref(lds), C.byref(hbm)))
+        return {"name": name.value.decode(), "n_cu": ncu.value, "lds_per_cu": lds.value, "hbm_bytes": hbm.value}
+
+    def synchronize(self):
+        _lib.check(self.lib.bfg_ctx_synchronize(self.handle), "bfg_ctx_synchronize")
+
+    # ---- uploads ---------------------------------------------------------------------
+    def to_device(self, array):
+        torch = _torch()
+        return torch.from_numpy(np.ascontiguousarray(array, dtype=np.float64)).to(self.device)
+
+    def zeros(self, *shape):
+        torch = _torch()
+        return torch.zeros(*shape, dtype=torch.float64, device=self.device)
+
+    def table(self, axes, values, log_values, cache_key=None):
+        """values: ndarray, or a zero-argument callable producing it (only called on a cache miss)"""
+        if cache_key is not None and cache_key in self._table_cache:
+            return self._table_cache[cache_key]
+        if callable(values):
+            values = values()
+        t = Table(self, axes, values, log_values)
+        if cache_key is not None:
+            if len(self._table_cache) > 8:
+                self._table_cache.clear()
+            self._table_cache[cache_key] = t
+        return t
+
+    def da_spline(self, background, z_max):
+        """D_a = CubicSpline(linspace(0, z_max + 0.1, 1000), D_A(1/(1+z)))   (HealpixRunner.py:297-299)"""
+        from scipy import interpolate
+        z_t = np.linspace(0, z_max + 0.1, 1000)
+        cs = interpolate.CubicSpline(z_t, background.angular_diameter_distance(1 / (1 + z_t)))
+        return Spline(self, cs.x, cs.c)
+
+    # ---- hot path --------------------------------------------------------------------
+    @staticmethod
+    def massdef_struct(background, mass_def):
+        Delta, rho_type = massdef_params(mass_def)
+        s = _lib.MassDefStruct()
+        s.Omega_m, s.Omega_l, s.Omega_r = background.Omega_m, background.Omega_l, background.Omega_r
+        s.w0, s.h, s.rho_crit0_h2 = background.w0, background.h, RHO_CRITICAL
+        s.Delta, s.rho_type = Delta, 0 if rho_type == "critical" else 1
+        return s
+
+    def shell_args(self, nside, d_catalog, n_halo, cat_stride, n_extra, epsilon_max, runner_md, model_md=None,
+                   model_epsilon_max=0.0, rdelta_sampling=False, include_pixel_size=False, variant="auto"):
+        a = _lib.ShellArgs()
+        a.nside, a.n_halo = int(nside), int(n_halo)
+        a.d_catalog = d_catalog.data_ptr() if n_halo else None
+        a.cat_stride, a.n_extra = int(cat_stride), int(n_extra)
+        a.epsilon_max = float(epsilon_max)
+        a.runner_md = runner_md
+        a.model_md = model_md if model_md is not None else runner_md
+        a.model_epsilon_max = float(model_epsilon_max)
+        a.rdelta_sampling = int(bool(rdelta_sampling))
+        a.include_pixel_size = int(bool(include_pixel_size))
+        a.variant = _lib.VARIANTS[variant]
+        return a
+
+    def paint_shell(self, args, table, spline, d_map):
+        _lib.check(self.lib.bfg_paint_shell(self.handle, C.byref(args), table.handle, spline.handle,
+                                            C.c_void_p(d_map.data_ptr())), "bfg_paint_shell")
+
+    def baryonify_offsets(self, args, table, spline, d_offsets):
+        _lib.check(self.lib.bfg_baryonify_offsets(self.handle, C.byref(args), table.handle, spline.handle,
+                                                  C.c_void_p(d_offsets.data_ptr())), "bfg_baryonify_offsets")
+
+    def regrid_shell(self, nside, d_offsets, d_in_map, d_out_map, d_sums=None):
+        _lib.check(self.lib.bfg_regrid_shell(self.handle, int(nside), C.c_void_p(d_offsets.data_ptr()),
+                                             C.c_void_p(d_in_map.data_ptr()), C.c_void_p(d_out_map.data_ptr()),
+                                             C.c_void_p(d_sums.data_ptr()) if d_sums is not None else None),
+                   "bfg_regrid_shell")
+
+    def absmax_sum(self, d_x):
+        amax, s = C.c_double(), C.c_double()
+        _lib.check(self.lib.bfg_reduce_absmax_sum(self.handle, d_x.numel(), C.c_void_p(d_x.data_ptr()),
+                                                  C.byref(amax), C.byref(s)), "bfg_reduce_absmax_sum")
+        return amax.value, s.value
+
+    def stats_reset(self):
+        _lib.check(self.lib.bfg_stats_reset(self.handle))
+
+    def stats(self):
+        st = _lib.Stats()
+        _lib.check(self.lib.bfg_stats_read(self.handle, C.byref(st)))
+        return {"pixel_updates": int(st.pixel_updates), "halos_out_of_table": int(st.halos_out_of_table),
+                "pixels_out_of_table": int(st.pixels_out_of_table), "halos_fallback4": int(st.halos_fallback4),
+                "warn_mask": int(st.warn_mask)}
+
+    def timing_enable(self, on=True):
+        _lib.check(self.lib.bfg_timing_enable(self.handle, int(bool(on))))
+
+    def timing_read(self, which):
+        ms, n = C.c_double(), C.c_int64()
+        _lib.check(self.lib.bfg_timing_read(self.handle, int(which), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def get_context(device=None):
+    """The process-wide Context of a GPU (default: torch's current device)."""
+    torch = require_gpu()
+    if device is None:
+        index = torch.cuda.current_device()
+    elif isinstance(device, int):
+        index = device
+    else:
+        index = torch.device(device).index or 0
+    with _lock:
+        ctx = _contexts.get(index)
+        if ctx is None:
+            ctx = _contexts[index] = Context(index)
+    return ctx
+
+
+def emit_range_warnings(stats, what="table"):
+    """The reference warns per halo when a query leaves the table (BaryonCorrection.py:382-394);
+    the kernels return one bit-mask per process() instead."""
+    m = stats["warn_mask"]
+    if m & _lib.WARN_Z_RANGE:
+        warnings.warn(f"Requested redshift range outside {what}'s range "
+                      f"({stats['halos_out_of_table']} halos outside the (z, M) hull contribute nothing)", UserWarning)
+    if m & _lib.WARN_M_RANGE:
+        warnings.warn(f"Requested log_Mass range outside {what}'s range "
+                      f"({stats['halos_out_of_table']} halos outside the (z, M) hull contribute nothing)", UserWarning)
+    if m & _lib.WARN_R_RANGE:
+        warnings.warn(f"Requested Radius range outside {what}'s range "
+                      f"({stats['pixels_out_of_table']} pixel queries contribute nothing)", UserWarning)

@@ -1,0 +1,124 @@
+"""
+Host-side containers of the shell path, mirroring the reference's
+BaryonForge/utils/io.py: `HaloLightConeCatalog` (:9-140) and `LightconeShell`
+(:290-379).  Same constructor signatures, attributes and error behaviour;
+healpy is not needed (npix2nside is arithmetic, FITS reading is out of scope).
+"""
+import warnings
+
+import numpy as np
+
+from ..background import check_cosmology_dict
+
+__all__ = ["HaloLightConeCatalog", "LightconeShell", "npix2nside", "nside2npix"]
+
+
+def nside2npix(nside):
+    return 12 * int(nside) * int(nside)
+
+
+def npix2nside(npix):
+    """hp.npix2nside (io.py:353): raises ValueError unless npix = 12 nside^2"""
+    nside = int(round(np.sqrt(npix / 12.0)))
+    if nside < 1 or 12 * nside * nside != npix:
+        raise ValueError("Wrong pixel number (it is not 12*nside**2)")
+    return nside
+
+
+class HaloLightConeCatalog(object):
+    """
+    Halo lightcone catalog: structured float64 array `cat` with fields
+    M, z, ra, dec (+ any extra per-halo properties, e.g. `cdelta`), and the
+    cosmology dict.  Mirrors utils/io.py:9-140.
+
+    Parameters
+    ----------
+    ra, dec : array_like   degrees
+    M : array_like         halo mass, Msun
+    z : array_like         redshift
+    cosmo : dict           needs Omega_m, sigma8, h, Omega_b, n_s, w0
+    **arrays               extra per-halo columns
+    """
+
+    def __init__(self, ra, dec, M, z, cosmo, **arrays):
+        t = np.float64
+        dtype = [("M", t), ("z", t), ("ra", t), ("dec", t)]
+        dtype = dtype + [(name, t) for name, arr in arrays.items()]
+        cat = np.zeros(len(ra), dtype)
+
+        if np.any(np.abs(dec) == 90):                                    # io.py:65-68
+            dec = np.asarray(dec).astype(t)
+            warnings.warn("Some halos found with declination exactly at the poles. Offsetting these by 4e-5 arcsec")
+            dec = np.clip(dec, -90 + 1e-8, 90 - 1e-8)
+
+        cat["ra"] = ra
+        cat["dec"] = dec
+        cat["z"] = z
+        cat["M"] = M
+        for name, arr in arrays.items():
+            cat[name] = arr
+        self.cat = cat
+
+        check_cosmology_dict(cosmo)                                      # io.py:79-85
+        self.cosmo = cosmo
+
+    @property
+    def data(self):
+        return self.cat
+
+    @property
+    def cosmology(self):
+        return self.cosmo
+
+    def __getitem__(self, key):                                          # io.py:104-129
+        other = {k: self.cat[k][key] for k in self.cat.dtype.names if k not in ["ra", "dec", "M", "z"]}
+        return HaloLightConeCatalog(ra=self.cat["ra"][key], dec=self.cat["dec"][key], M=self.cat["M"][key],
+                                    z=self.cat["z"][key], cosmo=self.cosmo, **other)
+
+    def __len__(self):
+        return self.cat.size
+
+    def records(self, extra_keys=()):
+        """float64 [n, 4 + len(extra_keys)] record matrix (M, z, ra, dec, extras...) for the device."""
+        cols = ["M", "z", "ra", "dec"] + list(extra_keys)
+        out = np.empty((self.cat.size, len(cols)), dtype=np.float64)
+        for i, c in enumerate(cols):
+            out[:, i] = self.cat[c]
+        return out
+
+    def __str__(self):
+        return (f"HaloLightConeCatalog with {self.cat.size} halos; fields {self.cat.dtype.names}; "
+                f"cosmology {self.cosmo}")
+
+
+class LightconeShell(object):
+    """
+    Full-sky HEALPix (RING) shell: `map`, `NSIDE`, `redshift`, `cosmo`.
+    Mirrors utils/io.py:290-379.  `path` accepts a .npy file (FITS needs healpy and is out of scope).
+    """
+
+    def __init__(self, map=None, path=None, cosmo=None, redshift=None):
+        if (path is None) & (map is None):
+            raise ValueError("Need to provide either path to map, or provide map values in healpix ring configuration")
+        elif isinstance(path, str):
+            if not path.endswith(".npy"):
+                raise NotImplementedError("only .npy maps can be read here (FITS needs healpy)")
+            self.map = np.load(path)
+        elif isinstance(map, np.ndarray):
+            self.map = map
+
+        self.NSIDE = npix2nside(self.map.size)
+        self.redshift = redshift
+
+        if cosmo is None:
+            raise ValueError("Not all cosmology parameters provided. I need Omega_m, sigma8, h, sigma8, Omega_b, n_s, w0")
+        check_cosmology_dict(cosmo)                                      # io.py:357-363
+        self.cosmo = cosmo
+
+    @property
+    def data(self):
+        return self.map
+
+    @property
+    def cosmology(self):
+        return self.cosmo

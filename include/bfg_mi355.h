@@ -1,0 +1,192 @@
+/*
+ * bfg_mi355.h -- C-ABI of libbfg_mi355.so: the MI355X (gfx950) implementation of
+ * BaryonForge's per-halo shell paint / baryonify hot path.
+ *
+ * The reference (DhayaaAnbajagane/BaryonForge) is pure Python and has NO FFI
+ * boundary of its own; its boundary is the Python class API
+ * (bfg.Runners / bfg.Profiles / bfg.utils).  This header is the boundary the
+ * build inserts beneath those classes: every entry point below names the
+ * reference code it replaces (paths relative to the reference checkout,
+ * BaryonForge/...).  The Python mirror of the reference classes lives in
+ * baryonforge_amd/ and binds this library with ctypes.
+ *
+ * Conventions
+ *   - plain C types, caller-owned buffers, no torch / numpy types;
+ *   - every function returns BFG_OK (0) or a negative bfg_status;
+ *   - pointers named d_* are DEVICE pointers (HBM of the context's GPU),
+ *     everything else is host memory that is only read during the call;
+ *   - all work is enqueued on the context's stream (the caller's hipStream_t
+ *     if one was given to bfg_ctx_create) and is asynchronous unless stated;
+ *   - maps are HEALPix RING-ordered float64[12*nside^2] like LightconeShell.map
+ *     (utils/io.py:341-353); catalogs are the float64 records of
+ *     HaloLightConeCatalog.cat (utils/io.py:56-75): (M, z, ra, dec, extras...).
+ */
+#ifndef BFG_MI355_H
+#define BFG_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BFG_ABI_VERSION 1
+
+typedef enum {
+    BFG_OK = 0,
+    BFG_ERR_INVALID = -1,      /* bad argument (shape, nside, null pointer)            */
+    BFG_ERR_HIP = -2,          /* a HIP runtime call failed; see bfg_last_error()      */
+    BFG_ERR_NO_DEVICE = -3,    /* no usable gfx950 device                              */
+    BFG_ERR_UNSUPPORTED = -4,  /* e.g. more table dimensions than BFG_MAX_DIM          */
+    BFG_ERR_NOMEM = -5
+} bfg_status;
+
+#define BFG_MAX_DIM 6          /* (ln(1+z), ln M, ln r) + up to 3 extra p_keys axes    */
+#define BFG_MAX_EXTRA (BFG_MAX_DIM - 3)
+
+typedef struct bfg_ctx bfg_ctx;        /* one per GPU / stream                         */
+typedef struct bfg_table bfg_table;    /* an interpolation table resident in HBM       */
+typedef struct bfg_spline bfg_spline;  /* the D_A(z) cubic spline resident in HBM      */
+
+/* ---- library / context ------------------------------------------------------- */
+int bfg_abi_version(void);
+const char *bfg_status_string(int status);
+const char *bfg_last_error(void);                 /* thread-local detail of the last BFG_ERR_HIP */
+int bfg_device_count(int *count);
+
+/* stream: an existing hipStream_t to enqueue on (e.g. torch's current stream),
+ * or NULL to let the context create and own one. */
+int bfg_ctx_create(int device_id, void *stream, bfg_ctx **out);
+int bfg_ctx_destroy(bfg_ctx *ctx);
+int bfg_ctx_synchronize(bfg_ctx *ctx);
+/* device name, CU count, LDS per CU etc. (for bench/DESIGN bookkeeping) */
+int bfg_ctx_device_info(bfg_ctx *ctx, char *name, int name_len, int *n_cu, int *lds_per_cu_bytes,
+                        int64_t *hbm_bytes);
+
+/* device-memory helpers so that a pure-C / pure-ctypes caller needs no other allocator */
+int bfg_dev_malloc(bfg_ctx *ctx, size_t bytes, void **d_ptr);
+int bfg_dev_free(bfg_ctx *ctx, void *d_ptr);
+int bfg_memcpy_h2d(bfg_ctx *ctx, void *d_dst, const void *src, size_t bytes);   /* synchronous */
+int bfg_memcpy_d2h(bfg_ctx *ctx, void *dst, const void *d_src, size_t bytes);   /* synchronous */
+int bfg_dev_memset_zero(bfg_ctx *ctx, void *d_ptr, size_t bytes);               /* async        */
+
+/* ---- tables -------------------------------------------------------------------
+ * Replaces the scipy RegularGridInterpolator objects the reference builds in
+ *   utils/Tabulate.py:270-271 (TabulatedProfile.interp2D/interp3D),
+ *   utils/Tabulate.py:589-590 (ParamTabulatedProfile),
+ *   Profiles/BaryonCorrection.py:322 (BaryonificationClass.interp_d)
+ * and evaluates them with the same semantics (method='linear',
+ * bounds_error=False, fill_value=nan; cell = largest i with axis[i] <= x,
+ * clipped to [0, n-2]).
+ * axes[d] has shape[d] strictly increasing entries; axis order is
+ * (ln(1+z), ln M, ln r, extras...), values is C-ordered with that shape.
+ * BFG_TABLE_LOG_VALUES: values are ln(T) and the read-out is exp(interp)
+ *   (Tabulate.py:314-315); otherwise the read-out is the interpolant itself
+ *   (BaryonCorrection.py:403-408).                                                */
+#define BFG_TABLE_LOG_VALUES 1u
+int bfg_table_create(bfg_ctx *ctx, int ndim, const int64_t *shape, const double *const *axes,
+                     const double *values, uint32_t flags, bfg_table **out);
+int bfg_table_destroy(bfg_ctx *ctx, bfg_table *table);
+
+/* Batched stand-alone read-out (the model.projected()/displacement() call of
+ * HealpixRunner.py:472 / :345 on its own): coords is host [npts][ndim], out host [npts].
+ * Synchronous; meant for tests and for users calling the model directly.          */
+int bfg_table_eval(bfg_ctx *ctx, const bfg_table *table, int64_t npts, const double *coords,
+                   double *out);
+
+/* ---- D_A(z) spline --------------------------------------------------------------
+ * Replaces D_a = CubicSpline(z_t, ccl.angular_diameter_distance(...)) of
+ * HealpixRunner.py:297-299 / :429-431: n knots, coef is scipy's PPoly layout
+ * c[4][n-1] (highest power first), evaluated per halo on the GPU.                  */
+int bfg_spline_create(bfg_ctx *ctx, int n_knots, const double *knots, const double *coef,
+                      bfg_spline **out);
+int bfg_spline_destroy(bfg_ctx *ctx, bfg_spline *spline);
+
+/* ---- per-halo radius: ccl MassDef.get_radius on a flat wCDM background ----------
+ * R = (M / (4.18879020479 * Delta * rho_x(a)))^(1/3)  [physical Mpc]
+ * (HealpixRunner.py:320, :454; BaryonCorrection.py:399), with
+ * rho_crit(a) = rho_crit0_h2 * h^2 * E^2(a),
+ * E^2(a) = Omega_m a^-3 + Omega_l a^(-3(1+w0)) + Omega_r a^-4.                     */
+typedef struct {
+    double Omega_m, Omega_l, Omega_r, w0, h;
+    double rho_crit0_h2;     /* 3 (100 km/s/Mpc)^2 / (8 pi G) in Msun/Mpc^3              */
+    double Delta;            /* overdensity                                              */
+    int32_t rho_type;        /* 0 = 'critical', 1 = 'matter'                             */
+    int32_t reserved;
+} bfg_massdef;
+
+/* ---- the hot path ---------------------------------------------------------------- */
+typedef struct {
+    int64_t nside;
+    int64_t n_halo;
+    const double *d_catalog;   /* device, [n_halo][cat_stride] float64 records (M, z, ra, dec, extras) */
+    int32_t cat_stride;        /* doubles per record = 4 + n_extra                        */
+    int32_t n_extra;           /* number of p_keys columns used as extra table coordinates */
+    double epsilon_max;        /* runner cut-out radius in units of R (DefaultRunner)     */
+    bfg_massdef runner_md;     /* runner.mass_def on the catalog cosmology                */
+    bfg_massdef model_md;      /* model.mass_def on the model cosmology (baryonify only)  */
+    double model_epsilon_max;  /* BaryonificationClass.epsilon_max (baryonify only)       */
+    int32_t rdelta_sampling;   /* BaryonificationClass.Rdelta_sampling                    */
+    int32_t include_pixel_size;/* PaintProfilesShell only                                 */
+    int32_t variant;           /* BFG_VARIANT_*                                           */
+    int32_t reserved;
+} bfg_shell_args;
+
+#define BFG_VARIANT_AUTO 0
+#define BFG_VARIANT_SCATTER_WAVE 1     /* one 64-lane wavefront per halo, global f64 atomics   */
+#define BFG_VARIANT_SCATTER_QUARTER 2  /* one 16-lane group per halo, global f64 atomics       */
+#define BFG_VARIANT_TILE_LDS 3         /* sky-tile privatised accumulation in LDS              */
+
+/* Counters the kernels maintain (device side), fetched with bfg_stats_read. */
+typedef struct {
+    uint64_t pixel_updates;   /* P_tot = sum_j |disc_j| (incl. the 4-neighbour fallback)  */
+    uint64_t halos_out_of_table; /* halos whose (z, M, extras) lie outside the table hull */
+    uint64_t pixels_out_of_table;/* pixel queries whose radius lies outside the r axis     */
+    uint64_t halos_fallback4; /* baryonify: halos that used the <4-pixel fallback          */
+    uint32_t warn_mask;       /* BFG_WARN_* bits (BaryonCorrection.py:382-394)             */
+    uint32_t reserved;
+} bfg_stats;
+#define BFG_WARN_Z_RANGE 1u
+#define BFG_WARN_M_RANGE 2u
+#define BFG_WARN_R_RANGE 4u
+
+/* PaintProfilesShell.process loop (Runners/HealpixRunner.py:449-481):
+ * d_map[pix] += profile, for every halo and every pixel of its disc.
+ * d_map is float64[12 nside^2] on the device and is accumulated INTO (zero it
+ * first for the reference's behaviour, :424).                                        */
+int bfg_paint_shell(bfg_ctx *ctx, const bfg_shell_args *args, const bfg_table *table,
+                    const bfg_spline *da_spline, double *d_map);
+
+/* BaryonifyShell.process halo loop (Runners/HealpixRunner.py:315-355) with
+ * BaryonificationClass._readout (Profiles/BaryonCorrection.py:331-419) inlined:
+ * d_offsets[pix][0..2] += displaced unit vector - pixel unit vector.
+ * d_offsets is float64[12 nside^2][3], accumulated INTO.                             */
+int bfg_baryonify_offsets(bfg_ctx *ctx, const bfg_shell_args *args, const bfg_table *table,
+                          const bfg_spline *da_spline, double *d_offsets);
+
+/* Final regrid (Runners/HealpixRunner.py:357-365 + regrid_pixels_hpix :17-71):
+ * every pixel with d_in_map != 0 is moved to pix2vec(p) + d_offsets[p] and
+ * deposited on its 4 bilinear neighbours into d_out_map (accumulated INTO).
+ * d_sums (device, 2 doubles, may be NULL) receives {sum(in_map), sum(deposits)}
+ * for the mass-conservation assert of :368-370.                                       */
+int bfg_regrid_shell(bfg_ctx *ctx, int64_t nside, const double *d_offsets, const double *d_in_map,
+                     double *d_out_map, double *d_sums);
+
+/* max |x| over a device array (np.allclose(orig_map, 0) early return, :293-294) and sum. */
+int bfg_reduce_absmax_sum(bfg_ctx *ctx, int64_t n, const double *d_x, double *absmax, double *sum);
+
+int bfg_stats_reset(bfg_ctx *ctx);
+int bfg_stats_read(bfg_ctx *ctx, bfg_stats *out);   /* synchronises the stream */
+
+/* Optional per-kernel timing with hipEvents on the context's stream (bench.py's
+ * roofline leg).  which: 0 = halo preparation, 1 = paint / offsets kernel(s),
+ * 2 = regrid.  Returns the accumulated milliseconds and launch count since the
+ * last enable.                                                                        */
+int bfg_timing_enable(bfg_ctx *ctx, int enable);
+int bfg_timing_read(bfg_ctx *ctx, int which, double *ms_total, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BFG_MI355_H */

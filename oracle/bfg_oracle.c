@@ -561,6 +561,9 @@ typedef struct {
 static void *paint_worker(void *arg)
 {
     orc_worker_t *w = (orc_worker_t *)arg;
+    /* the worker owns its zero map (empty_shell of Parallelize.py:257); touching it here keeps
+     * the page faults inside the worker, as they are in the reference's separate processes */
+    memset(w->map, 0, sizeof(double) * (size_t)(12 * w->job->nside * w->job->nside));
     w->ptot = paint_range(w->job, w->j0, w->j1, 0, w->map);
     return NULL;
 }
@@ -583,7 +586,7 @@ int64_t orc_paint_shell_splitjoin(int njobs, int64_t nside, int64_t n_halo, cons
         w[i].job = &job;
         w[i].j0 = (int64_t)i * per; if (w[i].j0 > n_halo) w[i].j0 = n_halo;
         w[i].j1 = (int64_t)(i + 1) * per; if (w[i].j1 > n_halo) w[i].j1 = n_halo;
-        w[i].map = (double *)calloc((size_t)npix, sizeof(double));
+        w[i].map = (double *)malloc((size_t)npix * sizeof(double));
         pthread_create(&th[i], NULL, paint_worker, &w[i]);
     }
     int64_t ptot = 0;

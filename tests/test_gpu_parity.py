@@ -1,0 +1,294 @@
+"""
+GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through the
+reference-shaped Python API -> ctypes C-ABI -> libbfg_mi355.so, against
+  (1) the golden vectors captured from the reference's own code (tests/golden/), and
+  (2) the CPU oracle on the same seeded inputs,
+at the north-star tolerance: <= 1e-5 relative on non-zero pixels.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import baryonforge_amd as bfg
+from baryonforge_amd import synthetic as syn
+from oracle import oracle as orc
+from util import assert_maps_close, oracle_baryonify, oracle_paint
+
+RTOL = 1e-5  # north_star: "to within 1e-5 relative on non-zero pixels"
+# Regridded maps contain deposits with bilinear weights ~1e-12 that are pure rounding noise of
+# acos()/atan2() near the poles (healpy's vec2ang has the same conditioning); they are compared
+# absolutely, at 1e-9 of the map's maximum.
+BFLOOR = 1e-9
+VARIANTS = ["scatter_wave", "scatter_quarter"]
+
+
+def _paint_model(zax, Max, rax, T, pax=None):
+    if pax is None:
+        return bfg.TabulatedProfile.from_arrays(zax, Max, rax, T)
+    return bfg.ParamTabulatedProfile.from_arrays(zax, Max, rax, T, other_params={"cdelta": pax})
+
+
+# --------------------------------------------------------------------------- read-out
+def test_table_readout_matches_reference(golden):
+    g = golden("readout.npz")
+    prof = bfg.TabulatedProfile.from_arrays(g["ro_zax"], g["ro_Max"], g["ro_rax"], g["ro_T2D"], g["ro_T2D"] * 2.0)
+    for i, M in enumerate(g["ro_M"]):
+        for j, a in enumerate(g["ro_a"]):
+            for fn, ref in ((prof.projected, g["ro_projected"]), (prof.real, g["ro_real"])):
+                got = fn(None, g["ro_r"], M, a)
+                assert np.array_equal(np.isnan(got), np.isnan(ref[i, j]))
+                m = ~np.isnan(got)
+                np.testing.assert_allclose(got[m], ref[i, j][m], rtol=1e-12, atol=0)
+    # scalar-argument shape semantics (Tabulate.py:321-325)
+    assert np.ndim(prof.projected(None, 0.5, 1e14, 0.8)) == 0
+    assert prof.projected(None, np.array([0.5, 1.0]), np.array([1e13, 1e14, 1e15]), 0.8).shape == (3, 2)
+
+
+def test_param_table_readout_matches_reference(golden):
+    g = golden("readout.npz")
+    prof = bfg.ParamTabulatedProfile.from_arrays(g["rp_zax"], g["rp_Max"], g["rp_rax"], g["rp_T2D"],
+                                                 other_params={"cdelta": g["rp_pax"]})
+    for i, M in enumerate(g["rp_M"]):
+        for j, c in enumerate(g["rp_cd"]):
+            got = prof.projected(None, g["ro_r"], M, float(g["rp_a"]), cdelta=c)
+            ref = g["rp_projected"][i, j]
+            assert np.array_equal(np.isnan(got), np.isnan(ref))
+            np.testing.assert_allclose(got[~np.isnan(got)], ref[~np.isnan(ref)], rtol=1e-12, atol=0)
+    with pytest.raises(AssertionError):
+        prof.projected(None, g["ro_r"], 1e14, 0.8)
+
+
+@pytest.mark.parametrize("tag", ["rd0", "rd1"])
+def test_displacement_readout_matches_reference(golden, cosmo, tag):
+    import warnings
+    g = golden("readout.npz")
+    disp = bfg.Baryonification2D.from_arrays(g[f"rb_{tag}_zax"], g[f"rb_{tag}_Max"], g[f"rb_{tag}_rax"], g[f"rb_{tag}_d"],
+                                             cosmo, epsilon_max=float(g[f"rb_{tag}_eps"]), Rdelta_sampling=(tag == "rd1"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i, M in enumerate(g["ro_M"]):
+            for j, a in enumerate(g["ro_a"]):
+                got = disp.displacement(g["ro_r"], M, a)
+                ref = g[f"rb_{tag}_disp"][i, j]
+                assert np.array_equal(np.isnan(got), np.isnan(ref))
+                np.testing.assert_allclose(got[~np.isnan(got)], ref[~np.isnan(ref)], rtol=1e-11, atol=1e-300)
+    with pytest.warns(UserWarning):
+        disp.displacement(g["ro_r"], 1e17, 0.8)
+
+
+# --------------------------------------------------------------------------- golden runner outputs
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_paint_shell_golden(golden, cosmo, tag, variant):
+    g = golden("paint_shell.npz")
+    nside = int(g[f"{tag}_nside"])
+    Cat = bfg.HaloLightConeCatalog(g[f"{tag}_ra"], g[f"{tag}_dec"], g[f"{tag}_M"], g[f"{tag}_z"], cosmo)
+    Shell = bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo)
+    model = _paint_model(g[f"{tag}_zax"], g[f"{tag}_Max"], g[f"{tag}_rax"], g[f"{tag}_T2D"])
+    R = bfg.PaintProfilesShell(Cat, Shell, epsilon_max=float(g[f"{tag}_eps"]), model=model,
+                               include_pixel_size=bool(g[f"{tag}_ips"]), verbose=False, variant=variant)
+    got = R.process()
+    ref = g[f"{tag}_map"]
+    assert got.dtype == np.float64 and got.shape == ref.shape
+    assert_maps_close(got, ref, RTOL, what=f"paint {tag}")
+    assert np.array_equal(got != 0, ref != 0)
+    assert R.last_stats["pixel_updates"] >= np.count_nonzero(ref)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_paint_shell_golden_param(golden, cosmo, variant):
+    g = golden("paint_shell.npz")
+    Cat = bfg.HaloLightConeCatalog(g["p_ra"], g["p_dec"], g["p_M"], g["p_z"], cosmo, cdelta=g["p_cdelta"])
+    Shell = bfg.LightconeShell(map=np.zeros(12 * 32 * 32), cosmo=cosmo)
+    model = _paint_model(g["p_zax"], g["p_Max"], g["p_rax"], g["p_T2D"], g["p_pax"])
+    got = bfg.PaintProfilesShell(Cat, Shell, epsilon_max=float(g["p_eps"]), model=model, verbose=False,
+                                 variant=variant).process()
+    assert_maps_close(got, g["p_map"], RTOL, what="paint p_keys")
+    assert np.array_equal(got != 0, g["p_map"] != 0)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_baryonify_shell_golden(golden, cosmo, tag, variant):
+    import warnings
+    g = golden("baryonify_shell.npz")
+    Cat = bfg.HaloLightConeCatalog(g[f"{tag}_ra"], g[f"{tag}_dec"], g[f"{tag}_M"], g[f"{tag}_z"], cosmo)
+    Shell = bfg.LightconeShell(map=g[f"{tag}_map_in"].copy(), cosmo=cosmo)
+    model = bfg.Baryonification2D.from_arrays(g[f"{tag}_zax"], g[f"{tag}_Max"], g[f"{tag}_rax"], g[f"{tag}_d"], cosmo,
+                                              epsilon_max=float(g[f"{tag}_eps_model"]),
+                                              Rdelta_sampling=bool(g[f"{tag}_rdelta"]))
+    R = bfg.BaryonifyShell(Cat, Shell, epsilon_max=float(g[f"{tag}_eps"]), model=model, verbose=False, variant=variant)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = R.process()
+    ref = g[f"{tag}_map_out"]
+    assert_maps_close(got, ref, RTOL, floor=BFLOOR, what=f"baryonify {tag}")
+    assert np.isclose(got.sum(), g[f"{tag}_map_in"].sum())
+    assert R.last_stats["halos_fallback4"] > 0   # the fixtures contain discs with < 4 pixels
+
+
+# --------------------------------------------------------------------------- oracle on seeded synthetic inputs
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_paint_config0_nside256_1e3(cosmo, variant):
+    """BASELINE config[0]: PaintProfilesShell, 1e3 halos, NSIDE = 256, pressure table"""
+    ra, dec, M, z = syn.catalog(1000, seed=42)
+    zax, Max, rax, T = syn.pressure_table()
+    ref, ptot = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax), T, 256, 10)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    Shell = bfg.LightconeShell(map=np.zeros(12 * 256 * 256), cosmo=cosmo)
+    R = bfg.PaintProfilesShell(Cat, Shell, 10, _paint_model(zax, Max, rax, T), verbose=False, variant=variant)
+    got = R.process()
+    assert_maps_close(got, ref, RTOL, what="config0")
+    assert R.last_stats["pixel_updates"] == ptot
+    assert np.array_equal(got != 0, ref != 0)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("shape", [(10, 30, 100), (2, 30, 2000)])
+def test_paint_nside1024_vs_oracle(cosmo, variant, shape):
+    """BASELINE config[1] geometry (NSIDE = 1024, eps = 10) on a 2e4-halo sample the oracle finishes in seconds;
+    default table shape and the notebooks' 2 x 30 x 2000 stress shape; one table with non-finite nodes."""
+    ra, dec, M, z = syn.catalog(20000, seed=42)
+    zax, Max, rax, T = syn.pressure_table(*shape, bad_block=(shape[2] == 100))
+    ref, ptot = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax), T, 1024, 10)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    Shell = bfg.LightconeShell(map=np.zeros(12 * 1024 * 1024), cosmo=cosmo)
+    R = bfg.PaintProfilesShell(Cat, Shell, 10, _paint_model(zax, Max, rax, T), verbose=False, variant=variant)
+    got = R.process()
+    assert R.last_stats["pixel_updates"] == ptot
+    assert_maps_close(got, ref, RTOL, what=f"paint 1024 {shape}")
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_paint_eps20_steep_and_massdef(cosmo, variant):
+    ra, dec, M, z = syn.catalog(3000, seed=43, steep=True)
+    zax, Max, rax, T = syn.pressure_table()
+    ref, ptot = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax), T, 512, 20, include_pixel_size=True,
+                             Delta=500, rho_type="matter")
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    Shell = bfg.LightconeShell(map=np.zeros(12 * 512 * 512), cosmo=cosmo)
+    R = bfg.PaintProfilesShell(Cat, Shell, 20, _paint_model(zax, Max, rax, T), mass_def=bfg.MassDef(500, "matter"),
+                               include_pixel_size=True, verbose=False, variant=variant)
+    got = R.process()
+    assert R.last_stats["pixel_updates"] == ptot
+    assert_maps_close(got, ref, RTOL, what="eps20 steep")
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("rdelta", [False, True])
+def test_baryonify_nside256_vs_oracle(cosmo, variant, rdelta):
+    import warnings
+    ra, dec, M, z = syn.catalog(2000, seed=44)
+    zax, Max, rax, d = syn.displacement_table(rdelta=rdelta)
+    m_in = syn.mass_map(256)
+    m_in[::7] = 0.0
+    ref = oracle_baryonify(cosmo, ra, dec, M, z, (zax, Max, rax), d, 256, 10, 20, m_in, rdelta=rdelta)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    Shell = bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo)
+    model = bfg.Baryonification2D.from_arrays(zax, Max, rax, d, cosmo, epsilon_max=20, Rdelta_sampling=rdelta)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = bfg.BaryonifyShell(Cat, Shell, 10, model, verbose=False, variant=variant).process()
+    assert_maps_close(got, ref, RTOL, floor=BFLOOR, what="baryonify 256")
+    assert not np.allclose(got, m_in)
+
+
+def test_baryonify_offsets_nside1024_vs_oracle(cosmo):
+    """BASELINE config[2] geometry on a 5e3-halo sample: the offset field itself, then mass conservation"""
+    import warnings
+    ra, dec, M, z = syn.catalog(5000, seed=45)
+    zax, Max, rax, d = syn.displacement_table()
+    off_ref, ptot = oracle_baryonify(cosmo, ra, dec, M, z, (zax, Max, rax), d, 1024, 10, 20, None, offsets_only=True)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    Shell = bfg.LightconeShell(map=syn.mass_map(1024), cosmo=cosmo)
+    model = bfg.Baryonification2D.from_arrays(zax, Max, rax, d, cosmo, epsilon_max=20)
+    R = bfg.BaryonifyShell(Cat, Shell, 10, model, verbose=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        off = R.offsets_device().cpu().numpy()
+        assert R.last_stats["pixel_updates"] == ptot
+        assert_maps_close(off, off_ref, RTOL, floor=1e-10, what="offsets 1024")
+        out = R.process()
+    assert np.isclose(out.sum(), Shell.map.sum(), rtol=1e-12)
+
+
+# --------------------------------------------------------------------------- full-size properties (no oracle)
+def test_paint_full_size_linearity_1e5(cosmo):
+    """BASELINE config[1] at full size (1e5 halos, NSIDE 1024): painting is linear in halos
+    (HealpixRunner.py:481) -> map(A u B) == map(A) + map(B); variants agree; P_tot adds up."""
+    ra, dec, M, z = syn.catalog(100000, seed=42)
+    zax, Max, rax, T = syn.pressure_table()
+    model = _paint_model(zax, Max, rax, T)
+    Shell = bfg.LightconeShell(map=np.zeros(12 * 1024 * 1024), cosmo=cosmo)
+
+    def run(sel, variant="auto"):
+        Cat = bfg.HaloLightConeCatalog(ra[sel], dec[sel], M[sel], z[sel], cosmo)
+        R = bfg.PaintProfilesShell(Cat, Shell, 10, model, verbose=False, variant=variant)
+        return R.process(), R.last_stats["pixel_updates"]
+    full, p_full = run(slice(None))
+    a, p_a = run(slice(0, 50000))
+    b, p_b = run(slice(50000, None))
+    assert p_full == p_a + p_b
+    assert_maps_close(a + b, full, 1e-10, what="linearity")
+    w, p_w = run(slice(None), "scatter_wave")
+    assert p_w == p_full
+    assert_maps_close(w, full, 1e-10, what="variants")
+    assert np.all(full >= 0) and np.isfinite(full).all()
+
+
+# --------------------------------------------------------------------------- edge cases and errors
+def test_edge_cases(cosmo):
+    zax, Max, rax, T = syn.pressure_table()
+    model = _paint_model(zax, Max, rax, T)
+    nside = 64
+    Shell = bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo)
+    # empty catalog
+    e = np.array([])
+    out = bfg.PaintProfilesShell(bfg.HaloLightConeCatalog(e, e, e, e, cosmo), Shell, 10, model, verbose=False).process()
+    assert out.shape == (12 * nside * nside,) and not out.any()
+    # a halo whose (z, M) is outside the table paints nothing; poles; phi wrap; huge disc (pole inside)
+    ra = np.array([10.0, 0.0, 359.999, 45.0, 200.0])
+    dec = np.array([5.0, 90.0, -90.0, 89.9, -89.95])
+    M = np.array([1e17, 1e15, 1e15, 5e15, 5e15])
+    z = np.array([0.3, 0.05, 0.05, 0.02, 0.02])
+    with pytest.warns(UserWarning):
+        Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    for variant in VARIANTS:
+        R = bfg.PaintProfilesShell(Cat, Shell, 10, model, verbose=False, variant=variant)
+        got = R.process()
+        ref, ptot = oracle_paint(cosmo, Cat.cat["ra"], Cat.cat["dec"], M, z, (zax, Max, rax), T, nside, 10)
+        assert R.last_stats["pixel_updates"] == ptot
+        assert R.last_stats["halos_out_of_table"] == 1
+        assert_maps_close(got, ref, RTOL, what="edge")
+
+
+def test_error_conventions(cosmo):
+    zax, Max, rax, T = syn.pressure_table()
+    model = _paint_model(zax, Max, rax, T)
+    Shell = bfg.LightconeShell(map=np.zeros(12 * 16 * 16), cosmo=cosmo)
+    one = np.array([1.0])
+    Cat = bfg.HaloLightConeCatalog(one, one, one * 1e14, one * 0.3, cosmo)
+    with pytest.raises(NotImplementedError):
+        bfg.PaintProfilesShell(Cat, Shell, 10, model, use_ellipticity=True)
+    with pytest.raises(AssertionError):
+        bfg.PaintProfilesShell(Cat, Shell, 10, None, verbose=False).process()
+    with pytest.raises(AssertionError):   # z > 30
+        bfg.PaintProfilesShell(bfg.HaloLightConeCatalog(one, one, one * 1e14, one * 31.0, cosmo), Shell, 10, model,
+                               verbose=False).process()
+    with pytest.raises(NameError):        # table never built
+        bfg.PaintProfilesShell(Cat, Shell, 10, bfg.TabulatedProfile(object(), cosmo), verbose=False).process()
+    with pytest.raises(TypeError):
+        bfg.PaintProfilesShell(Cat, Shell, 10, object(), verbose=False).process()
+    # zero map early return hands back the input object (HealpixRunner.py:293-294)
+    zd = syn.displacement_table()
+    disp = bfg.Baryonification2D.from_arrays(*zd, cosmo)
+    zero = np.zeros(12 * 16 * 16)
+    assert bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=zero, cosmo=cosmo), 10, disp, verbose=False).process() is zero
+    # p_keys with a model of the wrong type
+    class Fake(object):
+        pass
+    f = Fake()
+    f.p_keys = ["cdelta"]
+    with pytest.raises(AssertionError):
+        bfg.PaintProfilesShell(Cat, Shell, 10, f, verbose=False).process()

@@ -1,0 +1,247 @@
+"""
+CPU-only tests (no GPU): the host logic that mirrors the reference API, the C-ABI library
+(loads, exports every symbol of include/bfg_mi355.h, refuses to compute without a GPU),
+the host-side table builder against the reference's golden output, sky-patch sharding.
+"""
+import ctypes
+import os
+import re
+import warnings
+
+import numpy as np
+import pytest
+
+import baryonforge_amd as bfg
+from baryonforge_amd import _lib, sharding, synthetic as syn
+from baryonforge_amd.background import Background, MassDef
+from oracle import oracle as orc
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ C-ABI library
+def test_library_exports_every_declared_symbol():
+    L = _lib.load()
+    header = open(os.path.join(REPO, "include", "bfg_mi355.h")).read()
+    declared = set(re.findall(r"\b(bfg_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.bfg_abi_version() == 1
+    assert L.bfg_status_string(0) == b"ok" and b"invalid" in L.bfg_status_string(-1)
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(_lib.MassDefStruct) == 7 * 8 + 8
+    assert ctypes.sizeof(_lib.Stats) == 4 * 8 + 8
+    assert ctypes.sizeof(_lib.ShellArgs) == 8 + 8 + 8 + 4 + 4 + 8 + 2 * 64 + 8 + 4 * 4
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = _lib.load()
+    n = ctypes.c_int(-1)
+    assert L.bfg_device_count(ctypes.byref(n)) == 0 and n.value == 0
+    h = ctypes.c_void_p()
+    assert L.bfg_ctx_create(0, None, ctypes.byref(h)) == -3          # BFG_ERR_NO_DEVICE
+    zax, Max, rax, T = syn.pressure_table(4, 5, 20)
+    one = np.array([1.0])
+    Cat = bfg.HaloLightConeCatalog(one, one, one * 1e14, one * 0.3, syn.COSMO)
+    Shell = bfg.LightconeShell(map=np.zeros(12 * 4 * 4), cosmo=syn.COSMO)
+    with pytest.raises(_lib.BFGError):                                 # no silent CPU fallback
+        bfg.PaintProfilesShell(Cat, Shell, 10, bfg.TabulatedProfile.from_arrays(zax, Max, rax, T), verbose=False).process()
+
+
+def test_product_never_imports_the_oracle():
+    for root, _, files in os.walk(os.path.join(REPO, "baryonforge_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+                assert "libbfg_oracle" not in src, f
+
+
+# ------------------------------------------------------------------ containers (io.py)
+def test_catalog_and_shell_containers():
+    c = dict(syn.COSMO)
+    ra, dec, M, z = syn.catalog(50)
+    cat = bfg.HaloLightConeCatalog(ra, dec, M, z, c, cdelta=np.arange(50.0))
+    assert cat.cat.dtype.names == ("M", "z", "ra", "dec", "cdelta") and cat.cat.dtype[0] == np.float64
+    assert cat.cosmology is c and cat.data is cat.cat
+    sub = cat[10:20]
+    assert isinstance(sub, bfg.HaloLightConeCatalog) and sub.cat.size == 10 and sub.cat["cdelta"][0] == 10
+    sub = cat[np.array([3, 1])]
+    assert sub.cat["M"][0] == M[3]
+    rec = cat.records(["cdelta"])
+    assert rec.shape == (50, 5) and rec[7, 0] == M[7] and rec[7, 2] == ra[7] and rec[7, 4] == 7
+    with pytest.raises(ValueError):
+        bfg.HaloLightConeCatalog(ra, dec, M, z, {"Omega_m": 0.3})
+    with pytest.warns(UserWarning):
+        p = bfg.HaloLightConeCatalog(np.zeros(2), np.array([90.0, -90.0]), M[:2], z[:2], c)
+    assert p.cat["dec"][0] == 90 - 1e-8 and p.cat["dec"][1] == -90 + 1e-8
+    sh = bfg.LightconeShell(map=np.zeros(12 * 8 * 8), cosmo=c, redshift=0.3)
+    assert sh.NSIDE == 8 and sh.redshift == 0.3 and sh.data is sh.map
+    with pytest.raises(ValueError):
+        bfg.LightconeShell(map=np.zeros(100), cosmo=c)
+    with pytest.raises(ValueError):
+        bfg.LightconeShell(cosmo=c)
+    with pytest.raises(ValueError):
+        bfg.LightconeShell(map=np.zeros(12), cosmo={"h": 0.7})
+
+
+def test_runner_attributes_and_errors():
+    c = dict(syn.COSMO)
+    cat = bfg.HaloLightConeCatalog(*syn.catalog(5), c)
+    sh = bfg.LightconeShell(map=np.zeros(12), cosmo=c)
+    R = bfg.PaintProfilesShell(cat, sh, 10, None)
+    for k in ("HaloLightConeCatalog", "LightconeShell", "cosmo", "model", "epsilon_max", "mass_def", "verbose",
+              "use_ellipticity", "include_pixel_size"):
+        assert hasattr(R, k)                                            # read by Parallelize.py:237-243
+    assert R.mass_def.Delta == 200 and R.mass_def.rho_type == "critical"
+    with pytest.raises(NotImplementedError):
+        bfg.BaryonifyShell(cat, sh, 10, None, use_ellipticity=True)
+    with pytest.raises(AssertionError):
+        R.process()                                                     # "You must provide a model"
+    # zero map: early return of the very same array object, before any GPU work (HealpixRunner.py:293-294)
+    assert bfg.BaryonifyShell(cat, sh, 10, None).process() is sh.map
+    hm = bfg.regrid_pixels_hpix(np.zeros(10), np.ones(5), np.ones([5, 4], dtype=int), np.ones([5, 4]) * 0.25)
+    assert hm[1] == 5.0 and hm.sum() == 5.0
+
+
+# ------------------------------------------------------------------ background vs the oracle's independent one
+def test_background_matches_oracle_background():
+    for c in (dict(syn.COSMO), dict(syn.COSMO, w0=-0.8, Omega_m=0.25, h=0.68)):
+        bg = Background(c)
+        a = 1 / (1 + np.array([1e-3, 0.05, 0.45, 1.0, 3.0, 30.0]))
+        np.testing.assert_allclose(bg.angular_diameter_distance(a), orc.angular_diameter_distance(c, a), rtol=1e-12)
+        for md in (MassDef(200, "critical"), MassDef(500, "matter")):
+            np.testing.assert_allclose(md.get_radius(c, 3e14, a), orc.get_radius(c, 3e14, a, md.Delta, md.rho_type),
+                                       rtol=1e-14)
+    # textbook anchor: flat LCDM Om = 0.3, h = 0.7 -> D_C(z = 0.5) ~ 1888.6 Mpc (radiation shifts it by ~1e-4)
+    assert Background(syn.COSMO).comoving_radial_distance(1 / 1.5) == pytest.approx(1888.6, rel=3e-4)
+    assert abs(Background(syn.COSMO).E2(1.0) - 1.0) < 1e-14
+
+
+# ------------------------------------------------------------------ table construction (host)
+class _Sigma(object):
+    """analytic projected profile, same stand-in as tests/golden/make_golden.py"""
+
+    def __init__(self, core, slope):
+        self.core, self.slope, self.cutoff = core, slope, None
+
+    def set_parameter(self, k, v):
+        setattr(self, k, v)
+
+    def projected(self, cosmo, r, M, a):
+        M = np.atleast_1d(M)
+        R = (orc.get_radius(syn.COSMO, M, a) / a)[:, None]
+        x = np.atleast_1d(r)[None, :] / (self.core * R)
+        S = M[:, None] / (2 * np.pi * (self.core * R) ** 2) * (1 + x * x) ** (-self.slope)
+        return S * np.exp(-np.atleast_1d(r)[None, :] / (30 * R))
+
+    real = projected
+
+
+def test_baryonification2d_table_builder_matches_reference(golden):
+    g = golden("table_builder.npz")
+    DMO, DMB = _Sigma(0.25, 1.6), _Sigma(0.45, 1.6)
+    B2 = bfg.Baryonification2D(DMO, DMB, dict(syn.COSMO), epsilon_max=20, N_int=500)
+    assert DMO.cutoff == 1000 and DMB.cutoff == 1000                    # BaryonCorrection.py:99-100
+    a = float(g["tb_a"])
+    np.testing.assert_allclose(DMO.projected(None, g["tb_rint"], g["tb_M"], a) * a, g["tb_Sigma_DMO"], rtol=1e-13)
+    np.testing.assert_allclose(B2.get_masses(DMO, g["tb_r"], g["tb_M"], a), g["tb_M_DMO"], rtol=1e-12)
+    np.testing.assert_allclose(B2.get_masses(DMB, g["tb_r"], g["tb_M"], a), g["tb_M_DMB"], rtol=1e-12)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        B2.setup_interpolator(z_min=0.1, z_max=0.5, N_samples_z=3, M_min=1e12, M_max=1e16, N_samples_Mass=5,
+                              R_min=1e-3, R_max=1e2, N_samples_R=50, verbose=False)
+    assert B2.raw_input_d.shape == g["tb_d_interp"].shape and B2.p_keys == [] and B2.Rdelta_sampling is False
+    np.testing.assert_allclose(B2.raw_input_d, g["tb_d_interp"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(np.exp(B2.raw_input_z_range) - 1, g["tb_z_tab"], rtol=1e-14)
+    with pytest.raises(NotImplementedError):
+        bfg.BaryonificationClass(DMO, DMB, syn.COSMO).get_masses(DMO, g["tb_r"], 1e14, a)
+    with pytest.raises(NameError):
+        bfg.Baryonification2D(DMO, DMB, syn.COSMO).displacement(1.0, 1e14, 0.8)
+
+
+def test_tabulated_profile_setup_fills_reference_layout():
+    class Model(_Sigma):
+        mass_def = None
+    m = Model(0.3, 1.5)
+    prof = bfg.TabulatedProfile(m, syn.COSMO)
+    with pytest.raises(NameError):
+        prof.projected(None, 1.0, 1e14, 0.8)
+    prof.setup_interpolator(z_min=0.01, z_max=1, N_samples_z=4, N_samples_Mass=5, N_samples_R=12, verbose=False)
+    assert prof.raw_input_2D.shape == (4, 5, 12)
+    z = np.geomspace(0.01, 1, 4)
+    np.testing.assert_allclose(prof.raw_input_z_range, np.log(1 + z))
+    np.testing.assert_allclose(prof.raw_input_M_range, np.log(np.geomspace(1e12, 1e16, 5)))
+    np.testing.assert_allclose(prof.raw_input_r_range, np.log(np.geomspace(1e-3, 1e2, 12)))
+    a1 = 1 / (1 + z[1])                                                  # the factor a of Tabulate.py:259
+    np.testing.assert_allclose(prof.raw_input_2D[1], m.projected(None, np.geomspace(1e-3, 1e2, 12),
+                                                                np.geomspace(1e12, 1e16, 5), a1) * a1)
+    np.testing.assert_allclose(prof.raw_input_3D[1], m.real(None, np.geomspace(1e-3, 1e2, 12),
+                                                          np.geomspace(1e12, 1e16, 5), a1))
+    pp = bfg.ParamTabulatedProfile(m, syn.COSMO)
+    pp.setup_interpolator(N_samples_z=2, N_samples_Mass=3, N_samples_R=6, other_params={"core": np.array([0.2, 0.4])},
+                          verbose=False)
+    assert pp.p_keys == ["core"] and pp.raw_input_2D.shape == (2, 3, 6, 2)
+    assert np.all(pp.raw_input_2D[..., 0] != pp.raw_input_2D[..., 1])
+    np.testing.assert_array_equal(pp.raw_input_core_range, [0.2, 0.4])
+    with pytest.raises(AssertionError):
+        bfg.ParamTabulatedProfile(prof, syn.COSMO)
+    with pytest.raises(ValueError):
+        bfg.TabulatedProfile.from_arrays(np.zeros(3), np.zeros(4), np.zeros(5), np.zeros((3, 4, 6)))
+
+
+# ------------------------------------------------------------------ sharding
+def test_ang2pix_nest_is_a_consistent_spatial_key():
+    rng = np.random.default_rng(0)
+    ra = np.degrees(rng.uniform(0, 2 * np.pi, 20000))
+    dec = np.degrees(np.arcsin(rng.uniform(-1, 1, 20000)))
+    for nside in (1, 8, 1024):
+        p = sharding.ang2pix_nest(nside, ra, dec)
+        assert p.min() >= 0 and p.max() < 12 * nside * nside
+    # NEST hierarchy: parent pixel = child >> 2
+    assert np.array_equal(sharding.ang2pix_nest(8, ra, dec), sharding.ang2pix_nest(16, ra, dec) >> 2)
+    # equal-area: uniform points populate the 768 nside-8 pixels evenly
+    cnt = np.bincount(sharding.ang2pix_nest(8, ra, dec), minlength=768)
+    assert cnt.min() > 5 and cnt.max() < 60
+    # base pixel of a few known directions (north cap faces 0..3, equatorial 4..7, south 8..11)
+    assert list(sharding.ang2pix_nest(1, [45.0, 135.0, 0.0, 90.0, 45.0], [60.0, 60.0, 0.0, 0.0, -60.0])) == [0, 1, 4, 5, 8]
+    # agrees with the oracle's RING geometry: points of one nside-4 NEST pixel are close on the sky
+    v = orc.ang2vec(ra, dec, lonlat=True)
+    p = sharding.ang2pix_nest(4, ra, dec)
+    for k in rng.integers(0, 192, 10):
+        vv = v[p == k]
+        assert np.all(vv @ vv.mean(0) / np.linalg.norm(vv.mean(0)) > np.cos(0.45))
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_shard_by_sky_patch_partitions_and_balances(world):
+    ra, dec, M, z = syn.catalog(20000, seed=3)
+    w = sharding.estimate_disc_pixels(syn.COSMO, M, z, 10, 1024)
+    assert np.all(w > 16) and np.isfinite(w).all()
+    shards = sharding.shard_by_sky_patch(ra, dec, w, world)
+    assert len(shards) == world
+    allidx = np.concatenate(shards)
+    assert np.array_equal(np.sort(allidx), np.arange(20000))            # disjoint and complete
+    loads = np.array([w[s].sum() for s in shards])
+    assert loads.max() / loads.mean() < 1.25                            # balanced by pixel work, not by count
+    if world > 1:                                                       # contiguous NEST ranges
+        hi = [sharding.ang2pix_nest(8, ra[s], dec[s]).max() for s in shards if s.size]
+        lo = [sharding.ang2pix_nest(8, ra[s], dec[s]).min() for s in shards if s.size]
+        assert all(lo[i + 1] > hi[i] for i in range(len(hi) - 1))
+    fine = sharding.ang2pix_nest(1024, ra[shards[0]], dec[shards[0]])
+    assert np.all(np.diff(fine) >= 0)                                   # sorted for locality inside a shard
+
+
+def test_estimate_disc_pixels_tracks_the_oracle_count():
+    ra, dec, M, z = syn.catalog(300, seed=5)
+    est = sharding.estimate_disc_pixels(syn.COSMO, M, z, 10, 256, overhead=0.0)
+    a, R, D = orc.halo_scalars(syn.COSMO, M, z)
+    cnt = np.array([orc.query_disc(256, orc.ang2vec(ra[i], dec[i], lonlat=True), R[i] * 10 / D[i]).size
+                    for i in range(300)])
+    assert abs(est.sum() / cnt.sum() - 1) < 0.05
