@@ -242,4 +242,20 @@ __device__ inline int group_inclusive_scan(int v, int lane)
     return v;
 }
 
+// ---- sky tiles of the LDS-privatised variant (bfg_tile.hpp) ----------------------------------
+constexpr int kTileRings = 64;      // TR: rings per band
+constexpr int kTileWidth = 32;      // TW: max pixels of one ring inside one sector
+constexpr int kMaxPairsPerHalo = 64;
+constexpr int kLogTab = 128;
+constexpr int kExpTab = 64;
+
+struct TileGeom {
+    int nbands;
+    int ntiles;
+    const int32_t *band_ns;      // [nbands]   sectors per band
+    const int32_t *band_tile0;   // [nbands+1] first tile id of a band
+    const int32_t *band_nrmin;   // [nbands]   shortest ring of the band
+    const int32_t *tile_band;    // [ntiles]
+};
+
 }  // namespace bfg

@@ -41,10 +41,11 @@ static thread_local std::string g_last_error;
         }                                                                                   \
     } while (0)
 
-enum { F_X0 = 0, F_Y0, F_Z0, F_PTHETA, F_PPHI, F_D, F_A, F_R, F_RM, F_RADIUS, F_LNM, F_LNZ, F_NF };
+enum { F_X0 = 0, F_Y0, F_Z0, F_ST, F_PTHETA, F_PPHI, F_D, F_A, F_R, F_RM, F_RADIUS, F_LNM, F_LNZ, F_NF };
 enum { I_RFIRST = 0, I_RLAST, I_IRMIN, I_IRMAX, I_FLAGS, I_NI };
 #define HF_OOB 1        // (z, M, extras) outside the table hull, or NaN
 #define HF_SKIP 2       // nothing to do for this halo (NaN radius etc.)
+#define HF_SCATTER 4    // tile variant: this halo is left to the global-atomic scatter kernel
 
 struct DevTable {
     int ndim;                       // 3 + n_extra
@@ -74,6 +75,7 @@ struct bfg_spline {
     double *d_coef;   // [4][n-1]
 };
 
+namespace bfg { struct HaloTile; }
 struct bfg_ctx {
     int device;
     hipStream_t stream;
@@ -89,12 +91,23 @@ struct bfg_ctx {
     double *d_cw;       // [BFG_MAX_DIM-1][cap]
     bfg_stats *d_stats;
     double *d_red;      // scratch for reductions [4]
+    // tile variant: geometry of the current nside, binning buffers, ln / exp tables
+    int64_t tile_nside;
+    TileGeom geo;
+    int32_t *d_geo;                 // band_ns | band_tile0 | band_nrmin | tile_band
+    int32_t *d_tile_count, *d_tile_start, *d_pairs;
+    int64_t pair_cap;
+    unsigned long long *d_pair_total;
+    double *d_mathtab;              // logtab (256 doubles) | exptab (64 doubles)
+    bfg::HaloTile *d_ht;            // [cap_halo]
+    double2 *d_hwin;                // [hwin_cap] pre-blended row windows
+    int64_t hwin_cap;
     // timing: a growing pool of event pairs per kernel class, resolved lazily in bfg_timing_read
     bool timing;
-    std::vector<hipEvent_t> *ev_a[3], *ev_b[3];
-    size_t ev_used[3];
-    double t_ms[3];
-    int64_t t_n[3];
+    std::vector<hipEvent_t> *ev_a[5], *ev_b[5];
+    size_t ev_used[5];
+    double t_ms[5];
+    int64_t t_n[5];
 };
 
 struct ShellParams {
@@ -114,6 +127,7 @@ struct ShellParams {
     double pixfac_area;      // pixarea if include_pixel_size else 0
     double *out;             // map [npix] or offsets [npix][3]
     bfg_stats *stats;
+    int only_flagged;        // process only halos the tile binning flagged HF_SCATTER
 };
 
 // ------------------------------------------------------------------------------------
@@ -135,7 +149,15 @@ struct PrepParams {
     double *cw;
     bfg_stats *stats;
     int want_model_radius;
+    bfg::HaloTile *ht;       // tile variant: per-halo 128-byte records (may be null)
+    int win_nodes;
+    double pixfac_area;
 };
+
+#define MODE_PAINT 0
+#define MODE_BARYONIFY 1
+constexpr int kMaxCorner = 1 << (BFG_MAX_DIM - 1);
+#include "bfg_tile.hpp"
 
 __device__ inline double massdef_radius(const bfg_massdef &md, double M, double a)
 {
@@ -182,7 +204,7 @@ __global__ __launch_bounds__(256) void halo_prep_kernel(const PrepParams P)
 
     double *rec = P.rec + j;
     const int64_t cap = P.cap;
-    rec[F_X0 * cap] = x0; rec[F_Y0 * cap] = y0; rec[F_Z0 * cap] = z0v;
+    rec[F_X0 * cap] = x0; rec[F_Y0 * cap] = y0; rec[F_Z0 * cap] = z0v; rec[F_ST * cap] = st;
     rec[F_PTHETA * cap] = ptheta; rec[F_PPHI * cap] = pphi;
     rec[F_D * cap] = D; rec[F_A * cap] = a; rec[F_R * cap] = R;
     rec[F_RM * cap] = P.want_model_radius ? massdef_radius(P.md_model, M, a) / a : 0.0;  // BaryonCorrection.py:399
@@ -235,13 +257,28 @@ __global__ __launch_bounds__(256) void halo_prep_kernel(const PrepParams P)
     irec[I_RFIRST * cap] = rfirst; irec[I_RLAST * cap] = rlast;
     irec[I_IRMIN * cap] = irmin; irec[I_IRMAX * cap] = irmax;
     irec[I_FLAGS * cap] = flags;
+    if (P.ht) {
+        HaloTile h;
+        h.st = st; h.ct = z0v; h.pphi = pphi;
+        h.S = (D / a) * (D / a);
+        h.cosr = cos(radius);
+        h.z0 = cos(ptheta);
+        h.xa = 1.0 / sqrt((1.0 - h.z0) * (1.0 + h.z0));
+        h.pixfac = (P.pixfac_area != 0.0) ? P.pixfac_area * (D * D) : 1.0;
+        h.rfirst = rfirst; h.rlast = rlast; h.irmin = irmin; h.irmax = irmax;
+        // staged row window: ends at the node above the largest radius of the disc
+        const double sr = sin(0.5 * fmin(radius, kPi));
+        const double rho_max = 0.5 * log(4.0 * h.S * sr * sr);
+        int win_lo = find_interval(P.tab.raxis, P.tab.nr, rho_max) + 1 - (P.win_nodes - 1);
+        if (win_lo > P.tab.nr - P.win_nodes) win_lo = P.tab.nr - P.win_nodes;
+        if (win_lo < 0) win_lo = 0;
+        h.win_lo = win_lo; h.flags = flags; h.pad0 = 0; h.pad1 = 0;
+        h.spare[0] = h.spare[1] = h.spare[2] = h.spare[3] = 0.0;
+        P.ht[j] = h;
+    }
 }
 
-#define MODE_PAINT 0
-#define MODE_BARYONIFY 1
-
 // per-group LDS layout (G entries each), followed by the (axis, value) window
-constexpr int kMaxCorner = 1 << (BFG_MAX_DIM - 1);
 template <int G>
 struct RingLds {
     int32_t cum[G];
@@ -269,6 +306,7 @@ __global__ __launch_bounds__(256) void shell_scatter_kernel(const ShellParams P)
     const int64_t cap = P.cap;
     const int32_t flags = P.irec[I_FLAGS * cap + j];
     if (flags & HF_SKIP) return;
+    if (P.only_flagged && !(flags & HF_SCATTER)) return;
     // paint: a halo outside the table hull paints NaN -> 0 everywhere (HealpixRunner.py:473);
     // baryonify: offset NaN -> 0 (:347) -- but its pixels still count toward P_tot.
     const bool halo_oob = (flags & HF_OOB) != 0;
@@ -637,12 +675,24 @@ int bfg_ctx_create(int device_id, void *stream, bfg_ctx **out)
     c->n_cu = prop.multiProcessorCount;
     c->lds_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
     c->max_dyn_lds = prop.sharedMemPerBlock;
-    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
-    else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    if (stream == BFG_STREAM_OWN) { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    else { c->stream = (hipStream_t)stream; c->own_stream = false; }   // NULL = the legacy default stream
     HIP_TRY(hipMalloc((void **)&c->d_stats, sizeof(bfg_stats)));
     HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(bfg_stats), c->stream));
     HIP_TRY(hipMalloc((void **)&c->d_red, 4 * sizeof(double)));
-    for (int k = 0; k < 3; ++k) { c->ev_a[k] = new std::vector<hipEvent_t>(); c->ev_b[k] = new std::vector<hipEvent_t>(); }
+    for (int k = 0; k < 5; ++k) { c->ev_a[k] = new std::vector<hipEvent_t>(); c->ev_b[k] = new std::vector<hipEvent_t>(); }
+    {   // ln / exp tables of the tile kernels: {1/c, ln c} with c = 1 + (i + 0.5)/128, and 2^(j/64)
+        std::vector<double> mt(2 * kLogTab + kExpTab);
+        for (int i = 0; i < kLogTab; ++i) {
+            double cc = 1.0 + ((double)i + 0.5) / (double)kLogTab;
+            mt[2 * i] = 1.0 / cc; mt[2 * i + 1] = std::log(cc);
+        }
+        for (int j = 0; j < kExpTab; ++j) mt[2 * kLogTab + j] = std::exp2((double)j / (double)kExpTab);
+        HIP_TRY(hipMalloc((void **)&c->d_mathtab, mt.size() * sizeof(double)));
+        HIP_TRY(hipMemcpyAsync(c->d_mathtab, mt.data(), mt.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMalloc((void **)&c->d_pair_total, sizeof(unsigned long long)));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     *out = c;
     return BFG_OK;
 }
@@ -663,9 +713,16 @@ int bfg_ctx_destroy(bfg_ctx *c)
     if (c->d_irec) (void)hipFree(c->d_irec);
     if (c->d_cidx) (void)hipFree(c->d_cidx);
     if (c->d_cw) (void)hipFree(c->d_cw);
+    if (c->d_ht) (void)hipFree(c->d_ht);
+    if (c->d_hwin) (void)hipFree(c->d_hwin);
     (void)hipFree(c->d_stats);
     (void)hipFree(c->d_red);
-    for (int k = 0; k < 3; ++k) {
+    if (c->d_geo) (void)hipFree(c->d_geo);
+    if (c->d_tile_count) (void)hipFree(c->d_tile_count);
+    if (c->d_tile_start) (void)hipFree(c->d_tile_start);
+    if (c->d_pairs) (void)hipFree(c->d_pairs);
+    (void)hipFree(c->d_mathtab); (void)hipFree(c->d_pair_total);
+    for (int k = 0; k < 5; ++k) {
         for (hipEvent_t e : *c->ev_a[k]) (void)hipEventDestroy(e);
         for (hipEvent_t e : *c->ev_b[k]) (void)hipEventDestroy(e);
         delete c->ev_a[k]; delete c->ev_b[k];
@@ -808,7 +865,7 @@ int bfg_table_create(bfg_ctx *c, int ndim, const int64_t *shape, const double *c
     double dr = (r[NR - 1] - r[0]) / (double)(NR - 1);
     bool uni = dr > 0;
     for (int64_t i = 0; i < NR && uni; ++i)
-        if (std::fabs(r[i] - (r[0] + dr * (double)i)) > 1e-6 * dr) uni = false;
+        if (std::fabs(r[i] - (r[0] + dr * (double)i)) > 1e-9 * dr) uni = false;
     D.r_uniform = uni ? 1 : 0; D.r0 = r[0]; D.inv_dr = uni ? 1.0 / dr : 0.0;
     HIP_TRY(hipMemcpyAsync(t->d_blob, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -881,13 +938,14 @@ static int ensure_workspace(bfg_ctx *c, int64_t n)
 {
     if (n <= c->cap_halo) return BFG_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->d_rec) { (void)hipFree(c->d_rec); (void)hipFree(c->d_irec); (void)hipFree(c->d_cidx); (void)hipFree(c->d_cw); }
-    c->d_rec = nullptr; c->cap_halo = 0;
+    if (c->d_rec) { (void)hipFree(c->d_rec); (void)hipFree(c->d_irec); (void)hipFree(c->d_cidx); (void)hipFree(c->d_cw); (void)hipFree(c->d_ht); }
+    c->d_rec = nullptr; c->d_ht = nullptr; c->cap_halo = 0;
     int64_t cap = (n + 1023) / 1024 * 1024;
     HIP_TRY(hipMalloc((void **)&c->d_rec, (size_t)cap * F_NF * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&c->d_irec, (size_t)cap * I_NI * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void **)&c->d_cidx, (size_t)cap * (BFG_MAX_DIM - 1) * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void **)&c->d_cw, (size_t)cap * (BFG_MAX_DIM - 1) * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&c->d_ht, (size_t)cap * sizeof(HaloTile)));
     c->cap_halo = cap;
     return BFG_OK;
 }
@@ -923,6 +981,58 @@ static void timing_end(bfg_ctx *c, int which)
     c->ev_used[which] += 1;
 }
 
+// tile geometry of one nside (cached) and the binning buffers
+static int ensure_tiles(bfg_ctx *c, int64_t nside, int64_t n_halo)
+{
+    if (c->tile_nside != nside) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_geo) { (void)hipFree(c->d_geo); (void)hipFree(c->d_tile_count); (void)hipFree(c->d_tile_start); }
+        c->d_geo = nullptr; c->d_tile_count = nullptr; c->d_tile_start = nullptr; c->tile_nside = 0;
+        const int64_t nrings = 4 * nside - 1;
+        const int nbands = (int)((nrings + kTileRings - 1) / kTileRings);
+        std::vector<int32_t> ns(nbands), t0(nbands + 1), nrmin(nbands);
+        int ntiles = 0;
+        for (int b = 0; b < nbands; ++b) {
+            int64_t lo = 1 + (int64_t)b * kTileRings, hi = std::min<int64_t>(nrings, lo + kTileRings - 1);
+            int64_t mx = 0, mn = INT64_MAX;
+            for (int64_t r = lo; r <= hi; ++r) {
+                int64_t nr = (r < nside) ? 4 * r : (r <= 3 * nside ? 4 * nside : 4 * (4 * nside - r));
+                mx = std::max(mx, nr); mn = std::min(mn, nr);
+            }
+            ns[b] = (int32_t)((mx + kTileWidth - 1) / kTileWidth);
+            nrmin[b] = (int32_t)mn;
+            t0[b] = ntiles;
+            ntiles += ns[b];
+        }
+        t0[nbands] = ntiles;
+        std::vector<int32_t> blob;
+        blob.insert(blob.end(), ns.begin(), ns.end());
+        blob.insert(blob.end(), t0.begin(), t0.end());
+        blob.insert(blob.end(), nrmin.begin(), nrmin.end());
+        for (int b = 0; b < nbands; ++b) for (int s = 0; s < ns[b]; ++s) blob.push_back(b);
+        HIP_TRY(hipMalloc((void **)&c->d_geo, blob.size() * sizeof(int32_t)));
+        HIP_TRY(hipMemcpyAsync(c->d_geo, blob.data(), blob.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMalloc((void **)&c->d_tile_count, (size_t)ntiles * sizeof(int32_t)));
+        HIP_TRY(hipMalloc((void **)&c->d_tile_start, (size_t)(ntiles + 1) * sizeof(int32_t)));
+        c->geo.nbands = nbands; c->geo.ntiles = ntiles;
+        c->geo.band_ns = c->d_geo;
+        c->geo.band_tile0 = c->d_geo + nbands;
+        c->geo.band_nrmin = c->d_geo + 2 * nbands + 1;
+        c->geo.tile_band = c->d_geo + 3 * nbands + 1;
+        c->tile_nside = nside;
+    }
+    const int64_t want = 8 * n_halo + 65536;
+    if (want > c->pair_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_pairs) (void)hipFree(c->d_pairs);
+        c->d_pairs = nullptr; c->pair_cap = 0;
+        HIP_TRY(hipMalloc((void **)&c->d_pairs, (size_t)want * sizeof(int32_t)));
+        c->pair_cap = want;
+    }
+    return BFG_OK;
+}
+
 static int check_args(const bfg_shell_args *a, const bfg_table *t, const bfg_spline *s, const void *d_out)
 {
     if (!a || !t || !s || !d_out) return BFG_ERR_INVALID;
@@ -949,6 +1059,31 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     rc = ensure_workspace(c, a->n_halo);
     if (rc) return rc;
 
+    int variant = a->variant;
+    // the tile variant needs a uniform ln r axis (direct cell computation); paint only for now
+    const bool tile_ok = (mode == MODE_PAINT) && t->dev.r_uniform && a->nside >= 8 && a->n_halo < (1ll << 31);
+    if (variant == BFG_VARIANT_AUTO) variant = tile_ok ? BFG_VARIANT_TILE_LDS : BFG_VARIANT_SCATTER_QUARTER;
+    if (variant == BFG_VARIANT_TILE_LDS && !tile_ok) variant = BFG_VARIANT_SCATTER_QUARTER;
+    const bool tile = (variant == BFG_VARIANT_TILE_LDS);
+    // row window of the tile path: ~3.5 e-folds of radius below the disc edge (r_max/33 .. r_max)
+    int win_nodes = 0;
+    if (tile) {
+        win_nodes = (int)std::ceil(3.5 * t->dev.inv_dr) + 2;
+        win_nodes = std::max(8, std::min(win_nodes, 256));
+        win_nodes = (int)std::min<int64_t>(win_nodes, t->dev.nr);
+        rc = ensure_tiles(c, a->nside, a->n_halo);
+        if (rc) return rc;
+        const int64_t want = a->n_halo * (int64_t)win_nodes;
+        if (want > c->hwin_cap) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->d_hwin) (void)hipFree(c->d_hwin);
+            c->d_hwin = nullptr; c->hwin_cap = 0;
+            HIP_TRY(hipMalloc((void **)&c->d_hwin, (size_t)want * sizeof(double2)));
+            c->hwin_cap = want;
+        }
+    }
+    const double pixfac_area = a->include_pixel_size ? 4.0 * kPi / (double)(12 * a->nside * a->nside) : 0.0;
+
     PrepParams pp;
     std::memset(&pp, 0, sizeof(pp));
     pp.hpx = make_hpx(a->nside);
@@ -961,6 +1096,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     pp.rec = c->d_rec; pp.irec = c->d_irec; pp.cidx = c->d_cidx; pp.cw = c->d_cw;
     pp.stats = c->d_stats;
     pp.want_model_radius = (mode == MODE_BARYONIFY);
+    pp.ht = tile ? c->d_ht : nullptr; pp.win_nodes = win_nodes; pp.pixfac_area = pixfac_area;
     timing_begin(c, 0);
     hipLaunchKernelGGL(halo_prep_kernel, dim3((unsigned)((a->n_halo + 255) / 256)), dim3(256), 0, c->stream, pp);
     HIP_TRY(hipGetLastError());
@@ -973,12 +1109,60 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     sp.cat = a->d_catalog; sp.cat_stride = a->cat_stride;
     sp.tab = t->dev;
     sp.eps_model = a->model_epsilon_max; sp.rdelta = a->rdelta_sampling;
-    sp.pixfac_area = a->include_pixel_size ? 4.0 * kPi / (double)pp.hpx.npix : 0.0;
+    sp.pixfac_area = pixfac_area;
     sp.out = d_out; sp.stats = c->d_stats;
 
-    int variant = a->variant;
-    if (variant == BFG_VARIANT_AUTO || variant == BFG_VARIANT_TILE_LDS) variant = BFG_VARIANT_SCATTER_QUARTER;
+    if (tile) {
+        timing_begin(c, 3);
+        HIP_TRY(hipMemsetAsync(c->d_tile_count, 0, (size_t)c->geo.ntiles * sizeof(int32_t), c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_pair_total, 0, sizeof(unsigned long long), c->stream));
+        BinParams bp;
+        std::memset(&bp, 0, sizeof(bp));
+        bp.hpx = pp.hpx; bp.n_halo = a->n_halo; bp.cap = c->cap_halo;
+        bp.rec = c->d_rec; bp.irec = c->d_irec; bp.ht = c->d_ht; bp.geo = c->geo;
+        bp.tile_count = c->d_tile_count; bp.tile_start = c->d_tile_start; bp.pairs = c->d_pairs;
+        bp.pair_total = c->d_pair_total; bp.pair_cap = c->pair_cap; bp.mode = mode;
+        const unsigned hgrid = (unsigned)((a->n_halo + 255) / 256);
+        bp.fill = 0;
+        hipLaunchKernelGGL(tile_bin_kernel, dim3(hgrid), dim3(256), 0, c->stream, bp);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->geo.ntiles, c->d_tile_count,
+                           c->d_tile_start);
+        bp.fill = 1;
+        hipLaunchKernelGGL(tile_bin_kernel, dim3(hgrid), dim3(256), 0, c->stream, bp);
+        RowParams rp;
+        std::memset(&rp, 0, sizeof(rp));
+        rp.n_halo = a->n_halo; rp.cap = c->cap_halo; rp.ht = c->d_ht; rp.cidx = c->d_cidx; rp.cw = c->d_cw;
+        rp.tab = t->dev; rp.win_nodes = win_nodes; rp.hwin = c->d_hwin;
+        const int64_t nrow = a->n_halo * (int64_t)win_nodes;
+        hipLaunchKernelGGL(halo_row_kernel, dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, c->stream, rp);
+        HIP_TRY(hipGetLastError());
+        timing_end(c, 3);
+
+        TileParams tp;
+        std::memset(&tp, 0, sizeof(tp));
+        tp.hpx = pp.hpx; tp.n_halo = a->n_halo; tp.cap = c->cap_halo;
+        tp.ht = c->d_ht; tp.cidx = c->d_cidx; tp.cw = c->d_cw;
+        tp.tab = t->dev; tp.geo = c->geo; tp.tile_start = c->d_tile_start; tp.pairs = c->d_pairs;
+        tp.hwin = c->d_hwin; tp.win_nodes = win_nodes;
+        tp.out = d_out; tp.stats = c->d_stats;
+        tp.logtab = reinterpret_cast<const double2 *>(c->d_mathtab);
+        tp.exptab = c->d_mathtab + 2 * kLogTab;
+        const size_t tlds = tile_lds_bytes();
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_tile_kernel<MODE_PAINT>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+            attr_set = true;
+        }
+        timing_begin(c, 1);
+        hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT>), dim3((unsigned)c->geo.ntiles), dim3(kTileThreads), tlds,
+                           c->stream, tp);
+        HIP_TRY(hipGetLastError());
+        timing_end(c, 1);
+        sp.only_flagged = 1;     // leftovers: halos the binning left to the global-atomic kernel
+    }
     const int G = (variant == BFG_VARIANT_SCATTER_WAVE) ? 64 : 16;
+    const int tslot = (variant == BFG_VARIANT_TILE_LDS) ? 4 : 1;
     const int gpb = 256 / G;
     // LDS: ring records + per-group (axis, value) window; keep a block at or under 64 KiB
     const size_t ring_bytes = (G == 64 ? sizeof(RingLds<64>) : sizeof(RingLds<16>)) * (size_t)gpb;
@@ -988,7 +1172,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     sp.win_nodes = win;
     const size_t lds = ring_bytes + (size_t)win * sizeof(double2) * (size_t)gpb;
     const unsigned grid = (unsigned)((a->n_halo + gpb - 1) / gpb);
-    timing_begin(c, 1);
+    timing_begin(c, tslot);
     if (mode == MODE_PAINT) {
         if (G == 64) hipLaunchKernelGGL((shell_scatter_kernel<64, MODE_PAINT>), dim3(grid), dim3(256), lds, c->stream, sp);
         else hipLaunchKernelGGL((shell_scatter_kernel<16, MODE_PAINT>), dim3(grid), dim3(256), lds, c->stream, sp);
@@ -997,7 +1181,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         else hipLaunchKernelGGL((shell_scatter_kernel<16, MODE_BARYONIFY>), dim3(grid), dim3(256), lds, c->stream, sp);
     }
     HIP_TRY(hipGetLastError());
-    timing_end(c, 1);
+    timing_end(c, tslot);
     return BFG_OK;
 }
 
@@ -1071,7 +1255,7 @@ int bfg_timing_enable(bfg_ctx *c, int enable)
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->timing = enable != 0;
-    for (int k = 0; k < 3; ++k) { c->t_ms[k] = 0; c->t_n[k] = 0; c->ev_used[k] = 0; }
+    for (int k = 0; k < 5; ++k) { c->t_ms[k] = 0; c->t_n[k] = 0; c->ev_used[k] = 0; }
     return BFG_OK;
 }
 
@@ -1079,7 +1263,7 @@ int bfg_timing_read(bfg_ctx *c, int which, double *ms_total, int64_t *launches)
 {
     int rc = ctx_enter(c);
     if (rc) return rc;
-    if (which < 0 || which > 2) return BFG_ERR_INVALID;
+    if (which < 0 || which > 4) return BFG_ERR_INVALID;
     timing_fold(c, which);
     if (ms_total) *ms_total = c->t_ms[which];
     if (launches) *launches = c->t_n[which];

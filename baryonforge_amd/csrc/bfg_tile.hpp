@@ -1,0 +1,500 @@
+// bfg_tile.hpp -- sky-tile privatised variant of the paint kernel (BFG_VARIANT_TILE_LDS).
+//
+// Why: measured on MI355X (profiles/r01_atomic_microbench.txt) global f64 atomics top out at
+// 1.0-1.3e11 adds/s for the 8-16 pixel ring segments a disc produces, i.e. >= 2 ms for the
+// 2.8e8 pixel-updates of the headline workload, while LDS f64 atomics (ds_add_f64) run at
+// 2.0e12 adds/s.  So the map is cut into sky tiles (kTileRings consecutive rings x one phi
+// sector, <= kTileWidth pixels per ring row); every (halo, tile) overlap is binned on the device;
+// one workgroup per tile accumulates all its halos into an LDS copy of the tile and writes the
+// tile back with plain coalesced stores (each pixel belongs to exactly one tile: no global
+// atomics on this path).
+//
+// Work decomposition inside a tile workgroup (512 threads = 8 wavefronts), per chunk of pairs:
+//   stage a  one thread per (halo, tile) pair  : halo record -> ring range inside the band
+//   stage b  one thread per (pair, ring)       : query_disc ring window, clipped to the sector
+//                                                -> 64-byte segment record in LDS
+//   stage c  one lane per segment, 64 segments per wave batch: wave prefix scan of the pixel
+//            counts, then a flattened, fully populated loop over the pixels of the batch:
+//            sin^2(dphi/2) polynomial -> chord^2 = A + B sin^2 -> table-driven ln -> cell and
+//            fraction on the uniform ln r axis -> the halo's pre-blended profile row (value,
+//            forward difference; built once per halo by halo_row_kernel) -> table-driven exp
+//            -> ds_add_f64 into the tile.
+// All arithmetic is float64; the ln / exp kernels are table + short polynomial
+// (|rel err| < 1e-12), not libm calls.
+#pragma once
+#include "bfg_device.hpp"
+
+namespace bfg {
+
+// ---- table-driven ln / exp (float64) -----------------------------------------------------------
+// ln: x = 2^e m, m in [1, 2); c = 1 + (idx + 0.5)/128 from the top 7 mantissa bits;
+//     ln x = e ln2 + ln c + log1p(m/c - 1), |m/c - 1| < 2^-8, 4-term series (rel err ~2e-13).
+__device__ inline double fast_log(double x, const double2 *__restrict__ tab)
+{
+    const int hi = __double2hiint(x);
+    const int lo = __double2loint(x);
+    const int e = (hi >> 20) - 1023;                 // x is positive, finite and normal here
+    const int idx = (hi >> 13) & (kLogTab - 1);
+    const double m = __hiloint2double((hi & 0x000FFFFF) | 0x3FF00000, lo);
+    const double2 t = tab[idx];                      // {1/c, ln c}
+    const double r = fma(m, t.x, -1.0);
+    double p = fma(r, -0.25, 1.0 / 3.0);
+    p = fma(r, p, -0.5);
+    p = fma(r, p, 1.0);
+    return fma((double)e, 0.693147180559945309417232, fma(r, p, t.y));
+}
+
+// exp: L = k ln2/64 + r, |r| <= ln2/128; exp L = 2^(k>>6) * 2^((k&63)/64) * (1 + r + r^2/2 + r^3/6 + r^4/24)
+__device__ inline double fast_exp(double L, const double *__restrict__ tab)
+{
+    const double kf = rint(L * 92.332482616893656877476);          // 64 / ln 2
+    double r = fma(kf, -0.010830424696249145459412, L);             // ln2 / 64 (hi)
+    r = fma(kf, -2.5728046223276688e-19, r);                        //          (lo)
+    const int k = (int)kf;
+    double p = fma(r, 1.0 / 24.0, 1.0 / 6.0);
+    p = fma(r, p, 0.5);
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    return ldexp(tab[k & (kExpTab - 1)] * p, k >> 6);
+}
+
+// sin^2(h) for |h| <= 0.5 (series to h^12, rel err < 3e-11 of h^2); exact sin beyond
+__device__ inline double sin_squared(double h)
+{
+    const double h2 = h * h;
+    if (h2 <= 0.25) {
+        double p = fma(h2, -2.0 / 467775.0, 2.0 / 14175.0);
+        p = fma(h2, p, -1.0 / 315.0);
+        p = fma(h2, p, 2.0 / 45.0);
+        p = fma(h2, p, -1.0 / 3.0);
+        p = fma(h2, p, 1.0);
+        return h2 * p;
+    }
+    const double s = sin(h);
+    return s * s;
+}
+
+// Per-halo record of the tile path (one 128-byte line per halo, written by halo_prep_kernel)
+struct __align__(16) HaloTile {
+    double st, ct, pphi, S;          // sin/cos of the halo colatitude, longitude, (D/a)^2
+    double cosr, z0, xa, pixfac;     // query_disc constants, pixarea * D^2 (or 1)
+    int32_t rfirst, rlast, irmin, irmax;
+    int32_t win_lo, flags, pad0, pad1;
+    double spare[4];
+};
+static_assert(sizeof(HaloTile) == 128, "HaloTile must be one 128-byte line");
+
+struct __align__(16) Seg {           // one ring segment of one halo inside one tile (64 bytes)
+    int32_t iplo, abase, excl, win_lo;
+    double hstep, c0, Aq, Bq;
+    int64_t hoff;                    // index of the halo's row window in hwin
+    double pixfac;
+};
+static_assert(sizeof(Seg) == 64, "Seg must be 64 bytes");
+
+struct __align__(16) RingRow {       // one ring of the tile's band (computed once per workgroup)
+    double z, sth, phistep, phioff;
+    int32_t nr, k0, k1, rowoff;      // rowoff = row * TW - k0
+};
+
+struct TileParams {
+    Hpx hpx;
+    int64_t n_halo, cap;
+    const HaloTile *ht;
+    const int32_t *cidx;             // outer-cell indices / weights (slow path only)
+    const double *cw;
+    DevTable tab;
+    TileGeom geo;
+    const int32_t *tile_start;       // [ntiles+1]
+    const int32_t *pairs;            // halo ids grouped by tile
+    const double2 *hwin;             // [n_halo][win_nodes] {B_i, B_{i+1} - B_i}
+    int win_nodes;
+    double *out;
+    bfg_stats *stats;
+    const double2 *logtab;           // [128] {1/c, ln c}
+    const double *exptab;            // [64]  2^(j/64)
+};
+
+struct BinParams {
+    Hpx hpx;
+    int64_t n_halo, cap;
+    const double *rec;
+    int32_t *irec;
+    HaloTile *ht;
+    TileGeom geo;
+    int32_t *tile_count;     // [ntiles] (count pass) / cursor (fill pass)
+    const int32_t *tile_start;
+    int32_t *pairs;
+    unsigned long long *pair_total;
+    long long pair_cap;
+    int fill;
+    int mode;                // MODE_PAINT / MODE_BARYONIFY
+};
+
+// sectors of band b whose phi range can intersect the disc: [s_lo, s_lo + n) modulo NS
+__device__ inline void band_sectors(const TileGeom &G, int b, double pphi, double dphi_bound, int &s_lo, int &n)
+{
+    const int NS = G.band_ns[b];
+    const double half = dphi_bound + 2.0 * kTwoPi / (double)G.band_nrmin[b];   // two pixels of slack
+    if (!(half < kPi) || NS == 1) { s_lo = 0; n = NS; return; }
+    const double f = (double)NS * kInvTwoPi;
+    const int a = (int)floor((pphi - half) * f);
+    const int e = (int)floor((pphi + half) * f);
+    n = e - a + 1;
+    if (n >= NS) { s_lo = 0; n = NS; return; }
+    s_lo = ((a % NS) + NS) % NS;
+}
+
+// Bin halos into tiles: count pass (fill = 0) and fill pass (fill = 1).  Halos that overlap too
+// many tiles, lie outside the table hull, or would overflow the pair buffer are flagged
+// HF_SCATTER and left to the global-atomic scatter kernel.
+__global__ __launch_bounds__(256) void tile_bin_kernel(const BinParams P)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P.n_halo) return;
+    const int64_t cap = P.cap;
+    int32_t flags = P.irec[I_FLAGS * cap + j];
+    if (flags & HF_SKIP) return;
+    if (P.fill && (flags & HF_SCATTER)) return;
+    const int32_t rfirst = P.irec[I_RFIRST * cap + j], rlast = P.irec[I_RLAST * cap + j];
+    const int32_t irmin = P.irec[I_IRMIN * cap + j], irmax = P.irec[I_IRMAX * cap + j];
+    const double ptheta = P.rec[F_PTHETA * cap + j], pphi = P.rec[F_PPHI * cap + j];
+    const double radius = P.rec[F_RADIUS * cap + j];
+    bool to_scatter = (flags & HF_OOB) != 0;
+    int b0 = 0, b1 = -1;
+    if (rlast >= rfirst) { b0 = (rfirst - 1) / kTileRings; b1 = (rlast - 1) / kTileRings; }
+    else if (P.mode == MODE_BARYONIFY) to_scatter = true;        // empty disc -> 4-neighbour fallback
+    // longitude half-extent of the disc: asin(sin r / sin theta0), or everything if a pole is inside
+    double dphi_bound = kPi;
+    const bool pole_inside = (rfirst < irmin) || (rlast > irmax) || !(radius < kPi) || (ptheta - radius <= 0) ||
+                             (ptheta + radius >= kPi);
+    if (!pole_inside) {
+        const double q = sin(radius) / sin(ptheta);
+        dphi_bound = (q < 1.0) ? asin(q) : kPi;
+    }
+    int npairs = 0;
+    for (int b = b0; b <= b1; ++b) { int s_lo, n; band_sectors(P.geo, b, pphi, dphi_bound, s_lo, n); npairs += n; }
+    if (!P.fill) {
+        if (npairs > kMaxPairsPerHalo) to_scatter = true;
+        if (!to_scatter && npairs > 0) {
+            unsigned long long pos = atomicAdd(P.pair_total, (unsigned long long)npairs);
+            if ((long long)(pos + npairs) > P.pair_cap) to_scatter = true;
+        }
+        if (to_scatter) { P.irec[I_FLAGS * cap + j] = flags | HF_SCATTER; P.ht[j].flags = flags | HF_SCATTER; return; }
+    }
+    for (int b = b0; b <= b1; ++b) {
+        int s_lo, n;
+        band_sectors(P.geo, b, pphi, dphi_bound, s_lo, n);
+        const int NS = P.geo.band_ns[b], t0 = P.geo.band_tile0[b];
+        for (int i = 0; i < n; ++i) {
+            int s = s_lo + i; if (s >= NS) s -= NS;
+            const int tile = t0 + s;
+            if (!P.fill) atomicAdd(&P.tile_count[tile], 1);
+            else {
+                const int pos = atomicAdd(&P.tile_count[tile], 1);      // cursor
+                P.pairs[P.tile_start[tile] + pos] = (int32_t)j;
+            }
+        }
+    }
+}
+
+// exclusive scan of tile_count into tile_start[ntiles+1]; single workgroup
+__global__ __launch_bounds__(1024) void tile_scan_kernel(int ntiles, int32_t *count, int32_t *start)
+{
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < ntiles; base += 1024) {
+        const int i = base + threadIdx.x;
+        int v = (i < ntiles) ? count[i] : 0;
+        int incl = v;
+        for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(incl, d, 64); if ((threadIdx.x & 63) >= d) incl += o; }
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
+        const int c = carry;
+        if (i < ntiles) { start[i] = c + woff + incl - v; count[i] = 0; }   // count becomes the fill cursor
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) start[ntiles] = carry;
+}
+
+// Per-halo blended radial row: hwin[j][e] = {B_i, B_{i+1} - B_i}, i = win_lo_j + e, where
+// B_i = sum over the 2^(ndim-1) corners of the halo's (z, M, extras) cell of w_c * T[c][i].
+// One thread per (halo, node); built once per halo instead of once per (halo, tile) pair.
+struct RowParams {
+    int64_t n_halo, cap;
+    const HaloTile *ht;
+    const int32_t *cidx;
+    const double *cw;
+    DevTable tab;
+    int win_nodes;
+    double2 *hwin;
+};
+
+__global__ __launch_bounds__(256) void halo_row_kernel(const RowParams P)
+{
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t j = gid / P.win_nodes;
+    const int e = (int)(gid - j * P.win_nodes);
+    if (j >= P.n_halo) return;
+    const int flags = P.ht[j].flags;
+    if (flags & (HF_SKIP | HF_OOB)) return;
+    const DevTable &T = P.tab;
+    const int ir = P.ht[j].win_lo + e;
+    const int ir1 = min(ir + 1, T.nr - 1);
+    double b0 = 0.0, b1 = 0.0;
+    const int ncorner = 1 << T.nouter;
+    for (int c = 0; c < ncorner; ++c) {
+        double w = 1.0;
+        int64_t off = 0;
+        for (int k = 0; k < T.nouter; ++k) {
+            const int bit = (c >> (T.nouter - 1 - k)) & 1;
+            const double y = P.cw[k * P.cap + j];
+            const int i = P.cidx[k * P.cap + j];
+            w = w * (bit ? y : 1.0 - y);
+            off += (int64_t)(i + bit) * T.ostride[k];
+        }
+        b0 = fma(T.values[off + ir], w, b0);
+        b1 = fma(T.values[off + ir1], w, b1);
+    }
+    P.hwin[j * P.win_nodes + e] = make_double2(b0, b1 - b0);
+}
+
+constexpr int kTileThreads = 512;
+constexpr int kPairChunk = 64;       // pairs examined per chunk (one wavefront scans them)
+constexpr int kSegMax = 768;         // segment records per chunk (48 KiB of LDS)
+constexpr int kSlotMax = kSegMax / 2;// (pair, ring) slots per chunk; each may add one wrapped second piece
+
+__host__ __device__ inline size_t tile_lds_bytes()
+{
+    return (size_t)kTileRings * kTileWidth * sizeof(double) + kLogTab * sizeof(double2) + kExpTab * sizeof(double) +
+           kTileRings * sizeof(RingRow) + kSegMax * sizeof(Seg) + (3 * kPairChunk + 4) * sizeof(int32_t) +
+           (kTileThreads / 64) * 64 * sizeof(int32_t) + 4 * sizeof(int32_t);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileParams P)
+{
+    constexpr int TR = kTileRings, TW = kTileWidth, NT = kTileThreads, NW = kTileThreads / 64;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    double *acc = reinterpret_cast<double *>(smem_raw);                       // [TR*TW]
+    double2 *logtab = reinterpret_cast<double2 *>(acc + TR * TW);             // [128]
+    double *exptab = reinterpret_cast<double *>(logtab + kLogTab);            // [64]
+    RingRow *rows = reinterpret_cast<RingRow *>(exptab + kExpTab);            // [TR]
+    Seg *segs = reinterpret_cast<Seg *>(rows + TR);                           // [kSegMax]
+    int32_t *pr_halo = reinterpret_cast<int32_t *>(segs + kSegMax);           // [kPairChunk]
+    int32_t *pr_ra = pr_halo + kPairChunk;                                    // first ring of the pair in the band
+    int32_t *pr_off = pr_ra + kPairChunk;                                     // exclusive slot offsets [kPairChunk + 1]
+    int32_t *flagbuf = pr_off + kPairChunk + 4;                               // [NW][64] start-of-segment markers
+    int32_t *ctl = flagbuf + NW * 64;                                         // n_take, nslots, extra
+
+    const int tile = blockIdx.x;
+    const int n_pairs = P.tile_start[tile + 1] - P.tile_start[tile];
+    if (n_pairs == 0) return;
+    const Hpx &hp = P.hpx;
+    const DevTable &T = P.tab;
+    const int band = P.geo.tile_band[tile];
+    const int sector = tile - P.geo.band_tile0[band];
+    const int NS = P.geo.band_ns[band];
+    const int ring_lo = 1 + band * TR;
+    const int ring_hi = min((int)(4 * hp.nside - 1), ring_lo + TR - 1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    for (int i = tid; i < TR * TW; i += NT) acc[i] = 0.0;
+    if (tid < kLogTab) logtab[tid] = P.logtab[tid];
+    if (tid < kExpTab) exptab[tid] = P.exptab[tid];
+    if (tid < TR) {
+        const int ring = ring_lo + tid;
+        RingRow rr;
+        rr.z = 0; rr.sth = 0; rr.phistep = 0; rr.phioff = 0; rr.nr = 1; rr.k0 = 0; rr.k1 = 0; rr.rowoff = 0;
+        if (ring <= ring_hi) {
+            const RingGeom g = ring_geom(hp, ring);
+            rr.z = g.z;                // identical formula to ring2z, which query_disc uses
+            rr.sth = g.sth; rr.phistep = g.phistep; rr.phioff = g.phioff; rr.nr = g.nr;
+            rr.k0 = (int)(((int64_t)sector * g.nr) / NS);
+            rr.k1 = (int)(((int64_t)(sector + 1) * g.nr) / NS);
+            rr.rowoff = tid * TW - rr.k0;
+        }
+        rows[tid] = rr;
+    }
+    __syncthreads();
+
+    const double inv_dr = T.inv_dr;
+    const double t_c = (-T.r0) * inv_dr, t_m = 0.5 * inv_dr;     // cell coordinate t = ln(x) * t_m + t_c
+    const int NRm1 = T.nr - 1;
+    const int W = P.win_nodes;
+    unsigned long long my_pixels = 0, n_r_oob = 0;
+    const int32_t *plist = P.pairs + P.tile_start[tile];
+
+    for (int base = 0; base < n_pairs;) {
+        // ---- stage a: one thread per pair of the chunk ------------------------------------------
+        if (wave == 0) {
+            int nrings = 0, ra = 0, j = -1;
+            const bool valid = base + lane < n_pairs;
+            if (valid) {
+                j = plist[base + lane];
+                const HaloTile &h = P.ht[j];
+                ra = max(h.rfirst, ring_lo);
+                const int rb = min(h.rlast, ring_hi);
+                nrings = max(0, rb - ra + 1);
+            }
+            int cum = nrings;
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(cum, d, 64); if (lane >= d) cum += o; }
+            // take the longest prefix of pairs whose (pair, ring) slots fit; always at least one pair
+            const bool fits = valid && (cum <= kSlotMax || lane == 0);
+            const unsigned long long fm = __ballot(fits);
+            const int first_bad = __ffsll((long long)~fm);          // 1-based; 0 if all 64 fit
+            const int n_take = first_bad ? first_bad - 1 : 64;
+            pr_halo[lane] = j; pr_ra[lane] = ra; pr_off[lane] = cum - nrings;
+            if (lane == n_take - 1) { pr_off[n_take] = cum; ctl[0] = n_take; ctl[1] = cum; ctl[2] = 0; }
+        }
+        __syncthreads();
+        const int n_take = ctl[0], nslots = ctl[1];
+
+        // ---- stage b: one thread per (pair, ring) slot ----------------------------------------------
+        for (int slot = tid; slot < nslots; slot += NT) {
+            int lo_ = 0, hi_ = n_take - 1;          // pair p with pr_off[p] <= slot < pr_off[p+1]
+            while (lo_ < hi_) { const int mid = (lo_ + hi_ + 1) >> 1; if (pr_off[mid] <= slot) lo_ = mid; else hi_ = mid - 1; }
+            const int p = lo_;
+            const int j = pr_halo[p];
+            const int ring = pr_ra[p] + (slot - pr_off[p]);
+            const RingRow rr = rows[ring - ring_lo];
+            const HaloTile &h = P.ht[j];
+            const double st = h.st, ct = h.ct, pphi = h.pphi, S = h.S;
+            const int nr = rr.nr;
+            int lo = 0, cnt = 0;
+            if (ring < h.irmin || ring > h.irmax) cnt = nr;         // ring entirely inside the disc
+            else {
+                const double x = (h.cosr - rr.z * h.z0) * h.xa;
+                const double ysq = 1.0 - rr.z * rr.z - x * x;
+                const double dphi = (ysq <= 0.0) ? 0.0 : atan2(sqrt(ysq), x);
+                if (dphi > 0.0) {
+                    const double shift = (rr.phioff != 0.0) ? 0.5 : 0.0;
+                    const int64_t l64 = (int64_t)floor((double)nr * kInvTwoPi * (pphi - dphi) - shift) + 1;
+                    const int64_t h64 = (int64_t)floor((double)nr * kInvTwoPi * (pphi + dphi) - shift);
+                    int64_t c = h64 - l64 + 1;
+                    if (c > nr) c = nr;
+                    if (c > 0) { cnt = (int)c; lo = (int)l64; }      // unwrapped: lo in (-nr, 1.5 nr)
+                }
+            }
+            Seg sg;
+            sg.iplo = 0; sg.abase = 0; sg.excl = 0; sg.win_lo = h.win_lo;
+            sg.hstep = 0.5 * rr.phistep;
+            sg.c0 = 0.5 * (rr.phioff * rr.phistep - pphi);
+            const double ds = rr.sth - st, dz = rr.z - ct;
+            sg.Aq = (ds * ds + dz * dz) * S;
+            sg.Bq = 4.0 * rr.sth * st * S;
+            sg.hoff = (int64_t)j * W;
+            sg.pixfac = h.pixfac;
+            int np = 0;
+            if (cnt > 0) {
+#pragma unroll
+                for (int mi = 0; mi < 3; ++mi) {
+                    const int m = (mi == 0) ? 0 : (mi == 1 ? -1 : 1);
+                    const int aa = max(lo, rr.k0 + m * nr), bb = min(lo + cnt, rr.k1 + m * nr);
+                    if (bb > aa && np < 2) {
+                        sg.iplo = aa; sg.excl = bb - aa; sg.abase = rr.rowoff - m * nr;   // excl = count for now
+                        if (np == 0) segs[slot] = sg;
+                        else segs[nslots + atomicAdd(&ctl[2], 1)] = sg;                 // at most one per slot
+                        ++np;
+                    }
+                }
+            }
+            if (np == 0) { sg.excl = 0; segs[slot] = sg; }
+        }
+        __syncthreads();
+        const int nseg = nslots + ctl[2];
+
+        // ---- stage c: 64 segments per wave batch, flattened pixel loop --------------------------------
+        int32_t *flg = flagbuf + wave * 64;
+        for (int b0 = wave * 64; b0 < nseg; b0 += NW * 64) {
+            const int sidx = b0 + lane;
+            const int cnt = (sidx < nseg) ? segs[sidx].excl : 0;
+            int cum = cnt;
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(cum, d, 64); if (lane >= d) cum += o; }
+            const int excl = cum - cnt;
+            const int total = __shfl(cum, 63, 64);
+            if (sidx < nseg) segs[sidx].excl = excl;
+            my_pixels += (lane == 0) ? (unsigned long long)total : 0ull;
+            for (int q0 = 0; q0 < total; q0 += 64) {
+                // which segment does pixel q0 + lane belong to?  start-of-segment markers + ballot
+                flg[lane] = 0;
+                __builtin_amdgcn_wave_barrier();
+                if (cnt > 0 && excl >= q0 && excl < q0 + 64) flg[excl - q0] = lane + 1;
+                __builtin_amdgcn_wave_barrier();
+                const int mark = flg[lane];
+                const unsigned long long mm = __ballot(mark != 0);
+                const unsigned long long below = mm & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+                // no marker at or before this lane: the segment that contains pixel q0
+                const unsigned long long started = __ballot(cnt > 0 && excl < q0);
+                const int carry = 63 - __clzll((long long)started);
+                const int src = below ? (63 - __clzll((long long)below)) : 0;
+                const int from_mark = __shfl(mark, src, 64) - 1;
+                const int sl = below ? from_mark : carry;
+                const int q = q0 + lane;
+                if (q < total) {
+                    const Seg &sg = segs[b0 + sl];
+                    const int ipu = sg.iplo + (q - sg.excl);               // unwrapped pixel index in the ring
+                    const double h = fma((double)ipu, sg.hstep, sg.c0);
+                    const double x = fma(sg.Bq, sin_squared(h), sg.Aq);    // r_com^2
+                    double v = 0.0;
+                    if (x > 0.0) {
+                        const double tt = fma(fast_log(x, logtab), t_m, t_c);
+                        if (tt >= 0.0 && tt <= (double)NRm1) {
+                            int i = (int)tt; if (i > NRm1 - 1) i = NRm1 - 1;
+                            const double frac = tt - (double)i;
+                            const int e = i - sg.win_lo;
+                            double L;
+                            if (e >= 0 && e < W - 1) { const double2 w2 = P.hwin[sg.hoff + e]; L = fma(frac, w2.y, w2.x); }
+                            else {                       // rare: cell outside the halo's staged row window
+                                const int64_t j = sg.hoff / W;
+                                double c0v = 0.0, c1v = 0.0;
+                                const int ncorner = 1 << T.nouter;
+                                for (int c = 0; c < ncorner; ++c) {
+                                    double w = 1.0; int64_t off = 0;
+                                    for (int k = 0; k < T.nouter; ++k) {
+                                        const int bit = (c >> (T.nouter - 1 - k)) & 1;
+                                        const double y = P.cw[k * P.cap + j];
+                                        w = w * (bit ? y : 1.0 - y);
+                                        off += (int64_t)(P.cidx[k * P.cap + j] + bit) * T.ostride[k];
+                                    }
+                                    c0v = fma(T.values[off + i], w, c0v);
+                                    c1v = fma(T.values[off + i + 1], w, c1v);
+                                }
+                                L = fma(frac, c1v - c0v, c0v);
+                            }
+                            // NaN / +-inf / overflowing L paint nothing (HealpixRunner.py:473)
+                            if (L > -746.0 && L < 709.0) v = fast_exp(L, exptab) * sg.pixfac;
+                        } else ++n_r_oob;
+                    } else ++n_r_oob;
+                    if (v != 0.0) unsafeAtomicAdd(&acc[sg.abase + ipu], v);
+                }
+            }
+        }
+        __syncthreads();
+        base += n_take;
+    }
+    if (my_pixels) atomicAdd((unsigned long long *)&P.stats->pixel_updates, my_pixels);
+    if (n_r_oob) {
+        atomicAdd((unsigned long long *)&P.stats->pixels_out_of_table, n_r_oob);
+        atomicOr(&P.stats->warn_mask, BFG_WARN_R_RANGE);
+    }
+    // write the tile back: every pixel belongs to exactly one tile -> plain read-modify-write
+    for (int i = tid; i < TR * TW; i += NT) {
+        const int row = i / TW, col = i % TW;
+        const int ring = ring_lo + row;
+        if (ring > ring_hi) break;
+        const double v = acc[i];
+        if (v == 0.0) continue;
+        int64_t start, nr64; bool shifted;
+        ring_info_small(hp, ring, start, nr64, shifted);
+        P.out[start + rows[row].k0 + col] += v;
+    }
+}
+
+}  // namespace bfg

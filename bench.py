@@ -184,6 +184,8 @@ def main():
     k_ms, k_n = ctx.timing_read(1)
     p_ms, p_n = ctx.timing_read(0)
     r_ms, r_n = ctx.timing_read(2)
+    b_ms, b_n = ctx.timing_read(3)
+    l_ms, l_n = ctx.timing_read(4)
     ctx.timing_enable(False)
     ptot_step = stats["pixel_updates"] / max(args.steps, 1)
     if dist is not None:
@@ -215,7 +217,9 @@ def main():
             traffic = json.load(open(tfile)).get(f"{args.workload}_{args.variant}_n{args.halos}_nside{nside}")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "shell_scatter_kernel", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+    tile = args.workload == "paint" and args.variant in ("auto", "tile_lds")
+    roofline = {"bound": "hbm", "kernel": "shell_tile_kernel" if tile else "shell_scatter_kernel",
+                "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                 "kernel_ms": k_ms / max(k_n, 1), "kernel_launches": k_n,
                 "algorithmic_bytes_per_launch": kernel_bytes,
@@ -223,6 +227,8 @@ def main():
                 "pixel_updates_per_launch": ptot_step,
                 "pixel_updates_per_s": ptot_step / kernel_s if kernel_s > 0 else 0.0,
                 "prep_kernel_ms": p_ms / max(p_n, 1),
+                "tile_binning_ms": (b_ms / b_n) if b_n else None,
+                "leftover_scatter_kernel_ms": (l_ms / l_n) if l_n else None,
                 "regrid_kernel_ms": (r_ms / r_n) if r_n else None,
                 "step_algorithmic_GBps": (kernel_bytes + 16.0 * npix * (1 if args.workload == "paint" else 8)) /
                                          (dt / args.steps) / 1e9}

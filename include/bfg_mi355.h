@@ -55,8 +55,10 @@ const char *bfg_status_string(int status);
 const char *bfg_last_error(void);                 /* thread-local detail of the last BFG_ERR_HIP */
 int bfg_device_count(int *count);
 
-/* stream: an existing hipStream_t to enqueue on (e.g. torch's current stream),
- * or NULL to let the context create and own one. */
+/* stream: the hipStream_t to enqueue on -- e.g. torch's current stream; NULL is the legacy
+ * default stream (which IS torch's default stream) -- or BFG_STREAM_OWN to let the context
+ * create and own a non-blocking stream of its own. */
+#define BFG_STREAM_OWN ((void *)(intptr_t)-1)
 int bfg_ctx_create(int device_id, void *stream, bfg_ctx **out);
 int bfg_ctx_destroy(bfg_ctx *ctx);
 int bfg_ctx_synchronize(bfg_ctx *ctx);
@@ -180,9 +182,10 @@ int bfg_stats_reset(bfg_ctx *ctx);
 int bfg_stats_read(bfg_ctx *ctx, bfg_stats *out);   /* synchronises the stream */
 
 /* Optional per-kernel timing with hipEvents on the context's stream (bench.py's
- * roofline leg).  which: 0 = halo preparation, 1 = paint / offsets kernel(s),
- * 2 = regrid.  Returns the accumulated milliseconds and launch count since the
- * last enable.                                                                        */
+ * roofline leg).  which: 0 = halo preparation kernel, 1 = the dominant shell kernel
+ * (tile kernel, or the scatter kernel of the scatter variants), 2 = regrid kernel,
+ * 3 = tile binning (count + scan + fill), 4 = left-over scatter kernel of the tile
+ * variant.  Returns the accumulated milliseconds and launch count since the last enable. */
 int bfg_timing_enable(bfg_ctx *ctx, int enable);
 int bfg_timing_read(bfg_ctx *ctx, int which, double *ms_total, int64_t *launches);
 

@@ -20,7 +20,7 @@ RTOL = 1e-5  # north_star: "to within 1e-5 relative on non-zero pixels"
 # acos()/atan2() near the poles (healpy's vec2ang has the same conditioning); they are compared
 # absolutely, at 1e-9 of the map's maximum.
 BFLOOR = 1e-9
-VARIANTS = ["scatter_wave", "scatter_quarter"]
+VARIANTS = ["scatter_wave", "scatter_quarter", "tile_lds"]
 
 
 def _paint_model(zax, Max, rax, T, pax=None):
@@ -231,9 +231,10 @@ def test_paint_full_size_linearity_1e5(cosmo):
     b, p_b = run(slice(50000, None))
     assert p_full == p_a + p_b
     assert_maps_close(a + b, full, 1e-10, what="linearity")
-    w, p_w = run(slice(None), "scatter_wave")
-    assert p_w == p_full
-    assert_maps_close(w, full, 1e-10, what="variants")
+    for other in ("scatter_wave", "scatter_quarter"):   # "auto" is the LDS tile variant
+        w, p_w = run(slice(None), other)
+        assert p_w == p_full
+        assert_maps_close(w, full, 1e-8, what=f"variants {other}")
     assert np.all(full >= 0) and np.isfinite(full).all()
 
 
