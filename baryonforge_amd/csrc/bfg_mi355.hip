@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -1070,6 +1071,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     if (tile) {
         win_nodes = (int)std::ceil(3.5 * t->dev.inv_dr) + 2;
         win_nodes = std::max(8, std::min(win_nodes, 256));
+        if (win_nodes <= kWinLds + kWinLds / 4) win_nodes = std::min(win_nodes, kWinLds);   // fits the LDS staging
         win_nodes = (int)std::min<int64_t>(win_nodes, t->dev.nr);
         rc = ensure_tiles(c, a->nside, a->n_halo);
         if (rc) return rc;
@@ -1147,16 +1149,23 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         tp.out = d_out; tp.stats = c->d_stats;
         tp.logtab = reinterpret_cast<const double2 *>(c->d_mathtab);
         tp.exptab = c->d_mathtab + 2 * kLogTab;
+        { const char *dbg = std::getenv("BFG_DEBUG"); tp.debug = dbg ? std::atoi(dbg) : 0; }
         const size_t tlds = tile_lds_bytes();
         static bool attr_set = false;
         if (!attr_set) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_tile_kernel<MODE_PAINT>),
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_tile_kernel<MODE_PAINT, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_tile_kernel<MODE_PAINT, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
             attr_set = true;
         }
         timing_begin(c, 1);
-        hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT>), dim3((unsigned)c->geo.ntiles), dim3(kTileThreads), tlds,
-                           c->stream, tp);
+        if (win_nodes <= kWinLds)
+            hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, true>), dim3((unsigned)c->geo.ntiles), dim3(kTileThreads),
+                               tlds, c->stream, tp);
+        else
+            hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, false>), dim3((unsigned)c->geo.ntiles), dim3(kTileThreads),
+                               tlds, c->stream, tp);
         HIP_TRY(hipGetLastError());
         timing_end(c, 1);
         sp.only_flagged = 1;     // leftovers: halos the binning left to the global-atomic kernel

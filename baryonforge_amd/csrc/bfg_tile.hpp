@@ -84,13 +84,17 @@ struct __align__(16) HaloTile {
 };
 static_assert(sizeof(HaloTile) == 128, "HaloTile must be one 128-byte line");
 
-struct __align__(16) Seg {           // one ring segment of one halo inside one tile (64 bytes)
-    int32_t iplo, abase, excl, win_lo;
-    double hstep, c0, Aq, Bq;
-    int64_t hoff;                    // index of the halo's row window in hwin
-    double pixfac;
+struct __align__(16) Seg {           // one ring segment of one halo inside one tile (48 bytes)
+    int32_t iplo, abase, excl, pidx; // first (unwrapped) pixel, tile address base, pixel offset, pair slot | win_lo << 8
+    double hstep, c0, Aq, Bq;        // h = ip * hstep + c0 ;  r_com^2 = Aq + Bq sin^2(h)
 };
-static_assert(sizeof(Seg) == 64, "Seg must be 64 bytes");
+static_assert(sizeof(Seg) == 48, "Seg must be 48 bytes");
+
+struct __align__(16) PairInfo {      // per (halo, tile) pair of the current chunk (32 bytes)
+    double pixfac;
+    int64_t hoff;                    // index of the halo's row window in hwin
+    int32_t win_lo, halo, ra, pad;
+};
 
 struct __align__(16) RingRow {       // one ring of the tile's band (computed once per workgroup)
     double z, sth, phistep, phioff;
@@ -113,6 +117,7 @@ struct TileParams {
     bfg_stats *stats;
     const double2 *logtab;           // [128] {1/c, ln c}
     const double *exptab;            // [64]  2^(j/64)
+    int debug;                       // ablation switches for profiling (BFG_DEBUG env; 0 in production)
 };
 
 struct BinParams {
@@ -247,6 +252,8 @@ __global__ __launch_bounds__(256) void halo_row_kernel(const RowParams P)
     const DevTable &T = P.tab;
     const int ir = P.ht[j].win_lo + e;
     const int ir1 = min(ir + 1, T.nr - 1);
+    // B_{i+1} is the neighbouring lane's B_i, except at the end of a window or of the wavefront
+    const bool own_next = (e == P.win_nodes - 1) || ((threadIdx.x & 63) == 63);
     double b0 = 0.0, b1 = 0.0;
     const int ncorner = 1 << T.nouter;
     for (int c = 0; c < ncorner; ++c) {
@@ -260,38 +267,45 @@ __global__ __launch_bounds__(256) void halo_row_kernel(const RowParams P)
             off += (int64_t)(i + bit) * T.ostride[k];
         }
         b0 = fma(T.values[off + ir], w, b0);
-        b1 = fma(T.values[off + ir1], w, b1);
+        if (own_next) b1 = fma(T.values[off + ir1], w, b1);
     }
+    const double nb = __shfl_down(b0, 1, 64);      // lane + 1 holds node e + 1 of the same halo when !own_next
+    if (!own_next) b1 = nb;
     P.hwin[j * P.win_nodes + e] = make_double2(b0, b1 - b0);
 }
 
 constexpr int kTileThreads = 512;
-constexpr int kPairChunk = 64;       // pairs examined per chunk (one wavefront scans them)
-constexpr int kSegMax = 768;         // segment records per chunk (48 KiB of LDS)
+constexpr int kPairMax = 24;         // pairs per chunk: their row windows are staged in LDS
+constexpr int kSegMax = 768;         // segment records per chunk (36 KiB of LDS)
 constexpr int kSlotMax = kSegMax / 2;// (pair, ring) slots per chunk; each may add one wrapped second piece
+constexpr int kWinLds = 32;          // row windows up to this many nodes are staged in LDS
+constexpr int kPixMax = 4096;        // pixel -> segment table entries per round (8 KiB of LDS)
+constexpr int kSegGroups = kSegMax / 64;
 
 __host__ __device__ inline size_t tile_lds_bytes()
 {
     return (size_t)kTileRings * kTileWidth * sizeof(double) + kLogTab * sizeof(double2) + kExpTab * sizeof(double) +
-           kTileRings * sizeof(RingRow) + kSegMax * sizeof(Seg) + (3 * kPairChunk + 4) * sizeof(int32_t) +
-           (kTileThreads / 64) * 64 * sizeof(int32_t) + 4 * sizeof(int32_t);
+           kTileRings * sizeof(RingRow) + kSegMax * sizeof(Seg) + kPairMax * sizeof(PairInfo) +
+           (size_t)kPairMax * kWinLds * sizeof(double2) + kPixMax * sizeof(uint16_t) +
+           (kPairMax + 4) * sizeof(int32_t) + (kSegGroups + 4) * sizeof(int32_t) + 8 * sizeof(int32_t);
 }
 
-template <int MODE>
+template <int MODE, bool WIN_LDS>
 __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileParams P)
 {
-    constexpr int TR = kTileRings, TW = kTileWidth, NT = kTileThreads, NW = kTileThreads / 64;
+    constexpr int TR = kTileRings, TW = kTileWidth, NT = kTileThreads;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     double *acc = reinterpret_cast<double *>(smem_raw);                       // [TR*TW]
     double2 *logtab = reinterpret_cast<double2 *>(acc + TR * TW);             // [128]
     double *exptab = reinterpret_cast<double *>(logtab + kLogTab);            // [64]
     RingRow *rows = reinterpret_cast<RingRow *>(exptab + kExpTab);            // [TR]
     Seg *segs = reinterpret_cast<Seg *>(rows + TR);                           // [kSegMax]
-    int32_t *pr_halo = reinterpret_cast<int32_t *>(segs + kSegMax);           // [kPairChunk]
-    int32_t *pr_ra = pr_halo + kPairChunk;                                    // first ring of the pair in the band
-    int32_t *pr_off = pr_ra + kPairChunk;                                     // exclusive slot offsets [kPairChunk + 1]
-    int32_t *flagbuf = pr_off + kPairChunk + 4;                               // [NW][64] start-of-segment markers
-    int32_t *ctl = flagbuf + NW * 64;                                         // n_take, nslots, extra
+    PairInfo *pinfo = reinterpret_cast<PairInfo *>(segs + kSegMax);           // [kPairMax]
+    double2 *pwin = reinterpret_cast<double2 *>(pinfo + kPairMax);            // [kPairMax][kWinLds]
+    uint16_t *ptab = reinterpret_cast<uint16_t *>(pwin + kPairMax * kWinLds); // [kPixMax] pixel -> segment
+    int32_t *pr_off = reinterpret_cast<int32_t *>(ptab + kPixMax);            // exclusive slot offsets [kPairMax + 1]
+    int32_t *gtot = pr_off + kPairMax + 4;                                    // per 64-segment group pixel totals
+    int32_t *ctl = gtot + kSegGroups + 4;                                     // n_take, nslots, extra
 
     const int tile = blockIdx.x;
     const int n_pairs = P.tile_start[tile + 1] - P.tile_start[tile];
@@ -322,27 +336,78 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
         }
         rows[tid] = rr;
     }
-    __syncthreads();
 
     const double inv_dr = T.inv_dr;
     const double t_c = (-T.r0) * inv_dr, t_m = 0.5 * inv_dr;     // cell coordinate t = ln(x) * t_m + t_c
     const int NRm1 = T.nr - 1;
     const int W = P.win_nodes;
+    constexpr bool win_in_lds = WIN_LDS;     // row windows of <= kWinLds nodes live in LDS, longer ones stay in HBM/L2
     unsigned long long my_pixels = 0, n_r_oob = 0;
     const int32_t *plist = P.pairs + P.tile_start[tile];
 
+    // wave 0 keeps the next chunk's pair records in flight while the others compute (stage a prefetch)
+    int nx_j = -1, nx_first = 0, nx_last = -1;
+    auto prefetch = [&](int base) {
+        nx_j = -1; nx_first = 0; nx_last = -1;
+        if (lane < kPairMax && base + lane < n_pairs) {
+            nx_j = plist[base + lane];
+            nx_first = P.ht[nx_j].rfirst; nx_last = P.ht[nx_j].rlast;
+        }
+    };
+    if (wave == 0) prefetch(0);
+    __syncthreads();
+
+    // one pixel of the flattened chunk: segment record -> chord^2 -> ln -> row read-out -> exp -> LDS add
+    auto paint_pixel = [&](int pglob, int sidx) {
+        const Seg &sg = segs[sidx];
+        const int ipu = sg.iplo + (pglob - sg.excl);                       // unwrapped pixel index in the ring
+        const double h = fma((double)ipu, sg.hstep, sg.c0);
+        const double x = fma(sg.Bq, sin_squared(h), sg.Aq);                // r_com^2
+        const int pidx = sg.pidx & 0xFF, win_lo = sg.pidx >> 8;
+        double v = 0.0;
+        if (x > 0.0) {
+            const double tt = fma(fast_log(x, logtab), t_m, t_c);
+            if (tt >= 0.0 && tt <= (double)NRm1) {
+                int i = (int)tt; if (i > NRm1 - 1) i = NRm1 - 1;
+                const double frac = tt - (double)i;
+                const int e = i - win_lo;
+                double L;
+                if (e >= 0 && e < W - 1) {
+                    double2 w2;
+                    if constexpr (win_in_lds) w2 = pwin[pidx * kWinLds + e];     // ds_read_b128
+                    else w2 = P.hwin[pinfo[pidx].hoff + e];                      // global_load_dwordx4
+                    L = fma(frac, w2.y, w2.x);
+                } else {                                 // rare: cell outside the halo's staged row window
+                    const int64_t j = pinfo[pidx].halo;
+                    double c0v = 0.0, c1v = 0.0;
+                    const int ncorner = 1 << T.nouter;
+                    for (int c = 0; c < ncorner; ++c) {
+                        double w = 1.0; int64_t off = 0;
+                        for (int k = 0; k < T.nouter; ++k) {
+                            const int bit = (c >> (T.nouter - 1 - k)) & 1;
+                            const double y = P.cw[k * P.cap + j];
+                            w = w * (bit ? y : 1.0 - y);
+                            off += (int64_t)(P.cidx[k * P.cap + j] + bit) * T.ostride[k];
+                        }
+                        c0v = fma(T.values[off + i], w, c0v);
+                        c1v = fma(T.values[off + i + 1], w, c1v);
+                    }
+                    L = fma(frac, c1v - c0v, c0v);
+                }
+                // NaN / +-inf / overflowing L paint nothing (HealpixRunner.py:473)
+                if (L > -746.0 && L < 709.0) v = fast_exp(L, exptab) * pinfo[pidx].pixfac;
+            } else ++n_r_oob;
+        } else ++n_r_oob;
+        if (v != 0.0) unsafeAtomicAdd(&acc[sg.abase + ipu], v);
+    };
+
     for (int base = 0; base < n_pairs;) {
-        // ---- stage a: one thread per pair of the chunk ------------------------------------------
+        // ---- stage a: one lane per pair of the chunk (wave 0) ---------------------------------------
         if (wave == 0) {
-            int nrings = 0, ra = 0, j = -1;
-            const bool valid = base + lane < n_pairs;
-            if (valid) {
-                j = plist[base + lane];
-                const HaloTile &h = P.ht[j];
-                ra = max(h.rfirst, ring_lo);
-                const int rb = min(h.rlast, ring_hi);
-                nrings = max(0, rb - ra + 1);
-            }
+            const int j = nx_j;
+            const bool valid = j >= 0;
+            const int ra = max(nx_first, ring_lo);
+            const int nrings = valid ? max(0, min(nx_last, ring_hi) - ra + 1) : 0;
             int cum = nrings;
             for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(cum, d, 64); if (lane >= d) cum += o; }
             // take the longest prefix of pairs whose (pair, ring) slots fit; always at least one pair
@@ -350,19 +415,31 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
             const unsigned long long fm = __ballot(fits);
             const int first_bad = __ffsll((long long)~fm);          // 1-based; 0 if all 64 fit
             const int n_take = first_bad ? first_bad - 1 : 64;
-            pr_halo[lane] = j; pr_ra[lane] = ra; pr_off[lane] = cum - nrings;
+            if (lane < n_take) {
+                const HaloTile &h = P.ht[j];
+                PairInfo pi;
+                pi.pixfac = h.pixfac; pi.hoff = (int64_t)j * W; pi.win_lo = h.win_lo; pi.halo = j; pi.ra = ra; pi.pad = 0;
+                pinfo[lane] = pi;
+                pr_off[lane] = cum - nrings;
+            }
             if (lane == n_take - 1) { pr_off[n_take] = cum; ctl[0] = n_take; ctl[1] = cum; ctl[2] = 0; }
+            prefetch(base + n_take);                                 // loads fly during stages b and c
         }
         __syncthreads();
         const int n_take = ctl[0], nslots = ctl[1];
 
-        // ---- stage b: one thread per (pair, ring) slot ----------------------------------------------
+        // ---- stage b: one thread per (pair, ring) slot; row windows -> LDS -----------------------------
+        if constexpr (win_in_lds)
+            for (int idx = tid; idx < n_take * W; idx += NT) {
+                const int p = idx / W, e = idx - p * W;
+                pwin[p * kWinLds + e] = P.hwin[pinfo[p].hoff + e];
+            }
         for (int slot = tid; slot < nslots; slot += NT) {
             int lo_ = 0, hi_ = n_take - 1;          // pair p with pr_off[p] <= slot < pr_off[p+1]
             while (lo_ < hi_) { const int mid = (lo_ + hi_ + 1) >> 1; if (pr_off[mid] <= slot) lo_ = mid; else hi_ = mid - 1; }
             const int p = lo_;
-            const int j = pr_halo[p];
-            const int ring = pr_ra[p] + (slot - pr_off[p]);
+            const int j = pinfo[p].halo;
+            const int ring = pinfo[p].ra + (slot - pr_off[p]);
             const RingRow rr = rows[ring - ring_lo];
             const HaloTile &h = P.ht[j];
             const double st = h.st, ct = h.ct, pphi = h.pphi, S = h.S;
@@ -383,14 +460,12 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
                 }
             }
             Seg sg;
-            sg.iplo = 0; sg.abase = 0; sg.excl = 0; sg.win_lo = h.win_lo;
+            sg.iplo = 0; sg.abase = 0; sg.excl = 0; sg.pidx = p | (h.win_lo << 8);   // pair slot | row window start
             sg.hstep = 0.5 * rr.phistep;
             sg.c0 = 0.5 * (rr.phioff * rr.phistep - pphi);
             const double ds = rr.sth - st, dz = rr.z - ct;
             sg.Aq = (ds * ds + dz * dz) * S;
             sg.Bq = 4.0 * rr.sth * st * S;
-            sg.hoff = (int64_t)j * W;
-            sg.pixfac = h.pixfac;
             int np = 0;
             if (cnt > 0) {
 #pragma unroll
@@ -410,70 +485,56 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
         __syncthreads();
         const int nseg = nslots + ctl[2];
 
-        // ---- stage c: 64 segments per wave batch, flattened pixel loop --------------------------------
-        int32_t *flg = flagbuf + wave * 64;
-        for (int b0 = wave * 64; b0 < nseg; b0 += NW * 64) {
-            const int sidx = b0 + lane;
-            const int cnt = (sidx < nseg) ? segs[sidx].excl : 0;
-            int cum = cnt;
-            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(cum, d, 64); if (lane >= d) cum += o; }
-            const int excl = cum - cnt;
-            const int total = __shfl(cum, 63, 64);
-            if (sidx < nseg) segs[sidx].excl = excl;
-            my_pixels += (lane == 0) ? (unsigned long long)total : 0ull;
-            for (int q0 = 0; q0 < total; q0 += 64) {
-                // which segment does pixel q0 + lane belong to?  start-of-segment markers + ballot
-                flg[lane] = 0;
-                __builtin_amdgcn_wave_barrier();
-                if (cnt > 0 && excl >= q0 && excl < q0 + 64) flg[excl - q0] = lane + 1;
-                __builtin_amdgcn_wave_barrier();
-                const int mark = flg[lane];
-                const unsigned long long mm = __ballot(mark != 0);
-                const unsigned long long below = mm & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-                // no marker at or before this lane: the segment that contains pixel q0
-                const unsigned long long started = __ballot(cnt > 0 && excl < q0);
-                const int carry = 63 - __clzll((long long)started);
-                const int src = below ? (63 - __clzll((long long)below)) : 0;
-                const int from_mark = __shfl(mark, src, 64) - 1;
-                const int sl = below ? from_mark : carry;
-                const int q = q0 + lane;
-                if (q < total) {
-                    const Seg &sg = segs[b0 + sl];
-                    const int ipu = sg.iplo + (q - sg.excl);               // unwrapped pixel index in the ring
-                    const double h = fma((double)ipu, sg.hstep, sg.c0);
-                    const double x = fma(sg.Bq, sin_squared(h), sg.Aq);    // r_com^2
-                    double v = 0.0;
-                    if (x > 0.0) {
-                        const double tt = fma(fast_log(x, logtab), t_m, t_c);
-                        if (tt >= 0.0 && tt <= (double)NRm1) {
-                            int i = (int)tt; if (i > NRm1 - 1) i = NRm1 - 1;
-                            const double frac = tt - (double)i;
-                            const int e = i - sg.win_lo;
-                            double L;
-                            if (e >= 0 && e < W - 1) { const double2 w2 = P.hwin[sg.hoff + e]; L = fma(frac, w2.y, w2.x); }
-                            else {                       // rare: cell outside the halo's staged row window
-                                const int64_t j = sg.hoff / W;
-                                double c0v = 0.0, c1v = 0.0;
-                                const int ncorner = 1 << T.nouter;
-                                for (int c = 0; c < ncorner; ++c) {
-                                    double w = 1.0; int64_t off = 0;
-                                    for (int k = 0; k < T.nouter; ++k) {
-                                        const int bit = (c >> (T.nouter - 1 - k)) & 1;
-                                        const double y = P.cw[k * P.cap + j];
-                                        w = w * (bit ? y : 1.0 - y);
-                                        off += (int64_t)(P.cidx[k * P.cap + j] + bit) * T.ostride[k];
-                                    }
-                                    c0v = fma(T.values[off + i], w, c0v);
-                                    c1v = fma(T.values[off + i + 1], w, c1v);
-                                }
-                                L = fma(frac, c1v - c0v, c0v);
-                            }
-                            // NaN / +-inf / overflowing L paint nothing (HealpixRunner.py:473)
-                            if (L > -746.0 && L < 709.0) v = fast_exp(L, exptab) * sg.pixfac;
-                        } else ++n_r_oob;
-                    } else ++n_r_oob;
-                    if (v != 0.0) unsafeAtomicAdd(&acc[sg.abase + ipu], v);
+        // ---- stage s: block-wide exclusive scan of the segments' pixel counts ---------------------------
+        const int ngroups = (nseg + 63) >> 6;
+        int my_cnt[2] = {0, 0}, my_excl[2] = {0, 0};
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int g = wave + r * 8;                               // 64-segment group of this wave
+            if (g < ngroups) {
+                const int sidx = g * 64 + lane;
+                const int cnt = (sidx < nseg) ? segs[sidx].excl : 0;
+                int cum = cnt;
+                for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(cum, d, 64); if (lane >= d) cum += o; }
+                my_cnt[r] = cnt; my_excl[r] = cum - cnt;
+                if (lane == 63) gtot[g] = cum;
+            }
+        }
+        __syncthreads();
+        int ptotal = 0;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int g = wave + r * 8;
+            int goff = 0;
+            for (int k = 0; k < ngroups; ++k) { const int t = gtot[k]; if (k < g) goff += t; ptotal += (r == 0) ? t : 0; }
+            if (g < ngroups) {
+                const int sidx = g * 64 + lane;
+                my_excl[r] += goff;
+                if (sidx < nseg) segs[sidx].excl = my_excl[r];
+            }
+        }
+        my_pixels += (tid == 0) ? (unsigned long long)ptotal : 0ull;
+
+        // ---- stage c: rounds of kPixMax pixels: pixel -> segment table, then one thread per pixel -------
+        for (int pbase = 0; pbase < ptotal; pbase += kPixMax) {
+            if (pbase > 0) __syncthreads();                           // previous round's readers are done
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int g = wave + r * 8;
+                if (g < ngroups && my_cnt[r] > 0) {
+                    const int sidx = g * 64 + lane;
+                    const int a0 = max(my_excl[r], pbase), a1 = min(my_excl[r] + my_cnt[r], pbase + kPixMax);
+                    for (int q = a0; q < a1; ++q) ptab[q - pbase] = (uint16_t)sidx;
                 }
+            }
+            __syncthreads();
+            const int pend = min(ptotal, pbase + kPixMax);
+            for (int q = pbase + tid; q < pend; q += 2 * NT) {        // two independent pixels per thread
+                const int q2 = q + NT;
+                const int s1 = ptab[q - pbase];
+                const int s2 = (q2 < pend) ? ptab[q2 - pbase] : -1;
+                paint_pixel(q, s1);
+                if (s2 >= 0) paint_pixel(q2, s2);
             }
         }
         __syncthreads();
