@@ -89,7 +89,8 @@ def load(build_if_missing=True):
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = C.CDLL(_build.SO)
+    # BFG_SO: load an alternative build of the library (A/B timing of kernel variants)
+    L = C.CDLL(os.environ.get("BFG_SO", _build.SO))
     L.bfg_abi_version.restype = C.c_int
     L.bfg_status_string.restype = C.c_char_p
     L.bfg_status_string.argtypes = [C.c_int]

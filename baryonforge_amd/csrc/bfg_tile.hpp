@@ -58,20 +58,32 @@ __device__ inline double fast_exp(double L, const double *__restrict__ tab)
     return ldexp(tab[k & (kExpTab - 1)] * p, k >> 6);
 }
 
-// sin^2(h) for |h| <= 0.5 (series to h^12, rel err < 3e-11 of h^2); exact sin beyond
+// sin^2(q) for |q| <= 0.5: series to q^12 (rel err < 3e-11)
+__device__ inline double sin_squared_small(double q2)
+{
+    double p = fma(q2, -2.0 / 467775.0, 2.0 / 14175.0);
+    p = fma(q2, p, -1.0 / 315.0);
+    p = fma(q2, p, 2.0 / 45.0);
+    p = fma(q2, p, -1.0 / 3.0);
+    p = fma(q2, p, 1.0);
+    return q2 * p;
+}
+
+// sin^2(h) for |h| <= 4 without libm: the series on h/8 and three angle doublings
+// sin^2(2a) = 4 sin^2(a) (1 - sin^2(a)).  (h = dphi/2 lies in [-pi/2, pi/2]; large |h| only near the poles.)
+__device__ inline double sin_squared_wide(double h)
+{
+    const double q = 0.125 * h;
+    double s = sin_squared_small(q * q);
+    s = 4.0 * s * (1.0 - s);
+    s = 4.0 * s * (1.0 - s);
+    return 4.0 * s * (1.0 - s);
+}
+
 __device__ inline double sin_squared(double h)
 {
     const double h2 = h * h;
-    if (h2 <= 0.25) {
-        double p = fma(h2, -2.0 / 467775.0, 2.0 / 14175.0);
-        p = fma(h2, p, -1.0 / 315.0);
-        p = fma(h2, p, 2.0 / 45.0);
-        p = fma(h2, p, -1.0 / 3.0);
-        p = fma(h2, p, 1.0);
-        return h2 * p;
-    }
-    const double s = sin(h);
-    return s * s;
+    return (h2 <= 0.25) ? sin_squared_small(h2) : sin_squared_wide(h);
 }
 
 // Per-halo record of the tile path (one 128-byte line per halo, written by halo_prep_kernel)
@@ -357,48 +369,70 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
     if (wave == 0) prefetch(0);
     __syncthreads();
 
-    // one pixel of the flattened chunk: segment record -> chord^2 -> ln -> row read-out -> exp -> LDS add
-    auto paint_pixel = [&](int pglob, int sidx) {
-        const Seg &sg = segs[sidx];
-        const int ipu = sg.iplo + (pglob - sg.excl);                       // unwrapped pixel index in the ring
-        const double h = fma((double)ipu, sg.hstep, sg.c0);
-        const double x = fma(sg.Bq, sin_squared(h), sg.Aq);                // r_com^2
-        const int pidx = sg.pidx & 0xFF, win_lo = sg.pidx >> 8;
-        double v = 0.0;
-        if (x > 0.0) {
-            const double tt = fma(fast_log(x, logtab), t_m, t_c);
-            if (tt >= 0.0 && tt <= (double)NRm1) {
-                int i = (int)tt; if (i > NRm1 - 1) i = NRm1 - 1;
-                const double frac = tt - (double)i;
-                const int e = i - win_lo;
-                double L;
-                if (e >= 0 && e < W - 1) {
-                    double2 w2;
-                    if constexpr (win_in_lds) w2 = pwin[pidx * kWinLds + e];     // ds_read_b128
-                    else w2 = P.hwin[pinfo[pidx].hoff + e];                      // global_load_dwordx4
-                    L = fma(frac, w2.y, w2.x);
-                } else {                                 // rare: cell outside the halo's staged row window
-                    const int64_t j = pinfo[pidx].halo;
-                    double c0v = 0.0, c1v = 0.0;
-                    const int ncorner = 1 << T.nouter;
-                    for (int c = 0; c < ncorner; ++c) {
-                        double w = 1.0; int64_t off = 0;
-                        for (int k = 0; k < T.nouter; ++k) {
-                            const int bit = (c >> (T.nouter - 1 - k)) & 1;
-                            const double y = P.cw[k * P.cap + j];
-                            w = w * (bit ? y : 1.0 - y);
-                            off += (int64_t)(P.cidx[k * P.cap + j] + bit) * T.ostride[k];
-                        }
-                        c0v = fma(T.values[off + i], w, c0v);
-                        c1v = fma(T.values[off + i + 1], w, c1v);
+    // Two pixels of the flattened chunk per call, written branch-free so the two dependency chains
+    // (segment record -> chord^2 -> ln -> row read-out -> exp -> LDS add) interleave in one wavefront.
+    // valid2 = false: only the first pixel exists.
+    auto paint2 = [&](int q1, int s1, int q2, int s2, bool valid2) {
+        const Seg sgA = segs[s1];
+        const Seg sgB = segs[valid2 ? s2 : s1];
+        const int ipuA = sgA.iplo + (q1 - sgA.excl);                       // unwrapped pixel index in the ring
+        const int ipuB = sgB.iplo + ((valid2 ? q2 : q1) - sgB.excl);
+        const double hA = fma((double)ipuA, sgA.hstep, sgA.c0);
+        const double hB = fma((double)ipuB, sgB.hstep, sgB.c0);
+        const double hA2 = hA * hA, hB2 = hB * hB;
+        double sA = sin_squared_small(hA2), sB = sin_squared_small(hB2);
+        if (__any(hA2 > 0.25 || hB2 > 0.25)) {                             // wave-uniform, only near the poles
+            if (hA2 > 0.25) sA = sin_squared_wide(hA);
+            if (hB2 > 0.25) sB = sin_squared_wide(hB);
+        }
+        const double xA = fma(sgA.Bq, sA, sgA.Aq), xB = fma(sgB.Bq, sB, sgB.Aq);   // r_com^2
+        // x = 0 or NaN falls out of the range test below (ln of the bit pattern is hugely negative / NaN)
+        const double tA = fma(fast_log(xA, logtab), t_m, t_c), tB = fma(fast_log(xB, logtab), t_m, t_c);
+        const bool okA = (tA >= 0.0) && (tA <= (double)NRm1);
+        const bool okB = (tB >= 0.0) && (tB <= (double)NRm1) && valid2;
+        const int iA = min(max((int)tA, 0), NRm1 - 1), iB = min(max((int)tB, 0), NRm1 - 1);
+        const double fA = tA - (double)iA, fB = tB - (double)iB;
+        const int pA = sgA.pidx & 0xFF, pB = sgB.pidx & 0xFF;
+        const int eA = iA - (sgA.pidx >> 8), eB = iB - (sgB.pidx >> 8);
+        const bool inA = (eA >= 0) && (eA < W - 1), inB = (eB >= 0) && (eB < W - 1);
+        double LA, LB;
+        if constexpr (win_in_lds) {
+            const double2 wA = pwin[pA * kWinLds + min(max(eA, 0), kWinLds - 2)];
+            const double2 wB = pwin[pB * kWinLds + min(max(eB, 0), kWinLds - 2)];
+            LA = fma(fA, wA.y, wA.x); LB = fma(fB, wB.y, wB.x);
+        } else {
+            const double2 wA = P.hwin[pinfo[pA].hoff + min(max(eA, 0), W - 2)];
+            const double2 wB = P.hwin[pinfo[pB].hoff + min(max(eB, 0), W - 2)];
+            LA = fma(fA, wA.y, wA.x); LB = fma(fB, wB.y, wB.x);
+        }
+        if (__any((okA && !inA) || (okB && !inB))) {                       // rare: cell outside the staged row window
+            auto slow = [&](int pidx, int i, double frac) {
+                const int64_t j = pinfo[pidx].halo;
+                double c0v = 0.0, c1v = 0.0;
+                const int ncorner = 1 << T.nouter;
+                for (int c = 0; c < ncorner; ++c) {
+                    double w = 1.0; int64_t off = 0;
+                    for (int k = 0; k < T.nouter; ++k) {
+                        const int bit = (c >> (T.nouter - 1 - k)) & 1;
+                        const double y = P.cw[k * P.cap + j];
+                        w = w * (bit ? y : 1.0 - y);
+                        off += (int64_t)(P.cidx[k * P.cap + j] + bit) * T.ostride[k];
                     }
-                    L = fma(frac, c1v - c0v, c0v);
+                    c0v = fma(T.values[off + i], w, c0v);
+                    c1v = fma(T.values[off + i + 1], w, c1v);
                 }
-                // NaN / +-inf / overflowing L paint nothing (HealpixRunner.py:473)
-                if (L > -746.0 && L < 709.0) v = fast_exp(L, exptab) * pinfo[pidx].pixfac;
-            } else ++n_r_oob;
-        } else ++n_r_oob;
-        if (v != 0.0) unsafeAtomicAdd(&acc[sg.abase + ipu], v);
+                return fma(frac, c1v - c0v, c0v);
+            };
+            if (okA && !inA) LA = slow(pA, iA, fA);
+            if (okB && !inB) LB = slow(pB, iB, fB);
+        }
+        // NaN / +-inf / overflowing L paint nothing (HealpixRunner.py:473)
+        const bool goA = okA && (LA > -746.0) && (LA < 709.0), goB = okB && (LB > -746.0) && (LB < 709.0);
+        const double vA = fast_exp(fmin(fmax(LA, -746.0), 709.0), exptab) * pinfo[pA].pixfac;
+        const double vB = fast_exp(fmin(fmax(LB, -746.0), 709.0), exptab) * pinfo[pB].pixfac;
+        n_r_oob += (okA ? 0 : 1) + ((okB || !valid2) ? 0 : 1);
+        if (goA && vA != 0.0) unsafeAtomicAdd(&acc[sgA.abase + ipuA], vA);
+        if (goB && vB != 0.0) unsafeAtomicAdd(&acc[sgB.abase + ipuB], vB);
     };
 
     for (int base = 0; base < n_pairs;) {
@@ -531,10 +565,10 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
             const int pend = min(ptotal, pbase + kPixMax);
             for (int q = pbase + tid; q < pend; q += 2 * NT) {        // two independent pixels per thread
                 const int q2 = q + NT;
+                const bool valid2 = q2 < pend;
                 const int s1 = ptab[q - pbase];
-                const int s2 = (q2 < pend) ? ptab[q2 - pbase] : -1;
-                paint_pixel(q, s1);
-                if (s2 >= 0) paint_pixel(q2, s2);
+                const int s2 = valid2 ? ptab[q2 - pbase] : s1;
+                paint2(q, s1, q2, s2, valid2);
             }
         }
         __syncthreads();
