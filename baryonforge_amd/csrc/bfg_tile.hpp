@@ -293,6 +293,10 @@ constexpr int kSlotMax = kSegMax / 2;// (pair, ring) slots per chunk; each may a
 constexpr int kWinLds = 32;          // row windows up to this many nodes are staged in LDS
 constexpr int kPixMax = 4096;        // pixel -> segment table entries per round (8 KiB of LDS)
 constexpr int kSegGroups = kSegMax / 64;
+#ifndef BFG_PIX_PER_THREAD
+#define BFG_PIX_PER_THREAD 1
+#endif
+constexpr int kPixPerThread = BFG_PIX_PER_THREAD;
 
 __host__ __device__ inline size_t tile_lds_bytes()
 {
@@ -369,70 +373,74 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
     if (wave == 0) prefetch(0);
     __syncthreads();
 
-    // Two pixels of the flattened chunk per call, written branch-free so the two dependency chains
+    // NPX pixels of the flattened chunk per call, written branch-free so that the NPX dependency chains
     // (segment record -> chord^2 -> ln -> row read-out -> exp -> LDS add) interleave in one wavefront.
-    // valid2 = false: only the first pixel exists.
-    auto paint2 = [&](int q1, int s1, int q2, int s2, bool valid2) {
-        const Seg sgA = segs[s1];
-        const Seg sgB = segs[valid2 ? s2 : s1];
-        const int ipuA = sgA.iplo + (q1 - sgA.excl);                       // unwrapped pixel index in the ring
-        const int ipuB = sgB.iplo + ((valid2 ? q2 : q1) - sgB.excl);
-        const double hA = fma((double)ipuA, sgA.hstep, sgA.c0);
-        const double hB = fma((double)ipuB, sgB.hstep, sgB.c0);
-        const double hA2 = hA * hA, hB2 = hB * hB;
-        double sA = sin_squared_small(hA2), sB = sin_squared_small(hB2);
-        if (__any(hA2 > 0.25 || hB2 > 0.25)) {                             // wave-uniform, only near the poles
-            if (hA2 > 0.25) sA = sin_squared_wide(hA);
-            if (hB2 > 0.25) sB = sin_squared_wide(hB);
+    constexpr int NPX = kPixPerThread;
+    auto paintN = [&](const int (&q)[NPX], const int (&sx)[NPX], const bool (&valid)[NPX]) {
+        int ipu[NPX], pidx[NPX], ii[NPX], ee[NPX], addr[NPX];
+        double xx[NPX], ff[NPX], LL[NPX];
+        bool ok[NPX], in[NPX];
+        bool any_wide = false;
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) {
+            const Seg sg = segs[sx[u]];
+            ipu[u] = sg.iplo + (q[u] - sg.excl);                           // unwrapped pixel index in the ring
+            addr[u] = sg.abase + ipu[u];
+            pidx[u] = sg.pidx;
+            const double h = fma((double)ipu[u], sg.hstep, sg.c0);
+            const double h2 = h * h;
+            double s2 = sin_squared_small(h2);
+            if (h2 > 0.25) { s2 = sin_squared_wide(h); any_wide = true; }   // only near the poles
+            xx[u] = fma(sg.Bq, s2, sg.Aq);                                 // r_com^2
         }
-        const double xA = fma(sgA.Bq, sA, sgA.Aq), xB = fma(sgB.Bq, sB, sgB.Aq);   // r_com^2
-        // x = 0 or NaN falls out of the range test below (ln of the bit pattern is hugely negative / NaN)
-        const double tA = fma(fast_log(xA, logtab), t_m, t_c), tB = fma(fast_log(xB, logtab), t_m, t_c);
-        const bool okA = (tA >= 0.0) && (tA <= (double)NRm1);
-        const bool okB = (tB >= 0.0) && (tB <= (double)NRm1) && valid2;
-        const int iA = min(max((int)tA, 0), NRm1 - 1), iB = min(max((int)tB, 0), NRm1 - 1);
-        const double fA = tA - (double)iA, fB = tB - (double)iB;
-        const int pA = sgA.pidx & 0xFF, pB = sgB.pidx & 0xFF;
-        const int eA = iA - (sgA.pidx >> 8), eB = iB - (sgB.pidx >> 8);
-        const bool inA = (eA >= 0) && (eA < W - 1), inB = (eB >= 0) && (eB < W - 1);
-        double LA, LB;
-        if constexpr (win_in_lds) {
-            const double2 wA = pwin[pA * kWinLds + min(max(eA, 0), kWinLds - 2)];
-            const double2 wB = pwin[pB * kWinLds + min(max(eB, 0), kWinLds - 2)];
-            LA = fma(fA, wA.y, wA.x); LB = fma(fB, wB.y, wB.x);
-        } else {
-            const double2 wA = P.hwin[pinfo[pA].hoff + min(max(eA, 0), W - 2)];
-            const double2 wB = P.hwin[pinfo[pB].hoff + min(max(eB, 0), W - 2)];
-            LA = fma(fA, wA.y, wA.x); LB = fma(fB, wB.y, wB.x);
+        bool any_slow = false;
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) {
+            // x = 0 or NaN falls out of the range test (ln of the bit pattern is hugely negative / NaN)
+            const double t = fma(fast_log(xx[u], logtab), t_m, t_c);
+            ok[u] = (t >= 0.0) && (t <= (double)NRm1) && valid[u];
+            ii[u] = min(max((int)t, 0), NRm1 - 1);
+            ff[u] = t - (double)ii[u];
+            ee[u] = ii[u] - (pidx[u] >> 8);
+            pidx[u] &= 0xFF;
+            in[u] = (ee[u] >= 0) && (ee[u] < W - 1);
+            any_slow |= ok[u] && !in[u];
+            double2 w2;
+            if constexpr (win_in_lds) w2 = pwin[pidx[u] * kWinLds + min(max(ee[u], 0), kWinLds - 2)];
+            else w2 = P.hwin[pinfo[pidx[u]].hoff + min(max(ee[u], 0), W - 2)];
+            LL[u] = fma(ff[u], w2.y, w2.x);
         }
-        if (__any((okA && !inA) || (okB && !inB))) {                       // rare: cell outside the staged row window
-            auto slow = [&](int pidx, int i, double frac) {
-                const int64_t j = pinfo[pidx].halo;
-                double c0v = 0.0, c1v = 0.0;
-                const int ncorner = 1 << T.nouter;
-                for (int c = 0; c < ncorner; ++c) {
-                    double w = 1.0; int64_t off = 0;
-                    for (int k = 0; k < T.nouter; ++k) {
-                        const int bit = (c >> (T.nouter - 1 - k)) & 1;
-                        const double y = P.cw[k * P.cap + j];
-                        w = w * (bit ? y : 1.0 - y);
-                        off += (int64_t)(P.cidx[k * P.cap + j] + bit) * T.ostride[k];
+        (void)any_wide;
+        if (__any(any_slow)) {                                             // rare: cell outside the staged row window
+#pragma unroll
+            for (int u = 0; u < NPX; ++u) {
+                if (ok[u] && !in[u]) {
+                    const int64_t j = pinfo[pidx[u]].halo;
+                    double c0v = 0.0, c1v = 0.0;
+                    const int ncorner = 1 << T.nouter;
+                    for (int c = 0; c < ncorner; ++c) {
+                        double w = 1.0; int64_t off = 0;
+                        for (int k = 0; k < T.nouter; ++k) {
+                            const int bit = (c >> (T.nouter - 1 - k)) & 1;
+                            const double y = P.cw[k * P.cap + j];
+                            w = w * (bit ? y : 1.0 - y);
+                            off += (int64_t)(P.cidx[k * P.cap + j] + bit) * T.ostride[k];
+                        }
+                        c0v = fma(T.values[off + ii[u]], w, c0v);
+                        c1v = fma(T.values[off + ii[u] + 1], w, c1v);
                     }
-                    c0v = fma(T.values[off + i], w, c0v);
-                    c1v = fma(T.values[off + i + 1], w, c1v);
+                    LL[u] = fma(ff[u], c1v - c0v, c0v);
                 }
-                return fma(frac, c1v - c0v, c0v);
-            };
-            if (okA && !inA) LA = slow(pA, iA, fA);
-            if (okB && !inB) LB = slow(pB, iB, fB);
+            }
         }
-        // NaN / +-inf / overflowing L paint nothing (HealpixRunner.py:473)
-        const bool goA = okA && (LA > -746.0) && (LA < 709.0), goB = okB && (LB > -746.0) && (LB < 709.0);
-        const double vA = fast_exp(fmin(fmax(LA, -746.0), 709.0), exptab) * pinfo[pA].pixfac;
-        const double vB = fast_exp(fmin(fmax(LB, -746.0), 709.0), exptab) * pinfo[pB].pixfac;
-        n_r_oob += (okA ? 0 : 1) + ((okB || !valid2) ? 0 : 1);
-        if (goA && vA != 0.0) unsafeAtomicAdd(&acc[sgA.abase + ipuA], vA);
-        if (goB && vB != 0.0) unsafeAtomicAdd(&acc[sgB.abase + ipuB], vB);
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) {
+            // NaN / +-inf / overflowing L paint nothing (HealpixRunner.py:473)
+            const bool go = ok[u] && (LL[u] > -746.0) && (LL[u] < 709.0);
+            const double v = fast_exp(fmin(fmax(LL[u], -746.0), 709.0), exptab) * pinfo[pidx[u]].pixfac;
+            n_r_oob += (ok[u] || !valid[u]) ? 0 : 1;
+            if (go && v != 0.0) unsafeAtomicAdd(&acc[addr[u]], v);
+        }
     };
 
     for (int base = 0; base < n_pairs;) {
@@ -463,12 +471,29 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
         const int n_take = ctl[0], nslots = ctl[1];
 
         // ---- stage b: one thread per (pair, ring) slot; row windows -> LDS -----------------------------
-        if constexpr (win_in_lds)
-            for (int idx = tid; idx < n_take * W; idx += NT) {
-                const int p = idx / W, e = idx - p * W;
-                pwin[p * kWinLds + e] = P.hwin[pinfo[p].hoff + e];
+        // row windows of the chunk's pairs -> LDS.  With full-width windows the copy is an LDS-DMA
+        // (global_load_lds_dwordx4: no VGPRs, asynchronous; drained by the barrier that ends stage b), so its
+        // latency overlaps the slot work below.  dest = wave-uniform base + lane * 16 B  ==  pwin[idx].
+        if constexpr (win_in_lds) {
+            if (W == kWinLds) {
+#pragma unroll
+                for (int r = 0; r < (kPairMax * kWinLds + NT - 1) / NT; ++r) {
+                    const int idx = tid + r * NT;
+                    if (idx < n_take * kWinLds) {
+                        const double2 *src = P.hwin + pinfo[idx / kWinLds].hoff + (idx % kWinLds);
+                        double2 *dst = pwin + r * NT + wave * 64;                   // wave-uniform
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+                    }
+                }
+            } else {
+                for (int idx = tid; idx < n_take * W; idx += NT) {
+                    const int p = idx / W, e = idx - p * W;
+                    pwin[p * kWinLds + e] = P.hwin[pinfo[p].hoff + e];
+                }
             }
-        for (int slot = tid; slot < nslots; slot += NT) {
+        }
+        for (int slot = tid; slot < nslots && !(P.debug & 8); slot += NT) {
             int lo_ = 0, hi_ = n_take - 1;          // pair p with pr_off[p] <= slot < pr_off[p+1]
             while (lo_ < hi_) { const int mid = (lo_ + hi_ + 1) >> 1; if (pr_off[mid] <= slot) lo_ = mid; else hi_ = mid - 1; }
             const int p = lo_;
@@ -550,7 +575,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
         my_pixels += (tid == 0) ? (unsigned long long)ptotal : 0ull;
 
         // ---- stage c: rounds of kPixMax pixels: pixel -> segment table, then one thread per pixel -------
-        for (int pbase = 0; pbase < ptotal; pbase += kPixMax) {
+        for (int pbase = 0; pbase < ptotal && !(P.debug & 2); pbase += kPixMax) {
             if (pbase > 0) __syncthreads();                           // previous round's readers are done
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
@@ -563,12 +588,17 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
             }
             __syncthreads();
             const int pend = min(ptotal, pbase + kPixMax);
-            for (int q = pbase + tid; q < pend; q += 2 * NT) {        // two independent pixels per thread
-                const int q2 = q + NT;
-                const bool valid2 = q2 < pend;
-                const int s1 = ptab[q - pbase];
-                const int s2 = valid2 ? ptab[q2 - pbase] : s1;
-                paint2(q, s1, q2, s2, valid2);
+            for (int q0 = pbase + tid; q0 < pend; q0 += NPX * NT) {   // NPX independent pixels per thread
+                int q[NPX], sx[NPX];
+                bool valid[NPX];
+#pragma unroll
+                for (int u = 0; u < NPX; ++u) {
+                    q[u] = q0 + u * NT;
+                    valid[u] = q[u] < pend;
+                    if (!valid[u]) q[u] = q0;
+                    sx[u] = ptab[q[u] - pbase];
+                }
+                paintN(q, sx, valid);
             }
         }
         __syncthreads();
