@@ -258,4 +258,16 @@ struct TileGeom {
     const int32_t *tile_band;    // [ntiles]
 };
 
+
+// what the halo -> tile binning needs (count pass inside halo_prep_kernel, fill pass in tile_fill_kernel)
+struct BinCtx {
+    TileGeom geo;
+    int32_t *tile_count;          // [ntiles] counts, then fill cursors
+    const int32_t *tile_start;    // [ntiles+1]
+    int32_t *pairs;
+    unsigned long long *pair_total;
+    long long pair_cap;
+    int mode;                     // MODE_PAINT / MODE_BARYONIFY
+};
+
 }  // namespace bfg

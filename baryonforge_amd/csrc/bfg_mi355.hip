@@ -153,6 +153,7 @@ struct PrepParams {
     bfg::HaloTile *ht;       // tile variant: per-halo 128-byte records (may be null)
     int win_nodes;
     double pixfac_area;
+    bfg::BinCtx bin;         // tile variant: count pass of the halo -> tile binning
 };
 
 #define MODE_PAINT 0
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(256) void halo_prep_kernel(const PrepParams P)
         atomicAdd((unsigned long long *)&P.stats->halos_out_of_table, 1ull);
         atomicOr(&P.stats->warn_mask, warn);
     }
+    if (P.ht) flags = tile_bin_halo(P.bin, false, j, flags, rfirst, rlast, irmin, irmax, ptheta, pphi, radius);
     irec[I_RFIRST * cap] = rfirst; irec[I_RLAST * cap] = rlast;
     irec[I_IRMIN * cap] = irmin; irec[I_IRMAX * cap] = irmax;
     irec[I_FLAGS * cap] = flags;
@@ -1023,7 +1025,11 @@ static int ensure_tiles(bfg_ctx *c, int64_t nside, int64_t n_halo)
         c->geo.tile_band = c->d_geo + 3 * nbands + 1;
         c->tile_nside = nside;
     }
-    const int64_t want = 8 * n_halo + 65536;
+    int64_t want = 8 * n_halo + 65536;
+    if (const char *pc = std::getenv("BFG_PAIR_CAP")) {      // test hook: force a tiny pair buffer (overflow fallback)
+        want = std::max<int64_t>(1, std::atoll(pc));
+        if (want != c->pair_cap) { HIP_TRY(hipStreamSynchronize(c->stream)); if (c->d_pairs) (void)hipFree(c->d_pairs); c->d_pairs = nullptr; c->pair_cap = 0; }
+    }
     if (want > c->pair_cap) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->d_pairs) (void)hipFree(c->d_pairs);
@@ -1099,6 +1105,12 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     pp.stats = c->d_stats;
     pp.want_model_radius = (mode == MODE_BARYONIFY);
     pp.ht = tile ? c->d_ht : nullptr; pp.win_nodes = win_nodes; pp.pixfac_area = pixfac_area;
+    if (tile) {
+        pp.bin.geo = c->geo; pp.bin.tile_count = c->d_tile_count; pp.bin.tile_start = c->d_tile_start;
+        pp.bin.pairs = c->d_pairs; pp.bin.pair_total = c->d_pair_total; pp.bin.pair_cap = c->pair_cap;
+        pp.bin.mode = mode;
+        HIP_TRY(hipMemsetAsync(c->d_tile_count, 0, (size_t)c->geo.ntiles * sizeof(int32_t), c->stream));
+    }
     timing_begin(c, 0);
     hipLaunchKernelGGL(halo_prep_kernel, dim3((unsigned)((a->n_halo + 255) / 256)), dim3(256), 0, c->stream, pp);
     HIP_TRY(hipGetLastError());
@@ -1116,27 +1128,18 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
 
     if (tile) {
         timing_begin(c, 3);
-        HIP_TRY(hipMemsetAsync(c->d_tile_count, 0, (size_t)c->geo.ntiles * sizeof(int32_t), c->stream));
-        HIP_TRY(hipMemsetAsync(c->d_pair_total, 0, sizeof(unsigned long long), c->stream));
-        BinParams bp;
-        std::memset(&bp, 0, sizeof(bp));
-        bp.hpx = pp.hpx; bp.n_halo = a->n_halo; bp.cap = c->cap_halo;
-        bp.rec = c->d_rec; bp.irec = c->d_irec; bp.ht = c->d_ht; bp.geo = c->geo;
-        bp.tile_count = c->d_tile_count; bp.tile_start = c->d_tile_start; bp.pairs = c->d_pairs;
-        bp.pair_total = c->d_pair_total; bp.pair_cap = c->pair_cap; bp.mode = mode;
-        const unsigned hgrid = (unsigned)((a->n_halo + 255) / 256);
-        bp.fill = 0;
-        hipLaunchKernelGGL(tile_bin_kernel, dim3(hgrid), dim3(256), 0, c->stream, bp);
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->geo.ntiles, c->d_tile_count,
                            c->d_tile_start);
-        bp.fill = 1;
-        hipLaunchKernelGGL(tile_bin_kernel, dim3(hgrid), dim3(256), 0, c->stream, bp);
+        FillParams fp;
+        std::memset(&fp, 0, sizeof(fp));
+        fp.n_halo = a->n_halo; fp.cap = c->cap_halo; fp.rec = c->d_rec; fp.irec = c->d_irec; fp.ht = c->d_ht; fp.bin = pp.bin;
+        hipLaunchKernelGGL(tile_fill_kernel, dim3((unsigned)((a->n_halo + 255) / 256)), dim3(256), 0, c->stream, fp);
         RowParams rp;
         std::memset(&rp, 0, sizeof(rp));
         rp.n_halo = a->n_halo; rp.cap = c->cap_halo; rp.ht = c->d_ht; rp.cidx = c->d_cidx; rp.cw = c->d_cw;
         rp.tab = t->dev; rp.win_nodes = win_nodes; rp.hwin = c->d_hwin;
-        const int64_t nrow = a->n_halo * (int64_t)win_nodes;
-        hipLaunchKernelGGL(halo_row_kernel, dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, c->stream, rp);
+        const int hpb = 256 / win_nodes;
+        hipLaunchKernelGGL(halo_row_kernel, dim3((unsigned)((a->n_halo + hpb - 1) / hpb)), dim3(256), 0, c->stream, rp);
         HIP_TRY(hipGetLastError());
         timing_end(c, 3);
 
@@ -1145,7 +1148,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         tp.hpx = pp.hpx; tp.n_halo = a->n_halo; tp.cap = c->cap_halo;
         tp.ht = c->d_ht; tp.cidx = c->d_cidx; tp.cw = c->d_cw;
         tp.tab = t->dev; tp.geo = c->geo; tp.tile_start = c->d_tile_start; tp.pairs = c->d_pairs;
-        tp.hwin = c->d_hwin; tp.win_nodes = win_nodes;
+        tp.hwin = c->d_hwin; tp.win_nodes = win_nodes; tp.pair_cap = c->pair_cap;
         tp.out = d_out; tp.stats = c->d_stats;
         tp.logtab = reinterpret_cast<const double2 *>(c->d_mathtab);
         tp.exptab = c->d_mathtab + 2 * kLogTab;

@@ -129,23 +129,8 @@ struct TileParams {
     bfg_stats *stats;
     const double2 *logtab;           // [128] {1/c, ln c}
     const double *exptab;            // [64]  2^(j/64)
+    long long pair_cap;              // capacity of pairs[]; a larger total means the binning fell back to scatter
     int debug;                       // ablation switches for profiling (BFG_DEBUG env; 0 in production)
-};
-
-struct BinParams {
-    Hpx hpx;
-    int64_t n_halo, cap;
-    const double *rec;
-    int32_t *irec;
-    HaloTile *ht;
-    TileGeom geo;
-    int32_t *tile_count;     // [ntiles] (count pass) / cursor (fill pass)
-    const int32_t *tile_start;
-    int32_t *pairs;
-    unsigned long long *pair_total;
-    long long pair_cap;
-    int fill;
-    int mode;                // MODE_PAINT / MODE_BARYONIFY
 };
 
 // sectors of band b whose phi range can intersect the disc: [s_lo, s_lo + n) modulo NS
@@ -162,25 +147,21 @@ __device__ inline void band_sectors(const TileGeom &G, int b, double pphi, doubl
     s_lo = ((a % NS) + NS) % NS;
 }
 
-// Bin halos into tiles: count pass (fill = 0) and fill pass (fill = 1).  Halos that overlap too
-// many tiles, lie outside the table hull, or would overflow the pair buffer are flagged
-// HF_SCATTER and left to the global-atomic scatter kernel.
-__global__ __launch_bounds__(256) void tile_bin_kernel(const BinParams P)
+// Bin one halo into the tiles its disc's bounding box (ring band x longitude extent) overlaps.
+// fill = false: count pass (runs inside halo_prep_kernel); returns the halo's flags, with HF_SCATTER set
+// if it overlaps too many tiles or lies outside the table hull -- such halos are left to the
+// global-atomic scatter kernel.  fill = true: second pass, writes the pair lists.  If the total number of
+// pairs (known on the device after the scan) exceeds the pair buffer, the fill pass flags EVERY halo
+// HF_SCATTER and the tile kernel exits: the call degrades to the scatter kernel instead of overflowing.
+__device__ inline int tile_bin_halo(const BinCtx &B, bool fill, int64_t j, int flags, int rfirst, int rlast,
+                                    int irmin, int irmax, double ptheta, double pphi, double radius)
 {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= P.n_halo) return;
-    const int64_t cap = P.cap;
-    int32_t flags = P.irec[I_FLAGS * cap + j];
-    if (flags & HF_SKIP) return;
-    if (P.fill && (flags & HF_SCATTER)) return;
-    const int32_t rfirst = P.irec[I_RFIRST * cap + j], rlast = P.irec[I_RLAST * cap + j];
-    const int32_t irmin = P.irec[I_IRMIN * cap + j], irmax = P.irec[I_IRMAX * cap + j];
-    const double ptheta = P.rec[F_PTHETA * cap + j], pphi = P.rec[F_PPHI * cap + j];
-    const double radius = P.rec[F_RADIUS * cap + j];
+    if (flags & HF_SKIP) return flags;
+    if (fill && (flags & HF_SCATTER)) return flags;
     bool to_scatter = (flags & HF_OOB) != 0;
     int b0 = 0, b1 = -1;
     if (rlast >= rfirst) { b0 = (rfirst - 1) / kTileRings; b1 = (rlast - 1) / kTileRings; }
-    else if (P.mode == MODE_BARYONIFY) to_scatter = true;        // empty disc -> 4-neighbour fallback
+    else if (B.mode == MODE_BARYONIFY) to_scatter = true;        // empty disc -> 4-neighbour fallback
     // longitude half-extent of the disc: asin(sin r / sin theta0), or everything if a pole is inside
     double dphi_bound = kPi;
     const bool pole_inside = (rfirst < irmin) || (rlast > irmax) || !(radius < kPi) || (ptheta - radius <= 0) ||
@@ -189,30 +170,50 @@ __global__ __launch_bounds__(256) void tile_bin_kernel(const BinParams P)
         const double q = sin(radius) / sin(ptheta);
         dphi_bound = (q < 1.0) ? asin(q) : kPi;
     }
-    int npairs = 0;
-    for (int b = b0; b <= b1; ++b) { int s_lo, n; band_sectors(P.geo, b, pphi, dphi_bound, s_lo, n); npairs += n; }
-    if (!P.fill) {
+    if (!fill) {
+        int npairs = 0;
+        for (int b = b0; b <= b1; ++b) { int s_lo, n; band_sectors(B.geo, b, pphi, dphi_bound, s_lo, n); npairs += n; }
         if (npairs > kMaxPairsPerHalo) to_scatter = true;
-        if (!to_scatter && npairs > 0) {
-            unsigned long long pos = atomicAdd(P.pair_total, (unsigned long long)npairs);
-            if ((long long)(pos + npairs) > P.pair_cap) to_scatter = true;
-        }
-        if (to_scatter) { P.irec[I_FLAGS * cap + j] = flags | HF_SCATTER; P.ht[j].flags = flags | HF_SCATTER; return; }
+        if (to_scatter) return flags | HF_SCATTER;
     }
     for (int b = b0; b <= b1; ++b) {
         int s_lo, n;
-        band_sectors(P.geo, b, pphi, dphi_bound, s_lo, n);
-        const int NS = P.geo.band_ns[b], t0 = P.geo.band_tile0[b];
+        band_sectors(B.geo, b, pphi, dphi_bound, s_lo, n);
+        const int NS = B.geo.band_ns[b], t0 = B.geo.band_tile0[b];
         for (int i = 0; i < n; ++i) {
             int s = s_lo + i; if (s >= NS) s -= NS;
             const int tile = t0 + s;
-            if (!P.fill) atomicAdd(&P.tile_count[tile], 1);
+            if (!fill) atomicAdd(&B.tile_count[tile], 1);
             else {
-                const int pos = atomicAdd(&P.tile_count[tile], 1);      // cursor
-                P.pairs[P.tile_start[tile] + pos] = (int32_t)j;
+                const int pos = atomicAdd(&B.tile_count[tile], 1);      // cursor
+                B.pairs[B.tile_start[tile] + pos] = (int32_t)j;
             }
         }
     }
+    return flags;
+}
+
+struct FillParams {
+    int64_t n_halo, cap;
+    const double *rec;
+    int32_t *irec;
+    HaloTile *ht;
+    BinCtx bin;
+};
+
+__global__ __launch_bounds__(256) void tile_fill_kernel(const FillParams P)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P.n_halo) return;
+    const int64_t cap = P.cap;
+    if ((long long)P.bin.tile_start[P.bin.geo.ntiles] > P.bin.pair_cap) {        // pair buffer too small: all to scatter
+        const int f = P.irec[I_FLAGS * cap + j] | HF_SCATTER;
+        P.irec[I_FLAGS * cap + j] = f; P.ht[j].flags = f;
+        return;
+    }
+    tile_bin_halo(P.bin, true, j, P.irec[I_FLAGS * cap + j], P.irec[I_RFIRST * cap + j], P.irec[I_RLAST * cap + j],
+                  P.irec[I_IRMIN * cap + j], P.irec[I_IRMAX * cap + j], P.rec[F_PTHETA * cap + j],
+                  P.rec[F_PPHI * cap + j], P.rec[F_RADIUS * cap + j]);
 }
 
 // exclusive scan of tile_count into tile_start[ntiles+1]; single workgroup
@@ -255,35 +256,51 @@ struct RowParams {
 
 __global__ __launch_bounds__(256) void halo_row_kernel(const RowParams P)
 {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t j = gid / P.win_nodes;
-    const int e = (int)(gid - j * P.win_nodes);
-    if (j >= P.n_halo) return;
-    const int flags = P.ht[j].flags;
-    if (flags & (HF_SKIP | HF_OOB)) return;
+    // block = (256 / W) halos x W nodes; the halo's corner (row offset, weight) pairs are formed once in LDS
+    __shared__ double s_w[256 / 8][kMaxCorner];
+    __shared__ int64_t s_off[256 / 8][kMaxCorner];
+    __shared__ int s_winlo[256 / 8];
     const DevTable &T = P.tab;
-    const int ir = P.ht[j].win_lo + e;
+    const int W = P.win_nodes;
+    const int hpb = 256 / W;                                   // halos per block (W <= 256, W >= 8)
+    const int hl = threadIdx.x / W, e = threadIdx.x - hl * W;
+    const int64_t j = (int64_t)blockIdx.x * hpb + hl;
+    const bool live = (hl < hpb) && (j < P.n_halo);
+    const int ncorner = 1 << T.nouter;
+    bool skip = true;
+    if (live) {
+        const int flags = P.ht[j].flags;
+        skip = (flags & (HF_SKIP | HF_OOB)) != 0;
+        if (e == 0) s_winlo[hl] = P.ht[j].win_lo;
+        for (int c = e; c < ncorner; c += W) {
+            double w = 1.0;
+            int64_t off = 0;
+            for (int k = 0; k < T.nouter; ++k) {
+                const int bit = (c >> (T.nouter - 1 - k)) & 1;
+                const double y = P.cw[k * P.cap + j];
+                const int i = P.cidx[k * P.cap + j];
+                w = w * (bit ? y : 1.0 - y);
+                off += (int64_t)(i + bit) * T.ostride[k];
+            }
+            s_w[hl][c] = w; s_off[hl][c] = off;
+        }
+    }
+    __syncthreads();
+    if (!live || skip) return;
+    const int ir = s_winlo[hl] + e;
     const int ir1 = min(ir + 1, T.nr - 1);
     // B_{i+1} is the neighbouring lane's B_i, except at the end of a window or of the wavefront
-    const bool own_next = (e == P.win_nodes - 1) || ((threadIdx.x & 63) == 63);
+    const bool own_next = (e == W - 1) || ((threadIdx.x & 63) == 63);
     double b0 = 0.0, b1 = 0.0;
-    const int ncorner = 1 << T.nouter;
     for (int c = 0; c < ncorner; ++c) {
-        double w = 1.0;
-        int64_t off = 0;
-        for (int k = 0; k < T.nouter; ++k) {
-            const int bit = (c >> (T.nouter - 1 - k)) & 1;
-            const double y = P.cw[k * P.cap + j];
-            const int i = P.cidx[k * P.cap + j];
-            w = w * (bit ? y : 1.0 - y);
-            off += (int64_t)(i + bit) * T.ostride[k];
-        }
-        b0 = fma(T.values[off + ir], w, b0);
-        if (own_next) b1 = fma(T.values[off + ir1], w, b1);
+        const double w = s_w[hl][c];
+        const double *row = T.values + s_off[hl][c];
+        b0 = fma(row[ir], w, b0);
+        if (own_next) b1 = fma(row[ir1], w, b1);
     }
     const double nb = __shfl_down(b0, 1, 64);      // lane + 1 holds node e + 1 of the same halo when !own_next
     if (!own_next) b1 = nb;
-    P.hwin[j * P.win_nodes + e] = make_double2(b0, b1 - b0);
+    P.hwin[j * W + e] = make_double2(b0, b1 - b0);
 }
 
 constexpr int kTileThreads = 512;
@@ -325,7 +342,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
 
     const int tile = blockIdx.x;
     const int n_pairs = P.tile_start[tile + 1] - P.tile_start[tile];
-    if (n_pairs == 0) return;
+    if (n_pairs == 0 || (long long)P.tile_start[P.geo.ntiles] > P.pair_cap) return;
     const Hpx &hp = P.hpx;
     const DevTable &T = P.tab;
     const int band = P.geo.tile_band[tile];

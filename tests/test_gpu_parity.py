@@ -238,6 +238,23 @@ def test_paint_full_size_linearity_1e5(cosmo):
     assert np.all(full >= 0) and np.isfinite(full).all()
 
 
+def test_tile_pair_buffer_overflow_falls_back_to_scatter(cosmo, monkeypatch):
+    """If the (halo, tile) pair buffer is too small the whole call degrades to the scatter kernel -- same map."""
+    ra, dec, M, z = syn.catalog(3000, seed=46)
+    zax, Max, rax, T = syn.pressure_table()
+    ref, ptot = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax), T, 256, 10)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    Shell = bfg.LightconeShell(map=np.zeros(12 * 256 * 256), cosmo=cosmo)
+    monkeypatch.setenv("BFG_PAIR_CAP", "100")
+    R = bfg.PaintProfilesShell(Cat, Shell, 10, _paint_model(zax, Max, rax, T), verbose=False, variant="tile_lds")
+    got = R.process()
+    assert R.last_stats["pixel_updates"] == ptot
+    assert_maps_close(got, ref, RTOL, what="pair overflow fallback")
+    monkeypatch.delenv("BFG_PAIR_CAP")
+    got = R.process()
+    assert_maps_close(got, ref, RTOL, what="after fallback")
+
+
 # --------------------------------------------------------------------------- edge cases and errors
 def test_edge_cases(cosmo):
     zax, Max, rax, T = syn.pressure_table()
