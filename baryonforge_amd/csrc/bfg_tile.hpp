@@ -26,55 +26,54 @@
 
 namespace bfg {
 
-// ---- table-driven ln / exp (float64) -----------------------------------------------------------
-// ln: x = 2^e m, m in [1, 2); c = 1 + (idx + 0.5)/128 from the top 7 mantissa bits;
-//     ln x = e ln2 + ln c + log1p(m/c - 1), |m/c - 1| < 2^-8, 4-term series (rel err ~2e-13).
+// ---- table-driven ln / exp, series sin^2 (float64) ------------------------------------------------
+// Accuracy budget: the painted value is exp(B_i + f (B_{i+1} - B_i)), f = frac((ln x) * t_m + t_c); the parity
+// bar is 1e-5 relative.  These kernels are built for <= 1e-9 relative on the painted value:
+//   ln : x = 2^e m, m in [1, 2); c = 1 + (idx + 0.5)/128 from the top 7 mantissa bits;
+//        ln x = e ln2 + ln c + log1p(m/c - 1), |m/c - 1| < 2^-8, series to r^3 (abs err < 6e-11)
+//   exp: L = k ln2/64 + r, |r| <= ln2/128; exp L = 2^(k>>6) 2^((k&63)/64) (1 + r + r^2/2 + r^3/6) (rel err < 4e-11)
+//   sin^2(h): series to h^8 for h^2 <= 0.04 (rel err < 4e-10); wider angles (polar caps only) go through
+//        h/16 and four angle doublings sin^2(2a) = 4 sin^2(a) (1 - sin^2(a)).
 __device__ inline double fast_log(double x, const double2 *__restrict__ tab)
 {
     const int hi = __double2hiint(x);
     const int lo = __double2loint(x);
-    const int e = (hi >> 20) - 1023;                 // x is positive, finite and normal here
+    const int e = (hi >> 20) - 1023;                 // positive finite normal x; anything else is filtered by the caller
     const int idx = (hi >> 13) & (kLogTab - 1);
     const double m = __hiloint2double((hi & 0x000FFFFF) | 0x3FF00000, lo);
     const double2 t = tab[idx];                      // {1/c, ln c}
     const double r = fma(m, t.x, -1.0);
-    double p = fma(r, -0.25, 1.0 / 3.0);
-    p = fma(r, p, -0.5);
+    double p = fma(r, 1.0 / 3.0, -0.5);
     p = fma(r, p, 1.0);
     return fma((double)e, 0.693147180559945309417232, fma(r, p, t.y));
 }
 
-// exp: L = k ln2/64 + r, |r| <= ln2/128; exp L = 2^(k>>6) * 2^((k&63)/64) * (1 + r + r^2/2 + r^3/6 + r^4/24)
 __device__ inline double fast_exp(double L, const double *__restrict__ tab)
 {
     const double kf = rint(L * 92.332482616893656877476);          // 64 / ln 2
-    double r = fma(kf, -0.010830424696249145459412, L);             // ln2 / 64 (hi)
-    r = fma(kf, -2.5728046223276688e-19, r);                        //          (lo)
+    const double r = fma(kf, -0.010830424696249145459412, L);      // ln2 / 64
     const int k = (int)kf;
-    double p = fma(r, 1.0 / 24.0, 1.0 / 6.0);
-    p = fma(r, p, 0.5);
+    double p = fma(r, 1.0 / 6.0, 0.5);
     p = fma(r, p, 1.0);
     p = fma(r, p, 1.0);
     return ldexp(tab[k & (kExpTab - 1)] * p, k >> 6);
 }
 
-// sin^2(q) for |q| <= 0.5: series to q^12 (rel err < 3e-11)
+constexpr double kSinSmall = 0.04;                   // h^2 limit of the short series
 __device__ inline double sin_squared_small(double q2)
 {
-    double p = fma(q2, -2.0 / 467775.0, 2.0 / 14175.0);
-    p = fma(q2, p, -1.0 / 315.0);
-    p = fma(q2, p, 2.0 / 45.0);
+    double p = fma(q2, -1.0 / 315.0, 2.0 / 45.0);
     p = fma(q2, p, -1.0 / 3.0);
     p = fma(q2, p, 1.0);
     return q2 * p;
 }
 
-// sin^2(h) for |h| <= 4 without libm: the series on h/8 and three angle doublings
-// sin^2(2a) = 4 sin^2(a) (1 - sin^2(a)).  (h = dphi/2 lies in [-pi/2, pi/2]; large |h| only near the poles.)
+// sin^2(h) for |h| <= 3.2 without libm (h = dphi/2 lies in [-pi/2, pi/2]; large |h| only near the poles)
 __device__ inline double sin_squared_wide(double h)
 {
-    const double q = 0.125 * h;
+    const double q = 0.0625 * h;
     double s = sin_squared_small(q * q);
+    s = 4.0 * s * (1.0 - s);
     s = 4.0 * s * (1.0 - s);
     s = 4.0 * s * (1.0 - s);
     return 4.0 * s * (1.0 - s);
@@ -83,7 +82,7 @@ __device__ inline double sin_squared_wide(double h)
 __device__ inline double sin_squared(double h)
 {
     const double h2 = h * h;
-    return (h2 <= 0.25) ? sin_squared_small(h2) : sin_squared_wide(h);
+    return (h2 <= kSinSmall) ? sin_squared_small(h2) : sin_squared_wide(h);
 }
 
 // Per-halo record of the tile path (one 128-byte line per halo, written by halo_prep_kernel)
@@ -397,7 +396,6 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
         int ipu[NPX], pidx[NPX], ii[NPX], ee[NPX], addr[NPX];
         double xx[NPX], ff[NPX], LL[NPX];
         bool ok[NPX], in[NPX];
-        bool any_wide = false;
 #pragma unroll
         for (int u = 0; u < NPX; ++u) {
             const Seg sg = segs[sx[u]];
@@ -407,7 +405,9 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
             const double h = fma((double)ipu[u], sg.hstep, sg.c0);
             const double h2 = h * h;
             double s2 = sin_squared_small(h2);
-            if (h2 > 0.25) { s2 = sin_squared_wide(h); any_wide = true; }   // only near the poles
+            if (__any(h2 > kSinSmall)) {                                   // wave-uniform branch: only near the poles
+                if (h2 > kSinSmall) s2 = sin_squared_wide(h);
+            }
             xx[u] = fma(sg.Bq, s2, sg.Aq);                                 // r_com^2
         }
         bool any_slow = false;
@@ -427,7 +427,6 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
             else w2 = P.hwin[pinfo[pidx[u]].hoff + min(max(ee[u], 0), W - 2)];
             LL[u] = fma(ff[u], w2.y, w2.x);
         }
-        (void)any_wide;
         if (__any(any_slow)) {                                             // rare: cell outside the staged row window
 #pragma unroll
             for (int u = 0; u < NPX; ++u) {
@@ -453,8 +452,8 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
 #pragma unroll
         for (int u = 0; u < NPX; ++u) {
             // NaN / +-inf / overflowing L paint nothing (HealpixRunner.py:473)
-            const bool go = ok[u] && (LL[u] > -746.0) && (LL[u] < 709.0);
-            const double v = fast_exp(fmin(fmax(LL[u], -746.0), 709.0), exptab) * pinfo[pidx[u]].pixfac;
+            const bool go = ok[u] && (LL[u] > -746.0) && (LL[u] < 709.0);       // false for NaN too
+            const double v = fast_exp(LL[u], exptab) * pinfo[pidx[u]].pixfac;    // garbage when !go, never added
             n_r_oob += (ok[u] || !valid[u]) ? 0 : 1;
             if (go && v != 0.0) unsafeAtomicAdd(&acc[addr[u]], v);
         }
