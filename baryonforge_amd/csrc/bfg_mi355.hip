@@ -101,7 +101,7 @@ struct bfg_ctx {
     unsigned long long *d_pair_total;
     double *d_mathtab;              // logtab (256 doubles) | exptab (64 doubles)
     bfg::HaloTile *d_ht;            // [cap_halo]
-    double2 *d_hwin;                // [hwin_cap] pre-blended row windows
+    double *d_hwin;                 // [hwin_cap] pre-blended row windows
     int64_t hwin_cap;
     // timing: a growing pool of event pairs per kernel class, resolved lazily in bfg_timing_read
     bool timing;
@@ -1086,7 +1086,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
             HIP_TRY(hipStreamSynchronize(c->stream));
             if (c->d_hwin) (void)hipFree(c->d_hwin);
             c->d_hwin = nullptr; c->hwin_cap = 0;
-            HIP_TRY(hipMalloc((void **)&c->d_hwin, (size_t)want * sizeof(double2)));
+            HIP_TRY(hipMalloc((void **)&c->d_hwin, (size_t)want * sizeof(double)));
             c->hwin_cap = want;
         }
     }

@@ -122,7 +122,7 @@ struct TileParams {
     TileGeom geo;
     const int32_t *tile_start;       // [ntiles+1]
     const int32_t *pairs;            // halo ids grouped by tile
-    const double2 *hwin;             // [n_halo][win_nodes] {B_i, B_{i+1} - B_i}
+    const double *hwin;              // [n_halo][win_nodes] blended row values B_i, i = win_lo + e
     int win_nodes;
     double *out;
     bfg_stats *stats;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int ntiles, int32_t *co
     if (threadIdx.x == 0) start[ntiles] = carry;
 }
 
-// Per-halo blended radial row: hwin[j][e] = {B_i, B_{i+1} - B_i}, i = win_lo_j + e, where
+// Per-halo blended radial row: hwin[j][e] = B_i, i = win_lo_j + e, where
 // B_i = sum over the 2^(ndim-1) corners of the halo's (z, M, extras) cell of w_c * T[c][i].
 // One thread per (halo, node); built once per halo instead of once per (halo, tile) pair.
 struct RowParams {
@@ -250,7 +250,7 @@ struct RowParams {
     const double *cw;
     DevTable tab;
     int win_nodes;
-    double2 *hwin;
+    double *hwin;
 };
 
 __global__ __launch_bounds__(256) void halo_row_kernel(const RowParams P)
@@ -287,19 +287,9 @@ __global__ __launch_bounds__(256) void halo_row_kernel(const RowParams P)
     __syncthreads();
     if (!live || skip) return;
     const int ir = s_winlo[hl] + e;
-    const int ir1 = min(ir + 1, T.nr - 1);
-    // B_{i+1} is the neighbouring lane's B_i, except at the end of a window or of the wavefront
-    const bool own_next = (e == W - 1) || ((threadIdx.x & 63) == 63);
-    double b0 = 0.0, b1 = 0.0;
-    for (int c = 0; c < ncorner; ++c) {
-        const double w = s_w[hl][c];
-        const double *row = T.values + s_off[hl][c];
-        b0 = fma(row[ir], w, b0);
-        if (own_next) b1 = fma(row[ir1], w, b1);
-    }
-    const double nb = __shfl_down(b0, 1, 64);      // lane + 1 holds node e + 1 of the same halo when !own_next
-    if (!own_next) b1 = nb;
-    P.hwin[j * W + e] = make_double2(b0, b1 - b0);
+    double b0 = 0.0;
+    for (int c = 0; c < ncorner; ++c) b0 = fma(T.values[s_off[hl][c] + ir], s_w[hl][c], b0);
+    P.hwin[j * W + e] = b0;
 }
 
 constexpr int kTileThreads = 512;
@@ -318,7 +308,7 @@ __host__ __device__ inline size_t tile_lds_bytes()
 {
     return (size_t)kTileRings * kTileWidth * sizeof(double) + kLogTab * sizeof(double2) + kExpTab * sizeof(double) +
            kTileRings * sizeof(RingRow) + kSegMax * sizeof(Seg) + kPairMax * sizeof(PairInfo) +
-           (size_t)kPairMax * kWinLds * sizeof(double2) + kPixMax * sizeof(uint16_t) +
+           (size_t)kPairMax * kWinLds * sizeof(double) + kPixMax * sizeof(uint16_t) +
            (kPairMax + 4) * sizeof(int32_t) + (kSegGroups + 4) * sizeof(int32_t) + 8 * sizeof(int32_t);
 }
 
@@ -333,7 +323,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
     RingRow *rows = reinterpret_cast<RingRow *>(exptab + kExpTab);            // [TR]
     Seg *segs = reinterpret_cast<Seg *>(rows + TR);                           // [kSegMax]
     PairInfo *pinfo = reinterpret_cast<PairInfo *>(segs + kSegMax);           // [kPairMax]
-    double2 *pwin = reinterpret_cast<double2 *>(pinfo + kPairMax);            // [kPairMax][kWinLds]
+    double *pwin = reinterpret_cast<double *>(pinfo + kPairMax);              // [kPairMax][kWinLds] row values B_i
     uint16_t *ptab = reinterpret_cast<uint16_t *>(pwin + kPairMax * kWinLds); // [kPixMax] pixel -> segment
     int32_t *pr_off = reinterpret_cast<int32_t *>(ptab + kPixMax);            // exclusive slot offsets [kPairMax + 1]
     int32_t *gtot = pr_off + kPairMax + 4;                                    // per 64-segment group pixel totals
@@ -422,10 +412,15 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
             pidx[u] &= 0xFF;
             in[u] = (ee[u] >= 0) && (ee[u] < W - 1);
             any_slow |= ok[u] && !in[u];
-            double2 w2;
-            if constexpr (win_in_lds) w2 = pwin[pidx[u] * kWinLds + min(max(ee[u], 0), kWinLds - 2)];
-            else w2 = P.hwin[pinfo[pidx[u]].hoff + min(max(ee[u], 0), W - 2)];
-            LL[u] = fma(ff[u], w2.y, w2.x);
+            double B0, B1;
+            if constexpr (win_in_lds) {
+                const double *wp = pwin + pidx[u] * kWinLds + min(max(ee[u], 0), kWinLds - 2);
+                B0 = wp[0]; B1 = wp[1];
+            } else {
+                const double *wp = P.hwin + pinfo[pidx[u]].hoff + min(max(ee[u], 0), W - 2);
+                B0 = wp[0]; B1 = wp[1];
+            }
+            LL[u] = fma(ff[u], B1 - B0, B0);
         }
         if (__any(any_slow)) {                                             // rare: cell outside the staged row window
 #pragma unroll
@@ -492,15 +487,13 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
         // latency overlaps the slot work below.  dest = wave-uniform base + lane * 16 B  ==  pwin[idx].
         if constexpr (win_in_lds) {
             if (W == kWinLds) {
-#pragma unroll
-                for (int r = 0; r < (kPairMax * kWinLds + NT - 1) / NT; ++r) {
-                    const int idx = tid + r * NT;
-                    if (idx < n_take * kWinLds) {
-                        const double2 *src = P.hwin + pinfo[idx / kWinLds].hoff + (idx % kWinLds);
-                        double2 *dst = pwin + r * NT + wave * 64;                   // wave-uniform
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-                    }
+                // 16 B (two nodes) per lane, 16 lanes per pair; kPairMax * 16 <= NT lanes cover the chunk
+                static_assert(kPairMax * (kWinLds / 2) <= kTileThreads, "one DMA per thread covers the chunk");
+                if (tid < n_take * (kWinLds / 2)) {
+                    const double *src = P.hwin + pinfo[tid / (kWinLds / 2)].hoff + 2 * (tid % (kWinLds / 2));
+                    double *dst = pwin + wave * 128;                                  // wave-uniform; lane * 16 B added by HW
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
                 }
             } else {
                 for (int idx = tid; idx < n_take * W; idx += NT) {
