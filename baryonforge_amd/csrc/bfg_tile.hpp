@@ -293,8 +293,8 @@ __global__ __launch_bounds__(256) void halo_row_kernel(const RowParams P)
 }
 
 constexpr int kTileThreads = 512;
-constexpr int kPairMax = 24;         // pairs per chunk: their row windows are staged in LDS
-constexpr int kSegMax = 768;         // segment records per chunk (36 KiB of LDS)
+constexpr int kPairMax = 28;         // pairs per chunk: their row windows are staged in LDS
+constexpr int kSegMax = 896;         // segment records per chunk (36 KiB of LDS)
 constexpr int kSlotMax = kSegMax / 2;// (pair, ring) slots per chunk; each may add one wrapped second piece
 constexpr int kWinLds = 32;          // row windows up to this many nodes are staged in LDS
 constexpr int kPixMax = 4096;        // pixel -> segment table entries per round (8 KiB of LDS)
