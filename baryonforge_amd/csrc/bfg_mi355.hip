@@ -65,8 +65,6 @@ struct DevTable {
 struct bfg_table {
     DevTable dev;
     double *d_blob;                 // one allocation: axes + values
-    std::vector<std::vector<double>> h_axes;  // original order (z, M, r, extras...)
-    std::vector<double> h_values;   // original C order, for bfg_table_eval's bookkeeping
     std::vector<int64_t> shape;
 };
 
@@ -103,6 +101,7 @@ struct bfg_ctx {
     bfg::HaloTile *d_ht;            // [cap_halo]
     double *d_hwin;                 // [hwin_cap] pre-blended row windows
     int64_t hwin_cap;
+    bool tile_attr_set;             // MaxDynamicSharedMemorySize raised for the tile kernels on this device
     // timing: a growing pool of event pairs per kernel class, resolved lazily in bfg_timing_read
     bool timing;
     std::vector<hipEvent_t> *ev_a[5], *ev_b[5];
@@ -818,8 +817,6 @@ int bfg_table_create(bfg_ctx *c, int ndim, const int64_t *shape, const double *c
     }
     bfg_table *t = new bfg_table();
     t->shape.assign(shape, shape + ndim);
-    t->h_axes.resize(ndim);
-    for (int d = 0; d < ndim; ++d) t->h_axes[d].assign(axes[d], axes[d] + shape[d]);
     // permute values so that r (dim 2) is the fastest axis: [z][M][extras...][r]
     const int nouter = ndim - 1;
     std::vector<int> odim(nouter);   // outer k -> original dim
@@ -1154,13 +1151,12 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         tp.exptab = c->d_mathtab + 2 * kLogTab;
         { const char *dbg = std::getenv("BFG_DEBUG"); tp.debug = dbg ? std::atoi(dbg) : 0; }
         const size_t tlds = tile_lds_bytes();
-        static bool attr_set = false;
-        if (!attr_set) {
+        if (!c->tile_attr_set) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_tile_kernel<MODE_PAINT, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_tile_kernel<MODE_PAINT, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
-            attr_set = true;
+            c->tile_attr_set = true;
         }
         timing_begin(c, 1);
         if (win_nodes <= kWinLds)

@@ -1,0 +1,131 @@
+"""
+The drop-in boundary on its own: libbfg_mi355.so driven through ctypes with plain pointers and sizes only
+(no torch tensors, no numpy device arrays): context on its own stream, bfg_dev_malloc / bfg_memcpy_*,
+table + spline upload, bfg_paint_shell, bfg_baryonify_offsets + bfg_regrid_shell, bfg_stats_read --
+checked against the CPU oracle.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from baryonforge_amd import _lib, synthetic as syn
+from baryonforge_amd.background import Background, RHO_CRITICAL
+from oracle import oracle as orc
+from util import assert_maps_close
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Dev(object):
+    def __init__(self, L, ctx, nbytes):
+        self.L, self.ctx, self.n = L, ctx, nbytes
+        self.p = C.c_void_p()
+        _lib.check(L.bfg_dev_malloc(ctx, nbytes, C.byref(self.p)), "malloc")
+
+    def up(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        _lib.check(self.L.bfg_memcpy_h2d(self.ctx, self.p, arr.ctypes.data, arr.nbytes), "h2d")
+        return self
+
+    def zero(self):
+        _lib.check(self.L.bfg_dev_memset_zero(self.ctx, self.p, self.n), "memset")
+        return self
+
+    def down(self, shape):
+        out = np.empty(shape)
+        _lib.check(self.L.bfg_memcpy_d2h(self.ctx, out.ctypes.data, self.p, out.nbytes), "d2h")
+        return out
+
+    def free(self):
+        _lib.check(self.L.bfg_dev_free(self.ctx, self.p), "free")
+
+
+def _massdef(bg):
+    m = _lib.MassDefStruct()
+    m.Omega_m, m.Omega_l, m.Omega_r, m.w0, m.h = bg.Omega_m, bg.Omega_l, bg.Omega_r, bg.w0, bg.h
+    m.rho_crit0_h2, m.Delta, m.rho_type = RHO_CRITICAL, 200.0, 0
+    return m
+
+
+def _table(L, ctx, axes, values, flags):
+    axes = [np.ascontiguousarray(a, dtype=np.float64) for a in axes]
+    values = np.ascontiguousarray(values, dtype=np.float64)
+    h = C.c_void_p()
+    _lib.check(L.bfg_table_create(ctx, 3, (C.c_int64 * 3)(*values.shape), (C.POINTER(C.c_double) * 3)(*map(_dp, axes)),
+                                  _dp(values), flags, C.byref(h)), "table")
+    return h
+
+
+@pytest.mark.parametrize("variant", [0, 2, 3])
+def test_cabi_paint_and_baryonify_without_torch_types(cosmo, variant):
+    from scipy import interpolate
+    L = _lib.load()
+    ctx = C.c_void_p()
+    _lib.check(L.bfg_ctx_create(0, C.c_void_p(-1), C.byref(ctx)), "ctx")          # BFG_STREAM_OWN
+    name = C.create_string_buffer(128)
+    ncu = C.c_int()
+    _lib.check(L.bfg_ctx_device_info(ctx, name, 128, C.byref(ncu), None, None))
+    assert b"gfx950" in name.value and ncu.value >= 64
+
+    nside, npix, eps = 128, 12 * 128 * 128, 10.0
+    ra, dec, M, z = syn.catalog(800, seed=21, z=(0.1, 0.4))
+    bg = Background(cosmo)
+    z_t = np.linspace(0, z.max() + 0.1, 1000)
+    cs = interpolate.CubicSpline(z_t, bg.angular_diameter_distance(1 / (1 + z_t)))
+    spl = C.c_void_p()
+    knots, coef = np.ascontiguousarray(cs.x), np.ascontiguousarray(cs.c)
+    _lib.check(L.bfg_spline_create(ctx, knots.size, _dp(knots), _dp(coef), C.byref(spl)), "spline")
+    d_cat = Dev(L, ctx, 800 * 32).up(np.stack([M, z, ra, dec], 1))
+    a, R, D = orc.halo_scalars(cosmo, M, z)
+
+    args = _lib.ShellArgs()
+    args.nside, args.n_halo, args.d_catalog, args.cat_stride, args.n_extra = nside, 800, d_cat.p.value, 4, 0
+    args.epsilon_max, args.runner_md, args.model_md = eps, _massdef(bg), _massdef(bg)
+    args.model_epsilon_max, args.variant = 20.0, variant
+
+    # ---- paint
+    zax, Max, rax, T = syn.pressure_table()
+    tab = _table(L, ctx, (zax, Max, rax), np.log(T), _lib.BFG_TABLE_LOG_VALUES)
+    d_map = Dev(L, ctx, npix * 8).zero()
+    _lib.check(L.bfg_stats_reset(ctx))
+    _lib.check(L.bfg_paint_shell(ctx, C.byref(args), tab, spl, d_map.p), "paint")
+    st = _lib.Stats()
+    _lib.check(L.bfg_stats_read(ctx, C.byref(st)))
+    ref, ptot = orc.paint_shell(nside, ra, dec, M, a, D, R, (zax, Max, rax), np.log(T), eps)
+    assert st.pixel_updates == ptot
+    assert_maps_close(d_map.down(npix), ref, 1e-5, what="C-ABI paint")
+    # wrong table kind is refused, bad arguments are refused
+    lin = _table(L, ctx, (zax, Max, rax), T, 0)
+    assert L.bfg_paint_shell(ctx, C.byref(args), lin, spl, d_map.p) == -1
+    assert L.bfg_paint_shell(ctx, C.byref(args), tab, spl, None) == -1
+    _lib.check(L.bfg_table_destroy(ctx, lin))
+
+    # ---- baryonify: offsets + regrid
+    zax, Max, rax, d = syn.displacement_table()
+    dtab = _table(L, ctx, (zax, Max, rax), d, 0)
+    m_in = syn.mass_map(nside)
+    d_off, d_in, d_out, d_sums = Dev(L, ctx, npix * 24).zero(), Dev(L, ctx, npix * 8).up(m_in), \
+        Dev(L, ctx, npix * 8).zero(), Dev(L, ctx, 16)
+    _lib.check(L.bfg_baryonify_offsets(ctx, C.byref(args), dtab, spl, d_off.p), "offsets")
+    _lib.check(L.bfg_regrid_shell(ctx, nside, d_off.p, d_in.p, d_out.p, d_sums.p), "regrid")
+    _lib.check(L.bfg_ctx_synchronize(ctx))
+    got = d_out.down(npix)
+    ref = orc.baryonify_shell(nside, m_in, ra, dec, M, a, D, R, R / a, (zax, Max, rax), d, eps, 20.0)
+    assert_maps_close(got, ref, 1e-5, floor=1e-9, what="C-ABI baryonify")
+    sums = d_sums.down(2)
+    assert np.isclose(sums[0], m_in.sum(), rtol=1e-12) and np.isclose(sums[1], sums[0], rtol=1e-10)
+    amax, ssum = C.c_double(), C.c_double()
+    _lib.check(L.bfg_reduce_absmax_sum(ctx, npix, d_in.p, C.byref(amax), C.byref(ssum)))
+    assert amax.value == m_in.max() and np.isclose(ssum.value, m_in.sum(), rtol=1e-12)
+
+    for b in (d_cat, d_map, d_off, d_in, d_out, d_sums):
+        b.free()
+    _lib.check(L.bfg_table_destroy(ctx, tab))
+    _lib.check(L.bfg_table_destroy(ctx, dtab))
+    _lib.check(L.bfg_spline_destroy(ctx, spl))
+    _lib.check(L.bfg_ctx_destroy(ctx))
