@@ -243,13 +243,13 @@ __device__ inline int group_inclusive_scan(int v, int lane)
 }
 
 // ---- sky tiles of the LDS-privatised variant (bfg_tile.hpp) ----------------------------------
-constexpr int kTileRings = 64;      // TR: rings per band
 constexpr int kTileWidth = 32;      // TW: max pixels of one ring inside one sector
 constexpr int kMaxPairsPerHalo = 64;
 constexpr int kLogTab = 128;
 constexpr int kExpTab = 64;
 
 struct TileGeom {
+    int tr;                      // rings per band (64 for paint tiles, 32 for the 3-component offset tiles)
     int nbands;
     int ntiles;
     const int32_t *band_ns;      // [nbands]   sectors per band

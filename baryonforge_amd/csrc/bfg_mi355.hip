@@ -74,7 +74,7 @@ struct bfg_spline {
     double *d_coef;   // [4][n-1]
 };
 
-namespace bfg { struct HaloTile; }
+namespace bfg { struct HaloTile; struct HaloDisp; }
 struct bfg_ctx {
     int device;
     hipStream_t stream;
@@ -91,10 +91,14 @@ struct bfg_ctx {
     bfg_stats *d_stats;
     double *d_red;      // scratch for reductions [4]
     // tile variant: geometry of the current nside, binning buffers, ln / exp tables
-    int64_t tile_nside;
-    TileGeom geo;
-    int32_t *d_geo;                 // band_ns | band_tile0 | band_nrmin | tile_band
-    int32_t *d_tile_count, *d_tile_start, *d_pairs;
+    struct TileSet {                // tile geometry + binning buffers of one (nside, rings-per-tile)
+        int64_t nside;
+        TileGeom geo;
+        int32_t *d_geo;             // band_ns | band_tile0 | band_nrmin | tile_band
+        int32_t *d_tile_count, *d_tile_start;
+    } tiles[2];                     // [MODE_PAINT], [MODE_BARYONIFY]
+    int32_t *d_pairs;
+    bfg::HaloDisp *d_hd;            // [cap_halo] baryonify tile path
     int64_t pair_cap;
     unsigned long long *d_pair_total;
     double *d_mathtab;              // logtab (256 doubles) | exptab (64 doubles)
@@ -153,6 +157,9 @@ struct PrepParams {
     int win_nodes;
     double pixfac_area;
     bfg::BinCtx bin;         // tile variant: count pass of the halo -> tile binning
+    bfg::HaloDisp *hd;       // baryonify tile path
+    double eps_model;
+    int rdelta;
 };
 
 #define MODE_PAINT 0
@@ -255,7 +262,36 @@ __global__ __launch_bounds__(256) void halo_prep_kernel(const PrepParams P)
         atomicAdd((unsigned long long *)&P.stats->halos_out_of_table, 1ull);
         atomicOr(&P.stats->warn_mask, warn);
     }
-    if (P.ht) flags = tile_bin_halo(P.bin, false, j, flags, rfirst, rlast, irmin, irmax, ptheta, pphi, radius);
+    const double Rm_com = P.want_model_radius ? massdef_radius(P.md_model, M, a) / a : 1.0;
+    if (P.ht) {
+        if (P.bin.mode == MODE_BARYONIFY && !(flags & HF_SKIP) && rlast >= rfirst && rlast - rfirst < 8) {
+            // small disc: count its pixels exactly; fewer than 4 -> 4-neighbour fallback (HealpixRunner.py:333-334),
+            // which only the scatter kernel implements
+            const double cosr = cos(radius), zc = cos(ptheta);
+            const double xa_ = 1.0 / sqrt((1.0 - zc) * (1.0 + zc));
+            int total = 0;
+            for (int ring = rfirst; ring <= rlast; ++ring) {
+                int64_t sp_, nr_; bool sh_;
+                ring_info_small(P.hpx, ring, sp_, nr_, sh_);
+                if (ring < irmin || ring > irmax) { total += (int)nr_; continue; }
+                const double zr = ring2z(P.hpx, ring);
+                const double xx = (cosr - zr * zc) * xa_;
+                const double ysq = 1.0 - zr * zr - xx * xx;
+                const double dphi = (ysq <= 0.0) ? 0.0 : atan2(sqrt(ysq), xx);
+                if (dphi > 0.0) {
+                    const double shift = sh_ ? 0.5 : 0.0;
+                    const int64_t l64 = (int64_t)floor((double)nr_ * kInvTwoPi * (pphi - dphi) - shift) + 1;
+                    const int64_t h64 = (int64_t)floor((double)nr_ * kInvTwoPi * (pphi + dphi) - shift);
+                    int64_t cc = h64 - l64 + 1;
+                    if (cc > nr_) cc = nr_;
+                    if (cc > 0) total += (int)cc;
+                }
+            }
+            if (total < 4) flags |= HF_SCATTER;
+        }
+        if (!(flags & HF_SCATTER))
+            flags = tile_bin_halo(P.bin, false, j, flags, rfirst, rlast, irmin, irmax, ptheta, pphi, radius);
+    }
     irec[I_RFIRST * cap] = rfirst; irec[I_RLAST * cap] = rlast;
     irec[I_IRMIN * cap] = irmin; irec[I_IRMAX * cap] = irmax;
     irec[I_FLAGS * cap] = flags;
@@ -268,12 +304,21 @@ __global__ __launch_bounds__(256) void halo_prep_kernel(const PrepParams P)
         h.xa = 1.0 / sqrt((1.0 - h.z0) * (1.0 + h.z0));
         h.pixfac = (P.pixfac_area != 0.0) ? P.pixfac_area * (D * D) : 1.0;
         h.rfirst = rfirst; h.rlast = rlast; h.irmin = irmin; h.irmax = irmax;
-        // staged row window: ends at the node above the largest radius of the disc
+        // staged row window: ends at the node above the largest radius of the disc (on the table's radial axis)
         const double sr = sin(0.5 * fmin(radius, kPi));
-        const double rho_max = 0.5 * log(4.0 * h.S * sr * sr);
+        const double axis_shift = (P.hd && P.rdelta) ? log(Rm_com) : 0.0;
+        const double rho_max = 0.5 * log(4.0 * h.S * sr * sr) - axis_shift;
         int win_lo = find_interval(P.tab.raxis, P.tab.nr, rho_max) + 1 - (P.win_nodes - 1);
         if (win_lo > P.tab.nr - P.win_nodes) win_lo = P.tab.nr - P.win_nodes;
         if (win_lo < 0) win_lo = 0;
+        if (P.hd) {
+            HaloDisp hd;
+            hd.cp0 = cp; hd.sp0 = sp; hd.a = a; hd.D = D;
+            hd.xcut = (P.eps_model * Rm_com) * (P.eps_model * Rm_com);
+            hd.tshift = -axis_shift * P.tab.inv_dr;
+            hd.pad[0] = hd.pad[1] = 0.0;
+            P.hd[j] = hd;
+        }
         h.win_lo = win_lo; h.flags = flags; h.pad0 = 0; h.pad1 = 0;
         h.spare[0] = h.spare[1] = h.spare[2] = h.spare[3] = 0.0;
         P.ht[j] = h;
@@ -719,9 +764,12 @@ int bfg_ctx_destroy(bfg_ctx *c)
     if (c->d_hwin) (void)hipFree(c->d_hwin);
     (void)hipFree(c->d_stats);
     (void)hipFree(c->d_red);
-    if (c->d_geo) (void)hipFree(c->d_geo);
-    if (c->d_tile_count) (void)hipFree(c->d_tile_count);
-    if (c->d_tile_start) (void)hipFree(c->d_tile_start);
+    for (int m = 0; m < 2; ++m) {
+        if (c->tiles[m].d_geo) (void)hipFree(c->tiles[m].d_geo);
+        if (c->tiles[m].d_tile_count) (void)hipFree(c->tiles[m].d_tile_count);
+        if (c->tiles[m].d_tile_start) (void)hipFree(c->tiles[m].d_tile_start);
+    }
+    if (c->d_hd) (void)hipFree(c->d_hd);
     if (c->d_pairs) (void)hipFree(c->d_pairs);
     (void)hipFree(c->d_mathtab); (void)hipFree(c->d_pair_total);
     for (int k = 0; k < 5; ++k) {
@@ -938,14 +986,15 @@ static int ensure_workspace(bfg_ctx *c, int64_t n)
 {
     if (n <= c->cap_halo) return BFG_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->d_rec) { (void)hipFree(c->d_rec); (void)hipFree(c->d_irec); (void)hipFree(c->d_cidx); (void)hipFree(c->d_cw); (void)hipFree(c->d_ht); }
-    c->d_rec = nullptr; c->d_ht = nullptr; c->cap_halo = 0;
+    if (c->d_rec) { (void)hipFree(c->d_rec); (void)hipFree(c->d_irec); (void)hipFree(c->d_cidx); (void)hipFree(c->d_cw); (void)hipFree(c->d_ht); (void)hipFree(c->d_hd); }
+    c->d_rec = nullptr; c->d_ht = nullptr; c->d_hd = nullptr; c->cap_halo = 0;
     int64_t cap = (n + 1023) / 1024 * 1024;
     HIP_TRY(hipMalloc((void **)&c->d_rec, (size_t)cap * F_NF * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&c->d_irec, (size_t)cap * I_NI * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void **)&c->d_cidx, (size_t)cap * (BFG_MAX_DIM - 1) * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void **)&c->d_cw, (size_t)cap * (BFG_MAX_DIM - 1) * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&c->d_ht, (size_t)cap * sizeof(HaloTile)));
+    HIP_TRY(hipMalloc((void **)&c->d_hd, (size_t)cap * sizeof(HaloDisp)));
     c->cap_halo = cap;
     return BFG_OK;
 }
@@ -981,19 +1030,20 @@ static void timing_end(bfg_ctx *c, int which)
     c->ev_used[which] += 1;
 }
 
-// tile geometry of one nside (cached) and the binning buffers
-static int ensure_tiles(bfg_ctx *c, int64_t nside, int64_t n_halo)
+// tile geometry of one (nside, rings-per-tile) (cached per mode) and the binning buffers
+static int ensure_tiles(bfg_ctx *c, int mode, int tr, int64_t nside, int64_t n_halo)
 {
-    if (c->tile_nside != nside) {
+    bfg_ctx::TileSet &ts = c->tiles[mode];
+    if (ts.nside != nside || ts.geo.tr != tr) {
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (c->d_geo) { (void)hipFree(c->d_geo); (void)hipFree(c->d_tile_count); (void)hipFree(c->d_tile_start); }
-        c->d_geo = nullptr; c->d_tile_count = nullptr; c->d_tile_start = nullptr; c->tile_nside = 0;
+        if (ts.d_geo) { (void)hipFree(ts.d_geo); (void)hipFree(ts.d_tile_count); (void)hipFree(ts.d_tile_start); }
+        ts.d_geo = nullptr; ts.d_tile_count = nullptr; ts.d_tile_start = nullptr; ts.nside = 0;
         const int64_t nrings = 4 * nside - 1;
-        const int nbands = (int)((nrings + kTileRings - 1) / kTileRings);
+        const int nbands = (int)((nrings + tr - 1) / tr);
         std::vector<int32_t> ns(nbands), t0(nbands + 1), nrmin(nbands);
         int ntiles = 0;
         for (int b = 0; b < nbands; ++b) {
-            int64_t lo = 1 + (int64_t)b * kTileRings, hi = std::min<int64_t>(nrings, lo + kTileRings - 1);
+            int64_t lo = 1 + (int64_t)b * tr, hi = std::min<int64_t>(nrings, lo + tr - 1);
             int64_t mx = 0, mn = INT64_MAX;
             for (int64_t r = lo; r <= hi; ++r) {
                 int64_t nr = (r < nside) ? 4 * r : (r <= 3 * nside ? 4 * nside : 4 * (4 * nside - r));
@@ -1010,17 +1060,17 @@ static int ensure_tiles(bfg_ctx *c, int64_t nside, int64_t n_halo)
         blob.insert(blob.end(), t0.begin(), t0.end());
         blob.insert(blob.end(), nrmin.begin(), nrmin.end());
         for (int b = 0; b < nbands; ++b) for (int s = 0; s < ns[b]; ++s) blob.push_back(b);
-        HIP_TRY(hipMalloc((void **)&c->d_geo, blob.size() * sizeof(int32_t)));
-        HIP_TRY(hipMemcpyAsync(c->d_geo, blob.data(), blob.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMalloc((void **)&ts.d_geo, blob.size() * sizeof(int32_t)));
+        HIP_TRY(hipMemcpyAsync(ts.d_geo, blob.data(), blob.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipMalloc((void **)&c->d_tile_count, (size_t)ntiles * sizeof(int32_t)));
-        HIP_TRY(hipMalloc((void **)&c->d_tile_start, (size_t)(ntiles + 1) * sizeof(int32_t)));
-        c->geo.nbands = nbands; c->geo.ntiles = ntiles;
-        c->geo.band_ns = c->d_geo;
-        c->geo.band_tile0 = c->d_geo + nbands;
-        c->geo.band_nrmin = c->d_geo + 2 * nbands + 1;
-        c->geo.tile_band = c->d_geo + 3 * nbands + 1;
-        c->tile_nside = nside;
+        HIP_TRY(hipMalloc((void **)&ts.d_tile_count, (size_t)ntiles * sizeof(int32_t)));
+        HIP_TRY(hipMalloc((void **)&ts.d_tile_start, (size_t)(ntiles + 1) * sizeof(int32_t)));
+        ts.geo.tr = tr; ts.geo.nbands = nbands; ts.geo.ntiles = ntiles;
+        ts.geo.band_ns = ts.d_geo;
+        ts.geo.band_tile0 = ts.d_geo + nbands;
+        ts.geo.band_nrmin = ts.d_geo + 2 * nbands + 1;
+        ts.geo.tile_band = ts.d_geo + 3 * nbands + 1;
+        ts.nside = nside;
     }
     int64_t want = 8 * n_halo + 65536;
     if (const char *pc = std::getenv("BFG_PAIR_CAP")) {      // test hook: force a tiny pair buffer (overflow fallback)
@@ -1064,8 +1114,8 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     if (rc) return rc;
 
     int variant = a->variant;
-    // the tile variant needs a uniform ln r axis (direct cell computation); paint only for now
-    const bool tile_ok = (mode == MODE_PAINT) && t->dev.r_uniform && a->nside >= 8 && a->n_halo < (1ll << 31);
+    // the tile variant needs a uniform radial axis (direct cell computation)
+    const bool tile_ok = t->dev.r_uniform && a->nside >= 8 && a->n_halo < (1ll << 31);
     if (variant == BFG_VARIANT_AUTO) variant = tile_ok ? BFG_VARIANT_TILE_LDS : BFG_VARIANT_SCATTER_QUARTER;
     if (variant == BFG_VARIANT_TILE_LDS && !tile_ok) variant = BFG_VARIANT_SCATTER_QUARTER;
     const bool tile = (variant == BFG_VARIANT_TILE_LDS);
@@ -1076,7 +1126,8 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         win_nodes = std::max(8, std::min(win_nodes, 256));
         if (win_nodes <= kWinLds + kWinLds / 4) win_nodes = std::min(win_nodes, kWinLds);   // fits the LDS staging
         win_nodes = (int)std::min<int64_t>(win_nodes, t->dev.nr);
-        rc = ensure_tiles(c, a->nside, a->n_halo);
+        rc = ensure_tiles(c, mode, mode == MODE_PAINT ? TileCfg<MODE_PAINT>::TR : TileCfg<MODE_BARYONIFY>::TR, a->nside,
+                          a->n_halo);
         if (rc) return rc;
         const int64_t want = a->n_halo * (int64_t)win_nodes;
         if (want > c->hwin_cap) {
@@ -1103,10 +1154,13 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     pp.want_model_radius = (mode == MODE_BARYONIFY);
     pp.ht = tile ? c->d_ht : nullptr; pp.win_nodes = win_nodes; pp.pixfac_area = pixfac_area;
     if (tile) {
-        pp.bin.geo = c->geo; pp.bin.tile_count = c->d_tile_count; pp.bin.tile_start = c->d_tile_start;
+        pp.bin.geo = c->tiles[mode].geo; pp.bin.tile_count = c->tiles[mode].d_tile_count;
+        pp.bin.tile_start = c->tiles[mode].d_tile_start;
         pp.bin.pairs = c->d_pairs; pp.bin.pair_total = c->d_pair_total; pp.bin.pair_cap = c->pair_cap;
         pp.bin.mode = mode;
-        HIP_TRY(hipMemsetAsync(c->d_tile_count, 0, (size_t)c->geo.ntiles * sizeof(int32_t), c->stream));
+        pp.hd = (mode == MODE_BARYONIFY) ? c->d_hd : nullptr;
+        pp.eps_model = a->model_epsilon_max; pp.rdelta = a->rdelta_sampling;
+        HIP_TRY(hipMemsetAsync(c->tiles[mode].d_tile_count, 0, (size_t)c->tiles[mode].geo.ntiles * sizeof(int32_t), c->stream));
     }
     timing_begin(c, 0);
     hipLaunchKernelGGL(halo_prep_kernel, dim3((unsigned)((a->n_halo + 255) / 256)), dim3(256), 0, c->stream, pp);
@@ -1125,8 +1179,9 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
 
     if (tile) {
         timing_begin(c, 3);
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->geo.ntiles, c->d_tile_count,
-                           c->d_tile_start);
+        const bfg_ctx::TileSet &ts = c->tiles[mode];
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, ts.geo.ntiles, ts.d_tile_count,
+                           ts.d_tile_start);
         FillParams fp;
         std::memset(&fp, 0, sizeof(fp));
         fp.n_halo = a->n_halo; fp.cap = c->cap_halo; fp.rec = c->d_rec; fp.irec = c->d_irec; fp.ht = c->d_ht; fp.bin = pp.bin;
@@ -1144,27 +1199,37 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         std::memset(&tp, 0, sizeof(tp));
         tp.hpx = pp.hpx; tp.n_halo = a->n_halo; tp.cap = c->cap_halo;
         tp.ht = c->d_ht; tp.cidx = c->d_cidx; tp.cw = c->d_cw;
-        tp.tab = t->dev; tp.geo = c->geo; tp.tile_start = c->d_tile_start; tp.pairs = c->d_pairs;
+        tp.tab = t->dev; tp.geo = ts.geo; tp.tile_start = ts.d_tile_start; tp.pairs = c->d_pairs;
+        tp.hd = c->d_hd;
         tp.hwin = c->d_hwin; tp.win_nodes = win_nodes; tp.pair_cap = c->pair_cap;
         tp.out = d_out; tp.stats = c->d_stats;
         tp.logtab = reinterpret_cast<const double2 *>(c->d_mathtab);
         tp.exptab = c->d_mathtab + 2 * kLogTab;
         { const char *dbg = std::getenv("BFG_DEBUG"); tp.debug = dbg ? std::atoi(dbg) : 0; }
-        const size_t tlds = tile_lds_bytes();
         if (!c->tile_attr_set) {
+            const int lp = (int)tile_lds_bytes<MODE_PAINT>(), lb = (int)tile_lds_bytes<MODE_BARYONIFY>();
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_tile_kernel<MODE_PAINT, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lp));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_tile_kernel<MODE_PAINT, false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lp));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_tile_kernel<MODE_BARYONIFY, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_tile_kernel<MODE_BARYONIFY, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lb));
             c->tile_attr_set = true;
         }
+        const dim3 tgrid((unsigned)ts.geo.ntiles), tblock(kTileThreads);
+        const bool wl = win_nodes <= kWinLds;
         timing_begin(c, 1);
-        if (win_nodes <= kWinLds)
-            hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, true>), dim3((unsigned)c->geo.ntiles), dim3(kTileThreads),
-                               tlds, c->stream, tp);
-        else
-            hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, false>), dim3((unsigned)c->geo.ntiles), dim3(kTileThreads),
-                               tlds, c->stream, tp);
+        if (mode == MODE_PAINT) {
+            const size_t tlds = tile_lds_bytes<MODE_PAINT>();
+            if (wl) hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, true>), tgrid, tblock, tlds, c->stream, tp);
+            else hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, false>), tgrid, tblock, tlds, c->stream, tp);
+        } else {
+            const size_t tlds = tile_lds_bytes<MODE_BARYONIFY>();
+            if (wl) hipLaunchKernelGGL((shell_tile_kernel<MODE_BARYONIFY, true>), tgrid, tblock, tlds, c->stream, tp);
+            else hipLaunchKernelGGL((shell_tile_kernel<MODE_BARYONIFY, false>), tgrid, tblock, tlds, c->stream, tp);
+        }
         HIP_TRY(hipGetLastError());
         timing_end(c, 1);
         sp.only_flagged = 1;     // leftovers: halos the binning left to the global-atomic kernel

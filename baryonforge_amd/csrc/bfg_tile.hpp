@@ -101,11 +101,30 @@ struct __align__(16) Seg {           // one ring segment of one halo inside one 
 };
 static_assert(sizeof(Seg) == 48, "Seg must be 48 bytes");
 
-struct __align__(16) PairInfo {      // per (halo, tile) pair of the current chunk (32 bytes)
+// extra per-halo constants of the baryonify offsets path (written by halo_prep_kernel next to HaloTile)
+struct __align__(16) HaloDisp {
+    double cp0, sp0;                 // cos / sin of the halo longitude
+    double a, D;                     // scale factor, angular diameter distance [phys Mpc]
+    double xcut;                     // (model.epsilon_max * R_model_com)^2: displacement is zero at r_com^2 >= xcut
+    double tshift;                   // -ln(R_model_com) / dlnr for Rdelta_sampling tables, else 0
+    double pad[2];
+};
+static_assert(sizeof(HaloDisp) == 64, "HaloDisp must be 64 bytes");
+
+struct __align__(16) PairInfo {      // per (halo, tile) pair of the current chunk, paint (32 bytes)
     double pixfac;
     int64_t hoff;                    // index of the halo's row window in hwin
     int32_t win_lo, halo, ra, pad;
 };
+
+struct __align__(16) PairInfoDisp {  // ... baryonify (96 bytes)
+    double cp0, sp0, st, ct;         // halo unit vector = (st cp0, st sp0, ct)
+    double a, D, xcut, tshift;
+    int64_t hoff;
+    int32_t win_lo, halo, ra, pad;
+    double pad2;
+};
+static_assert(sizeof(PairInfoDisp) == 96, "PairInfoDisp must be 96 bytes");
 
 struct __align__(16) RingRow {       // one ring of the tile's band (computed once per workgroup)
     double z, sth, phistep, phioff;
@@ -116,6 +135,7 @@ struct TileParams {
     Hpx hpx;
     int64_t n_halo, cap;
     const HaloTile *ht;
+    const HaloDisp *hd;              // baryonify only
     const int32_t *cidx;             // outer-cell indices / weights (slow path only)
     const double *cw;
     DevTable tab;
@@ -159,7 +179,7 @@ __device__ inline int tile_bin_halo(const BinCtx &B, bool fill, int64_t j, int f
     if (fill && (flags & HF_SCATTER)) return flags;
     bool to_scatter = (flags & HF_OOB) != 0;
     int b0 = 0, b1 = -1;
-    if (rlast >= rfirst) { b0 = (rfirst - 1) / kTileRings; b1 = (rlast - 1) / kTileRings; }
+    if (rlast >= rfirst) { b0 = (rfirst - 1) / B.geo.tr; b1 = (rlast - 1) / B.geo.tr; }
     else if (B.mode == MODE_BARYONIFY) to_scatter = true;        // empty disc -> 4-neighbour fallback
     // longitude half-extent of the disc: asin(sin r / sin theta0), or everything if a pole is inside
     double dphi_bound = kPi;
@@ -293,36 +313,66 @@ __global__ __launch_bounds__(256) void halo_row_kernel(const RowParams P)
 }
 
 constexpr int kTileThreads = 512;
-constexpr int kPairMax = 28;         // pairs per chunk: their row windows are staged in LDS
-constexpr int kSegMax = 896;         // segment records per chunk (36 KiB of LDS)
-constexpr int kSlotMax = kSegMax / 2;// (pair, ring) slots per chunk; each may add one wrapped second piece
 constexpr int kWinLds = 32;          // row windows up to this many nodes are staged in LDS
 constexpr int kPixMax = 4096;        // pixel -> segment table entries per round (8 KiB of LDS)
-constexpr int kSegGroups = kSegMax / 64;
-#ifndef BFG_PIX_PER_THREAD
-#define BFG_PIX_PER_THREAD 1
-#endif
-constexpr int kPixPerThread = BFG_PIX_PER_THREAD;
 
+// per-mode shape of a tile workgroup: rings per tile, accumulators per pixel, LDS capacities of a chunk
+template <int MODE> struct TileCfg;
+template <> struct TileCfg<MODE_PAINT> {
+    static constexpr int TR = 64, NACC = 1, SEGMAX = 896, PAIRMAX = 28;
+    using Pair = PairInfo;
+};
+template <> struct TileCfg<MODE_BARYONIFY> {
+    static constexpr int TR = 32, NACC = 3, SEGMAX = 704, PAIRMAX = 22;
+    using Pair = PairInfoDisp;
+};
+
+template <int MODE>
 __host__ __device__ inline size_t tile_lds_bytes()
 {
-    return (size_t)kTileRings * kTileWidth * sizeof(double) + kLogTab * sizeof(double2) + kExpTab * sizeof(double) +
-           kTileRings * sizeof(RingRow) + kSegMax * sizeof(Seg) + kPairMax * sizeof(PairInfo) +
-           (size_t)kPairMax * kWinLds * sizeof(double) + kPixMax * sizeof(uint16_t) +
-           (kPairMax + 4) * sizeof(int32_t) + (kSegGroups + 4) * sizeof(int32_t) + 8 * sizeof(int32_t);
+    using Cfg = TileCfg<MODE>;
+    return (size_t)Cfg::TR * kTileWidth * Cfg::NACC * sizeof(double) + kLogTab * sizeof(double2) +
+           kExpTab * sizeof(double) + Cfg::TR * sizeof(RingRow) + Cfg::SEGMAX * sizeof(Seg) +
+           Cfg::PAIRMAX * sizeof(typename Cfg::Pair) + (size_t)Cfg::PAIRMAX * kWinLds * sizeof(double) +
+           kPixMax * sizeof(uint16_t) + (Cfg::PAIRMAX + 4) * sizeof(int32_t) +
+           ((Cfg::SEGMAX + 63) / 64 + 4) * sizeof(int32_t) + 8 * sizeof(int32_t);
+}
+
+// sin(h) for h^2 <= kSinSmall: odd series to h^7 (rel err < 3e-12)
+__device__ inline double sin_small(double h, double h2)
+{
+    double p = fma(h2, -1.0 / 5040.0, 1.0 / 120.0);
+    p = fma(h2, p, -1.0 / 6.0);
+    p = fma(h2, p, 1.0);
+    return h * p;
+}
+
+// (sin h, cos h) for |h| <= 3.2 without libm: series on h/16, then four angle doublings
+__device__ inline void sincos_wide(double h, double &sh, double &ch)
+{
+    const double q = 0.0625 * h;
+    double s = sin_small(q, q * q);
+    double c = sqrt(1.0 - s * s);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const double s2 = 2.0 * s * c; c = 1.0 - 2.0 * s * s; s = s2; }
+    sh = s; ch = c;
 }
 
 template <int MODE, bool WIN_LDS>
 __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileParams P)
 {
-    constexpr int TR = kTileRings, TW = kTileWidth, NT = kTileThreads;
+    using Cfg = TileCfg<MODE>;
+    using Pair = typename Cfg::Pair;
+    constexpr int TR = Cfg::TR, TW = kTileWidth, NT = kTileThreads, NACC = Cfg::NACC;
+    constexpr int kSegMax = Cfg::SEGMAX, kPairMax = Cfg::PAIRMAX, kSlotMax = kSegMax / 2;
+    constexpr int kSegGroups = (kSegMax + 63) / 64;
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    double *acc = reinterpret_cast<double *>(smem_raw);                       // [TR*TW]
-    double2 *logtab = reinterpret_cast<double2 *>(acc + TR * TW);             // [128]
+    double *acc = reinterpret_cast<double *>(smem_raw);                       // [TR*TW*NACC]
+    double2 *logtab = reinterpret_cast<double2 *>(acc + TR * TW * NACC);      // [128]
     double *exptab = reinterpret_cast<double *>(logtab + kLogTab);            // [64]
     RingRow *rows = reinterpret_cast<RingRow *>(exptab + kExpTab);            // [TR]
     Seg *segs = reinterpret_cast<Seg *>(rows + TR);                           // [kSegMax]
-    PairInfo *pinfo = reinterpret_cast<PairInfo *>(segs + kSegMax);           // [kPairMax]
+    Pair *pinfo = reinterpret_cast<Pair *>(segs + kSegMax);                   // [kPairMax]
     double *pwin = reinterpret_cast<double *>(pinfo + kPairMax);              // [kPairMax][kWinLds] row values B_i
     uint16_t *ptab = reinterpret_cast<uint16_t *>(pwin + kPairMax * kWinLds); // [kPixMax] pixel -> segment
     int32_t *pr_off = reinterpret_cast<int32_t *>(ptab + kPixMax);            // exclusive slot offsets [kPairMax + 1]
@@ -341,7 +391,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
     const int ring_hi = min((int)(4 * hp.nside - 1), ring_lo + TR - 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    for (int i = tid; i < TR * TW; i += NT) acc[i] = 0.0;
+    for (int i = tid; i < TR * TW * NACC; i += NT) acc[i] = 0.0;
     if (tid < kLogTab) logtab[tid] = P.logtab[tid];
     if (tid < kExpTab) exptab[tid] = P.exptab[tid];
     if (tid < TR) {
@@ -379,78 +429,101 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
     if (wave == 0) prefetch(0);
     __syncthreads();
 
-    // NPX pixels of the flattened chunk per call, written branch-free so that the NPX dependency chains
-    // (segment record -> chord^2 -> ln -> row read-out -> exp -> LDS add) interleave in one wavefront.
-    constexpr int NPX = kPixPerThread;
-    auto paintN = [&](const int (&q)[NPX], const int (&sx)[NPX], const bool (&valid)[NPX]) {
-        int ipu[NPX], pidx[NPX], ii[NPX], ee[NPX], addr[NPX];
-        double xx[NPX], ff[NPX], LL[NPX];
-        bool ok[NPX], in[NPX];
-#pragma unroll
-        for (int u = 0; u < NPX; ++u) {
-            const Seg sg = segs[sx[u]];
-            ipu[u] = sg.iplo + (q[u] - sg.excl);                           // unwrapped pixel index in the ring
-            addr[u] = sg.abase + ipu[u];
-            pidx[u] = sg.pidx;
-            const double h = fma((double)ipu[u], sg.hstep, sg.c0);
-            const double h2 = h * h;
+    // row read-out shared by both modes: interpolant at cell i, fraction f of the pair's blended row
+    auto read_row = [&](int pidx, int i, double f, int e, bool ok, bool in) -> double {
+        double B0, B1;
+        if constexpr (win_in_lds) {
+            const double *wp = pwin + pidx * kWinLds + min(max(e, 0), kWinLds - 2);
+            B0 = wp[0]; B1 = wp[1];
+        } else {
+            const double *wp = P.hwin + pinfo[pidx].hoff + min(max(e, 0), W - 2);
+            B0 = wp[0]; B1 = wp[1];
+        }
+        double L = fma(f, B1 - B0, B0);
+        if (__any(ok && !in)) {                                            // rare: cell outside the staged row window
+            if (ok && !in) {
+                const int64_t j = pinfo[pidx].halo;
+                double c0v = 0.0, c1v = 0.0;
+                const int ncorner = 1 << T.nouter;
+                for (int c = 0; c < ncorner; ++c) {
+                    double w = 1.0; int64_t off = 0;
+                    for (int k = 0; k < T.nouter; ++k) {
+                        const int bit = (c >> (T.nouter - 1 - k)) & 1;
+                        const double y = P.cw[k * P.cap + j];
+                        w = w * (bit ? y : 1.0 - y);
+                        off += (int64_t)(P.cidx[k * P.cap + j] + bit) * T.ostride[k];
+                    }
+                    c0v = fma(T.values[off + i], w, c0v);
+                    c1v = fma(T.values[off + i + 1], w, c1v);
+                }
+                L = fma(f, c1v - c0v, c0v);
+            }
+        }
+        return L;
+    };
+
+    // one pixel of the flattened chunk: segment record -> chord^2 -> ln -> row read-out -> accumulate in LDS
+    auto do_pixel = [&](int q, int sx) {
+        const Seg sg = segs[sx];
+        const int ipu = sg.iplo + (q - sg.excl);                           // unwrapped pixel index in the ring
+        const int addr = sg.abase + ipu;
+        const int pidx = sg.pidx & 0xFF;
+        const double h = fma((double)ipu, sg.hstep, sg.c0);
+        const double h2 = h * h;
+        if constexpr (MODE == MODE_PAINT) {
             double s2 = sin_squared_small(h2);
             if (__any(h2 > kSinSmall)) {                                   // wave-uniform branch: only near the poles
                 if (h2 > kSinSmall) s2 = sin_squared_wide(h);
             }
-            xx[u] = fma(sg.Bq, s2, sg.Aq);                                 // r_com^2
-        }
-        bool any_slow = false;
-#pragma unroll
-        for (int u = 0; u < NPX; ++u) {
+            const double x = fma(sg.Bq, s2, sg.Aq);                        // r_com^2
             // x = 0 or NaN falls out of the range test (ln of the bit pattern is hugely negative / NaN)
-            const double t = fma(fast_log(xx[u], logtab), t_m, t_c);
-            ok[u] = (t >= 0.0) && (t <= (double)NRm1) && valid[u];
-            ii[u] = min(max((int)t, 0), NRm1 - 1);
-            ff[u] = t - (double)ii[u];
-            ee[u] = ii[u] - (pidx[u] >> 8);
-            pidx[u] &= 0xFF;
-            in[u] = (ee[u] >= 0) && (ee[u] < W - 1);
-            any_slow |= ok[u] && !in[u];
-            double B0, B1;
-            if constexpr (win_in_lds) {
-                const double *wp = pwin + pidx[u] * kWinLds + min(max(ee[u], 0), kWinLds - 2);
-                B0 = wp[0]; B1 = wp[1];
-            } else {
-                const double *wp = P.hwin + pinfo[pidx[u]].hoff + min(max(ee[u], 0), W - 2);
-                B0 = wp[0]; B1 = wp[1];
-            }
-            LL[u] = fma(ff[u], B1 - B0, B0);
-        }
-        if (__any(any_slow)) {                                             // rare: cell outside the staged row window
-#pragma unroll
-            for (int u = 0; u < NPX; ++u) {
-                if (ok[u] && !in[u]) {
-                    const int64_t j = pinfo[pidx[u]].halo;
-                    double c0v = 0.0, c1v = 0.0;
-                    const int ncorner = 1 << T.nouter;
-                    for (int c = 0; c < ncorner; ++c) {
-                        double w = 1.0; int64_t off = 0;
-                        for (int k = 0; k < T.nouter; ++k) {
-                            const int bit = (c >> (T.nouter - 1 - k)) & 1;
-                            const double y = P.cw[k * P.cap + j];
-                            w = w * (bit ? y : 1.0 - y);
-                            off += (int64_t)(P.cidx[k * P.cap + j] + bit) * T.ostride[k];
-                        }
-                        c0v = fma(T.values[off + ii[u]], w, c0v);
-                        c1v = fma(T.values[off + ii[u] + 1], w, c1v);
-                    }
-                    LL[u] = fma(ff[u], c1v - c0v, c0v);
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < NPX; ++u) {
+            const double t = fma(fast_log(x, logtab), t_m, t_c);
+            const bool ok = (t >= 0.0) && (t <= (double)NRm1);
+            const int i = min(max((int)t, 0), NRm1 - 1);
+            const double f = t - (double)i;
+            const int e = i - (sg.pidx >> 8);
+            const bool in = (e >= 0) && (e < W - 1);
+            const double L = read_row(pidx, i, f, e, ok, in);
             // NaN / +-inf / overflowing L paint nothing (HealpixRunner.py:473)
-            const bool go = ok[u] && (LL[u] > -746.0) && (LL[u] < 709.0);       // false for NaN too
-            const double v = fast_exp(LL[u], exptab) * pinfo[pidx[u]].pixfac;    // garbage when !go, never added
-            n_r_oob += (ok[u] || !valid[u]) ? 0 : 1;
-            if (go && v != 0.0) unsafeAtomicAdd(&acc[addr[u]], v);
+            const bool go = ok && (L > -746.0) && (L < 709.0);             // false for NaN too
+            const double v = fast_exp(L, exptab) * pinfo[pidx].pixfac;     // garbage when !go, never added
+            n_r_oob += ok ? 0 : 1;
+            if (go && v != 0.0) unsafeAtomicAdd(&acc[addr], v);
+        } else {
+            // HealpixRunner.py:336-355 for one pixel; pidx packs pair slot | ring row << 8 | win_lo << 14
+            const Pair &pi = pinfo[pidx];
+            const RingRow &rr = rows[(sg.pidx >> 8) & 0x3F];
+            double sh = sin_small(h, h2), ch = sqrt(1.0 - sh * sh);        // sin, cos of dphi/2 (cos >= 0)
+            if (__any(h2 > kSinSmall)) { if (h2 > kSinSmall) sincos_wide(h, sh, ch); }
+            const double s2 = sh * sh;
+            const double x = fma(sg.Bq, s2, sg.Aq);                        // r_com^2
+            const double sd = 2.0 * sh * ch, cd = 1.0 - 2.0 * s2;          // sin, cos of dphi
+            const double cphi = pi.cp0 * cd - pi.sp0 * sd, sphi = pi.sp0 * cd + pi.cp0 * sd;
+            const double vx = rr.sth * cphi, vy = rr.sth * sphi, vz = rr.z;                 // pixel unit vector
+            const double dx = vx - pi.st * pi.cp0, dy = vy - pi.st * pi.sp0, dz = vz - pi.ct;   // vec - vec_j
+            const double t = fma(fast_log(x, logtab), t_m, t_c + pi.tshift);
+            const bool ok = (t >= 0.0) && (t <= (double)NRm1);
+            const int i = min(max((int)t, 0), NRm1 - 1);
+            const double f = t - (double)i;
+            const int e = i - (sg.pidx >> 14);
+            const bool in = (e >= 0) && (e < W - 1);
+            double d = read_row(pidx, i, f, e, ok, in);                    // comoving displacement; table holds d
+            n_r_oob += ok ? 0 : 1;
+            // zero outside the hull (NaN fill), beyond the model's epsilon_max R (BaryonCorrection.py:410-411),
+            // for non-finite table values and at r = 0 (HealpixRunner.py:347)
+            const bool use = ok && (x < pi.xcut) && (x > 0.0) && (fabs(d) < 1.0e300);
+            d = use ? d * pi.a : 0.0;                                      // physical (HealpixRunner.py:345)
+            if (d != 0.0) {
+                const double rc = sqrt(x);                                 // r_com; chord = rc a / D
+                const double chord = rc * pi.a / pi.D;
+                const double qq = pi.D * d * chord + d * d;                // |pos + off|^2 - D^2
+                const double nwn = sqrt(fma(pi.D, pi.D, qq));
+                const double g = -qq / (nwn * (nwn + pi.D));               // D / |nw| - 1 without cancellation
+                const double kk = d / (chord * nwn);                       // offset along (vec - vec_j) / chord, / |nw|
+                unsafeAtomicAdd(&acc[3 * addr + 0], fma(vx, g, dx * kk));
+                unsafeAtomicAdd(&acc[3 * addr + 1], fma(vy, g, dy * kk));
+                unsafeAtomicAdd(&acc[3 * addr + 2], fma(vz, g, dz * kk));
+            }
         }
     };
 
@@ -470,8 +543,15 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
             const int n_take = first_bad ? first_bad - 1 : 64;
             if (lane < n_take) {
                 const HaloTile &h = P.ht[j];
-                PairInfo pi;
-                pi.pixfac = h.pixfac; pi.hoff = (int64_t)j * W; pi.win_lo = h.win_lo; pi.halo = j; pi.ra = ra; pi.pad = 0;
+                Pair pi;
+                pi.hoff = (int64_t)j * W; pi.win_lo = h.win_lo; pi.halo = j; pi.ra = ra; pi.pad = 0;
+                if constexpr (MODE == MODE_PAINT) {
+                    pi.pixfac = h.pixfac;
+                } else {
+                    const HaloDisp &hd = P.hd[j];
+                    pi.cp0 = hd.cp0; pi.sp0 = hd.sp0; pi.st = h.st; pi.ct = h.ct;
+                    pi.a = hd.a; pi.D = hd.D; pi.xcut = hd.xcut; pi.tshift = hd.tshift; pi.pad2 = 0.0;
+                }
                 pinfo[lane] = pi;
                 pr_off[lane] = cum - nrings;
             }
@@ -482,12 +562,10 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
         const int n_take = ctl[0], nslots = ctl[1];
 
         // ---- stage b: one thread per (pair, ring) slot; row windows -> LDS -----------------------------
-        // row windows of the chunk's pairs -> LDS.  With full-width windows the copy is an LDS-DMA
-        // (global_load_lds_dwordx4: no VGPRs, asynchronous; drained by the barrier that ends stage b), so its
-        // latency overlaps the slot work below.  dest = wave-uniform base + lane * 16 B  ==  pwin[idx].
+        // With full-width windows the copy is an LDS-DMA (global_load_lds_dwordx4: no VGPRs, asynchronous;
+        // drained by the barrier that ends stage b).  dest = wave-uniform base + lane * 16 B == pwin[2 * tid].
         if constexpr (win_in_lds) {
             if (W == kWinLds) {
-                // 16 B (two nodes) per lane, 16 lanes per pair; kPairMax * 16 <= NT lanes cover the chunk
                 static_assert(kPairMax * (kWinLds / 2) <= kTileThreads, "one DMA per thread covers the chunk");
                 if (tid < n_take * (kWinLds / 2)) {
                     const double *src = P.hwin + pinfo[tid / (kWinLds / 2)].hoff + 2 * (tid % (kWinLds / 2));
@@ -502,13 +580,14 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
                 }
             }
         }
-        for (int slot = tid; slot < nslots && !(P.debug & 8); slot += NT) {
+        for (int slot = tid; slot < nslots; slot += NT) {
             int lo_ = 0, hi_ = n_take - 1;          // pair p with pr_off[p] <= slot < pr_off[p+1]
             while (lo_ < hi_) { const int mid = (lo_ + hi_ + 1) >> 1; if (pr_off[mid] <= slot) lo_ = mid; else hi_ = mid - 1; }
             const int p = lo_;
             const int j = pinfo[p].halo;
             const int ring = pinfo[p].ra + (slot - pr_off[p]);
-            const RingRow rr = rows[ring - ring_lo];
+            const int row = ring - ring_lo;
+            const RingRow rr = rows[row];
             const HaloTile &h = P.ht[j];
             const double st = h.st, ct = h.ct, pphi = h.pphi, S = h.S;
             const int nr = rr.nr;
@@ -528,7 +607,9 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
                 }
             }
             Seg sg;
-            sg.iplo = 0; sg.abase = 0; sg.excl = 0; sg.pidx = p | (h.win_lo << 8);   // pair slot | row window start
+            sg.iplo = 0; sg.abase = 0; sg.excl = 0;
+            if constexpr (MODE == MODE_PAINT) sg.pidx = p | (h.win_lo << 8);          // pair slot | row window start
+            else sg.pidx = p | (row << 8) | (h.win_lo << 14);                          // ... | ring row | ...
             sg.hstep = 0.5 * rr.phistep;
             sg.c0 = 0.5 * (rr.phioff * rr.phistep - pphi);
             const double ds = rr.sth - st, dz = rr.z - ct;
@@ -584,7 +665,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
         my_pixels += (tid == 0) ? (unsigned long long)ptotal : 0ull;
 
         // ---- stage c: rounds of kPixMax pixels: pixel -> segment table, then one thread per pixel -------
-        for (int pbase = 0; pbase < ptotal && !(P.debug & 2); pbase += kPixMax) {
+        for (int pbase = 0; pbase < ptotal; pbase += kPixMax) {
             if (pbase > 0) __syncthreads();                           // previous round's readers are done
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
@@ -597,18 +678,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
             }
             __syncthreads();
             const int pend = min(ptotal, pbase + kPixMax);
-            for (int q0 = pbase + tid; q0 < pend; q0 += NPX * NT) {   // NPX independent pixels per thread
-                int q[NPX], sx[NPX];
-                bool valid[NPX];
-#pragma unroll
-                for (int u = 0; u < NPX; ++u) {
-                    q[u] = q0 + u * NT;
-                    valid[u] = q[u] < pend;
-                    if (!valid[u]) q[u] = q0;
-                    sx[u] = ptab[q[u] - pbase];
-                }
-                paintN(q, sx, valid);
-            }
+            for (int q = pbase + tid; q < pend; q += NT) do_pixel(q, ptab[q - pbase]);
         }
         __syncthreads();
         base += n_take;
@@ -623,11 +693,14 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
         const int row = i / TW, col = i % TW;
         const int ring = ring_lo + row;
         if (ring > ring_hi) break;
-        const double v = acc[i];
-        if (v == 0.0) continue;
         int64_t start, nr64; bool shifted;
         ring_info_small(hp, ring, start, nr64, shifted);
-        P.out[start + rows[row].k0 + col] += v;
+        const int64_t pix = start + rows[row].k0 + col;
+#pragma unroll
+        for (int c = 0; c < NACC; ++c) {
+            const double v = acc[NACC * i + c];
+            if (v != 0.0) P.out[NACC * pix + c] += v;
+        }
     }
 }
 

@@ -217,7 +217,7 @@ def main():
             traffic = json.load(open(tfile)).get(f"{args.workload}_{args.variant}_n{args.halos}_nside{nside}")
         except Exception:
             traffic = None
-    tile = args.workload == "paint" and args.variant in ("auto", "tile_lds")
+    tile = args.variant in ("auto", "tile_lds")
     roofline = {"bound": "hbm", "kernel": "shell_tile_kernel" if tile else "shell_scatter_kernel",
                 "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
