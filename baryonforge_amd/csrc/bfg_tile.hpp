@@ -580,7 +580,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
                 }
             }
         }
-        for (int slot = tid; slot < nslots; slot += NT) {
+        for (int slot = tid; slot < nslots && !(P.debug & 8); slot += NT) {
             int lo_ = 0, hi_ = n_take - 1;          // pair p with pr_off[p] <= slot < pr_off[p+1]
             while (lo_ < hi_) { const int mid = (lo_ + hi_ + 1) >> 1; if (pr_off[mid] <= slot) lo_ = mid; else hi_ = mid - 1; }
             const int p = lo_;
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
         my_pixels += (tid == 0) ? (unsigned long long)ptotal : 0ull;
 
         // ---- stage c: rounds of kPixMax pixels: pixel -> segment table, then one thread per pixel -------
-        for (int pbase = 0; pbase < ptotal; pbase += kPixMax) {
+        for (int pbase = 0; pbase < ptotal && !(P.debug & 2); pbase += kPixMax) {
             if (pbase > 0) __syncthreads();                           // previous round's readers are done
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
