@@ -100,12 +100,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X GPU (no CPU fallback for the product path)")
+    # BFG_BENCH_BACKEND=gloo + BFG_BENCH_ONE_DEVICE=1: rehearsal of the multi-rank path on a one-GPU box
+    # (all ranks on cuda:0, gloo all-reduce); the driver's runs use one GPU per rank and nccl (= RCCL).
+    backend = os.environ.get("BFG_BENCH_BACKEND", "nccl")
+    if os.environ.get("BFG_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import baryonforge_amd as bfg
     from baryonforge_amd import sharding, synthetic as syn
