@@ -92,6 +92,11 @@ def cpu_baseline(args, cosmo, ra, dec, M, z, axes, T):
     return out
 
 
+def _mark(msg):
+    if os.environ.get("BFG_BENCH_VERBOSE"):
+        print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
     import torch
@@ -115,6 +120,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    _mark("process group up")
     import baryonforge_amd as bfg
     from baryonforge_amd import sharding, synthetic as syn
     from baryonforge_amd.background import Background
@@ -173,9 +179,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    _mark("inputs resident")
     for _ in range(args.warmup):
         step()
+    _mark("warmup issued")
     barrier()
+    _mark("warmup done")
     ctx.stats_reset()
     ctx.timing_enable(True)          # hipEvents around each kernel, on the kernels' own stream
     barrier()
@@ -184,6 +193,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    _mark("timed region done")
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
