@@ -238,6 +238,31 @@ def test_paint_full_size_linearity_1e5(cosmo):
     assert np.all(full >= 0) and np.isfinite(full).all()
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("nside", [8, 24, 37, 100])
+def test_paint_and_baryonify_any_nside(cosmo, nside, variant):
+    """RING-scheme NSIDE need not be a power of two (healpy accepts any NSIDE for RING maps)"""
+    import warnings
+    ra, dec, M, z = syn.catalog(300, seed=nside, z=(0.03, 0.2), logM=(13.5, 15.5))
+    zax, Max, rax, T = syn.pressure_table()
+    ref, ptot = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax), T, nside, 10)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    Shell = bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo)
+    R = bfg.PaintProfilesShell(Cat, Shell, 10, _paint_model(zax, Max, rax, T), verbose=False, variant=variant)
+    got = R.process()
+    assert R.last_stats["pixel_updates"] == ptot
+    assert_maps_close(got, ref, RTOL, what=f"paint nside {nside}")
+    zax, Max, rax, d = syn.displacement_table()
+    m_in = syn.mass_map(nside)
+    refb = oracle_baryonify(cosmo, ra, dec, M, z, (zax, Max, rax), d, nside, 10, 20, m_in)
+    model = bfg.Baryonification2D.from_arrays(zax, Max, rax, d, cosmo, epsilon_max=20)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gotb = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo), 10, model, verbose=False,
+                                  variant=variant).process()
+    assert_maps_close(gotb, refb, RTOL, floor=BFLOOR, what=f"baryonify nside {nside}")
+
+
 def test_tile_pair_buffer_overflow_falls_back_to_scatter(cosmo, monkeypatch):
     """If the (halo, tile) pair buffer is too small the whole call degrades to the scatter kernel -- same map."""
     ra, dec, M, z = syn.catalog(3000, seed=46)

@@ -31,6 +31,20 @@ def test_library_exports_every_declared_symbol():
     assert L.bfg_status_string(0) == b"ok" and b"invalid" in L.bfg_status_string(-1)
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/bfg_mi355.h must compile as C (the drop-in boundary is a C-ABI) and agree with the ctypes structs"""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "bfg_mi355.h"\n#include <stdio.h>\n'
+                   'int main(void){printf("%zu %zu %zu %d\\n", sizeof(bfg_massdef), sizeof(bfg_shell_args), '
+                   'sizeof(bfg_stats), BFG_ABI_VERSION); return 0;}\n')
+    exe = tmp_path / "t"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    assert [int(x) for x in out] == [ctypes.sizeof(_lib.MassDefStruct), ctypes.sizeof(_lib.ShellArgs),
+                                     ctypes.sizeof(_lib.Stats), 1]
+
+
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.MassDefStruct) == 7 * 8 + 8
     assert ctypes.sizeof(_lib.Stats) == 4 * 8 + 8
