@@ -59,6 +59,7 @@ struct DevTable {
     const double *values;           // permuted to [z][M][extras...][r]
     int log_values;
     int r_uniform;                  // ln r axis is a linspace to rounding
+    int hot;                        // a log table with finite |ln T| > 650: exp() range handling stays with the scatter kernels
     double r0, inv_dr;
 };
 
@@ -263,6 +264,10 @@ __global__ __launch_bounds__(256) void halo_prep_kernel(const PrepParams P)
         atomicOr(&P.stats->warn_mask, warn);
     }
     const double Rm_com = P.want_model_radius ? massdef_radius(P.md_model, M, a) / a : 1.0;
+    // paint: the tile path folds ln(pixarea D^2) into the halo's row window; keep exp() range handling exact
+    const double pixfac = (P.pixfac_area != 0.0) ? P.pixfac_area * (D * D) : 1.0;
+    const double lnpf = (P.pixfac_area != 0.0) ? log(pixfac) : 0.0;
+    if (P.ht && P.bin.mode == MODE_PAINT && !(fabs(lnpf) < 50.0)) flags |= HF_SCATTER;
     if (P.ht) {
         if (P.bin.mode == MODE_BARYONIFY && !(flags & HF_SKIP) && rlast >= rfirst && rlast - rfirst < 8) {
             // small disc: count its pixels exactly; fewer than 4 -> 4-neighbour fallback (HealpixRunner.py:333-334),
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(256) void halo_prep_kernel(const PrepParams P)
         h.cosr = cos(radius);
         h.z0 = cos(ptheta);
         h.xa = 1.0 / sqrt((1.0 - h.z0) * (1.0 + h.z0));
-        h.pixfac = (P.pixfac_area != 0.0) ? P.pixfac_area * (D * D) : 1.0;
+        h.pixfac = pixfac;
         h.rfirst = rfirst; h.rlast = rlast; h.irmin = irmin; h.irmax = irmax;
         // staged row window: ends at the node above the largest radius of the disc (on the table's radial axis)
         const double sr = sin(0.5 * fmin(radius, kPi));
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(256) void halo_prep_kernel(const PrepParams P)
             P.hd[j] = hd;
         }
         h.win_lo = win_lo; h.flags = flags; h.pad0 = 0; h.pad1 = 0;
-        h.spare[0] = h.spare[1] = h.spare[2] = h.spare[3] = 0.0;
+        h.spare[0] = lnpf; h.spare[1] = h.spare[2] = h.spare[3] = 0.0;
         P.ht[j] = h;
     }
 }
@@ -1023,6 +1028,8 @@ int bfg_table_create(bfg_ctx *c, int ndim, const int64_t *shape, const double *c
     for (int64_t i = 0; i < NR && uni; ++i)
         if (std::fabs(r[i] - (r[0] + dr * (double)i)) > 1e-9 * dr) uni = false;
     D.r_uniform = uni ? 1 : 0; D.r0 = r[0]; D.inv_dr = uni ? 1.0 / dr : 0.0;
+    if (D.log_values)
+        for (double v : perm) if (std::isfinite(v) && std::fabs(v) > 650.0) { D.hot = 1; break; }
     HIP_TRY(hipMemcpyAsync(t->d_blob, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     *out = t;
@@ -1223,7 +1230,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
 
     int variant = a->variant;
     // the tile variant needs a uniform radial axis (direct cell computation)
-    const bool tile_ok = t->dev.r_uniform && a->nside >= 8 && a->n_halo < (1ll << 31);
+    const bool tile_ok = t->dev.r_uniform && !t->dev.hot && a->nside >= 8 && a->n_halo < (1ll << 31);
     if (variant == BFG_VARIANT_AUTO) variant = tile_ok ? BFG_VARIANT_TILE_LDS : BFG_VARIANT_SCATTER_QUARTER;
     if (variant == BFG_VARIANT_TILE_LDS && !tile_ok) variant = BFG_VARIANT_SCATTER_QUARTER;
     const bool tile = (variant == BFG_VARIANT_TILE_LDS);
@@ -1462,3 +1469,16 @@ int bfg_timing_read(bfg_ctx *c, int which, double *ms_total, int64_t *launches)
 }
 
 }  // extern "C"
+
+#if BFG_STAGE_TIMING
+// profiling build only (not declared in include/bfg_mi355.h)
+extern "C" int bfg_debug_stage_cycles(bfg_ctx *c, unsigned long long *out8, int reset)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    (void)hipStreamSynchronize(c->stream);
+    if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(bfg::g_stage_cycles), 8 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(bfg::g_stage_cycles), z, sizeof(z)); }
+    return 0;
+}
+#endif

@@ -91,13 +91,17 @@ struct __align__(16) HaloTile {
     double cosr, z0, xa, pixfac;     // query_disc constants, pixarea * D^2 (or 1)
     int32_t rfirst, rlast, irmin, irmax;
     int32_t win_lo, flags, pad0, pad1;
-    double spare[4];
+    double spare[4];                 // [0] = ln(pixfac)
 };
 static_assert(sizeof(HaloTile) == 128, "HaloTile must be one 128-byte line");
 
 struct __align__(16) Seg {           // one ring segment of one halo inside one tile (48 bytes)
-    int32_t iplo, abase, excl, pidx; // first (unwrapped) pixel, tile address base, pixel offset, pair slot | win_lo << 8
-    double hstep, c0, Aq, Bq;        // h = ip * hstep + c0 ;  r_com^2 = Aq + Bq sin^2(h)
+    int32_t excl;                    // offset of the segment's first pixel in the chunk's flattened pixel list
+    int32_t abyte;                   // LDS byte offset of the accumulator of the segment's first pixel
+    int32_t wbyte;                   // LDS byte offset of B_0 of the pair's row window (node i at wbyte + 8 i);
+                                     // pair slot when the windows are not staged in LDS
+    int32_t pk;                      // paint: win_lo ; baryonify: pair slot | ring row << 5 | win_lo << 11
+    double hstep, c0, Aq, Bq;        // k-th pixel: h = k hstep + c0 ;  r_com^2 = Aq + Bq sin^2(h)
 };
 static_assert(sizeof(Seg) == 48, "Seg must be 48 bytes");
 
@@ -112,7 +116,7 @@ struct __align__(16) HaloDisp {
 static_assert(sizeof(HaloDisp) == 64, "HaloDisp must be 64 bytes");
 
 struct __align__(16) PairInfo {      // per (halo, tile) pair of the current chunk, paint (32 bytes)
-    double pixfac;
+    double lnpf;                     // ln(pixarea D^2), already folded into the row window (used by the rare direct read-out)
     int64_t hoff;                    // index of the halo's row window in hwin
     int32_t win_lo, halo, ra, pad;
 };
@@ -279,6 +283,7 @@ __global__ __launch_bounds__(256) void halo_row_kernel(const RowParams P)
     __shared__ double s_w[256 / 8][kMaxCorner];
     __shared__ int64_t s_off[256 / 8][kMaxCorner];
     __shared__ int s_winlo[256 / 8];
+    __shared__ double s_add[256 / 8];
     const DevTable &T = P.tab;
     const int W = P.win_nodes;
     const int hpb = 256 / W;                                   // halos per block (W <= 256, W >= 8)
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(256) void halo_row_kernel(const RowParams P)
     if (live) {
         const int flags = P.ht[j].flags;
         skip = (flags & (HF_SKIP | HF_OOB)) != 0;
-        if (e == 0) s_winlo[hl] = P.ht[j].win_lo;
+        if (e == 0) { s_winlo[hl] = P.ht[j].win_lo; s_add[hl] = T.log_values ? P.ht[j].spare[0] : 0.0; }
         for (int c = e; c < ncorner; c += W) {
             double w = 1.0;
             int64_t off = 0;
@@ -309,12 +314,32 @@ __global__ __launch_bounds__(256) void halo_row_kernel(const RowParams P)
     const int ir = s_winlo[hl] + e;
     double b0 = 0.0;
     for (int c = 0; c < ncorner; ++c) b0 = fma(T.values[s_off[hl][c] + ir], s_w[hl][c], b0);
-    P.hwin[j * W + e] = b0;
+    P.hwin[j * W + e] = b0 + s_add[hl];          // paint: ln(T) + ln(pixarea D^2), see shell_tile_kernel
 }
 
-constexpr int kTileThreads = 512;
+#ifndef BFG_TILE_THREADS
+#define BFG_TILE_THREADS 512
+#endif
+#ifndef BFG_TILE_WAVES_PER_SIMD
+#define BFG_TILE_WAVES_PER_SIMD 4
+#endif
+#ifndef BFG_PIXEL_PAIRS
+#define BFG_PIXEL_PAIRS 0
+#endif
+#ifndef BFG_STAGE_TIMING
+#define BFG_STAGE_TIMING 0
+#endif
+#if BFG_STAGE_TIMING
+__device__ unsigned long long g_stage_cycles[8];      // profiling build only: barrier-to-barrier cycles per stage
+#define BFG_TICK(slot) do { if (tid == 64) { const long long now_ = clock64(); st_acc[slot] += now_ - st_t; st_t = now_; } } while (0)
+#else
+#define BFG_TICK(slot) do { } while (0)
+#endif
+constexpr int kTileThreads = BFG_TILE_THREADS;
+constexpr int kTileWaves = kTileThreads / 64;
 constexpr int kWinLds = 32;          // row windows up to this many nodes are staged in LDS
-constexpr int kPixMax = 4096;        // pixel -> segment table entries per round (8 KiB of LDS)
+constexpr int kPixMax = 3840;        // pixel -> segment table entries per round (7.5 KiB of LDS)
+constexpr int kPrOff = 32;           // slot offsets of the chunk's pairs, padded with INT_MAX
 
 // per-mode shape of a tile workgroup: rings per tile, accumulators per pixel, LDS capacities of a chunk
 template <int MODE> struct TileCfg;
@@ -328,14 +353,13 @@ template <> struct TileCfg<MODE_BARYONIFY> {
 };
 
 template <int MODE>
-__host__ __device__ inline size_t tile_lds_bytes()
+__host__ __device__ constexpr size_t tile_lds_bytes()
 {
     using Cfg = TileCfg<MODE>;
     return (size_t)Cfg::TR * kTileWidth * Cfg::NACC * sizeof(double) + kLogTab * sizeof(double2) +
            kExpTab * sizeof(double) + Cfg::TR * sizeof(RingRow) + Cfg::SEGMAX * sizeof(Seg) +
            Cfg::PAIRMAX * sizeof(typename Cfg::Pair) + (size_t)Cfg::PAIRMAX * kWinLds * sizeof(double) +
-           kPixMax * sizeof(uint16_t) + (Cfg::PAIRMAX + 4) * sizeof(int32_t) +
-           ((Cfg::SEGMAX + 63) / 64 + 4) * sizeof(int32_t) + 8 * sizeof(int32_t);
+           kPixMax * sizeof(uint16_t) + kPrOff * sizeof(int32_t) + Cfg::SEGMAX * sizeof(uint8_t) + 8 * sizeof(int32_t);
 }
 
 // sin(h) for h^2 <= kSinSmall: odd series to h^7 (rel err < 3e-12)
@@ -358,26 +382,54 @@ __device__ inline void sincos_wide(double h, double &sh, double &ch)
     sh = s; ch = c;
 }
 
+// inclusive prefix sum over the 64 lanes of a wavefront with DPP row shifts / row broadcasts (no LDS round trips;
+// __shfl_up compiles to ds_bpermute, ~100 cycles per step)
+__device__ inline int wave_scan_incl(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 template <int MODE, bool WIN_LDS>
-__global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileParams P)
+__global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_tile_kernel(const TileParams P)
 {
     using Cfg = TileCfg<MODE>;
     using Pair = typename Cfg::Pair;
     constexpr int TR = Cfg::TR, TW = kTileWidth, NT = kTileThreads, NACC = Cfg::NACC;
     constexpr int kSegMax = Cfg::SEGMAX, kPairMax = Cfg::PAIRMAX, kSlotMax = kSegMax / 2;
-    constexpr int kSegGroups = (kSegMax + 63) / 64;
+    static_assert(kSegMax * sizeof(Seg) <= 65536, "ptab holds 16-bit byte offsets of segment records");
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    double *acc = reinterpret_cast<double *>(smem_raw);                       // [TR*TW*NACC]
-    double2 *logtab = reinterpret_cast<double2 *>(acc + TR * TW * NACC);      // [128]
-    double *exptab = reinterpret_cast<double *>(logtab + kLogTab);            // [64]
-    RingRow *rows = reinterpret_cast<RingRow *>(exptab + kExpTab);            // [TR]
-    Seg *segs = reinterpret_cast<Seg *>(rows + TR);                           // [kSegMax]
-    Pair *pinfo = reinterpret_cast<Pair *>(segs + kSegMax);                   // [kPairMax]
-    double *pwin = reinterpret_cast<double *>(pinfo + kPairMax);              // [kPairMax][kWinLds] row values B_i
-    uint16_t *ptab = reinterpret_cast<uint16_t *>(pwin + kPairMax * kWinLds); // [kPixMax] pixel -> segment
-    int32_t *pr_off = reinterpret_cast<int32_t *>(ptab + kPixMax);            // exclusive slot offsets [kPairMax + 1]
-    int32_t *gtot = pr_off + kPairMax + 4;                                    // per 64-segment group pixel totals
-    int32_t *ctl = gtot + kSegGroups + 4;                                     // n_take, nslots, extra
+    // LDS layout (byte offsets are compile-time constants: segment records carry LDS byte addresses)
+    constexpr int acc_off = 0;                                                // double [TR*TW*NACC]
+    constexpr int logtab_off = acc_off + TR * TW * NACC * (int)sizeof(double);    // double2 [128]
+    constexpr int exptab_off = logtab_off + kLogTab * (int)sizeof(double2);   // double [64]
+    constexpr int rows_off = exptab_off + kExpTab * (int)sizeof(double);      // RingRow [TR]
+    constexpr int segs_off = rows_off + TR * (int)sizeof(RingRow);            // Seg [kSegMax]
+    constexpr int pinfo_off = segs_off + kSegMax * (int)sizeof(Seg);          // Pair [kPairMax]
+    constexpr int pwin_off = pinfo_off + kPairMax * (int)sizeof(Pair);        // double [kPairMax][kWinLds] row values B_i
+    constexpr int ptab_off = pwin_off + kPairMax * kWinLds * (int)sizeof(double);   // uint16 [kPixMax] pixel -> segment
+    constexpr int proff_off = ptab_off + kPixMax * (int)sizeof(uint16_t);     // int32 [kPrOff] exclusive slot offsets of the pairs
+    constexpr int scnt_off = proff_off + kPrOff * (int)sizeof(int32_t);       // uint8 [kSegMax] pixel count of every segment
+    constexpr int ctl_off = scnt_off + kSegMax * (int)sizeof(uint8_t);        // n_take, nslots, extra segments, pixel total
+    static_assert(kSegMax % 16 == 0 && kPairMax < kPrOff && kSlotMax <= kTileThreads, "chunk shape");
+    double *acc = reinterpret_cast<double *>(smem_raw + acc_off);
+    double2 *logtab = reinterpret_cast<double2 *>(smem_raw + logtab_off);
+    double *exptab = reinterpret_cast<double *>(smem_raw + exptab_off);
+    RingRow *rows = reinterpret_cast<RingRow *>(smem_raw + rows_off);
+    Seg *segs = reinterpret_cast<Seg *>(smem_raw + segs_off);
+    Pair *pinfo = reinterpret_cast<Pair *>(smem_raw + pinfo_off);
+    double *pwin = reinterpret_cast<double *>(smem_raw + pwin_off);
+    uint16_t *ptab = reinterpret_cast<uint16_t *>(smem_raw + ptab_off);
+    int32_t *pr_off = reinterpret_cast<int32_t *>(smem_raw + proff_off);
+    uint8_t *scnt = reinterpret_cast<uint8_t *>(smem_raw + scnt_off);
+    int32_t *ctl = reinterpret_cast<int32_t *>(smem_raw + ctl_off);
+    static_assert(sizeof(RingRow) % 16 == 0 && sizeof(Pair) % 16 == 0, "16-byte aligned LDS records");
+    static_assert(ctl_off + 8 * sizeof(int32_t) == tile_lds_bytes<MODE>(), "layout and tile_lds_bytes() must agree");
 
     const int tile = blockIdx.x;
     const int n_pairs = P.tile_start[tile + 1] - P.tile_start[tile];
@@ -414,61 +466,71 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
     const int NRm1 = T.nr - 1;
     const int W = P.win_nodes;
     constexpr bool win_in_lds = WIN_LDS;     // row windows of <= kWinLds nodes live in LDS, longer ones stay in HBM/L2
-    unsigned long long my_pixels = 0, n_r_oob = 0;
+    unsigned long long my_pixels = 0;
     const int32_t *plist = P.pairs + P.tile_start[tile];
 
     // wave 0 keeps the next chunk's pair records in flight while the others compute (stage a prefetch)
-    int nx_j = -1, nx_first = 0, nx_last = -1;
+    int nx_j = -1, nx_first = 0, nx_last = -1, nx_wl = 0;
+    [[maybe_unused]] double nx_lnpf = 0.0;
     auto prefetch = [&](int base) {
         nx_j = -1; nx_first = 0; nx_last = -1;
         if (lane < kPairMax && base + lane < n_pairs) {
             nx_j = plist[base + lane];
-            nx_first = P.ht[nx_j].rfirst; nx_last = P.ht[nx_j].rlast;
+            const HaloTile &h = P.ht[nx_j];
+            nx_first = h.rfirst; nx_last = h.rlast; nx_wl = h.win_lo;
+            if constexpr (MODE == MODE_PAINT) nx_lnpf = h.spare[0];
         }
     };
     if (wave == 0) prefetch(0);
     __syncthreads();
 
-    // row read-out shared by both modes: interpolant at cell i, fraction f of the pair's blended row
-    auto read_row = [&](int pidx, int i, double f, int e, bool ok, bool in) -> double {
-        double B0, B1;
-        if constexpr (win_in_lds) {
-            const double *wp = pwin + pidx * kWinLds + min(max(e, 0), kWinLds - 2);
-            B0 = wp[0]; B1 = wp[1];
-        } else {
-            const double *wp = P.hwin + pinfo[pidx].hoff + min(max(e, 0), W - 2);
-            B0 = wp[0]; B1 = wp[1];
-        }
-        double L = fma(f, B1 - B0, B0);
-        if (__any(ok && !in)) {                                            // rare: cell outside the staged row window
-            if (ok && !in) {
-                const int64_t j = pinfo[pidx].halo;
-                double c0v = 0.0, c1v = 0.0;
-                const int ncorner = 1 << T.nouter;
-                for (int c = 0; c < ncorner; ++c) {
-                    double w = 1.0; int64_t off = 0;
-                    for (int k = 0; k < T.nouter; ++k) {
-                        const int bit = (c >> (T.nouter - 1 - k)) & 1;
-                        const double y = P.cw[k * P.cap + j];
-                        w = w * (bit ? y : 1.0 - y);
-                        off += (int64_t)(P.cidx[k * P.cap + j] + bit) * T.ostride[k];
-                    }
-                    c0v = fma(T.values[off + i], w, c0v);
-                    c1v = fma(T.values[off + i + 1], w, c1v);
-                }
-                L = fma(f, c1v - c0v, c0v);
+    unsigned int n_oob32 = 0;
+
+    // rare: a pixel whose table cell lies outside the pair's staged row window -> blend the corners directly
+    auto direct_row = [&](int pidx, double t) -> double {
+        const int i = min(max((int)t, 0), NRm1 - 1);
+        const double f = t - (double)i;
+        const int64_t j = pinfo[pidx].halo;
+        double c0v = 0.0, c1v = 0.0;
+        const int ncorner = 1 << T.nouter;
+        for (int c = 0; c < ncorner; ++c) {
+            double w = 1.0; int64_t off = 0;
+            for (int k = 0; k < T.nouter; ++k) {
+                const int bit = (c >> (T.nouter - 1 - k)) & 1;
+                const double y = P.cw[k * P.cap + j];
+                w = w * (bit ? y : 1.0 - y);
+                off += (int64_t)(P.cidx[k * P.cap + j] + bit) * T.ostride[k];
             }
+            c0v = fma(T.values[off + i], w, c0v);
+            c1v = fma(T.values[off + i + 1], w, c1v);
         }
+        double L = fma(f, c1v - c0v, c0v);
+        if constexpr (MODE == MODE_PAINT) L += pinfo[pidx].lnpf;
         return L;
     };
 
+    // interpolant of the pair's blended row at cell coordinate t (cell = trunc(t), clamped into the staged window
+    // [wl, wl + W - 2]); `in` = the cell really lies in the window (and t >= 0), otherwise the value is unusable
+    auto window_row = [&](const Seg &sg, int wl, int pidx, double t, bool &in) -> double {
+        const int i0 = (int)t;                                            // saturating conversion
+        const int ic = min(max(i0, wl), wl + W - 2);
+        in = (ic == i0) && (t >= 0.0);
+        const double f = t - (double)ic;
+        double B0, B1;
+        if constexpr (win_in_lds) {
+            const double *wp = reinterpret_cast<const double *>(smem_raw + sg.wbyte + 8 * ic);
+            B0 = wp[0]; B1 = wp[1];
+        } else {
+            const double *wp = P.hwin + pinfo[pidx].hoff + (ic - wl);
+            B0 = wp[0]; B1 = wp[1];
+        }
+        return fma(f, B1 - B0, B0);
+    };
+
     // one pixel of the flattened chunk: segment record -> chord^2 -> ln -> row read-out -> accumulate in LDS
-    auto do_pixel = [&](int q, int sx) {
-        const Seg sg = segs[sx];
-        const int ipu = sg.iplo + (q - sg.excl);                           // unwrapped pixel index in the ring
-        const int addr = sg.abase + ipu;
-        const int pidx = sg.pidx & 0xFF;
-        const double h = fma((double)ipu, sg.hstep, sg.c0);
+    auto do_pixel = [&](int q, const Seg &sg) {
+        const int k = q - sg.excl;                                         // pixel index inside the segment
+        const double h = fma((double)k, sg.hstep, sg.c0);
         const double h2 = h * h;
         if constexpr (MODE == MODE_PAINT) {
             double s2 = sin_squared_small(h2);
@@ -476,23 +538,28 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
                 if (h2 > kSinSmall) s2 = sin_squared_wide(h);
             }
             const double x = fma(sg.Bq, s2, sg.Aq);                        // r_com^2
-            // x = 0 or NaN falls out of the range test (ln of the bit pattern is hugely negative / NaN)
+            // x = 0 or NaN never lands in the window (ln of the bit pattern is hugely negative / NaN)
             const double t = fma(fast_log(x, logtab), t_m, t_c);
-            const bool ok = (t >= 0.0) && (t <= (double)NRm1);
-            const int i = min(max((int)t, 0), NRm1 - 1);
-            const double f = t - (double)i;
-            const int e = i - (sg.pidx >> 8);
-            const bool in = (e >= 0) && (e < W - 1);
-            const double L = read_row(pidx, i, f, e, ok, in);
-            // NaN / +-inf / overflowing L paint nothing (HealpixRunner.py:473)
-            const bool go = ok && (L > -746.0) && (L < 709.0);             // false for NaN too
-            const double v = fast_exp(L, exptab) * pinfo[pidx].pixfac;     // garbage when !go, never added
-            n_r_oob += ok ? 0 : 1;
-            if (go && v != 0.0) unsafeAtomicAdd(&acc[addr], v);
+            const int wl = sg.pk;
+            bool in;
+            double L = window_row(sg, wl, win_in_lds ? 0 : sg.wbyte, t, in);
+            if (!in) {                                                     // divergent and rare
+                if ((t >= 0.0) && (t <= (double)NRm1)) {
+                    const int pidx = win_in_lds ? (sg.wbyte + 8 * wl - pwin_off) / (8 * kWinLds) : sg.wbyte;
+                    L = direct_row(pidx, t); in = true;
+                } else n_oob32 += 1;
+            }
+            // NaN / +-inf L paint nothing (HealpixRunner.py:473).  L already holds + ln(pixarea D^2) (:478, folded
+            // into the row window by halo_row_kernel); tables with finite |ln T| > 650 never take this path, so a
+            // finite L is always inside exp's range
+            const bool go = in && (fabs(L) < 709.0);                       // false for NaN too
+            const double v = fast_exp(L, exptab);                          // garbage when !go, never added
+            if (go) unsafeAtomicAdd(reinterpret_cast<double *>(smem_raw + sg.abyte + 8 * k), v);
         } else {
-            // HealpixRunner.py:336-355 for one pixel; pidx packs pair slot | ring row << 8 | win_lo << 14
+            // HealpixRunner.py:336-355 for one pixel
+            const int pidx = sg.pk & 31, wl = sg.pk >> 11;
             const Pair &pi = pinfo[pidx];
-            const RingRow &rr = rows[(sg.pidx >> 8) & 0x3F];
+            const RingRow &rr = rows[(sg.pk >> 5) & 63];
             double sh = sin_small(h, h2), ch = sqrt(1.0 - sh * sh);        // sin, cos of dphi/2 (cos >= 0)
             if (__any(h2 > kSinSmall)) { if (h2 > kSinSmall) sincos_wide(h, sh, ch); }
             const double s2 = sh * sh;
@@ -502,16 +569,15 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
             const double vx = rr.sth * cphi, vy = rr.sth * sphi, vz = rr.z;                 // pixel unit vector
             const double dx = vx - pi.st * pi.cp0, dy = vy - pi.st * pi.sp0, dz = vz - pi.ct;   // vec - vec_j
             const double t = fma(fast_log(x, logtab), t_m, t_c + pi.tshift);
-            const bool ok = (t >= 0.0) && (t <= (double)NRm1);
-            const int i = min(max((int)t, 0), NRm1 - 1);
-            const double f = t - (double)i;
-            const int e = i - (sg.pidx >> 14);
-            const bool in = (e >= 0) && (e < W - 1);
-            double d = read_row(pidx, i, f, e, ok, in);                    // comoving displacement; table holds d
-            n_r_oob += ok ? 0 : 1;
+            bool in;
+            double d = window_row(sg, wl, pidx, t, in);                    // comoving displacement; table holds d
+            if (!in) {
+                if ((t >= 0.0) && (t <= (double)NRm1)) { d = direct_row(pidx, t); in = true; }
+                else n_oob32 += 1;
+            }
             // zero outside the hull (NaN fill), beyond the model's epsilon_max R (BaryonCorrection.py:410-411),
             // for non-finite table values and at r = 0 (HealpixRunner.py:347)
-            const bool use = ok && (x < pi.xcut) && (x > 0.0) && (fabs(d) < 1.0e300);
+            const bool use = in && (x < pi.xcut) && (x > 0.0) && (fabs(d) < 1.0e300);
             d = use ? d * pi.a : 0.0;                                      // physical (HealpixRunner.py:345)
             if (d != 0.0) {
                 const double rc = sqrt(x);                                 // r_com; chord = rc a / D
@@ -520,13 +586,55 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
                 const double nwn = sqrt(fma(pi.D, pi.D, qq));
                 const double g = -qq / (nwn * (nwn + pi.D));               // D / |nw| - 1 without cancellation
                 const double kk = d / (chord * nwn);                       // offset along (vec - vec_j) / chord, / |nw|
-                unsafeAtomicAdd(&acc[3 * addr + 0], fma(vx, g, dx * kk));
-                unsafeAtomicAdd(&acc[3 * addr + 1], fma(vy, g, dy * kk));
-                unsafeAtomicAdd(&acc[3 * addr + 2], fma(vz, g, dz * kk));
+                double *ap = reinterpret_cast<double *>(smem_raw + sg.abyte + 24 * k);
+                unsafeAtomicAdd(ap + 0, fma(vx, g, dx * kk));
+                unsafeAtomicAdd(ap + 1, fma(vy, g, dy * kk));
+                unsafeAtomicAdd(ap + 2, fma(vz, g, dz * kk));
             }
         }
     };
 
+    // two pixels per thread, interleaved by hand so that their dependent LDS round trips overlap
+    // (the kernel is latency-bound: ~3.6 waves per SIMD cannot hide ptab -> segment -> ln table -> row window -> exp table)
+    [[maybe_unused]] auto do_pixel2 = [&](int qa, const Seg &sa, int qb, const Seg &sb, bool vb) {
+        if constexpr (MODE == MODE_PAINT) {
+            const int ka = qa - sa.excl, kb = qb - sb.excl;
+            const double ha = fma((double)ka, sa.hstep, sa.c0), hb = fma((double)kb, sb.hstep, sb.c0);
+            const double ha2 = ha * ha, hb2 = hb * hb;
+            double s2a = sin_squared_small(ha2), s2b = sin_squared_small(hb2);
+            if (__any(fmax(ha2, hb2) > kSinSmall)) {
+                if (ha2 > kSinSmall) s2a = sin_squared_wide(ha);
+                if (hb2 > kSinSmall) s2b = sin_squared_wide(hb);
+            }
+            const double xa = fma(sa.Bq, s2a, sa.Aq), xb = fma(sb.Bq, s2b, sb.Aq);
+            const double ta = fma(fast_log(xa, logtab), t_m, t_c), tb = fma(fast_log(xb, logtab), t_m, t_c);
+            bool ina, inb;
+            double La = window_row(sa, sa.pk, win_in_lds ? 0 : sa.wbyte, ta, ina);
+            double Lb = window_row(sb, sb.pk, win_in_lds ? 0 : sb.wbyte, tb, inb);
+            if (!ina || (vb && !inb)) {                                    // divergent and rare
+                if (!ina) {
+                    if ((ta >= 0.0) && (ta <= (double)NRm1)) {
+                        const int pidx = win_in_lds ? (sa.wbyte + 8 * sa.pk - pwin_off) / (8 * kWinLds) : sa.wbyte;
+                        La = direct_row(pidx, ta); ina = true;
+                    } else n_oob32 += 1;
+                }
+                if (vb && !inb) {
+                    if ((tb >= 0.0) && (tb <= (double)NRm1)) {
+                        const int pidx = win_in_lds ? (sb.wbyte + 8 * sb.pk - pwin_off) / (8 * kWinLds) : sb.wbyte;
+                        Lb = direct_row(pidx, tb); inb = true;
+                    } else n_oob32 += 1;
+                }
+            }
+            const bool goa = ina && (fabs(La) < 709.0), gob = vb && inb && (fabs(Lb) < 709.0);
+            const double va = fast_exp(La, exptab), vbv = fast_exp(Lb, exptab);
+            if (goa) unsafeAtomicAdd(reinterpret_cast<double *>(smem_raw + sa.abyte + 8 * ka), va);
+            if (gob) unsafeAtomicAdd(reinterpret_cast<double *>(smem_raw + sb.abyte + 8 * kb), vbv);
+        }
+    };
+
+#if BFG_STAGE_TIMING
+    long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = clock64();
+#endif
     for (int base = 0; base < n_pairs;) {
         // ---- stage a: one lane per pair of the chunk (wave 0) ---------------------------------------
         if (wave == 0) {
@@ -534,32 +642,32 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
             const bool valid = j >= 0;
             const int ra = max(nx_first, ring_lo);
             const int nrings = valid ? max(0, min(nx_last, ring_hi) - ra + 1) : 0;
-            int cum = nrings;
-            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(cum, d, 64); if (lane >= d) cum += o; }
+            const int cum = wave_scan_incl(nrings);
             // take the longest prefix of pairs whose (pair, ring) slots fit; always at least one pair
             const bool fits = valid && (cum <= kSlotMax || lane == 0);
             const unsigned long long fm = __ballot(fits);
             const int first_bad = __ffsll((long long)~fm);          // 1-based; 0 if all 64 fit
             const int n_take = first_bad ? first_bad - 1 : 64;
             if (lane < n_take) {
-                const HaloTile &h = P.ht[j];
                 Pair pi;
-                pi.hoff = (int64_t)j * W; pi.win_lo = h.win_lo; pi.halo = j; pi.ra = ra; pi.pad = 0;
+                pi.hoff = (int64_t)j * W; pi.win_lo = nx_wl; pi.halo = j; pi.ra = ra; pi.pad = 0;
                 if constexpr (MODE == MODE_PAINT) {
-                    pi.pixfac = h.pixfac;
+                    pi.lnpf = nx_lnpf;
                 } else {
+                    const HaloTile &h = P.ht[j];
                     const HaloDisp &hd = P.hd[j];
                     pi.cp0 = hd.cp0; pi.sp0 = hd.sp0; pi.st = h.st; pi.ct = h.ct;
                     pi.a = hd.a; pi.D = hd.D; pi.xcut = hd.xcut; pi.tshift = hd.tshift; pi.pad2 = 0.0;
                 }
                 pinfo[lane] = pi;
-                pr_off[lane] = cum - nrings;
             }
-            if (lane == n_take - 1) { pr_off[n_take] = cum; ctl[0] = n_take; ctl[1] = cum; ctl[2] = 0; }
+            if (lane < kPrOff) pr_off[lane] = (lane < n_take) ? cum - nrings : 0x7fffffff;
+            if (lane == n_take - 1) { ctl[0] = n_take; ctl[1] = cum; ctl[2] = 0; ctl[3] = 0; }
             prefetch(base + n_take);                                 // loads fly during stages b and c
         }
         __syncthreads();
         const int n_take = ctl[0], nslots = ctl[1];
+        BFG_TICK(0);
 
         // ---- stage b: one thread per (pair, ring) slot; row windows -> LDS -----------------------------
         // With full-width windows the copy is an LDS-DMA (global_load_lds_dwordx4: no VGPRs, asynchronous;
@@ -580,114 +688,153 @@ __global__ __launch_bounds__(kTileThreads, 4) void shell_tile_kernel(const TileP
                 }
             }
         }
-        for (int slot = tid; slot < nslots && !(P.debug & 8); slot += NT) {
-            int lo_ = 0, hi_ = n_take - 1;          // pair p with pr_off[p] <= slot < pr_off[p+1]
-            while (lo_ < hi_) { const int mid = (lo_ + hi_ + 1) >> 1; if (pr_off[mid] <= slot) lo_ = mid; else hi_ = mid - 1; }
-            const int p = lo_;
-            const int j = pinfo[p].halo;
-            const int ring = pinfo[p].ra + (slot - pr_off[p]);
-            const int row = ring - ring_lo;
-            const RingRow rr = rows[row];
-            const HaloTile &h = P.ht[j];
-            const double st = h.st, ct = h.ct, pphi = h.pphi, S = h.S;
-            const int nr = rr.nr;
-            int lo = 0, cnt = 0;
-            if (ring < h.irmin || ring > h.irmax) cnt = nr;         // ring entirely inside the disc
-            else {
-                const double x = (h.cosr - rr.z * h.z0) * h.xa;
-                const double ysq = 1.0 - rr.z * rr.z - x * x;
-                const double dphi = (ysq <= 0.0) ? 0.0 : atan2(sqrt(ysq), x);
-                if (dphi > 0.0) {
-                    const double shift = (rr.phioff != 0.0) ? 0.5 : 0.0;
-                    const int64_t l64 = (int64_t)floor((double)nr * kInvTwoPi * (pphi - dphi) - shift) + 1;
-                    const int64_t h64 = (int64_t)floor((double)nr * kInvTwoPi * (pphi + dphi) - shift);
-                    int64_t c = h64 - l64 + 1;
-                    if (c > nr) c = nr;
-                    if (c > 0) { cnt = (int)c; lo = (int)l64; }      // unwrapped: lo in (-nr, 1.5 nr)
+        if (wave * 64 < nslots && !(P.debug & 8)) {                 // whole wavefronts: kSlotMax <= NT, one pass
+            const int slot = tid;
+            const bool live = slot < nslots;
+            // pair p with pr_off[p] <= slot < pr_off[p+1]: one LDS read, then a wave-uniform loop over the pairs
+            // that start inside this wavefront's 64 slots
+            int p;
+            {
+                const int sb = wave * 64;
+                const int myoff = (lane < kPrOff) ? pr_off[lane] : 0x7fffffff;
+                p = __popcll(__ballot(myoff <= sb)) - 1;
+                unsigned long long inside = __ballot(myoff > sb && myoff <= sb + 63);
+                while (inside) {
+                    const int kk = __ffsll((long long)inside) - 1;
+                    inside &= inside - 1;
+                    const int o = __builtin_amdgcn_readlane(myoff, kk);
+                    p += (slot >= o) ? 1 : 0;
                 }
             }
+            int cnt1 = 0, cnt2 = 0, aa1 = 0, aa2 = 0, ab1 = 0, ab2 = 0;
             Seg sg;
-            sg.iplo = 0; sg.abase = 0; sg.excl = 0;
-            if constexpr (MODE == MODE_PAINT) sg.pidx = p | (h.win_lo << 8);          // pair slot | row window start
-            else sg.pidx = p | (row << 8) | (h.win_lo << 14);                          // ... | ring row | ...
-            sg.hstep = 0.5 * rr.phistep;
-            sg.c0 = 0.5 * (rr.phioff * rr.phistep - pphi);
-            const double ds = rr.sth - st, dz = rr.z - ct;
-            sg.Aq = (ds * ds + dz * dz) * S;
-            sg.Bq = 4.0 * rr.sth * st * S;
-            int np = 0;
-            if (cnt > 0) {
+            sg.excl = 0; sg.abyte = 0; sg.wbyte = 0; sg.pk = 0; sg.hstep = 0; sg.c0 = 0; sg.Aq = 0; sg.Bq = 0;
+            if (live) {
+                const int j = pinfo[p].halo;
+                const int ring = pinfo[p].ra + (slot - pr_off[p]);
+                const int row = ring - ring_lo;
+                const RingRow rr = rows[row];
+                const HaloTile &h = P.ht[j];
+                const double st = h.st, ct = h.ct, pphi = h.pphi, S = h.S;
+                const int nr = rr.nr;
+                int lo = 0, cnt = 0;
+                if (ring < h.irmin || ring > h.irmax) cnt = nr;         // ring entirely inside the disc
+                else {
+                    const double x = (h.cosr - rr.z * h.z0) * h.xa;
+                    const double ysq = 1.0 - rr.z * rr.z - x * x;
+                    const double dphi = (ysq <= 0.0) ? 0.0 : atan2(sqrt(ysq), x);
+                    if (dphi > 0.0) {
+                        const double shift = (rr.phioff != 0.0) ? 0.5 : 0.0;
+                        const int64_t l64 = (int64_t)floor((double)nr * kInvTwoPi * (pphi - dphi) - shift) + 1;
+                        const int64_t h64 = (int64_t)floor((double)nr * kInvTwoPi * (pphi + dphi) - shift);
+                        int64_t c = h64 - l64 + 1;
+                        if (c > nr) c = nr;
+                        if (c > 0) { cnt = (int)c; lo = (int)l64; }      // unwrapped: lo in (-nr, 1.5 nr)
+                    }
+                }
+                const int wl = pinfo[p].win_lo;
+                sg.wbyte = win_in_lds ? pwin_off + p * (kWinLds * 8) - 8 * wl : p;
+                if constexpr (MODE == MODE_PAINT) sg.pk = wl;
+                else sg.pk = p | (row << 5) | (wl << 11);
+                sg.hstep = 0.5 * rr.phistep;
+                sg.c0 = 0.5 * (rr.phioff * rr.phistep - pphi);          // + first pixel * hstep, below
+                const double ds = rr.sth - st, dz = rr.z - ct;
+                sg.Aq = (ds * ds + dz * dz) * S;
+                sg.Bq = 4.0 * rr.sth * st * S;
+                // clip to the sector; a window that wraps around the ring can meet it twice
+                if (cnt > 0) {
 #pragma unroll
-                for (int mi = 0; mi < 3; ++mi) {
-                    const int m = (mi == 0) ? 0 : (mi == 1 ? -1 : 1);
-                    const int aa = max(lo, rr.k0 + m * nr), bb = min(lo + cnt, rr.k1 + m * nr);
-                    if (bb > aa && np < 2) {
-                        sg.iplo = aa; sg.excl = bb - aa; sg.abase = rr.rowoff - m * nr;   // excl = count for now
-                        if (np == 0) segs[slot] = sg;
-                        else segs[nslots + atomicAdd(&ctl[2], 1)] = sg;                 // at most one per slot
-                        ++np;
+                    for (int mi = 0; mi < 3; ++mi) {
+                        const int m = (mi == 0) ? 0 : (mi == 1 ? -1 : 1);
+                        const int aa = max(lo, rr.k0 + m * nr), bb = min(lo + cnt, rr.k1 + m * nr);
+                        if (bb > aa) {
+                            const int ab = acc_off + 8 * NACC * (rr.rowoff - m * nr + aa);
+                            if (cnt1 == 0) { cnt1 = bb - aa; aa1 = aa; ab1 = ab; }
+                            else if (cnt2 == 0) { cnt2 = bb - aa; aa2 = aa; ab2 = ab; }
+                        }
                     }
                 }
             }
-            if (np == 0) { sg.excl = 0; segs[slot] = sg; }
-        }
-        __syncthreads();
-        const int nseg = nslots + ctl[2];
-
-        // ---- stage s: block-wide exclusive scan of the segments' pixel counts ---------------------------
-        const int ngroups = (nseg + 63) >> 6;
-        int my_cnt[2] = {0, 0}, my_excl[2] = {0, 0};
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int g = wave + r * 8;                               // 64-segment group of this wave
-            if (g < ngroups) {
-                const int sidx = g * 64 + lane;
-                const int cnt = (sidx < nseg) ? segs[sidx].excl : 0;
-                int cum = cnt;
-                for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(cum, d, 64); if (lane >= d) cum += o; }
-                my_cnt[r] = cnt; my_excl[r] = cum - cnt;
-                if (lane == 63) gtot[g] = cum;
-            }
-        }
-        __syncthreads();
-        int ptotal = 0;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int g = wave + r * 8;
-            int goff = 0;
-            for (int k = 0; k < ngroups; ++k) { const int t = gtot[k]; if (k < g) goff += t; ptotal += (r == 0) ? t : 0; }
-            if (g < ngroups) {
-                const int sidx = g * 64 + lane;
-                my_excl[r] += goff;
-                if (sidx < nseg) segs[sidx].excl = my_excl[r];
-            }
-        }
-        my_pixels += (tid == 0) ? (unsigned long long)ptotal : 0ull;
-
-        // ---- stage c: rounds of kPixMax pixels: pixel -> segment table, then one thread per pixel -------
-        for (int pbase = 0; pbase < ptotal && !(P.debug & 2); pbase += kPixMax) {
-            if (pbase > 0) __syncthreads();                           // previous round's readers are done
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int g = wave + r * 8;
-                if (g < ngroups && my_cnt[r] > 0) {
-                    const int sidx = g * 64 + lane;
-                    const int a0 = max(my_excl[r], pbase), a1 = min(my_excl[r] + my_cnt[r], pbase + kPixMax);
-                    for (int q = a0; q < a1; ++q) ptab[q - pbase] = (uint16_t)sidx;
+            // offsets in the chunk's flattened pixel list: wave scan + one LDS atomic per wavefront (any order will do)
+            const int tot = cnt1 + cnt2;
+            const int incl = wave_scan_incl(tot);
+            const int wtot = __builtin_amdgcn_readlane(incl, 63);
+            int wbase = 0;
+            if (lane == 0 && wtot > 0) wbase = atomicAdd(&ctl[3], wtot);
+            wbase = __builtin_amdgcn_readfirstlane(wbase);
+            const int e1 = wbase + incl - tot;
+            if (live) {
+                scnt[slot] = (uint8_t)cnt1;
+                if (cnt1 > 0) {
+                    const double c0b = sg.c0;
+                    sg.excl = e1; sg.abyte = ab1; sg.c0 = fma((double)aa1, sg.hstep, c0b);
+                    segs[slot] = sg;
+                    const uint16_t o1 = (uint16_t)(slot * (int)sizeof(Seg));
+                    for (int q = e1; q < min(e1 + cnt1, kPixMax); ++q) ptab[q] = o1;
+                    if (cnt2 > 0) {                                     // at most one extra segment per slot
+                        const int idx2 = nslots + atomicAdd(&ctl[2], 1);
+                        scnt[idx2] = (uint8_t)cnt2;
+                        const int e2 = e1 + cnt1;
+                        sg.excl = e2; sg.abyte = ab2; sg.c0 = fma((double)aa2, sg.hstep, c0b);
+                        segs[idx2] = sg;
+                        const uint16_t o2 = (uint16_t)(idx2 * (int)sizeof(Seg));
+                        for (int q = e2; q < min(e2 + cnt2, kPixMax); ++q) ptab[q] = o2;
+                    }
                 }
             }
-            __syncthreads();
-            const int pend = min(ptotal, pbase + kPixMax);
-            for (int q = pbase + tid; q < pend; q += NT) do_pixel(q, ptab[q - pbase]);
         }
         __syncthreads();
+        BFG_TICK(1);
+        const int nseg = nslots + ctl[2];
+        const int ptotal = (P.debug & 2) ? 0 : ctl[3];
+        my_pixels += (tid == 0) ? (unsigned long long)ctl[3] : 0ull;
+
+        // ---- stage c: one thread per pixel of the flattened list (rounds of kPixMax pixels; the first round's
+        //      pixel -> segment table was filled by stage b) -------------------------------------------------
+        for (int pbase = 0; pbase < ptotal; pbase += kPixMax) {
+            if (pbase > 0) {                                          // rare: refill the table for the next round
+                __syncthreads();
+                for (int sidx = tid; sidx < nseg; sidx += NT) {
+                    const int cnt = scnt[sidx];
+                    if (cnt > 0) {
+                        const int ex = segs[sidx].excl;
+                        const int a0 = max(ex, pbase), a1 = min(ex + cnt, pbase + kPixMax);
+                        for (int q = a0; q < a1; ++q) ptab[q - pbase] = (uint16_t)(sidx * (int)sizeof(Seg));
+                    }
+                }
+                __syncthreads();
+            }
+            BFG_TICK(3);
+            const int pend = min(ptotal, pbase + kPixMax);
+            const uint16_t *pp = ptab + tid;
+            if constexpr (MODE == MODE_PAINT && BFG_PIXEL_PAIRS) {
+                for (int q = pbase + tid; q < pend; q += 2 * NT, pp += 2 * NT) {
+                    const bool vb = q + NT < pend;
+                    const int oa = pp[0], ob = vb ? pp[NT] : oa;
+                    const Seg sa = *reinterpret_cast<const Seg *>(smem_raw + segs_off + oa);
+                    const Seg sb = *reinterpret_cast<const Seg *>(smem_raw + segs_off + ob);
+                    do_pixel2(q, sa, q + NT, sb, vb);
+                }
+            } else {
+                for (int q = pbase + tid; q < pend; q += NT, pp += NT) {
+                    const Seg sg = *reinterpret_cast<const Seg *>(smem_raw + segs_off + *pp);     // by value: one burst of LDS reads
+                    do_pixel(q, sg);
+                }
+            }
+        }
+        BFG_TICK(4);
+        __syncthreads();
+        BFG_TICK(5);
         base += n_take;
     }
     if (my_pixels) atomicAdd((unsigned long long *)&P.stats->pixel_updates, my_pixels);
-    if (n_r_oob) {
-        atomicAdd((unsigned long long *)&P.stats->pixels_out_of_table, n_r_oob);
+    if (n_oob32) {
+        atomicAdd((unsigned long long *)&P.stats->pixels_out_of_table, (unsigned long long)n_oob32);
         atomicOr(&P.stats->warn_mask, BFG_WARN_R_RANGE);
     }
+#if BFG_STAGE_TIMING
+    if (tid == 64) for (int i = 0; i < 8; ++i) atomicAdd(&g_stage_cycles[i], (unsigned long long)st_acc[i]);
+#endif
     // write the tile back: every pixel belongs to exactly one tile -> plain read-modify-write
     for (int i = tid; i < TR * TW; i += NT) {
         const int row = i / TW, col = i % TW;

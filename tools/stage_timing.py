@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Profiling aid: barrier-to-barrier cycle breakdown of shell_tile_kernel.
+
+Needs a library built with -DBFG_STAGE_TIMING=1 (BFG_SO=path/to/that.so).  Prints, for the default bench workload,
+the share of workgroup time spent in each stage of the chunk loop (measured by one thread per workgroup)."""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401  (one HIP runtime per process)
+from baryonforge_amd import _lib, synthetic as syn
+from baryonforge_amd.background import Background
+from baryonforge_amd.engine import get_context
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+nside = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+workload = sys.argv[3] if len(sys.argv) > 3 else "paint"
+cosmo = dict(syn.COSMO)
+ra, dec, M, z = syn.catalog(n, seed=42)
+ctx = get_context(0)
+bg = Background(cosmo)
+d_cat = ctx.to_device(np.stack([M, z, ra, dec], axis=1))
+spline = ctx.da_spline(bg, float(np.max(z)))
+md = ctx.massdef_struct(bg, None)
+npix = 12 * nside * nside
+if workload == "paint":
+    zax, Max, rax, T = syn.pressure_table(10, 30, 100)
+    table = ctx.table([zax, Max, rax], np.log(T), log_values=True)
+    d_map = ctx.zeros(npix)
+    sargs = ctx.shell_args(nside, d_cat, n, 4, 0, 10.0, md)
+    run = lambda: ctx.paint_shell(sargs, table, spline, d_map)
+else:
+    zax, Max, rax, T = syn.displacement_table(10, 30, 100)
+    table = ctx.table([zax, Max, rax], T, log_values=False)
+    d_off = ctx.zeros(npix, 3)
+    sargs = ctx.shell_args(nside, d_cat, n, 4, 0, 10.0, md, model_md=md, model_epsilon_max=20.0)
+    run = lambda: ctx.baryonify_offsets(sargs, table, spline, d_off)
+L = _lib.load()
+fn = L.bfg_debug_stage_cycles
+fn.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+out = (ctypes.c_ulonglong * 8)()
+run(); run()
+fn(ctx.handle, out, 1)
+reps = 3
+for _ in range(reps):
+    run()
+fn(ctx.handle, out, 1)
+v = np.array(list(out), dtype=np.float64) / reps
+names = ["a: pair records (wave 0) + barrier", "b: ring windows -> segments + barrier", "s: block scan of pixel counts",
+         "c1: pixel->segment table + barrier", "c2: pixel loop (own pixels)", "c3: wait at the end-of-chunk barrier", "-", "-"]
+tot = v.sum()
+print(f"workload {workload} n={n} nside={nside}: {tot:.4g} cycles summed over workgroups per launch")
+for nm, x in zip(names, v):
+    if x:
+        print(f"  {nm:45s} {x:12.4g}  {100 * x / tot:5.1f} %")
