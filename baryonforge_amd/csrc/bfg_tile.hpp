@@ -100,7 +100,7 @@ struct __align__(16) Seg {           // one ring segment of one halo inside one 
     int32_t abyte;                   // LDS byte offset of the accumulator of the segment's first pixel
     int32_t wbyte;                   // LDS byte offset of B_0 of the pair's row window (node i at wbyte + 8 i);
                                      // pair slot when the windows are not staged in LDS
-    int32_t pk;                      // paint: win_lo ; baryonify: pair slot | ring row << 5 | win_lo << 11
+    int32_t pk;                      // paint: win_lo ; baryonify: pair slot | ring row << 6 | win_lo << 12
     double hstep, c0, Aq, Bq;        // k-th pixel: h = k hstep + c0 ;  r_com^2 = Aq + Bq sin^2(h)
 };
 static_assert(sizeof(Seg) == 48, "Seg must be 48 bytes");
@@ -338,17 +338,20 @@ __device__ unsigned long long g_stage_cycles[8];      // profiling build only: b
 constexpr int kTileThreads = BFG_TILE_THREADS;
 constexpr int kTileWaves = kTileThreads / 64;
 constexpr int kWinLds = 32;          // row windows up to this many nodes are staged in LDS
-constexpr int kPixMax = 3840;        // pixel -> segment table entries per round (7.5 KiB of LDS)
-constexpr int kPrOff = 32;           // slot offsets of the chunk's pairs, padded with INT_MAX
+constexpr int kPrOff = 64;           // slot offsets of the chunk's pairs (one per lane of a wavefront), padded with INT_MAX
+constexpr int kSegExtra = 64;        // LDS room for second pieces of ring windows that wrap around inside a sector
 
 // per-mode shape of a tile workgroup: rings per tile, accumulators per pixel, LDS capacities of a chunk
 template <int MODE> struct TileCfg;
 template <> struct TileCfg<MODE_PAINT> {
-    static constexpr int TR = 64, NACC = 1, SEGMAX = 896, PAIRMAX = 28;
+    // rings per tile, accumulators per pixel, (pair, ring) slots / pairs per chunk, pixel -> segment table entries per round
+    static constexpr int TR = 64, NACC = 1, SLOTMAX = 512, PAIRMAX = 60, PIXMAX = 6144;
+    static constexpr int SEGMAX = SLOTMAX + kSegExtra;
     using Pair = PairInfo;
 };
 template <> struct TileCfg<MODE_BARYONIFY> {
-    static constexpr int TR = 32, NACC = 3, SEGMAX = 704, PAIRMAX = 22;
+    static constexpr int TR = 32, NACC = 3, SLOTMAX = 448, PAIRMAX = 48, PIXMAX = 4096;
+    static constexpr int SEGMAX = SLOTMAX + kSegExtra;
     using Pair = PairInfoDisp;
 };
 
@@ -359,7 +362,7 @@ __host__ __device__ constexpr size_t tile_lds_bytes()
     return (size_t)Cfg::TR * kTileWidth * Cfg::NACC * sizeof(double) + kLogTab * sizeof(double2) +
            kExpTab * sizeof(double) + Cfg::TR * sizeof(RingRow) + Cfg::SEGMAX * sizeof(Seg) +
            Cfg::PAIRMAX * sizeof(typename Cfg::Pair) + (size_t)Cfg::PAIRMAX * kWinLds * sizeof(double) +
-           kPixMax * sizeof(uint16_t) + kPrOff * sizeof(int32_t) + Cfg::SEGMAX * sizeof(uint8_t) + 8 * sizeof(int32_t);
+           Cfg::PIXMAX * sizeof(uint16_t) + kPrOff * sizeof(int32_t) + Cfg::SEGMAX * sizeof(uint8_t) + 8 * sizeof(int32_t);
 }
 
 // sin(h) for h^2 <= kSinSmall: odd series to h^7 (rel err < 3e-12)
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
     using Cfg = TileCfg<MODE>;
     using Pair = typename Cfg::Pair;
     constexpr int TR = Cfg::TR, TW = kTileWidth, NT = kTileThreads, NACC = Cfg::NACC;
-    constexpr int kSegMax = Cfg::SEGMAX, kPairMax = Cfg::PAIRMAX, kSlotMax = kSegMax / 2;
+    constexpr int kSegMax = Cfg::SEGMAX, kPairMax = Cfg::PAIRMAX, kSlotMax = Cfg::SLOTMAX, kPixMax = Cfg::PIXMAX;
     static_assert(kSegMax * sizeof(Seg) <= 65536, "ptab holds 16-bit byte offsets of segment records");
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // LDS layout (byte offsets are compile-time constants: segment records carry LDS byte addresses)
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
     constexpr int proff_off = ptab_off + kPixMax * (int)sizeof(uint16_t);     // int32 [kPrOff] exclusive slot offsets of the pairs
     constexpr int scnt_off = proff_off + kPrOff * (int)sizeof(int32_t);       // uint8 [kSegMax] pixel count of every segment
     constexpr int ctl_off = scnt_off + kSegMax * (int)sizeof(uint8_t);        // n_take, nslots, extra segments, pixel total
-    static_assert(kSegMax % 16 == 0 && kPairMax < kPrOff && kSlotMax <= kTileThreads, "chunk shape");
+    static_assert(kSegMax % 16 == 0 && kPairMax <= kPrOff && kSlotMax <= kTileThreads && kPairMax <= 64, "chunk shape");
     double *acc = reinterpret_cast<double *>(smem_raw + acc_off);
     double2 *logtab = reinterpret_cast<double2 *>(smem_raw + logtab_off);
     double *exptab = reinterpret_cast<double *>(smem_raw + exptab_off);
@@ -557,9 +560,9 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
             if (go) unsafeAtomicAdd(reinterpret_cast<double *>(smem_raw + sg.abyte + 8 * k), v);
         } else {
             // HealpixRunner.py:336-355 for one pixel
-            const int pidx = sg.pk & 31, wl = sg.pk >> 11;
+            const int pidx = sg.pk & 63, wl = sg.pk >> 12;
             const Pair &pi = pinfo[pidx];
-            const RingRow &rr = rows[(sg.pk >> 5) & 63];
+            const RingRow &rr = rows[(sg.pk >> 6) & 63];
             double sh = sin_small(h, h2), ch = sqrt(1.0 - sh * sh);        // sin, cos of dphi/2 (cos >= 0)
             if (__any(h2 > kSinSmall)) { if (h2 > kSinSmall) sincos_wide(h, sh, ch); }
             const double s2 = sh * sh;
@@ -661,7 +664,7 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
                 }
                 pinfo[lane] = pi;
             }
-            if (lane < kPrOff) pr_off[lane] = (lane < n_take) ? cum - nrings : 0x7fffffff;
+            pr_off[lane] = (lane < n_take) ? cum - nrings : 0x7fffffff;
             if (lane == n_take - 1) { ctl[0] = n_take; ctl[1] = cum; ctl[2] = 0; ctl[3] = 0; }
             prefetch(base + n_take);                                 // loads fly during stages b and c
         }
@@ -674,12 +677,13 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
         // drained by the barrier that ends stage b).  dest = wave-uniform base + lane * 16 B == pwin[2 * tid].
         if constexpr (win_in_lds) {
             if (W == kWinLds) {
-                static_assert(kPairMax * (kWinLds / 2) <= kTileThreads, "one DMA per thread covers the chunk");
-                if (tid < n_take * (kWinLds / 2)) {
-                    const double *src = P.hwin + pinfo[tid / (kWinLds / 2)].hoff + 2 * (tid % (kWinLds / 2));
-                    double *dst = pwin + wave * 128;                                  // wave-uniform; lane * 16 B added by HW
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+                for (int i = tid; i - lane < n_take * (kWinLds / 2); i += NT) {          // whole wavefronts step together
+                    if (i < n_take * (kWinLds / 2)) {
+                        const double *src = P.hwin + pinfo[i / (kWinLds / 2)].hoff + 2 * (i % (kWinLds / 2));
+                        double *dst = pwin + 2 * (i - lane);                              // wave-uniform; lane * 16 B added by HW
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+                    }
                 }
             } else {
                 for (int idx = tid; idx < n_take * W; idx += NT) {
@@ -696,7 +700,7 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
             int p;
             {
                 const int sb = wave * 64;
-                const int myoff = (lane < kPrOff) ? pr_off[lane] : 0x7fffffff;
+                const int myoff = pr_off[lane];
                 p = __popcll(__ballot(myoff <= sb)) - 1;
                 unsigned long long inside = __ballot(myoff > sb && myoff <= sb + 63);
                 while (inside) {
@@ -735,7 +739,7 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
                 const int wl = pinfo[p].win_lo;
                 sg.wbyte = win_in_lds ? pwin_off + p * (kWinLds * 8) - 8 * wl : p;
                 if constexpr (MODE == MODE_PAINT) sg.pk = wl;
-                else sg.pk = p | (row << 5) | (wl << 11);
+                else sg.pk = p | (row << 6) | (wl << 12);
                 sg.hstep = 0.5 * rr.phistep;
                 sg.c0 = 0.5 * (rr.phioff * rr.phistep - pphi);          // + first pixel * hstep, below
                 const double ds = rr.sth - st, dz = rr.z - ct;
@@ -755,14 +759,23 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
                     }
                 }
             }
+            // a second piece needs its own segment record; should the chunk run out of them (only possible where a
+            // sector spans a whole ring, at the poles) the piece is painted right here, through the direct read-out
+            int idx2 = 0;
+            bool spill2 = false;
+            if (cnt2 > 0) { idx2 = nslots + atomicAdd(&ctl[2], 1); spill2 = idx2 >= kSegMax || (P.debug & 16); }   // debug bit 16: force the spill path (tests)
             // offsets in the chunk's flattened pixel list: wave scan + one LDS atomic per wavefront (any order will do)
-            const int tot = cnt1 + cnt2;
+            const int tot = cnt1 + (spill2 ? 0 : cnt2);
             const int incl = wave_scan_incl(tot);
             const int wtot = __builtin_amdgcn_readlane(incl, 63);
             int wbase = 0;
             if (lane == 0 && wtot > 0) wbase = atomicAdd(&ctl[3], wtot);
             wbase = __builtin_amdgcn_readfirstlane(wbase);
             const int e1 = wbase + incl - tot;
+#if BFG_STAGE_TIMING > 1
+            if (live) atomicAdd(&g_stage_cycles[6], 1ull);
+            if (cnt1 > 0) atomicAdd(&g_stage_cycles[7], 1ull);
+#endif
             if (live) {
                 scnt[slot] = (uint8_t)cnt1;
                 if (cnt1 > 0) {
@@ -771,21 +784,28 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
                     segs[slot] = sg;
                     const uint16_t o1 = (uint16_t)(slot * (int)sizeof(Seg));
                     for (int q = e1; q < min(e1 + cnt1, kPixMax); ++q) ptab[q] = o1;
-                    if (cnt2 > 0) {                                     // at most one extra segment per slot
-                        const int idx2 = nslots + atomicAdd(&ctl[2], 1);
+                    if (cnt2 > 0 && !spill2) {
                         scnt[idx2] = (uint8_t)cnt2;
                         const int e2 = e1 + cnt1;
                         sg.excl = e2; sg.abyte = ab2; sg.c0 = fma((double)aa2, sg.hstep, c0b);
                         segs[idx2] = sg;
                         const uint16_t o2 = (uint16_t)(idx2 * (int)sizeof(Seg));
                         for (int q = e2; q < min(e2 + cnt2, kPixMax); ++q) ptab[q] = o2;
+                    } else if (cnt2 > 0) {
+                        constexpr int wlf = 1 << 18;                   // a window no cell falls into -> direct_row()
+                        sg.excl = 0; sg.abyte = ab2; sg.c0 = fma((double)aa2, sg.hstep, c0b);
+                        sg.wbyte = win_in_lds ? pwin_off + p * (kWinLds * 8) - 8 * wlf : p;
+                        if constexpr (MODE == MODE_PAINT) sg.pk = wlf;
+                        else sg.pk = (sg.pk & 0xFFF) | (wlf << 12);
+                        for (int k = 0; k < cnt2; ++k) do_pixel(k, sg);
+                        my_pixels += (unsigned long long)cnt2;
                     }
                 }
             }
         }
         __syncthreads();
         BFG_TICK(1);
-        const int nseg = nslots + ctl[2];
+        const int nseg = min(nslots + ctl[2], kSegMax);
         const int ptotal = (P.debug & 2) ? 0 : ctl[3];
         my_pixels += (tid == 0) ? (unsigned long long)ctl[3] : 0ull;
 

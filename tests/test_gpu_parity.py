@@ -263,6 +263,33 @@ def test_paint_and_baryonify_any_nside(cosmo, nside, variant):
     assert_maps_close(gotb, refb, RTOL, floor=BFLOOR, what=f"baryonify nside {nside}")
 
 
+@pytest.mark.parametrize("nside", [8, 16])
+def test_tile_wrapped_window_spill_path(cosmo, nside, monkeypatch):
+    """ring windows that wrap around inside a sector produce a second segment; when a chunk runs out of segment
+    records the piece is painted through the direct read-out (forced here with debug bit 16)"""
+    import warnings
+    monkeypatch.setenv("BFG_DEBUG", "16")
+    ra, dec, M, z = syn.catalog(400, seed=5 + nside, z=(0.03, 0.2), logM=(13.5, 15.5))
+    ra[:200] = (ra[:200] * 0.02 - 3.0) % 360.0                      # many discs across phi = 0
+    zax, Max, rax, T = syn.pressure_table()
+    ref, ptot = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax), T, nside, 10)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), 10,
+                               _paint_model(zax, Max, rax, T), verbose=False, variant="tile_lds")
+    got = R.process()
+    assert R.last_stats["pixel_updates"] == ptot
+    assert_maps_close(got, ref, RTOL, what=f"paint spill nside {nside}")
+    zax, Max, rax, d = syn.displacement_table()
+    m_in = syn.mass_map(nside)
+    refb = oracle_baryonify(cosmo, ra, dec, M, z, (zax, Max, rax), d, nside, 10, 20, m_in)
+    model = bfg.Baryonification2D.from_arrays(zax, Max, rax, d, cosmo, epsilon_max=20)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gotb = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo), 10, model, verbose=False,
+                                  variant="tile_lds").process()
+    assert_maps_close(gotb, refb, RTOL, floor=BFLOOR, what=f"baryonify spill nside {nside}")
+
+
 def test_tile_pair_buffer_overflow_falls_back_to_scatter(cosmo, monkeypatch):
     """If the (halo, tile) pair buffer is too small the whole call degrades to the scatter kernel -- same map."""
     ra, dec, M, z = syn.catalog(3000, seed=46)
