@@ -130,6 +130,11 @@ struct __align__(16) PairInfoDisp {  // ... baryonify (96 bytes)
 };
 static_assert(sizeof(PairInfoDisp) == 96, "PairInfoDisp must be 96 bytes");
 
+struct __align__(16) DeferredPixel { // a pixel whose table cell lies outside the staged row window (queued, see drain)
+    int32_t halo, abyte;             // halo index, LDS byte offset of the pixel's accumulator
+    double t;                        // cell coordinate on the radial axis
+};
+
 struct __align__(16) RingRow {       // one ring of the tile's band (computed once per workgroup)
     double z, sth, phistep, phioff;
     int32_t nr, k0, k1, rowoff;      // rowoff = row * TW - k0
@@ -323,9 +328,6 @@ __global__ __launch_bounds__(256) void halo_row_kernel(const RowParams P)
 #ifndef BFG_TILE_WAVES_PER_SIMD
 #define BFG_TILE_WAVES_PER_SIMD 4
 #endif
-#ifndef BFG_PIXEL_PAIRS
-#define BFG_PIXEL_PAIRS 0
-#endif
 #ifndef BFG_STAGE_TIMING
 #define BFG_STAGE_TIMING 0
 #endif
@@ -345,12 +347,12 @@ constexpr int kSegExtra = 64;        // LDS room for second pieces of ring windo
 template <int MODE> struct TileCfg;
 template <> struct TileCfg<MODE_PAINT> {
     // rings per tile, accumulators per pixel, (pair, ring) slots / pairs per chunk, pixel -> segment table entries per round
-    static constexpr int TR = 64, NACC = 1, SLOTMAX = 512, PAIRMAX = 60, PIXMAX = 6144;
+    static constexpr int TR = 64, NACC = 1, SLOTMAX = 512, PAIRMAX = 60, PIXMAX = 4608, QCAP = 192;
     static constexpr int SEGMAX = SLOTMAX + kSegExtra;
     using Pair = PairInfo;
 };
 template <> struct TileCfg<MODE_BARYONIFY> {
-    static constexpr int TR = 32, NACC = 3, SLOTMAX = 448, PAIRMAX = 48, PIXMAX = 4096;
+    static constexpr int TR = 32, NACC = 3, SLOTMAX = 448, PAIRMAX = 48, PIXMAX = 4096, QCAP = 0;
     static constexpr int SEGMAX = SLOTMAX + kSegExtra;
     using Pair = PairInfoDisp;
 };
@@ -362,7 +364,8 @@ __host__ __device__ constexpr size_t tile_lds_bytes()
     return (size_t)Cfg::TR * kTileWidth * Cfg::NACC * sizeof(double) + kLogTab * sizeof(double2) +
            kExpTab * sizeof(double) + Cfg::TR * sizeof(RingRow) + Cfg::SEGMAX * sizeof(Seg) +
            Cfg::PAIRMAX * sizeof(typename Cfg::Pair) + (size_t)Cfg::PAIRMAX * kWinLds * sizeof(double) +
-           Cfg::PIXMAX * sizeof(uint16_t) + kPrOff * sizeof(int32_t) + Cfg::SEGMAX * sizeof(uint8_t) + 8 * sizeof(int32_t);
+           Cfg::PIXMAX * sizeof(uint16_t) + kPrOff * sizeof(int32_t) + Cfg::SEGMAX * sizeof(uint8_t) +
+           Cfg::QCAP * sizeof(DeferredPixel) + 8 * sizeof(int32_t);
 }
 
 // sin(h) for h^2 <= kSinSmall: odd series to h^7 (rel err < 3e-12)
@@ -418,7 +421,9 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
     constexpr int ptab_off = pwin_off + kPairMax * kWinLds * (int)sizeof(double);   // uint16 [kPixMax] pixel -> segment
     constexpr int proff_off = ptab_off + kPixMax * (int)sizeof(uint16_t);     // int32 [kPrOff] exclusive slot offsets of the pairs
     constexpr int scnt_off = proff_off + kPrOff * (int)sizeof(int32_t);       // uint8 [kSegMax] pixel count of every segment
-    constexpr int ctl_off = scnt_off + kSegMax * (int)sizeof(uint8_t);        // n_take, nslots, extra segments, pixel total
+    constexpr int kQCap = Cfg::QCAP;
+    constexpr int rq_off = scnt_off + kSegMax * (int)sizeof(uint8_t);         // DeferredPixel [kQCap]
+    constexpr int ctl_off = rq_off + kQCap * (int)sizeof(DeferredPixel);      // n_take, nslots, extra segments, pixel total, -, queue fill
     static_assert(kSegMax % 16 == 0 && kPairMax <= kPrOff && kSlotMax <= kTileThreads && kPairMax <= 64, "chunk shape");
     double *acc = reinterpret_cast<double *>(smem_raw + acc_off);
     double2 *logtab = reinterpret_cast<double2 *>(smem_raw + logtab_off);
@@ -430,6 +435,7 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
     uint16_t *ptab = reinterpret_cast<uint16_t *>(smem_raw + ptab_off);
     int32_t *pr_off = reinterpret_cast<int32_t *>(smem_raw + proff_off);
     uint8_t *scnt = reinterpret_cast<uint8_t *>(smem_raw + scnt_off);
+    [[maybe_unused]] DeferredPixel *rq = reinterpret_cast<DeferredPixel *>(smem_raw + rq_off);
     int32_t *ctl = reinterpret_cast<int32_t *>(smem_raw + ctl_off);
     static_assert(sizeof(RingRow) % 16 == 0 && sizeof(Pair) % 16 == 0, "16-byte aligned LDS records");
     static_assert(ctl_off + 8 * sizeof(int32_t) == tile_lds_bytes<MODE>(), "layout and tile_lds_bytes() must agree");
@@ -447,6 +453,7 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     for (int i = tid; i < TR * TW * NACC; i += NT) acc[i] = 0.0;
+    if (tid == 0) ctl[5] = 0;
     if (tid < kLogTab) logtab[tid] = P.logtab[tid];
     if (tid < kExpTab) exptab[tid] = P.exptab[tid];
     if (tid < TR) {
@@ -490,10 +497,9 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
     unsigned int n_oob32 = 0;
 
     // rare: a pixel whose table cell lies outside the pair's staged row window -> blend the corners directly
-    auto direct_row = [&](int pidx, double t) -> double {
+    auto direct_row_halo = [&](int64_t j, double t) -> double {
         const int i = min(max((int)t, 0), NRm1 - 1);
         const double f = t - (double)i;
-        const int64_t j = pinfo[pidx].halo;
         double c0v = 0.0, c1v = 0.0;
         const int ncorner = 1 << T.nouter;
         for (int c = 0; c < ncorner; ++c) {
@@ -507,9 +513,29 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
             c0v = fma(T.values[off + i], w, c0v);
             c1v = fma(T.values[off + i + 1], w, c1v);
         }
-        double L = fma(f, c1v - c0v, c0v);
+        return fma(f, c1v - c0v, c0v);
+    };
+    auto direct_row = [&](int pidx, double t) -> double {
+        double L = direct_row_halo(pinfo[pidx].halo, t);
         if constexpr (MODE == MODE_PAINT) L += pinfo[pidx].lnpf;
         return L;
+    };
+    // paint: those pixels (the innermost few of large discs, ~0.2 %) cost two dependent rounds of global loads.
+    // Done inline they stall their wavefront and, through the end-of-chunk barrier, the whole workgroup; so they
+    // are queued in LDS and drained by all threads at once when the queue is half full and at the end of the tile.
+    const int qcap = (P.debug & 32) ? min(4, kQCap) : kQCap;      // debug bit 32: tiny queue (tests the inline fallback)
+    [[maybe_unused]] auto drain = [&]() {
+        if constexpr (kQCap > 0) {
+            const int n = min(ctl[5], qcap);
+            for (int i = tid; i < n; i += NT) {
+                const DeferredPixel e = rq[i];
+                const double L = direct_row_halo(e.halo, e.t) + P.ht[e.halo].spare[0];
+                if (fabs(L) < 709.0) unsafeAtomicAdd(reinterpret_cast<double *>(smem_raw + e.abyte), fast_exp(L, exptab));
+            }
+            __syncthreads();
+            if (tid == 0) ctl[5] = 0;
+            __syncthreads();
+        }
     };
 
     // interpolant of the pair's blended row at cell coordinate t (cell = trunc(t), clamped into the staged window
@@ -549,7 +575,12 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
             if (!in) {                                                     // divergent and rare
                 if ((t >= 0.0) && (t <= (double)NRm1)) {
                     const int pidx = win_in_lds ? (sg.wbyte + 8 * wl - pwin_off) / (8 * kWinLds) : sg.wbyte;
-                    L = direct_row(pidx, t); in = true;
+                    const int qi = (kQCap > 0) ? atomicAdd(&ctl[5], 1) : kQCap;
+                    if (qi < qcap) {
+                        DeferredPixel e;
+                        e.halo = pinfo[pidx].halo; e.abyte = sg.abyte + 8 * k; e.t = t;
+                        rq[qi] = e;
+                    } else { L = direct_row(pidx, t); in = true; }         // queue full: inline
                 } else n_oob32 += 1;
             }
             // NaN / +-inf L paint nothing (HealpixRunner.py:473).  L already holds + ln(pixarea D^2) (:478, folded
@@ -594,44 +625,6 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
                 unsafeAtomicAdd(ap + 1, fma(vy, g, dy * kk));
                 unsafeAtomicAdd(ap + 2, fma(vz, g, dz * kk));
             }
-        }
-    };
-
-    // two pixels per thread, interleaved by hand so that their dependent LDS round trips overlap
-    // (the kernel is latency-bound: ~3.6 waves per SIMD cannot hide ptab -> segment -> ln table -> row window -> exp table)
-    [[maybe_unused]] auto do_pixel2 = [&](int qa, const Seg &sa, int qb, const Seg &sb, bool vb) {
-        if constexpr (MODE == MODE_PAINT) {
-            const int ka = qa - sa.excl, kb = qb - sb.excl;
-            const double ha = fma((double)ka, sa.hstep, sa.c0), hb = fma((double)kb, sb.hstep, sb.c0);
-            const double ha2 = ha * ha, hb2 = hb * hb;
-            double s2a = sin_squared_small(ha2), s2b = sin_squared_small(hb2);
-            if (__any(fmax(ha2, hb2) > kSinSmall)) {
-                if (ha2 > kSinSmall) s2a = sin_squared_wide(ha);
-                if (hb2 > kSinSmall) s2b = sin_squared_wide(hb);
-            }
-            const double xa = fma(sa.Bq, s2a, sa.Aq), xb = fma(sb.Bq, s2b, sb.Aq);
-            const double ta = fma(fast_log(xa, logtab), t_m, t_c), tb = fma(fast_log(xb, logtab), t_m, t_c);
-            bool ina, inb;
-            double La = window_row(sa, sa.pk, win_in_lds ? 0 : sa.wbyte, ta, ina);
-            double Lb = window_row(sb, sb.pk, win_in_lds ? 0 : sb.wbyte, tb, inb);
-            if (!ina || (vb && !inb)) {                                    // divergent and rare
-                if (!ina) {
-                    if ((ta >= 0.0) && (ta <= (double)NRm1)) {
-                        const int pidx = win_in_lds ? (sa.wbyte + 8 * sa.pk - pwin_off) / (8 * kWinLds) : sa.wbyte;
-                        La = direct_row(pidx, ta); ina = true;
-                    } else n_oob32 += 1;
-                }
-                if (vb && !inb) {
-                    if ((tb >= 0.0) && (tb <= (double)NRm1)) {
-                        const int pidx = win_in_lds ? (sb.wbyte + 8 * sb.pk - pwin_off) / (8 * kWinLds) : sb.wbyte;
-                        Lb = direct_row(pidx, tb); inb = true;
-                    } else n_oob32 += 1;
-                }
-            }
-            const bool goa = ina && (fabs(La) < 709.0), gob = vb && inb && (fabs(Lb) < 709.0);
-            const double va = fast_exp(La, exptab), vbv = fast_exp(Lb, exptab);
-            if (goa) unsafeAtomicAdd(reinterpret_cast<double *>(smem_raw + sa.abyte + 8 * ka), va);
-            if (gob) unsafeAtomicAdd(reinterpret_cast<double *>(smem_raw + sb.abyte + 8 * kb), vbv);
         }
     };
 
@@ -827,26 +820,18 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
             BFG_TICK(3);
             const int pend = min(ptotal, pbase + kPixMax);
             const uint16_t *pp = ptab + tid;
-            if constexpr (MODE == MODE_PAINT && BFG_PIXEL_PAIRS) {
-                for (int q = pbase + tid; q < pend; q += 2 * NT, pp += 2 * NT) {
-                    const bool vb = q + NT < pend;
-                    const int oa = pp[0], ob = vb ? pp[NT] : oa;
-                    const Seg sa = *reinterpret_cast<const Seg *>(smem_raw + segs_off + oa);
-                    const Seg sb = *reinterpret_cast<const Seg *>(smem_raw + segs_off + ob);
-                    do_pixel2(q, sa, q + NT, sb, vb);
-                }
-            } else {
-                for (int q = pbase + tid; q < pend; q += NT, pp += NT) {
-                    const Seg sg = *reinterpret_cast<const Seg *>(smem_raw + segs_off + *pp);     // by value: one burst of LDS reads
-                    do_pixel(q, sg);
-                }
+            for (int q = pbase + tid; q < pend; q += NT, pp += NT) {
+                const Seg sg = *reinterpret_cast<const Seg *>(smem_raw + segs_off + *pp);     // by value: one burst of LDS reads
+                do_pixel(q, sg);
             }
         }
         BFG_TICK(4);
         __syncthreads();
         BFG_TICK(5);
         base += n_take;
+        if constexpr (kQCap > 0) { if (ctl[5] >= qcap / 2) drain(); }     // uniform: ctl[5] is stable between the barriers
     }
+    if constexpr (kQCap > 0) { if (ctl[5] > 0) drain(); }
     if (my_pixels) atomicAdd((unsigned long long *)&P.stats->pixel_updates, my_pixels);
     if (n_oob32) {
         atomicAdd((unsigned long long *)&P.stats->pixels_out_of_table, (unsigned long long)n_oob32);

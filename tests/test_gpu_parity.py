@@ -263,6 +263,24 @@ def test_paint_and_baryonify_any_nside(cosmo, nside, variant):
     assert_maps_close(gotb, refb, RTOL, floor=BFLOOR, what=f"baryonify nside {nside}")
 
 
+def test_tile_deferred_pixel_queue_overflow(cosmo, monkeypatch):
+    """pixels below a halo's staged row window are queued in LDS and drained in batches; with a full queue they are
+    painted inline (forced here with debug bit 32: a 4-entry queue)"""
+    nside = 512
+    ra, dec, M, z = syn.catalog(2000, seed=77, z=(0.02, 0.1), logM=(14.5, 15.5))     # large discs: many inner pixels
+    zax, Max, rax, T = syn.pressure_table()
+    ref, ptot = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax), T, nside, 10)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    outs = []
+    for dbg in ("0", "32"):
+        monkeypatch.setenv("BFG_DEBUG", dbg)
+        R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), 10,
+                                   _paint_model(zax, Max, rax, T), verbose=False, variant="tile_lds")
+        outs.append(R.process())
+        assert R.last_stats["pixel_updates"] == ptot
+        assert_maps_close(outs[-1], ref, RTOL, what=f"paint deferred queue debug={dbg}")
+
+
 @pytest.mark.parametrize("nside", [8, 16])
 def test_tile_wrapped_window_spill_path(cosmo, nside, monkeypatch):
     """ring windows that wrap around inside a sector produce a second segment; when a chunk runs out of segment
