@@ -388,6 +388,37 @@ __device__ inline void sincos_wide(double h, double &sh, double &ch)
     sh = s; ch = c;
 }
 
+// atan2(y, x) for y >= 0 (result in [0, pi]), <= 2 ulp, without libm: the smaller of (|x|, y) over the larger is
+// brought to |u| <= 1/8 with atan(t) = atan(c) + atan((t - c) / (1 + c t)), c in {0, 1/4, 1/2, 3/4, 1}; one division
+// (v_rcp_f64 + two Newton steps + one correction of the quotient), odd series to u^17.  ocml's atan2 is ~3x longer.
+__device__ inline double atan2_upper(double y, double x)
+{
+    const double ax = fabs(x);
+    const double mx = fmax(ax, y), mn = fmin(ax, y);
+    double c = 0.0, ac = 0.0;
+    if (mn > 0.125 * mx) { c = 0.25; ac = 0.24497866312686415417; }
+    if (mn > 0.375 * mx) { c = 0.5; ac = 0.46364760900080611621; }
+    if (mn > 0.625 * mx) { c = 0.75; ac = 0.64350110879328438680; }
+    if (mn > 0.875 * mx) { c = 1.0; ac = 0.78539816339744830962; }
+    const double num = fma(-c, mx, mn), den = fma(c, mn, mx);
+    double r = __builtin_amdgcn_rcp(den);
+    r = fma(fma(-den, r, 1.0), r, r);
+    r = fma(fma(-den, r, 1.0), r, r);
+    double u = num * r;
+    u = fma(fma(-den, u, num), r, u);
+    const double u2 = u * u;
+    double p = fma(u2, 1.0 / 17.0, -1.0 / 15.0);
+    p = fma(u2, p, 1.0 / 13.0);
+    p = fma(u2, p, -1.0 / 11.0);
+    p = fma(u2, p, 1.0 / 9.0);
+    p = fma(u2, p, -1.0 / 7.0);
+    p = fma(u2, p, 1.0 / 5.0);
+    p = fma(u2, p, -1.0 / 3.0);
+    double a = ac + fma(u * u2, p, u);
+    a = (ax < y) ? 1.57079632679489661923 - a : a;
+    return (x < 0.0) ? 3.14159265358979323846 - a : a;
+}
+
 // inclusive prefix sum over the 64 lanes of a wavefront with DPP row shifts / row broadcasts (no LDS round trips;
 // __shfl_up compiles to ds_bpermute, ~100 cycles per step)
 __device__ inline int wave_scan_incl(int v)
@@ -556,6 +587,15 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
         return fma(f, B1 - B0, B0);
     };
 
+    // ptab[q0 .. q1) = off, two entries per store where aligned
+    auto fill_ptab = [&](int q0, int q1, uint32_t off) {
+        int q = q0;
+        if ((q & 1) && q < q1) { ptab[q] = (uint16_t)off; ++q; }
+        const uint32_t two = off | (off << 16);
+        for (; q + 1 < q1; q += 2) *reinterpret_cast<uint32_t *>(ptab + q) = two;
+        if (q < q1) ptab[q] = (uint16_t)off;
+    };
+
     // one pixel of the flattened chunk: segment record -> chord^2 -> ln -> row read-out -> accumulate in LDS
     auto do_pixel = [&](int q, const Seg &sg) {
         const int k = q - sg.excl;                                         // pixel index inside the segment
@@ -719,7 +759,7 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
                 else {
                     const double x = (h.cosr - rr.z * h.z0) * h.xa;
                     const double ysq = 1.0 - rr.z * rr.z - x * x;
-                    const double dphi = (ysq <= 0.0) ? 0.0 : atan2(sqrt(ysq), x);
+                    const double dphi = (ysq <= 0.0) ? 0.0 : atan2_upper(sqrt(ysq), x);
                     if (dphi > 0.0) {
                         const double shift = (rr.phioff != 0.0) ? 0.5 : 0.0;
                         const int64_t l64 = (int64_t)floor((double)nr * kInvTwoPi * (pphi - dphi) - shift) + 1;
@@ -775,15 +815,13 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
                     const double c0b = sg.c0;
                     sg.excl = e1; sg.abyte = ab1; sg.c0 = fma((double)aa1, sg.hstep, c0b);
                     segs[slot] = sg;
-                    const uint16_t o1 = (uint16_t)(slot * (int)sizeof(Seg));
-                    for (int q = e1; q < min(e1 + cnt1, kPixMax); ++q) ptab[q] = o1;
+                    fill_ptab(e1, min(e1 + cnt1, kPixMax), (uint32_t)(slot * (int)sizeof(Seg)));
                     if (cnt2 > 0 && !spill2) {
                         scnt[idx2] = (uint8_t)cnt2;
                         const int e2 = e1 + cnt1;
                         sg.excl = e2; sg.abyte = ab2; sg.c0 = fma((double)aa2, sg.hstep, c0b);
                         segs[idx2] = sg;
-                        const uint16_t o2 = (uint16_t)(idx2 * (int)sizeof(Seg));
-                        for (int q = e2; q < min(e2 + cnt2, kPixMax); ++q) ptab[q] = o2;
+                        fill_ptab(e2, min(e2 + cnt2, kPixMax), (uint32_t)(idx2 * (int)sizeof(Seg)));
                     } else if (cnt2 > 0) {
                         constexpr int wlf = 1 << 18;                   // a window no cell falls into -> direct_row()
                         sg.excl = 0; sg.abyte = ab2; sg.c0 = fma((double)aa2, sg.hstep, c0b);
