@@ -510,19 +510,31 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
     unsigned long long my_pixels = 0;
     const int32_t *plist = P.pairs + P.tile_start[tile];
 
-    // wave 0 keeps the next chunk's pair records in flight while the others compute (stage a prefetch)
+    // Wave 0 runs the pair pipeline two chunks deep, so that no stage waits for a dependent pair -> halo record load:
+    //   pjA / pjB  the pair list entries [base, base + 128) of the current chunk's first pair (issued one chunk ago);
+    //   nx_*       halo-record fields of the NEXT chunk's candidate pairs.
+    // Both sets of loads are issued at the start of stage c (not before the stage-b barrier, whose vmcnt(0) -- needed
+    // for the LDS-DMA -- would expose their latency) and are consumed in the next chunk's stage a.
+    int pjA = -1, pjB = -1;
     int nx_j = -1, nx_first = 0, nx_last = -1, nx_wl = 0;
     [[maybe_unused]] double nx_lnpf = 0.0;
-    auto prefetch = [&](int base) {
-        nx_j = -1; nx_first = 0; nx_last = -1;
-        if (lane < kPairMax && base + lane < n_pairs) {
-            nx_j = plist[base + lane];
+    auto load_list_windows = [&](int wb) {
+        pjA = (wb + lane < n_pairs) ? plist[wb + lane] : -1;
+        pjB = (wb + 64 + lane < n_pairs) ? plist[wb + 64 + lane] : -1;
+    };
+    auto load_records = [&]() {
+        nx_first = 0; nx_last = -1;
+        if (nx_j >= 0) {
             const HaloTile &h = P.ht[nx_j];
             nx_first = h.rfirst; nx_last = h.rlast; nx_wl = h.win_lo;
             if constexpr (MODE == MODE_PAINT) nx_lnpf = h.spare[0];
         }
     };
-    if (wave == 0) prefetch(0);
+    if (wave == 0) {
+        load_list_windows(0);
+        nx_j = (lane < kPairMax) ? pjA : -1;
+        load_records();
+    }
     __syncthreads();
 
     unsigned int n_oob32 = 0;
@@ -685,21 +697,16 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
             const int first_bad = __ffsll((long long)~fm);          // 1-based; 0 if all 64 fit
             const int n_take = first_bad ? first_bad - 1 : 64;
             if (lane < n_take) {
-                Pair pi;
+                Pair &pi = pinfo[lane];
                 pi.hoff = (int64_t)j * W; pi.win_lo = nx_wl; pi.halo = j; pi.ra = ra; pi.pad = 0;
-                if constexpr (MODE == MODE_PAINT) {
-                    pi.lnpf = nx_lnpf;
-                } else {
-                    const HaloTile &h = P.ht[j];
-                    const HaloDisp &hd = P.hd[j];
-                    pi.cp0 = hd.cp0; pi.sp0 = hd.sp0; pi.st = h.st; pi.ct = h.ct;
-                    pi.a = hd.a; pi.D = hd.D; pi.xcut = hd.xcut; pi.tshift = hd.tshift; pi.pad2 = 0.0;
-                }
-                pinfo[lane] = pi;
+                if constexpr (MODE == MODE_PAINT) pi.lnpf = nx_lnpf;   // baryonify: the rest is filled in stage b
             }
             pr_off[lane] = (lane < n_take) ? cum - nrings : 0x7fffffff;
             if (lane == n_take - 1) { ctl[0] = n_take; ctl[1] = cum; ctl[2] = 0; ctl[3] = 0; }
-            prefetch(base + n_take);                                 // loads fly during stages b and c
+            // candidates of the next chunk: list entries base + n_take + lane, out of the two list windows
+            const int idx = n_take + lane;
+            const int fa = __shfl(pjA, idx & 63), fb = __shfl(pjB, idx & 63);
+            nx_j = (lane < kPairMax) ? ((idx < 64) ? fa : fb) : -1;
         }
         __syncthreads();
         const int n_take = ctl[0], nslots = ctl[1];
@@ -709,7 +716,8 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
         // With full-width windows the copy is an LDS-DMA (global_load_lds_dwordx4: no VGPRs, asynchronous;
         // drained by the barrier that ends stage b).  dest = wave-uniform base + lane * 16 B == pwin[2 * tid].
         if constexpr (win_in_lds) {
-            if (W == kWinLds) {
+            if (P.debug & 64) {                                       // profiling: no window copy at all (wrong results)
+            } else if (W == kWinLds) {
                 for (int i = tid; i - lane < n_take * (kWinLds / 2); i += NT) {          // whole wavefronts step together
                     if (i < n_take * (kWinLds / 2)) {
                         const double *src = P.hwin + pinfo[i / (kWinLds / 2)].hoff + 2 * (i % (kWinLds / 2));
@@ -723,6 +731,17 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
                     const int p = idx / W, e = idx - p * W;
                     pwin[p * kWinLds + e] = P.hwin[pinfo[p].hoff + e];
                 }
+            }
+        }
+        if constexpr (MODE == MODE_BARYONIFY) {
+            static_assert(MODE != MODE_BARYONIFY || kSlotMax <= kTileThreads - 64, "the last wavefront has no slots");
+            if (wave == kTileWaves - 1 && lane < n_take) {              // per-pair constants of the pixel stage
+                Pair &pi = pinfo[lane];
+                const int j = pi.halo;
+                const HaloTile &h = P.ht[j];
+                const HaloDisp &hd = P.hd[j];
+                pi.cp0 = hd.cp0; pi.sp0 = hd.sp0; pi.st = h.st; pi.ct = h.ct;
+                pi.a = hd.a; pi.D = hd.D; pi.xcut = hd.xcut; pi.tshift = hd.tshift; pi.pad2 = 0.0;
             }
         }
         if (wave * 64 < nslots && !(P.debug & 8)) {                 // whole wavefronts: kSlotMax <= NT, one pass
@@ -839,6 +858,7 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
         const int nseg = min(nslots + ctl[2], kSegMax);
         const int ptotal = (P.debug & 2) ? 0 : ctl[3];
         my_pixels += (tid == 0) ? (unsigned long long)ctl[3] : 0ull;
+        if (wave == 0) { load_records(); load_list_windows(base + n_take); }   // in flight during the pixel stage
 
         // ---- stage c: one thread per pixel of the flattened list (rounds of kPixMax pixels; the first round's
         //      pixel -> segment table was filled by stage b) -------------------------------------------------
