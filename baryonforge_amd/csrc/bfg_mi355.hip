@@ -1230,7 +1230,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
 
     int variant = a->variant;
     // the tile variant needs a uniform radial axis (direct cell computation)
-    const bool tile_ok = t->dev.r_uniform && !t->dev.hot && a->nside >= 8 && a->n_halo < (1ll << 31);
+    const bool tile_ok = t->dev.r_uniform && !t->dev.hot && a->nside >= 8 && a->nside <= (1 << 24) && a->n_halo < (1ll << 31);
     if (variant == BFG_VARIANT_AUTO) variant = tile_ok ? BFG_VARIANT_TILE_LDS : BFG_VARIANT_SCATTER_QUARTER;
     if (variant == BFG_VARIANT_TILE_LDS && !tile_ok) variant = BFG_VARIANT_SCATTER_QUARTER;
     const bool tile = (variant == BFG_VARIANT_TILE_LDS);

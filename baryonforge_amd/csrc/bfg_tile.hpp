@@ -388,6 +388,18 @@ __device__ inline void sincos_wide(double h, double &sh, double &ch)
     sh = s; ch = c;
 }
 
+// sqrt(x) for x in (1e-290, 1e290) (here: 1 - z^2 - x^2 <= 1): v_rsq_f64 + Goldschmidt / Newton steps, <= 1 ulp; no
+// range scaling and no special cases, unlike libm's
+__device__ inline double sqrt_unit(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    g = fma(fma(-g, g, x), h, g);
+    return fma(fma(-g, g, x), h, g);
+}
+
 // atan2(y, x) for y >= 0 (result in [0, pi]), <= 2 ulp, without libm: the smaller of (|x|, y) over the larger is
 // brought to |u| <= 1/8 with atan(t) = atan(c) + atan((t - c) / (1 + c t)), c in {0, 1/4, 1/2, 3/4, 1}; one division
 // (v_rcp_f64 + two Newton steps + one correction of the quotient), odd series to u^17.  ocml's atan2 is ~3x longer.
@@ -711,6 +723,7 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
         __syncthreads();
         const int n_take = ctl[0], nslots = ctl[1];
         BFG_TICK(0);
+        BFG_TICK(6);
 
         // ---- stage b: one thread per (pair, ring) slot; row windows -> LDS -----------------------------
         // With full-width windows the copy is an LDS-DMA (global_load_lds_dwordx4: no VGPRs, asynchronous;
@@ -773,21 +786,26 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
                 const HaloTile &h = P.ht[j];
                 const double st = h.st, ct = h.ct, pphi = h.pphi, S = h.S;
                 const int nr = rr.nr;
+                // query_disc ring window.  Evaluated unconditionally so that every field of the halo record is
+                // fetched in one burst (a branch on irmin / irmax first serialises three L2 round trips); rings that
+                // lie entirely inside the disc (ring outside [irmin, irmax]) override the result.
+                const int irmin = h.irmin, irmax = h.irmax;
                 int lo = 0, cnt = 0;
-                if (ring < h.irmin || ring > h.irmax) cnt = nr;         // ring entirely inside the disc
-                else {
+                {
                     const double x = (h.cosr - rr.z * h.z0) * h.xa;
                     const double ysq = 1.0 - rr.z * rr.z - x * x;
-                    const double dphi = (ysq <= 0.0) ? 0.0 : atan2_upper(sqrt(ysq), x);
+                    const double dphi = (ysq > 0.0) ? atan2_upper(sqrt_unit(ysq), x) : 0.0;
                     if (dphi > 0.0) {
                         const double shift = (rr.phioff != 0.0) ? 0.5 : 0.0;
-                        const int64_t l64 = (int64_t)floor((double)nr * kInvTwoPi * (pphi - dphi) - shift) + 1;
-                        const int64_t h64 = (int64_t)floor((double)nr * kInvTwoPi * (pphi + dphi) - shift);
-                        int64_t c = h64 - l64 + 1;
-                        if (c > nr) c = nr;
-                        if (c > 0) { cnt = (int)c; lo = (int)l64; }      // unwrapped: lo in (-nr, 1.5 nr)
+                        // |nr (pphi -+ dphi) / 2 pi| < 2 nr <= 8 nside: 32-bit is enough (the tile variant needs nside <= 2^24)
+                        const double fn = (double)nr * kInvTwoPi;
+                        const int l32 = (int)floor(fn * (pphi - dphi) - shift) + 1;
+                        const int h32 = (int)floor(fn * (pphi + dphi) - shift);
+                        const int c = min(h32 - l32 + 1, nr);
+                        if (c > 0) { cnt = c; lo = l32; }                // unwrapped: lo in (-nr, 1.5 nr)
                     }
                 }
+                if (ring < irmin || ring > irmax) { cnt = nr; lo = 0; }  // ring entirely inside the disc
                 const int wl = pinfo[p].win_lo;
                 sg.wbyte = win_in_lds ? pwin_off + p * (kWinLds * 8) - 8 * wl : p;
                 if constexpr (MODE == MODE_PAINT) sg.pk = wl;
