@@ -347,7 +347,7 @@ constexpr int kSegExtra = 64;        // LDS room for second pieces of ring windo
 template <int MODE> struct TileCfg;
 template <> struct TileCfg<MODE_PAINT> {
     // rings per tile, accumulators per pixel, (pair, ring) slots / pairs per chunk, pixel -> segment table entries per round
-    static constexpr int TR = 64, NACC = 1, SLOTMAX = 512, PAIRMAX = 60, PIXMAX = 4608, QCAP = 192;
+    static constexpr int TR = 64, NACC = 1, SLOTMAX = 512, PAIRMAX = 56, PIXMAX = 6144, QCAP = 64;
     static constexpr int SEGMAX = SLOTMAX + kSegExtra;
     using Pair = PairInfo;
 };
@@ -723,7 +723,6 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
         __syncthreads();
         const int n_take = ctl[0], nslots = ctl[1];
         BFG_TICK(0);
-        BFG_TICK(6);
 
         // ---- stage b: one thread per (pair, ring) slot; row windows -> LDS -----------------------------
         // With full-width windows the copy is an LDS-DMA (global_load_lds_dwordx4: no VGPRs, asynchronous;
@@ -876,7 +875,9 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
         const int nseg = min(nslots + ctl[2], kSegMax);
         const int ptotal = (P.debug & 2) ? 0 : ctl[3];
         my_pixels += (tid == 0) ? (unsigned long long)ctl[3] : 0ull;
+        BFG_TICK(6);
         if (wave == 0) { load_records(); load_list_windows(base + n_take); }   // in flight during the pixel stage
+        BFG_TICK(7);
 
         // ---- stage c: one thread per pixel of the flattened list (rounds of kPixMax pixels; the first round's
         //      pixel -> segment table was filled by stage b) -------------------------------------------------
