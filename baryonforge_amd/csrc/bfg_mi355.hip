@@ -100,6 +100,7 @@ struct bfg_ctx {
     } tiles[2];                     // [MODE_PAINT], [MODE_BARYONIFY]
     int32_t *d_pairs;
     bfg::HaloDisp *d_hd;            // [cap_halo] baryonify tile path
+    int32_t *d_left;                // [cap_halo + 1] tile variant: [0] = count, then the halos left to the scatter kernel
     int64_t pair_cap;
     unsigned long long *d_pair_total;
     double *d_mathtab;              // logtab (256 doubles) | exptab (64 doubles)
@@ -133,6 +134,9 @@ struct ShellParams {
     double *out;             // map [npix] or offsets [npix][3]
     bfg_stats *stats;
     int only_flagged;        // process only halos the tile binning flagged HF_SCATTER
+    const int32_t *left;     // only_flagged: left[0] = count, left[1..] = the flagged halos (else nullptr)
+    const int32_t *pair_total_ptr;   // tile_start[ntiles] and the pair buffer capacity (overflow -> every halo is flagged)
+    long long pair_cap;
 };
 
 // ------------------------------------------------------------------------------------
@@ -159,6 +163,7 @@ struct PrepParams {
     double pixfac_area;
     bfg::BinCtx bin;         // tile variant: count pass of the halo -> tile binning
     bfg::HaloDisp *hd;       // baryonify tile path
+    int32_t *left;           // tile variant: left[0] = count, left[1..] = halos flagged for the scatter kernel
     double eps_model;
     int rdelta;
 };
@@ -300,6 +305,7 @@ __global__ __launch_bounds__(256) void halo_prep_kernel(const PrepParams P)
     irec[I_RFIRST * cap] = rfirst; irec[I_RLAST * cap] = rlast;
     irec[I_IRMIN * cap] = irmin; irec[I_IRMAX * cap] = irmax;
     irec[I_FLAGS * cap] = flags;
+    if (P.left && (flags & HF_SCATTER) && !(flags & HF_SKIP)) P.left[1 + atomicAdd(&P.left[0], 1)] = (int32_t)j;
     if (P.ht) {
         HaloTile h;
         h.st = st; h.ct = z0v; h.pphi = pphi;
@@ -344,17 +350,14 @@ struct RingLds {
 };
 
 template <int G, int MODE>
-__global__ __launch_bounds__(256) void shell_scatter_kernel(const ShellParams P)
+__device__ __forceinline__ void scatter_halo(const ShellParams &P, const int64_t j, unsigned char *smem_raw)
 {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
     constexpr int GPB = 256 / G;
     const int lane = threadIdx.x % G;
     const int grp = threadIdx.x / G;
     RingLds<G> *rl = reinterpret_cast<RingLds<G> *>(smem_raw) + grp;
     double2 *win = reinterpret_cast<double2 *>(smem_raw + sizeof(RingLds<G>) * GPB) + (size_t)grp * P.win_nodes;
 
-    const int64_t j = (int64_t)blockIdx.x * GPB + grp;
-    if (j >= P.n_halo) return;
     const int64_t cap = P.cap;
     const int32_t flags = P.irec[I_FLAGS * cap + j];
     if (flags & HF_SKIP) return;
@@ -560,6 +563,28 @@ __global__ __launch_bounds__(256) void shell_scatter_kernel(const ShellParams P)
     if (n_r_oob) {
         atomicAdd((unsigned long long *)&P.stats->pixels_out_of_table, n_r_oob);
         atomicOr(&P.stats->warn_mask, BFG_WARN_R_RANGE);
+    }
+}
+
+// One G-lane group per halo.  only_flagged (the tile variant's left-overs): a fixed grid strides over the compact
+// list of flagged halos the prep kernel built -- or over every halo if the pair buffer overflowed and the fill kernel
+// flagged them all.
+template <int G, int MODE>
+__global__ __launch_bounds__(256) void shell_scatter_kernel(const ShellParams P)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    constexpr int GPB = 256 / G;
+    const int grp = threadIdx.x / G;
+    const int64_t first = (int64_t)blockIdx.x * GPB + grp, stride = (int64_t)gridDim.x * GPB;
+    if (!P.left) {
+        if (first < P.n_halo) scatter_halo<G, MODE>(P, first, smem_raw);
+        return;
+    }
+    const bool all = (long long)P.pair_total_ptr[0] > P.pair_cap;
+    const int64_t n = all ? P.n_halo : (int64_t)P.left[0];
+    for (int64_t it = first; it < n; it += stride) {
+        scatter_halo<G, MODE>(P, all ? it : (int64_t)P.left[1 + it], smem_raw);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -883,6 +908,7 @@ int bfg_ctx_destroy(bfg_ctx *c)
         if (c->tiles[m].d_tile_start) (void)hipFree(c->tiles[m].d_tile_start);
     }
     if (c->d_hd) (void)hipFree(c->d_hd);
+    if (c->d_left) (void)hipFree(c->d_left);
     if (c->d_pairs) (void)hipFree(c->d_pairs);
     (void)hipFree(c->d_mathtab); (void)hipFree(c->d_pair_total);
     for (int k = 0; k < 5; ++k) {
@@ -1101,8 +1127,8 @@ static int ensure_workspace(bfg_ctx *c, int64_t n)
 {
     if (n <= c->cap_halo) return BFG_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->d_rec) { (void)hipFree(c->d_rec); (void)hipFree(c->d_irec); (void)hipFree(c->d_cidx); (void)hipFree(c->d_cw); (void)hipFree(c->d_ht); (void)hipFree(c->d_hd); }
-    c->d_rec = nullptr; c->d_ht = nullptr; c->d_hd = nullptr; c->cap_halo = 0;
+    if (c->d_rec) { (void)hipFree(c->d_rec); (void)hipFree(c->d_irec); (void)hipFree(c->d_cidx); (void)hipFree(c->d_cw); (void)hipFree(c->d_ht); (void)hipFree(c->d_hd); (void)hipFree(c->d_left); }
+    c->d_rec = nullptr; c->d_ht = nullptr; c->d_hd = nullptr; c->d_left = nullptr; c->cap_halo = 0;
     int64_t cap = (n + 1023) / 1024 * 1024;
     HIP_TRY(hipMalloc((void **)&c->d_rec, (size_t)cap * F_NF * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&c->d_irec, (size_t)cap * I_NI * sizeof(int32_t)));
@@ -1110,6 +1136,7 @@ static int ensure_workspace(bfg_ctx *c, int64_t n)
     HIP_TRY(hipMalloc((void **)&c->d_cw, (size_t)cap * (BFG_MAX_DIM - 1) * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&c->d_ht, (size_t)cap * sizeof(HaloTile)));
     HIP_TRY(hipMalloc((void **)&c->d_hd, (size_t)cap * sizeof(HaloDisp)));
+    HIP_TRY(hipMalloc((void **)&c->d_left, (size_t)(cap + 1) * sizeof(int32_t)));
     c->cap_halo = cap;
     return BFG_OK;
 }
@@ -1276,6 +1303,8 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         pp.hd = (mode == MODE_BARYONIFY) ? c->d_hd : nullptr;
         pp.eps_model = a->model_epsilon_max; pp.rdelta = a->rdelta_sampling;
         HIP_TRY(hipMemsetAsync(c->tiles[mode].d_tile_count, 0, (size_t)c->tiles[mode].geo.ntiles * sizeof(int32_t), c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_left, 0, sizeof(int32_t), c->stream));
+        pp.left = c->d_left;
     }
     timing_begin(c, 0);
     hipLaunchKernelGGL(halo_prep_kernel, dim3((unsigned)((a->n_halo + 255) / 256)), dim3(256), 0, c->stream, pp);
@@ -1305,8 +1334,13 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         std::memset(&rp, 0, sizeof(rp));
         rp.n_halo = a->n_halo; rp.cap = c->cap_halo; rp.ht = c->d_ht; rp.cidx = c->d_cidx; rp.cw = c->d_cw;
         rp.tab = t->dev; rp.win_nodes = win_nodes; rp.hwin = c->d_hwin;
-        const int hpb = 256 / win_nodes;
-        hipLaunchKernelGGL(halo_row_kernel, dim3((unsigned)((a->n_halo + hpb - 1) / hpb)), dim3(256), 0, c->stream, rp);
+        if (win_nodes % 4 == 0 && win_nodes >= 8) {
+            const int hpb = std::min(256 / (win_nodes / 4), 64);
+            hipLaunchKernelGGL(halo_row4_kernel, dim3((unsigned)((a->n_halo + hpb - 1) / hpb)), dim3(256), 0, c->stream, rp);
+        } else {
+            const int hpb = 256 / win_nodes;
+            hipLaunchKernelGGL(halo_row_kernel, dim3((unsigned)((a->n_halo + hpb - 1) / hpb)), dim3(256), 0, c->stream, rp);
+        }
         HIP_TRY(hipGetLastError());
         timing_end(c, 3);
 
@@ -1348,6 +1382,8 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         HIP_TRY(hipGetLastError());
         timing_end(c, 1);
         sp.only_flagged = 1;     // leftovers: halos the binning left to the global-atomic kernel
+        sp.left = c->d_left;
+        sp.pair_total_ptr = ts.d_tile_start + ts.geo.ntiles; sp.pair_cap = c->pair_cap;
     }
     const int G = (variant == BFG_VARIANT_SCATTER_WAVE) ? 64 : 16;
     const int tslot = (variant == BFG_VARIANT_TILE_LDS) ? 4 : 1;
@@ -1359,7 +1395,8 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     if (win < 2) return BFG_ERR_UNSUPPORTED;
     sp.win_nodes = win;
     const size_t lds = ring_bytes + (size_t)win * sizeof(double2) * (size_t)gpb;
-    const unsigned grid = (unsigned)((a->n_halo + gpb - 1) / gpb);
+    unsigned grid = (unsigned)((a->n_halo + gpb - 1) / gpb);
+    if (sp.left) grid = std::min(grid, 4096u);          // fixed grid striding over the left-over list
     timing_begin(c, tslot);
     if (mode == MODE_PAINT) {
         if (G == 64) hipLaunchKernelGGL((shell_scatter_kernel<64, MODE_PAINT>), dim3(grid), dim3(256), lds, c->stream, sp);

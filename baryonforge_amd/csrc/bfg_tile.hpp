@@ -322,6 +322,57 @@ __global__ __launch_bounds__(256) void halo_row_kernel(const RowParams P)
     P.hwin[j * W + e] = b0 + s_add[hl];          // paint: ln(T) + ln(pixarea D^2), see shell_tile_kernel
 }
 
+// Same for windows whose length is a multiple of 4: one thread per (halo, 4 consecutive nodes), i.e. 4 x 2^(ndim-1)
+// independent table loads in flight per thread (the one-node form is latency-bound).
+__global__ __launch_bounds__(256) void halo_row4_kernel(const RowParams P)
+{
+    constexpr int kHpbMax = 64;
+    __shared__ double s_w[kHpbMax][kMaxCorner];
+    __shared__ int64_t s_off[kHpbMax][kMaxCorner];
+    __shared__ int s_winlo[kHpbMax];
+    __shared__ double s_add[kHpbMax];
+    const DevTable &T = P.tab;
+    const int W = P.win_nodes;
+    const int tph = W >> 2;                                     // threads per halo
+    const int hpb = min(256 / tph, kHpbMax);                    // halos per block
+    const int hl = threadIdx.x / tph, e4 = (threadIdx.x - hl * tph) << 2;
+    const int64_t j = (int64_t)blockIdx.x * hpb + hl;
+    const bool live = (hl < hpb) && (j < P.n_halo);
+    const int ncorner = 1 << T.nouter;
+    bool skip = true;
+    if (live) {
+        const int flags = P.ht[j].flags;
+        skip = (flags & (HF_SKIP | HF_OOB)) != 0;
+        const int q = threadIdx.x - hl * tph;
+        if (q == 0) { s_winlo[hl] = P.ht[j].win_lo; s_add[hl] = T.log_values ? P.ht[j].spare[0] : 0.0; }
+        for (int c = q; c < ncorner; c += tph) {
+            double w = 1.0;
+            int64_t off = 0;
+            for (int k = 0; k < T.nouter; ++k) {
+                const int bit = (c >> (T.nouter - 1 - k)) & 1;
+                const double y = P.cw[k * P.cap + j];
+                const int i = P.cidx[k * P.cap + j];
+                w = w * (bit ? y : 1.0 - y);
+                off += (int64_t)(i + bit) * T.ostride[k];
+            }
+            s_w[hl][c] = w; s_off[hl][c] = off;
+        }
+    }
+    __syncthreads();
+    if (!live || skip) return;
+    const int ir = s_winlo[hl] + e4;
+    double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+    for (int c = 0; c < ncorner; ++c) {
+        const double *row = T.values + s_off[hl][c] + ir;
+        const double w = s_w[hl][c];
+        b0 = fma(row[0], w, b0); b1 = fma(row[1], w, b1); b2 = fma(row[2], w, b2); b3 = fma(row[3], w, b3);
+    }
+    const double add = s_add[hl];
+    double4 out;
+    out.x = b0 + add; out.y = b1 + add; out.z = b2 + add; out.w = b3 + add;
+    *reinterpret_cast<double4 *>(P.hwin + j * W + e4) = out;   // 32-byte aligned: W and e4 are multiples of 4
+}
+
 #ifndef BFG_TILE_THREADS
 #define BFG_TILE_THREADS 512
 #endif
