@@ -48,11 +48,29 @@ __device__ inline double fast_log(double x, const double2 *__restrict__ tab)
     return fma((double)e, 0.693147180559945309417232, fma(r, p, t.y));
 }
 
+// ln(x) + 1023 ln 2 (the exponent bias is left in; callers fold it into their additive constant)
+constexpr double kLogBias = 1023.0 * 0.693147180559945309417232;
+__device__ inline double fast_log_biased(double x, const double2 *__restrict__ tab)
+{
+    const int hi = __double2hiint(x);
+    const int lo = __double2loint(x);
+    const int eb = hi >> 20;                         // biased exponent of a positive finite normal x
+    const int idx = (hi >> 13) & (kLogTab - 1);
+    const double m = __hiloint2double((hi & 0x000FFFFF) | (0x3FF00000 & ~0x000FFFFF), lo);
+    const double2 t = tab[idx];                      // {1/c, ln c}
+    const double r = fma(m, t.x, -1.0);
+    double p = fma(r, 1.0 / 3.0, -0.5);
+    p = fma(r, p, 1.0);
+    return fma((double)eb, 0.693147180559945309417232, fma(r, p, t.y));
+}
+
 __device__ inline double fast_exp(double L, const double *__restrict__ tab)
 {
-    const double kf = rint(L * 92.332482616893656877476);          // 64 / ln 2
+    // round L * 64 / ln 2 to an integer with the 1.5 * 2^52 trick: the integer sits in the low word (|L| < 709 here)
+    const double km = fma(L, 92.332482616893656877476, 6755399441055744.0);
+    const int k = __double2loint(km);
+    const double kf = km - 6755399441055744.0;
     const double r = fma(kf, -0.010830424696249145459412, L);      // ln2 / 64
-    const int k = (int)kf;
     double p = fma(r, 1.0 / 6.0, 0.5);
     p = fma(r, p, 1.0);
     p = fma(r, p, 1.0);
@@ -98,9 +116,9 @@ static_assert(sizeof(HaloTile) == 128, "HaloTile must be one 128-byte line");
 struct __align__(16) Seg {           // one ring segment of one halo inside one tile (48 bytes)
     int32_t excl;                    // offset of the segment's first pixel in the chunk's flattened pixel list
     int32_t abyte;                   // LDS byte offset of the accumulator of the segment's first pixel
-    int32_t wbyte;                   // LDS byte offset of B_0 of the pair's row window (node i at wbyte + 8 i);
+    int32_t wbyte;                   // LDS byte offset of node -1 of the pair's row window (node i at wbyte + 8 (i + 1));
                                      // pair slot when the windows are not staged in LDS
-    int32_t pk;                      // paint: win_lo ; baryonify: pair slot | ring row << 6 | win_lo << 12
+    int32_t pk;                      // paint: win_lo + 1 ; baryonify: pair slot | ring row << 6 | (win_lo + 1) << 12
     double hstep, c0, Aq, Bq;        // k-th pixel: h = k hstep + c0 ;  r_com^2 = Aq + Bq sin^2(h)
 };
 static_assert(sizeof(Seg) == 48, "Seg must be 48 bytes");
@@ -482,6 +500,20 @@ __device__ inline double atan2_upper(double y, double x)
     return (x < 0.0) ? 3.14159265358979323846 - a : a;
 }
 
+__device__ inline int med3_i32(int x, int lo, int hi)      // clamp(x, lo, hi) in one instruction (lo <= hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
+    return r;
+}
+
+using lds_double = __attribute__((address_space(3))) double;
+template <typename T>
+__device__ inline __attribute__((address_space(3))) T *lds_ptr(unsigned byte_address)
+{
+    return (__attribute__((address_space(3))) T *)(uintptr_t)byte_address;
+}
+
 // inclusive prefix sum over the 64 lanes of a wavefront with DPP row shifts / row broadcasts (no LDS round trips;
 // __shfl_up compiles to ds_bpermute, ~100 cycles per step)
 __device__ inline int wave_scan_incl(int v)
@@ -567,6 +599,15 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
 
     const double inv_dr = T.inv_dr;
     const double t_c = (-T.r0) * inv_dr, t_m = 0.5 * inv_dr;     // cell coordinate t = ln(x) * t_m + t_c
+    // the pixel loop works with t1 = t + 1 from the exponent-biased logarithm: t1 = fast_log_biased(x) * t_m + t_c1
+    const double t_c1 = t_c + 1.0 - kLogBias * t_m;
+    // segment records carry absolute LDS byte addresses: the dynamic LDS block of this kernel (it has no static
+    // __shared__) starts at address 0; refuse to run otherwise
+    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_raw != 0u) {
+        if (threadIdx.x == 0) atomicOr(&P.stats->warn_mask, 0x80000000u);
+        return;
+    }
+    constexpr unsigned lds_base = 0u;
     const int NRm1 = T.nr - 1;
     const int W = P.win_nodes;
     constexpr bool win_in_lds = WIN_LDS;     // row windows of <= kWinLds nodes live in LDS, longer ones stay in HBM/L2
@@ -636,7 +677,9 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
             for (int i = tid; i < n; i += NT) {
                 const DeferredPixel e = rq[i];
                 const double L = direct_row_halo(e.halo, e.t) + P.ht[e.halo].spare[0];
-                if (fabs(L) < 709.0) unsafeAtomicAdd(reinterpret_cast<double *>(smem_raw + e.abyte), fast_exp(L, exptab));
+                if (fabs(L) < 709.0)
+                    __hip_atomic_fetch_add(lds_ptr<double>(lds_base + e.abyte), fast_exp(L, exptab), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             __syncthreads();
             if (tid == 0) ctl[5] = 0;
@@ -644,19 +687,20 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
         }
     };
 
-    // interpolant of the pair's blended row at cell coordinate t (cell = trunc(t), clamped into the staged window
-    // [wl, wl + W - 2]); `in` = the cell really lies in the window (and t >= 0), otherwise the value is unusable
-    auto window_row = [&](const Seg &sg, int wl, int pidx, double t, bool &in) -> double {
-        const int i0 = (int)t;                                            // saturating conversion
-        const int ic = min(max(i0, wl), wl + W - 2);
-        in = (ic == i0) && (t >= 0.0);
-        const double f = t - (double)ic;
+    // interpolant of the pair's blended row.  t1 = cell coordinate + 1 (so that truncation is a floor for everything
+    // that can be in range: t1 in (0, 1) -- below the table -- truncates to 0, never a window cell); wl1 = first cell
+    // of the staged window + 1; the segment's wbyte is biased by -8 to match.  `in` = the cell lies in the window.
+    auto window_row = [&](const Seg &sg, int wl1, int pidx, double t1, bool &in) -> double {
+        const int i1 = (int)t1;                                           // saturating conversion
+        const int ic = med3_i32(i1, wl1, wl1 + W - 2);
+        in = (ic == i1);
+        const double f = t1 - (double)ic;
         double B0, B1;
         if constexpr (win_in_lds) {
-            const double *wp = reinterpret_cast<const double *>(smem_raw + sg.wbyte + 8 * ic);
+            const lds_double *wp = lds_ptr<double>(lds_base + sg.wbyte + 8 * ic);
             B0 = wp[0]; B1 = wp[1];
         } else {
-            const double *wp = P.hwin + pinfo[pidx].hoff + (ic - wl);
+            const double *wp = P.hwin + pinfo[pidx].hoff + (ic - wl1);
             B0 = wp[0]; B1 = wp[1];
         }
         return fma(f, B1 - B0, B0);
@@ -667,6 +711,7 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
         int q = q0;
         if ((q & 1) && q < q1) { ptab[q] = (uint16_t)off; ++q; }
         const uint32_t two = off | (off << 16);
+#pragma unroll 1
         for (; q + 1 < q1; q += 2) *reinterpret_cast<uint32_t *>(ptab + q) = two;
         if (q < q1) ptab[q] = (uint16_t)off;
     };
@@ -683,13 +728,14 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
             }
             const double x = fma(sg.Bq, s2, sg.Aq);                        // r_com^2
             // x = 0 or NaN never lands in the window (ln of the bit pattern is hugely negative / NaN)
-            const double t = fma(fast_log(x, logtab), t_m, t_c);
-            const int wl = sg.pk;
+            const double t1 = fma(fast_log_biased(x, logtab), t_m, t_c1);
+            const int wl1 = sg.pk;
             bool in;
-            double L = window_row(sg, wl, win_in_lds ? 0 : sg.wbyte, t, in);
+            double L = window_row(sg, wl1, win_in_lds ? 0 : sg.wbyte, t1, in);
             if (!in) {                                                     // divergent and rare
+                const double t = t1 - 1.0;
                 if ((t >= 0.0) && (t <= (double)NRm1)) {
-                    const int pidx = win_in_lds ? (sg.wbyte + 8 * wl - pwin_off) / (8 * kWinLds) : sg.wbyte;
+                    const int pidx = win_in_lds ? (sg.wbyte + 8 * wl1 - pwin_off) / (8 * kWinLds) : sg.wbyte;
                     const int qi = (kQCap > 0) ? atomicAdd(&ctl[5], 1) : kQCap;
                     if (qi < qcap) {
                         DeferredPixel e;
@@ -703,10 +749,11 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
             // finite L is always inside exp's range
             const bool go = in && (fabs(L) < 709.0);                       // false for NaN too
             const double v = fast_exp(L, exptab);                          // garbage when !go, never added
-            if (go) unsafeAtomicAdd(reinterpret_cast<double *>(smem_raw + sg.abyte + 8 * k), v);
+            if (go) __hip_atomic_fetch_add(lds_ptr<double>(lds_base + sg.abyte + 8 * k), v, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
             // HealpixRunner.py:336-355 for one pixel
-            const int pidx = sg.pk & 63, wl = sg.pk >> 12;
+            const int pidx = sg.pk & 63, wl1 = sg.pk >> 12;
             const Pair &pi = pinfo[pidx];
             const RingRow &rr = rows[(sg.pk >> 6) & 63];
             double sh = sin_small(h, h2), ch = sqrt(1.0 - sh * sh);        // sin, cos of dphi/2 (cos >= 0)
@@ -717,10 +764,11 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
             const double cphi = pi.cp0 * cd - pi.sp0 * sd, sphi = pi.sp0 * cd + pi.cp0 * sd;
             const double vx = rr.sth * cphi, vy = rr.sth * sphi, vz = rr.z;                 // pixel unit vector
             const double dx = vx - pi.st * pi.cp0, dy = vy - pi.st * pi.sp0, dz = vz - pi.ct;   // vec - vec_j
-            const double t = fma(fast_log(x, logtab), t_m, t_c + pi.tshift);
+            const double t1 = fma(fast_log_biased(x, logtab), t_m, t_c1 + pi.tshift);
             bool in;
-            double d = window_row(sg, wl, pidx, t, in);                    // comoving displacement; table holds d
+            double d = window_row(sg, wl1, pidx, t1, in);                  // comoving displacement; table holds d
             if (!in) {
+                const double t = t1 - 1.0;
                 if ((t >= 0.0) && (t <= (double)NRm1)) { d = direct_row(pidx, t); in = true; }
                 else n_oob32 += 1;
             }
@@ -735,10 +783,10 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
                 const double nwn = sqrt(fma(pi.D, pi.D, qq));
                 const double g = -qq / (nwn * (nwn + pi.D));               // D / |nw| - 1 without cancellation
                 const double kk = d / (chord * nwn);                       // offset along (vec - vec_j) / chord, / |nw|
-                double *ap = reinterpret_cast<double *>(smem_raw + sg.abyte + 24 * k);
-                unsafeAtomicAdd(ap + 0, fma(vx, g, dx * kk));
-                unsafeAtomicAdd(ap + 1, fma(vy, g, dy * kk));
-                unsafeAtomicAdd(ap + 2, fma(vz, g, dz * kk));
+                lds_double *ap = lds_ptr<double>(lds_base + sg.abyte + 24 * k);
+                __hip_atomic_fetch_add(ap + 0, fma(vx, g, dx * kk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(ap + 1, fma(vy, g, dy * kk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(ap + 2, fma(vz, g, dz * kk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
     };
@@ -857,9 +905,10 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
                 }
                 if (ring < irmin || ring > irmax) { cnt = nr; lo = 0; }  // ring entirely inside the disc
                 const int wl = pinfo[p].win_lo;
-                sg.wbyte = win_in_lds ? pwin_off + p * (kWinLds * 8) - 8 * wl : p;
-                if constexpr (MODE == MODE_PAINT) sg.pk = wl;
-                else sg.pk = p | (row << 6) | (wl << 12);
+                // window start + 1 and the LDS address of node (cell - 1): see window_row
+                sg.wbyte = win_in_lds ? pwin_off + p * (kWinLds * 8) - 8 * (wl + 1) : p;
+                if constexpr (MODE == MODE_PAINT) sg.pk = wl + 1;
+                else sg.pk = p | (row << 6) | ((wl + 1) << 12);
                 sg.hstep = 0.5 * rr.phistep;
                 sg.c0 = 0.5 * (rr.phioff * rr.phistep - pphi);          // + first pixel * hstep, below
                 const double ds = rr.sth - st, dz = rr.z - ct;
@@ -867,14 +916,20 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
                 sg.Bq = 4.0 * rr.sth * st * S;
                 // clip to the sector; a window that wraps around the ring can meet it twice
                 if (cnt > 0) {
+                    const bool wraps = (lo < 0) || (lo + cnt > nr);
+                    if (!__any(wraps)) {                                // the usual case for a whole wavefront
+                        const int aa = max(lo, rr.k0), bb = min(lo + cnt, rr.k1);
+                        if (bb > aa) { cnt1 = bb - aa; aa1 = aa; ab1 = acc_off + 8 * NACC * (rr.rowoff + aa); }
+                    } else {
 #pragma unroll
-                    for (int mi = 0; mi < 3; ++mi) {
-                        const int m = (mi == 0) ? 0 : (mi == 1 ? -1 : 1);
-                        const int aa = max(lo, rr.k0 + m * nr), bb = min(lo + cnt, rr.k1 + m * nr);
-                        if (bb > aa) {
-                            const int ab = acc_off + 8 * NACC * (rr.rowoff - m * nr + aa);
-                            if (cnt1 == 0) { cnt1 = bb - aa; aa1 = aa; ab1 = ab; }
-                            else if (cnt2 == 0) { cnt2 = bb - aa; aa2 = aa; ab2 = ab; }
+                        for (int mi = 0; mi < 3; ++mi) {
+                            const int m = (mi == 0) ? 0 : (mi == 1 ? -1 : 1);
+                            const int aa = max(lo, rr.k0 + m * nr), bb = min(lo + cnt, rr.k1 + m * nr);
+                            if (bb > aa) {
+                                const int ab = acc_off + 8 * NACC * (rr.rowoff - m * nr + aa);
+                                if (cnt1 == 0) { cnt1 = bb - aa; aa1 = aa; ab1 = ab; }
+                                else if (cnt2 == 0) { cnt2 = bb - aa; aa2 = aa; ab2 = ab; }
+                            }
                         }
                     }
                 }
