@@ -149,14 +149,31 @@ def main():
         zax, Max, rax, T = syn.pressure_table(*shape)
         with np.errstate(all="ignore"):
             table = ctx.table([zax, Max, rax], np.log(T), log_values=True)
-        d_map = ctx.zeros(npix)
         sargs = ctx.shell_args(nside, d_cat, idx.size, 4, 0, args.eps, md, variant=args.variant)
+        # N > 1: consecutive shells go to alternating map buffers, so the all-reduce of shell k (async, on RCCL's own
+        # stream) overlaps the painting of shell k+1; every collective is waited for before its buffer is reused and
+        # before the timed region ends (finish()).
+        nbuf = 2 if dist is not None else 1
+        d_maps = [ctx.zeros(npix) for _ in range(nbuf)]
+        pending = [None] * nbuf
+        counter = [0]
 
         def step():
-            d_map.zero_()
-            ctx.paint_shell(sargs, table, spline, d_map)
+            b = counter[0] % nbuf
+            counter[0] += 1
+            if pending[b] is not None:
+                pending[b].wait()            # the current stream waits for that buffer's all-reduce
+                pending[b] = None
+            d_maps[b].zero_()
+            ctx.paint_shell(sargs, table, spline, d_maps[b])
             if dist is not None:
-                dist.all_reduce(d_map, op=dist.ReduceOp.SUM)
+                pending[b] = dist.all_reduce(d_maps[b], op=dist.ReduceOp.SUM, async_op=True)
+
+        def finish():
+            for b in range(nbuf):
+                if pending[b] is not None:
+                    pending[b].wait()
+                    pending[b] = None
     else:
         zax, Max, rax, T = syn.displacement_table(*shape)
         table = ctx.table([zax, Max, rax], T, log_values=False)
@@ -174,6 +191,9 @@ def main():
                 dist.all_reduce(d_off, op=dist.ReduceOp.SUM)
             ctx.regrid_shell(nside, d_off, d_in, d_map, None)
 
+        def finish():
+            pass
+
     def barrier():
         if dist is not None:
             dist.barrier()
@@ -182,6 +202,7 @@ def main():
     _mark("inputs resident")
     for _ in range(args.warmup):
         step()
+    finish()
     _mark("warmup issued")
     barrier()
     _mark("warmup done")
@@ -191,6 +212,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    finish()                         # every outstanding collective has completed inside the timed region
     barrier()
     dt = time.perf_counter() - t0
     _mark("timed region done")
@@ -260,7 +282,7 @@ def main():
                                f"table {shape[0]}x{shape[1]}x{shape[2]}, catalog "
                                f"{'dn/dlnM~M^-0.9' if args.steep else 'log10M~U(12,15.5)'}, z~U(0.4,0.5), seed 42",
                    "variant": args.variant, "halos_per_gpu": args.halos, "nside": nside,
-                   "sharding": "sky patch (NEST nside 8) + RCCL all-reduce of the map" if world > 1 else "none",
+                   "sharding": "sky patch (NEST nside 8) + RCCL all-reduce of the map, overlapped with the next shell (two map buffers)" if world > 1 else "none",
                    "pixel_updates_total_per_step": ptot_all},
         "roofline": roofline,
     }
