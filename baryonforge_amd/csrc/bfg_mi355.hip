@@ -640,7 +640,38 @@ __global__ __launch_bounds__(256) void regrid_kernel(Hpx hp, const double *__res
 constexpr int kRgHalo = 4;
 constexpr int kRgRows = 64 + 2 * kRgHalo;
 constexpr int kRgWidth = kTileWidth + 2 * kRgHalo;
-struct RgRow { int64_t start; int32_t nr, istart, w, pad; };
+struct __align__(16) RgRow {
+    int64_t start;                   // first pixel of the ring
+    int32_t nr, istart, w, shifted;  // ring length; first ring index of the LDS row (may be < 0: modulo nr); row width
+    double theta;                    // ring colatitude as get_ring_info2 gives it (get_interpol's theta1 / theta2)
+    double z, sth, phistep, phioff;  // pixel-centre geometry of the ring (ring_geom)
+};
+
+// (sin, cos) of an angle in [0, 2 pi] without libm: Cody-Waite reduction by pi/2, degree-13 / -14 series on
+// [-pi/4, pi/4] (<= 2 ulp); libm's version carries a large-argument path that is never needed here
+__device__ inline void sincos_2pi(double a, double &s, double &c)
+{
+    const double qf = rint(a * 0.63661977236758134308);                       // 2 / pi
+    const int q = (int)qf;
+    double r = fma(qf, -1.57079632679489655800e+00, a);                       // pi/2 hi
+    r = fma(qf, -6.12323399573676603587e-17, r);                              // pi/2 lo
+    const double r2 = r * r;
+    double ps = fma(r2, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(r2, ps, 2.75573137070700676789e-06);
+    ps = fma(r2, ps, -1.98412698298579493134e-04);
+    ps = fma(r2, ps, 8.33333333332248946124e-03);
+    ps = fma(r2, ps, -1.66666666666666324348e-01);
+    const double sn = fma(r * r2, ps, r);
+    double pc = fma(r2, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(r2, pc, -2.75573143513906633035e-07);
+    pc = fma(r2, pc, 2.48015872894767294178e-05);
+    pc = fma(r2, pc, -1.38888888888741095749e-03);
+    pc = fma(r2, pc, 4.16666666666666019037e-02);
+    const double cs = fma(r2 * r2, pc, fma(r2, -0.5, 1.0));
+    const double s0 = (q & 1) ? cs : sn, c0 = (q & 1) ? sn : cs;
+    s = (q & 2) ? -s0 : s0;
+    c = ((q + 1) & 2) ? -c0 : c0;
+}
 
 __global__ __launch_bounds__(256) void regrid_tile_kernel(Hpx hp, TileGeom geo, const double *__restrict__ off,
                                                           const double *__restrict__ in_map,
@@ -653,26 +684,60 @@ __global__ __launch_bounds__(256) void regrid_tile_kernel(Hpx hp, TileGeom geo, 
     const int band = geo.tile_band[tile];
     const int sector = tile - geo.band_tile0[band];
     const int NS = geo.band_ns[band];
+    const int nl4 = (int)(4 * hp.nside);
     const int ring_lo = 1 + band * geo.tr;
-    const int ring_hi = min((int)(4 * hp.nside - 1), ring_lo + geo.tr - 1);
+    const int ring_hi = min(nl4 - 1, ring_lo + geo.tr - 1);
     const int row_ring0 = ring_lo - kRgHalo;                       // ring of LDS row 0 (may be < 1)
     const int tid = threadIdx.x;
     for (int i = tid; i < kRgRows * kRgWidth; i += 256) acc[i] = 0.0;
     if (tid < kRgRows) {
         const int ring = row_ring0 + tid;
-        RgRow r; r.start = 0; r.nr = 0; r.istart = 0; r.w = 0; r.pad = 0;
-        if (ring >= 1 && ring <= 4 * hp.nside - 1 && ring <= ring_hi + kRgHalo) {
-            int64_t sp, nr; bool sh;
-            ring_info_small(hp, ring, sp, nr, sh);
+        RgRow r;
+        r.start = 0; r.nr = 0; r.istart = 0; r.w = 0; r.shifted = 0; r.theta = 0; r.z = 0; r.sth = 0; r.phistep = 0; r.phioff = 0;
+        if (ring >= 1 && ring <= nl4 - 1 && ring <= ring_hi + kRgHalo) {
+            int64_t sp, nr; bool sh; double th;
+            ring_info2(hp, ring, sp, nr, th, sh);
             const int k0 = (int)(((int64_t)sector * nr) / NS), k1 = (int)(((int64_t)(sector + 1) * nr) / NS);
-            r.start = sp; r.nr = (int)nr;
+            r.start = sp; r.nr = (int)nr; r.shifted = sh ? 1 : 0; r.theta = th;
             r.w = min(k1 - k0 + 2 * kRgHalo, (int)nr);
             r.w = min(r.w, kRgWidth);
             r.istart = k0 - kRgHalo;                                // may be negative: taken modulo nr
+            const RingGeom g = ring_geom(hp, ring);
+            r.z = g.z; r.sth = g.sth; r.phistep = g.phistep; r.phioff = g.phioff;
         }
         rows[tid] = r;
     }
     __syncthreads();
+
+    // one bilinear neighbour ring of get_interpol: (start, nr, theta, shift) from the LDS table when the ring is one
+    // of the tile's rows (almost always), else recomputed
+    auto ring_of = [&](int ir, int64_t &sp, int &nr, double &th, bool &sh, int &lr) {
+        lr = ir - row_ring0;
+        if (lr >= 0 && lr < kRgRows && rows[lr].nr > 0) {
+            const RgRow &t = rows[lr];
+            sp = t.start; nr = t.nr; th = t.theta; sh = t.shifted != 0;
+        } else {
+            int64_t n64;
+            ring_info2(hp, ir, sp, n64, th, sh);
+            nr = (int)n64; lr = -1;
+        }
+    };
+    // deposit d on ring index i of ring row lr (lr < 0: not an LDS row) / pixel sp + i
+    auto deposit = [&](int lr, int64_t sp, int i, double d) {
+        if (d == 0.0) return;
+        bool local = lr >= 0;
+        int rel = 0;
+        if (local) {
+            const RgRow &t = rows[lr];
+            rel = i - t.istart;
+            if (rel >= t.nr) rel -= t.nr;
+            if (rel < 0) rel += t.nr;
+            local = (rel >= 0) && (rel < t.w);
+        }
+        if (local) unsafeAtomicAdd(&acc[lr * kRgWidth + rel], d);
+        else unsafeAtomicAdd(out_map + sp + i, d);
+    };
+
     double v_in = 0.0, v_dep = 0.0;
     for (int e = tid; e < geo.tr * kTileWidth; e += 256) {
         const int row = e / kTileWidth, col = e % kTileWidth;
@@ -687,37 +752,74 @@ __global__ __launch_bounds__(256) void regrid_tile_kernel(Hpx hp, TileGeom geo, 
         const double val = in_map[p];
         v_in += val;
         if (val == 0.0) continue;                                      // :359
-        const RingGeom g = ring_geom(hp, ring);
         double sphi, cphi;
-        sincos(((double)ip + g.phioff) * g.phistep, &sphi, &cphi);
-        const double vx = g.sth * cphi + off[3 * p + 0];               // :357
-        const double vy = g.sth * sphi + off[3 * p + 1];
-        const double vz = g.z + off[3 * p + 2];
+        sincos_2pi(((double)ip + sr.phioff) * sr.phistep, sphi, cphi);
+        const double vx = sr.sth * cphi + off[3 * p + 0];              // :357
+        const double vy = sr.sth * sphi + off[3 * p + 1];
+        const double vz = sr.z + off[3 * p + 2];
         const double dnorm = sqrt(vx * vx + vy * vy + vz * vz);        // hp.vec2ang :358
-        const double theta = acos(vz / dnorm);
-        double phi = atan2(vy, vx);
-        if (phi < 0) phi += kTwoPi;
-        int64_t cp[4]; double cw[4];
-        get_interpol(hp, theta, phi, cp, cw);                          // :361
-        for (int k = 0; k < 4; ++k) {
-            const double d = cw[k] * val;                              // :64-68
-            v_dep += d;
-            if (d == 0.0) continue;
-            int64_t tr_, ti_;
-            pix2ring(hp, cp[k], tr_, ti_);
-            const int lr = (int)tr_ - row_ring0;
-            bool local = (lr >= 0) && (lr < kRgRows);
-            int rel = 0;
-            if (local) {
-                const RgRow &t = rows[lr];
-                rel = (int)ti_ - t.istart;
-                if (rel >= t.nr) rel -= t.nr;
-                if (rel < 0) rel += t.nr;
-                local = (t.nr > 0) && (rel >= 0) && (rel < t.w);
-            }
-            if (local) unsafeAtomicAdd(&acc[lr * kRgWidth + rel], d);
-            else unsafeAtomicAdd(out_map + cp[k], d);
+        const double z = vz / dnorm;                                   // = cos(theta) to rounding
+        const double theta = atan2_upper(sqrt((1.0 - z) * (1.0 + z)), z);     // acos(z)
+        const double aphi = (vx == 0.0 && vy == 0.0) ? 0.0 : atan2_upper(fabs(vy), vx);
+        const double phi = (vy < 0.0) ? kTwoPi - aphi : aphi;          // atan2(vy, vx) brought to [0, 2 pi)
+        // healpix_cxx get_interpol (:361), ring by ring, with (ring, index) kept instead of pixel numbers
+        const int ir1 = (int)ring_above(hp, z), ir2 = ir1 + 1;
+        double theta1 = 0.0, theta2 = 0.0;
+        int64_t sp1 = 0, sp2 = 0;
+        int i1a = 0, i1b = 0, i2a = 0, i2b = 0, lr1 = -1, lr2 = -1, nr1 = 0, nr2 = 0;
+        double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
+        if (ir1 > 0) {
+            bool sh;
+            ring_of(ir1, sp1, nr1, theta1, sh, lr1);
+            const double dphi = kTwoPi / (double)nr1;
+            const double hs = sh ? 0.5 : 0.0;
+            const double tmp = phi / dphi - hs;
+            int ia = (tmp < 0) ? (int)tmp - 1 : (int)tmp;
+            const double ww = (phi - ((double)ia + hs) * dphi) / dphi;
+            int ib = ia + 1;
+            if (ia < 0) ia += nr1;
+            if (ib >= nr1) ib -= nr1;
+            i1a = ia; i1b = ib; w0 = 1 - ww; w1 = ww;
         }
+        if (ir2 < nl4) {
+            bool sh;
+            ring_of(ir2, sp2, nr2, theta2, sh, lr2);
+            const double dphi = kTwoPi / (double)nr2;
+            const double hs = sh ? 0.5 : 0.0;
+            const double tmp = phi / dphi - hs;
+            int ia = (tmp < 0) ? (int)tmp - 1 : (int)tmp;
+            const double ww = (phi - ((double)ia + hs) * dphi) / dphi;
+            int ib = ia + 1;
+            if (ia < 0) ia += nr2;
+            if (ib >= nr2) ib -= nr2;
+            i2a = ia; i2b = ib; w2 = 1 - ww; w3 = ww;
+        }
+        if (ir1 == 0) {                                                // above the first ring: its 4 pixels share the rest
+            const double wtheta = theta / theta2;
+            w2 *= wtheta; w3 *= wtheta;
+            const double fac = (1 - wtheta) * 0.25;
+            w0 = fac; w1 = fac; w2 += fac; w3 += fac;
+            sp1 = 0; lr1 = (1 - row_ring0 < kRgRows && 1 - row_ring0 >= 0 && rows[1 - row_ring0].nr > 0) ? 1 - row_ring0 : -1;
+            i1a = (i2a + 2) & 3; i1b = (i2b + 2) & 3;                  // ring 1 starts at pixel 0
+        } else if (ir2 == nl4) {                                       // below the last ring
+            const double wtheta = (theta - theta1) / (kPi - theta1);
+            w0 *= 1 - wtheta; w1 *= 1 - wtheta;
+            const double fac = wtheta * 0.25;
+            w0 += fac; w1 += fac; w2 = fac; w3 = fac;
+            const int lrl = (nl4 - 1) - row_ring0;
+            sp2 = hp.npix - 4; lr2 = (lrl >= 0 && lrl < kRgRows && rows[lrl].nr > 0) ? lrl : -1;
+            i2a = (i1a + 2) & 3; i2b = (i1b + 2) & 3;                  // the last ring holds pixels npix-4 .. npix-1
+        } else {
+            const double wtheta = (theta - theta1) / (theta2 - theta1);
+            w0 *= 1 - wtheta; w1 *= 1 - wtheta;
+            w2 *= wtheta; w3 *= wtheta;
+        }
+        const double d0 = w0 * val, d1 = w1 * val, d2 = w2 * val, d3 = w3 * val;   // :64-68
+        v_dep += d0; v_dep += d1; v_dep += d2; v_dep += d3;
+        deposit(lr1, sp1, i1a, d0);
+        deposit(lr1, sp1, i1b, d1);
+        deposit(lr2, sp2, i2a, d2);
+        deposit(lr2, sp2, i2b, d3);
     }
     __syncthreads();
     for (int i = tid; i < kRgRows * kRgWidth; i += 256) {
