@@ -1583,6 +1583,10 @@ int bfg_stats_read(bfg_ctx *c, bfg_stats *out)
     if (!out) return BFG_ERR_INVALID;
     HIP_TRY(hipMemcpyAsync(out, c->d_stats, sizeof(bfg_stats), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (out->warn_mask & 0x80000000u) {       // a tile kernel refused to run (its LDS layout assumption was violated)
+        g_last_error = "shell_tile_kernel: dynamic LDS does not start at address 0; results of the tile variant are invalid";
+        return BFG_ERR_UNSUPPORTED;
+    }
     return BFG_OK;
 }
 
