@@ -416,7 +416,7 @@ constexpr int kSegExtra = 64;        // LDS room for second pieces of ring windo
 template <int MODE> struct TileCfg;
 template <> struct TileCfg<MODE_PAINT> {
     // rings per tile, accumulators per pixel, (pair, ring) slots / pairs per chunk, pixel -> segment table entries per round
-    static constexpr int TR = 64, NACC = 1, SLOTMAX = 512, PAIRMAX = 56, PIXMAX = 6144, QCAP = 64;
+    static constexpr int TR = 64, NACC = 1, SLOTMAX = 512, PAIRMAX = 56, PIXMAX = 6144, QCAP = 120;
     static constexpr int SEGMAX = SLOTMAX + kSegExtra;
     using Pair = PairInfo;
 };
