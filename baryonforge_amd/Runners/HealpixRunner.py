@@ -20,10 +20,10 @@ import numpy as np
 
 from ..background import Background, MassDef
 from ..engine import emit_range_warnings, get_context
-from ..utils.Tabulate import ParamTabulatedProfile
+from ..utils.Tabulate import ParamTabulatedProfile, _get_parameter
 from ..Profiles.BaryonCorrection import BaryonificationClass
 
-__all__ = ["DefaultRunner", "BaryonifyShell", "PaintProfilesShell", "regrid_pixels_hpix"]
+__all__ = ["DefaultRunner", "BaryonifyShell", "PaintProfilesShell", "PaintProfilesAnisShell", "regrid_pixels_hpix"]
 
 
 def regrid_pixels_hpix(hmap, parent_pix_vals, child_pix, child_weights):
@@ -149,6 +149,104 @@ class PaintProfilesShell(DefaultRunner):
         """returns new_map : float64[Npix] (RING), the sum over halos of the painted profiles"""
         new_map = self.process_device().cpu().numpy()
         return new_map.reshape(np.shape(self.LightconeShell.map))
+
+
+class _ProductTable(object):
+    """ln-space product of two tabulated profiles on one grid: exp(L1) * exp(L2) = exp(L1 + L2), and a multilinear
+    read-out is linear in the node values, so the table of ln T1 + ln T2 reads out the product exactly."""
+
+    def __init__(self, a, b, keys):
+        for k in ["raw_input_z_range", "raw_input_M_range", "raw_input_r_range"] + ["raw_input_%s_range" % q for q in keys]:
+            if not np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))):
+                raise ValueError(f"PaintProfilesAnisShell: model and Tracer_model must be tabulated on the same grid ({k} differs)")
+            setattr(self, k, np.asarray(getattr(a, k), dtype=np.float64))
+        with np.errstate(all="ignore"):
+            self.ln_product = np.log(np.asarray(a.raw_input_2D, dtype=np.float64)) + \
+                np.log(np.asarray(b.raw_input_2D, dtype=np.float64))
+
+
+class PaintProfilesAnisShell(DefaultRunner):
+    """
+    Tracer-weighted painting (HealpixRunner.py:486-640): every halo paints `model` x `Tracer_model`, weighted per
+    pixel by the input map over the total-mass map painted from `Mtot_model` (plus a uniform background):
+
+        new[p] = orig[p] / Mtot[p] * sum_j Paint_j(r) Tracer_j(r) [pixarea D_j^2]
+                 + background_val * global_tracer_fraction * (dV drho_m / Mtot[p]) * orig[p]
+
+    The per-pixel weights factor out of the halo sum, so the job is two launches of the paint kernel (Mtot_model with
+    include_pixel_size, and the ln-space product table of model and Tracer_model) and element-wise work on the GPU.
+    """
+
+    def __init__(self, HaloLightConeCatalog, LightConeShell, epsilon_max, model, Tracer_model, Mtot_model,
+                 background_val, global_tracer_fraction, mass_def=None, include_pixel_size=False,
+                 use_ellipticity=False, verbose=True, variant="auto"):
+        self.Tracer_model = Tracer_model
+        self.Mtot_model = Mtot_model
+        self.background_val = background_val
+        self.global_tracer_fraction = global_tracer_fraction
+        super().__init__(HaloLightConeCatalog, LightConeShell, epsilon_max, model, use_ellipticity, mass_def,
+                         include_pixel_size, verbose, variant)
+
+    def process(self):
+        import warnings
+        from scipy import interpolate
+        assert self.model is not None, "You must provide a model"
+        keys = self._keys_checked()
+        for m in (self.model, self.Tracer_model, self.Mtot_model):
+            if not _is_paint_table(m):
+                if hasattr(m, "setup_interpolator"):
+                    raise NameError("No Table created. Run setup_interpolator() method first")
+                raise TypeError(f"PaintProfilesAnisShell on the MI355X path needs tabulated models; got {type(m)}")
+        import torch
+        ctx = get_context()
+        orig_map = np.asarray(self.LightconeShell.map)
+        NSIDE = self.LightconeShell.NSIDE
+        npix = 12 * NSIDE * NSIDE
+        pixarea = 4.0 * np.pi / npix
+        bg = Background(self.cosmo)
+        cat = self.HaloLightConeCatalog.cat
+        z_m = np.max(cat["z"]) if cat.size else 0.0
+        z_t = np.linspace(0, z_m + 0.1, 1000)                              # :553-555
+        D_a = interpolate.CubicSpline(z_t, bg.angular_diameter_distance(1 / (1 + z_t)))
+
+        # total mass distribution of the halos (:565-571), then the uniform background (:573-582)
+        d_mtot = PaintProfilesShell(self.HaloLightConeCatalog, self.LightconeShell, self.epsilon_max, self.Mtot_model,
+                                    use_ellipticity=self.use_ellipticity, mass_def=self.mass_def,
+                                    include_pixel_size=True, verbose=self.verbose, variant=self.variant).process_device()
+        dL = 2 * _get_parameter(self.Mtot_model, "proj_cutoff")           # proj_cutoff == Lproj / 2
+        dD = float(D_a(self.LightconeShell.redshift))
+        dV = pixarea * ((dD + dL) ** 3 - dD ** 3)
+        rho_halos = float(d_mtot.sum().item()) / (dV * npix)
+        rho_m = float(bg.rho_x(1 / (self.LightconeShell.redshift + 1), "matter"))
+        drho_m = float(np.clip(rho_m - rho_halos, 0, None))
+        d_mtot += dV * drho_m
+        if self.verbose:
+            print(f"Inputted halos contribute {100*(rho_halos/rho_m):0.2f}% of the total matter density.")
+            print("Remaining density is assigned to a uniform background.")
+        if rho_halos > rho_m:
+            warnings.warn("Inputted halos contribute more mass than is available for this mean matter density."
+                          "Your Mtot_model profiles are either too extended or you are using the wrong cosmology.")
+
+        # sum over halos of Paint x Tracer [x pixarea D^2]: one paint of the product table
+        prod = _ProductTable(self.model, self.Tracer_model, keys)
+        bgc, spline, d_cat, stride = self._device_inputs(ctx, keys)
+        table = ctx.table(_table_axes(prod, keys), prod.ln_product, log_values=True)
+        d_sum = ctx.zeros(npix)
+        args = ctx.shell_args(NSIDE, d_cat, d_cat.shape[0], stride, len(keys), self.epsilon_max,
+                              ctx.massdef_struct(bgc, self.mass_def), include_pixel_size=self.include_pixel_size,
+                              variant=self.variant)
+        ctx.stats_reset()
+        ctx.paint_shell(args, table, spline, d_sum)
+        self.last_stats = ctx.stats()
+
+        d_orig = ctx.to_device(np.ascontiguousarray(orig_map, dtype=np.float64).reshape(-1))
+        pos = d_mtot > 0
+        safe = torch.where(pos, d_mtot, torch.ones_like(d_mtot))
+        w = torch.where(pos, d_orig / safe, torch.zeros_like(d_orig))      # Mfrac weights (:619-620)
+        new_map = d_sum * w
+        new_map += (self.background_val * self.global_tracer_fraction) * torch.where(pos, (dV * drho_m) / safe,
+                                                                                     torch.zeros_like(safe)) * d_orig
+        return new_map.cpu().numpy().reshape(orig_map.shape)
 
 
 class BaryonifyShell(DefaultRunner):

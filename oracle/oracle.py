@@ -342,3 +342,50 @@ def baryonify_shell(nside, orig_map, ra, dec, M, a, D, R, R_model_com, axes, val
     new_map = regrid_shell(nside, off, orig_map)
     assert np.isclose(np.sum(new_map), np.sum(orig_map))  # :368-370
     return new_map
+
+
+def paint_anis_shell(cosmo, nside, orig_map, shell_redshift, ra, dec, M, z, axes, T_paint, T_tracer, T_mtot,
+                     proj_cutoff, background_val, global_tracer_fraction, eps_run, include_pixel_size=False):
+    """PaintProfilesAnisShell.process (HealpixRunner.py:513-640), restated halo by halo in numpy (small cases only).
+    axes = (ln(1+z), ln M, ln r) shared by the three tables; T_* are the raw (not log) projected tables."""
+    from scipy import interpolate
+    ra, dec, M, z = map(_f, (ra, dec, M, z))
+    orig_map = _f(orig_map)
+    npix = nside2npix(nside)
+    pixarea = nside2pixarea(nside)
+    a, R, D = halo_scalars(cosmo, M, z)
+    z_t = np.linspace(0, np.max(z) + 0.1, 1000)
+    D_a = interpolate.CubicSpline(z_t, angular_diameter_distance(cosmo, 1 / (1 + z_t)))       # :553-555
+    with np.errstate(all="ignore"):
+        lnP, lnT, lnM_ = np.log(_f(T_paint)), np.log(_f(T_tracer)), np.log(_f(T_mtot))
+    Mtot_map, _ = paint_shell(nside, ra, dec, M, a, D, R, axes, lnM_, eps_run, include_pixel_size=True)   # :565-571
+    dL = 2 * proj_cutoff                                                                       # :573
+    dD = D_a(shell_redshift)
+    dV = pixarea * ((dD + dL) ** 3 - dD ** 3)
+    rho_halos = np.sum(Mtot_map) / (dV * Mtot_map.size)
+    rho_m = rho_x(cosmo, 1 / (shell_redshift + 1), "matter")                                   # :580
+    drho_m = np.clip(rho_m - rho_halos, 0, None)
+    Mtot_map = Mtot_map + dV * drho_m
+    new_map = np.zeros(npix)
+    for j in range(ra.size):                                                                   # :595-625
+        vec_j = ang2vec(ra[j], dec[j], lonlat=True)
+        pixind = query_disc(nside, vec_j, R[j] * eps_run / D[j], inclusive=False, nest=False)
+        if pixind.size == 0:
+            continue
+        vec = np.stack(pix2vec(nside, pixind), axis=1)
+        r_sep = np.sqrt(np.sum((vec * D[j] - vec_j * D[j]) ** 2, axis=1))
+        with np.errstate(all="ignore"):
+            pts = np.stack([np.full(pixind.size, np.log(1 / a[j])), np.full(pixind.size, np.log(M[j])),
+                            np.log(r_sep / a[j])], axis=1)
+            Painting = np.exp(interp_linear(axes, lnP, pts))
+            Canvas = np.exp(interp_linear(axes, lnT, pts))
+        Painting = np.where(np.isfinite(Painting), Painting, 0)
+        Canvas = np.where(np.isfinite(Canvas), Canvas, 0)
+        Mfrac = np.divide(Canvas, Mtot_map[pixind], out=np.zeros_like(Canvas), where=Mtot_map[pixind] > 0)
+        Mfrac = Mfrac * orig_map[pixind]
+        if include_pixel_size:
+            Painting = Painting * (pixarea * D[j] ** 2)
+        new_map[pixind] += Painting * Mfrac
+    Mfrac = np.divide(dV * drho_m, Mtot_map, out=np.zeros_like(Mtot_map), where=Mtot_map > 0) * orig_map   # :628-630
+    return new_map + background_val * global_tracer_fraction * Mfrac
+

@@ -77,6 +77,10 @@ def install_stubs():
         def compute_sigma(self):
             pass
 
+        def rho_x(self, a, species, is_comoving=False):
+            assert species == "matter" and not is_comoving
+            return orc.rho_x(self.d, a, "matter")
+
     def angular_diameter_distance(cosmo, a):
         return orc.angular_diameter_distance(cosmo.d, a)
 
@@ -210,7 +214,8 @@ def rgi(axes, values, **kw):
     return interpolate.RegularGridInterpolator(tuple(axes), values, bounds_error=False, **kw)
 
 
-def main():
+def main(only=None):
+    """only: None = regenerate every fixture; 'anis' = just anis_shell.npz (added later; the others stay untouched)"""
     ccl, tab, bc, io, run = load_reference()
     warnings.simplefilter("ignore")
     np.seterr(all="ignore")
@@ -250,6 +255,9 @@ def main():
         obj.interp_d = rgi(axes, d, fill_value=np.nan)        # BaryonCorrection.py:322
         obj.Rdelta_sampling = rdelta
         return obj
+
+    if only == "anis":
+        return anis_section(ccl, io, run, make_tabulated, mdef)
 
     # ---------------------------------------------------------------- 1. read-outs
     out = {}
@@ -389,10 +397,45 @@ def main():
     np.savez_compressed(os.path.join(HERE, "table_builder.npz"), **out)
     print("table_builder d range", np.nanmin(B2.raw_input_d), np.nanmax(B2.raw_input_d))
 
+    anis_section(ccl, io, run, make_tabulated, mdef)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 
+def anis_section(ccl, io, run, make_tabulated, mdef):
+    """6. PaintProfilesAnisShell.process (HealpixRunner.py:513-640), run verbatim: three tabulated models on one grid"""
+    out = {}
+    for tag, nside, n, seed, eps, ips in (("a", 32, 80, 61, 10, False), ("b", 64, 120, 62, 8, True)):
+        ra, dec, M, z = catalog(n, seed)
+        zax, Max, rax, T = paint_table()
+        zz, MM, rr = np.meshgrid(np.exp(zax) - 1, np.exp(Max), np.exp(rax), indexing="ij")
+        Rc = r200c_com(MM, zz)
+        # tracer: shallower profile; total mass: projected density [Msun / Mpc^2] so that include_pixel_size gives masses
+        Ttr = 3.0 * (MM / 1e14) ** 0.8 * (1 + (rr / (0.5 * Rc)) ** 2) ** -1.0 / (1 + zz)
+        Tm = MM / (2 * np.pi * (0.3 * Rc) ** 2) * (1 + (rr / (0.3 * Rc)) ** 2) ** -1.5 / (1 + zz)
+        if tag == "b":
+            Ttr = Ttr.copy(); Ttr[2, 3, 5:8] = np.nan            # non-finite canvas nodes -> 0
+        paint, tracer, mtot = (make_tabulated(zax, Max, rax, t) for t in (T, Ttr, Tm))
+        mtot.proj_cutoff = 40.0                                 # found by _get_parameter (Tabulate.py:66-96)
+        rng = np.random.default_rng(seed + 100)
+        m_in = rng.uniform(0.0, 3.0, orc.nside2npix(nside))
+        m_in[rng.uniform(size=m_in.size) < 0.1] = 0.0
+        zshell = 0.2
+        Cat = io.HaloLightConeCatalog(ra, dec, M, z, COSMO)
+        Shell = io.LightconeShell(map=m_in, cosmo=COSMO, redshift=zshell)
+        bval, gfrac = 0.7, 0.35
+        res = run.PaintProfilesAnisShell(Cat, Shell, eps, paint, tracer, mtot, bval, gfrac, mass_def=mdef,
+                                         include_pixel_size=ips, verbose=False).process()
+        out.update({f"{tag}_nside": np.array(nside), f"{tag}_ra": ra, f"{tag}_dec": dec, f"{tag}_M": M, f"{tag}_z": z,
+                    f"{tag}_eps": np.array(eps), f"{tag}_ips": np.array(ips), f"{tag}_zax": zax, f"{tag}_Max": Max,
+                    f"{tag}_rax": rax, f"{tag}_T_paint": T, f"{tag}_T_tracer": Ttr, f"{tag}_T_mtot": Tm,
+                    f"{tag}_proj_cutoff": np.array(40.0), f"{tag}_map_in": m_in, f"{tag}_redshift": np.array(zshell),
+                    f"{tag}_background_val": np.array(bval), f"{tag}_global_tracer_fraction": np.array(gfrac),
+                    f"{tag}_map_out": res})
+        print("anis", tag, "sum", res.sum(), "nonzero", np.count_nonzero(res))
+    np.savez_compressed(os.path.join(HERE, "anis_shell.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else None)

@@ -96,6 +96,49 @@ def test_paint_shell_golden(golden, cosmo, tag, variant):
     assert R.last_stats["pixel_updates"] >= np.count_nonzero(ref)
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_paint_anis_shell_golden(golden, cosmo, tag):
+    """PaintProfilesAnisShell (HealpixRunner.py:486-640) against the reference's own run"""
+    g = golden("anis_shell.npz")
+    nside = int(g[f"{tag}_nside"])
+    axes = (g[f"{tag}_zax"], g[f"{tag}_Max"], g[f"{tag}_rax"])
+    paint = bfg.TabulatedProfile.from_arrays(*axes, g[f"{tag}_T_paint"])
+    tracer = bfg.TabulatedProfile.from_arrays(*axes, g[f"{tag}_T_tracer"])
+    mtot = bfg.TabulatedProfile.from_arrays(*axes, g[f"{tag}_T_mtot"])
+    mtot.proj_cutoff = float(g[f"{tag}_proj_cutoff"])
+    Cat = bfg.HaloLightConeCatalog(g[f"{tag}_ra"], g[f"{tag}_dec"], g[f"{tag}_M"], g[f"{tag}_z"], cosmo)
+    Shell = bfg.LightconeShell(map=g[f"{tag}_map_in"].copy(), cosmo=cosmo, redshift=float(g[f"{tag}_redshift"]))
+    R = bfg.PaintProfilesAnisShell(Cat, Shell, float(g[f"{tag}_eps"]), paint, tracer, mtot,
+                                   float(g[f"{tag}_background_val"]), float(g[f"{tag}_global_tracer_fraction"]),
+                                   include_pixel_size=bool(g[f"{tag}_ips"]), verbose=False)
+    got = R.process()
+    ref = g[f"{tag}_map_out"]
+    assert got.dtype == np.float64 and got.shape == ref.shape
+    assert_maps_close(got, ref, RTOL, what=f"anis {tag}")
+    assert np.array_equal(got != 0, ref != 0)
+
+
+def test_paint_anis_shell_vs_oracle(cosmo):
+    """a larger case than the golden one, against the oracle's halo-by-halo restatement"""
+    nside = 128
+    ra, dec, M, z = syn.catalog(1500, seed=91, z=(0.05, 0.3), logM=(13.0, 15.3))
+    zax, Max, rax, T = syn.pressure_table()
+    zz, MM, rr = np.meshgrid(np.exp(zax) - 1, np.exp(Max), np.exp(rax), indexing="ij")
+    Ttr = 2.0 * (MM / 1e14) ** 0.7 / (1 + (rr / 0.4) ** 2)
+    Tm = MM / (1 + (rr / 0.2) ** 2) ** 1.5
+    m_in = syn.mass_map(nside)
+    ref = orc.paint_anis_shell(cosmo, nside, m_in, 0.15, ra, dec, M, z, (zax, Max, rax), T, Ttr, Tm, 30.0, 1.3, 0.2,
+                                  10, include_pixel_size=True)
+    mk = lambda t: bfg.TabulatedProfile.from_arrays(zax, Max, rax, t)
+    mtot = mk(Tm)
+    mtot.proj_cutoff = 30.0
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    Shell = bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo, redshift=0.15)
+    got = bfg.PaintProfilesAnisShell(Cat, Shell, 10, mk(T), mk(Ttr), mtot, 1.3, 0.2, include_pixel_size=True,
+                                     verbose=False).process()
+    assert_maps_close(got, ref, RTOL, what="anis vs oracle")
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 def test_paint_shell_golden_param(golden, cosmo, variant):
     g = golden("paint_shell.npz")

@@ -259,3 +259,27 @@ def test_estimate_disc_pixels_tracks_the_oracle_count():
     cnt = np.array([orc.query_disc(256, orc.ang2vec(ra[i], dec[i], lonlat=True), R[i] * 10 / D[i]).size
                     for i in range(300)])
     assert abs(est.sum() / cnt.sum() - 1) < 0.05
+
+
+def test_anis_runner_conventions(cosmo):
+    """PaintProfilesAnisShell mirrors the reference constructor (HealpixRunner.py:501-511) and fails loudly off-GPU"""
+    ra, dec, M, z = syn.catalog(10, seed=3)
+    zax, Max, rax, T = syn.pressure_table()
+    t = bfg.TabulatedProfile.from_arrays(zax, Max, rax, T)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    Shell = bfg.LightconeShell(map=np.ones(12 * 8 * 8), cosmo=cosmo, redshift=0.2)
+    R = bfg.PaintProfilesAnisShell(Cat, Shell, 10, t, t, t, 0.5, 0.1, verbose=False)
+    assert (R.Tracer_model, R.Mtot_model, R.background_val, R.global_tracer_fraction) == (t, t, 0.5, 0.1)
+    with pytest.raises(NotImplementedError):
+        bfg.PaintProfilesAnisShell(Cat, Shell, 10, t, t, t, 0.5, 0.1, use_ellipticity=True)
+    from baryonforge_amd.Runners.HealpixRunner import _ProductTable
+    prod = _ProductTable(t, t, [])
+    np.testing.assert_allclose(prod.ln_product, 2 * np.log(T))
+    t2 = bfg.TabulatedProfile.from_arrays(zax, Max, rax + 0.1, T)
+    with pytest.raises(ValueError):
+        _ProductTable(t, t2, [])
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception):
+            R.process()
+

@@ -138,3 +138,19 @@ def test_regrid_pixels_hpix(golden):
     g = golden("regrid.npz")
     hm = o.regrid_pixels_hpix(np.zeros(g["hmap"].size), g["vals"], g["child_pix"], g["child_weights"])
     np.testing.assert_allclose(hm, g["hmap"], rtol=1e-15, atol=0)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_oracle_anis_shell_matches_reference(golden, cosmo, tag):
+    """oracle restatement of PaintProfilesAnisShell.process vs the reference's own run (tests/golden/make_golden.py anis)"""
+    g = golden("anis_shell.npz")
+    got = o.paint_anis_shell(cosmo, int(g[f"{tag}_nside"]), g[f"{tag}_map_in"], float(g[f"{tag}_redshift"]),
+                               g[f"{tag}_ra"], g[f"{tag}_dec"], g[f"{tag}_M"], g[f"{tag}_z"],
+                               (g[f"{tag}_zax"], g[f"{tag}_Max"], g[f"{tag}_rax"]), g[f"{tag}_T_paint"],
+                               g[f"{tag}_T_tracer"], g[f"{tag}_T_mtot"], float(g[f"{tag}_proj_cutoff"]),
+                               float(g[f"{tag}_background_val"]), float(g[f"{tag}_global_tracer_fraction"]),
+                               float(g[f"{tag}_eps"]), include_pixel_size=bool(g[f"{tag}_ips"]))
+    ref = g[f"{tag}_map_out"]
+    assert np.array_equal(got != 0, ref != 0)
+    np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-300)
+
