@@ -389,3 +389,54 @@ def paint_anis_shell(cosmo, nside, orig_map, shell_redshift, ra, dec, M, z, axes
     Mfrac = np.divide(dV * drho_m, Mtot_map, out=np.zeros_like(Mtot_map), where=Mtot_map > 0) * orig_map   # :628-630
     return new_map + background_val * global_tracer_fraction * Mfrac
 
+
+def displacement_readout(cosmo, axes, values, r, M, a, eps_model, rdelta_sampling=False, Delta=200, rho_type="critical",
+                         lnM=None):
+    """BaryonificationClass._readout for scalar M, a (BaryonCorrection.py:331-419): linear table of comoving
+    displacement on (ln(1+z), ln M, ln r [- ln R_com]), NaN outside the hull, 0 where r >= eps_model * R_com.
+    lnM: the table coordinate if it is not ln(M) in float64 (a float32 catalog column gives a float32 logarithm, :397)."""
+    r = _f(np.atleast_1d(r))
+    R = float(get_radius(cosmo, M, a, Delta, rho_type)) / a                 # comoving Mpc (:399)
+    with np.errstate(all="ignore"):
+        r_in = np.log(r) - (np.log(R) if rdelta_sampling else 0.0)
+    pts = np.stack([np.full(r.size, np.log(1 / a)), np.full(r.size, np.log(M) if lnM is None else lnM), r_in], axis=1)
+    d = interp_linear(axes, values, pts)
+    return np.where(r < eps_model * R, d, 0.0)                              # :410-411
+
+
+def baryonify_snapshot(cosmo, L, redshift, px, py, pz, hM, hx, hy, hz, axes, values, eps_run, eps_model,
+                       rdelta_sampling=False, Delta=200, rho_type="critical"):
+    """BaryonifySnapshot.process (SnapshotRunner.py:176-275) restated with scipy's periodic KDTree (:99).
+    pz / hz = None: 2D snapshot.  The reference keeps the halo columns in float32 (io.py:204): positions and masses are
+    widened exactly, but the table coordinate ln M is a float32 logarithm (BaryonCorrection.py:397 on a float32 M).
+    Returns the displaced, box-wrapped particle coordinates [n, ndim]."""
+    from scipy.spatial import KDTree
+    is2D = pz is None
+    P = np.stack([_f(px), _f(py)] + ([] if is2D else [_f(pz)]), axis=1)
+    H = np.stack([_f(np.asarray(c, dtype=np.float32)) for c in ([hx, hy] + ([] if is2D else [hz]))], axis=1)
+    tree = KDTree(P, boxsize=L)                                              # :99
+    tot = np.zeros_like(P)
+    a = 1 / (1 + redshift)
+    for j in range(H.shape[0]):                                              # :212-258
+        M32 = np.float32(hM[j])
+        M_j = float(M32)
+        lnM_j = float(np.log(M32))
+        R_j = float(get_radius(cosmo, M_j, a, Delta, rho_type))
+        R_q = np.clip(eps_run * R_j / a, 0, L / 2)
+        inds = tree.query_ball_point(H[j], R_q)
+        if len(inds) == 0:
+            continue
+        dd = P[inds] - H[j]
+        dd = np.where(dd > L / 2, dd - L, dd)                                # compute_distance / enforce_periodicity
+        dd = np.where(dd < -L / 2, dd + L, dd)
+        d = np.sqrt(np.sum(dd ** 2, axis=1))
+        with np.errstate(all="ignore"):
+            off = displacement_readout(cosmo, axes, values, d, M_j, a, eps_model, rdelta_sampling, Delta, rho_type,
+                                       lnM=lnM_j)
+            off = np.where(np.isfinite(off), off, 0)                         # :231 / :248
+            tot[inds] += off[:, None] * (dd / d[:, None])
+    new = P + tot
+    new = np.where(new > L, new - L, new)                                    # :268-273
+    new = np.where(new < 0, new + L, new)
+    return new
+

@@ -89,7 +89,8 @@ def install_stubs():
             self.Delta, self.rho_type = Delta, rho_type
 
         def get_radius(self, cosmo, M, a):
-            return orc.get_radius(cosmo.d, M, a, self.Delta, self.rho_type)
+            # libccl takes C doubles: float32 catalog columns (io.py:204) are widened before any arithmetic
+            return orc.get_radius(cosmo.d, np.float64(M), np.float64(a), self.Delta, self.rho_type)
 
     class _Prec(object):
         def to_dict(self):
@@ -258,6 +259,8 @@ def main(only=None):
 
     if only == "anis":
         return anis_section(ccl, io, run, make_tabulated, mdef)
+    if only == "snapshot":
+        return snapshot_section(io, make_disp, mdef)
 
     # ---------------------------------------------------------------- 1. read-outs
     out = {}
@@ -398,6 +401,7 @@ def main(only=None):
     print("table_builder d range", np.nanmin(B2.raw_input_d), np.nanmax(B2.raw_input_d))
 
     anis_section(ccl, io, run, make_tabulated, mdef)
+    snapshot_section(io, make_disp, mdef)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
@@ -435,6 +439,40 @@ def anis_section(ccl, io, run, make_tabulated, mdef):
                     f"{tag}_map_out": res})
         print("anis", tag, "sum", res.sum(), "nonzero", np.count_nonzero(res))
     np.savez_compressed(os.path.join(HERE, "anis_shell.npz"), **out)
+
+
+def snapshot_section(io, make_disp, mdef):
+    """7. BaryonifySnapshot.process (SnapshotRunner.py:176-275), run verbatim (scipy KDTree is installed here)"""
+    snap = load("BaryonForge.Runners.SnapshotRunner", "Runners/SnapshotRunner.py")
+    out = {}
+    for tag, is2D, L, npart, nhalo, seed, eps, rdelta, emod in (("a", False, 120.0, 14000, 60, 71, 10, False, 20),
+                                                                ("b", True, 200.0, 12000, 80, 72, 8, True, 4),
+                                                                ("c", False, 60.0, 8000, 25, 73, 30, False, 6)):
+        rng = np.random.default_rng(seed)
+        zd, Md, rd, d = disp_table(rdelta=rdelta)
+        if tag == "c":
+            d = d.copy(); d[1:3, 4:6, 12:15] = np.nan          # non-finite nodes -> no displacement (:248)
+        disp = make_disp(zd, Md, rd, d, rdelta=rdelta, eps=emod)
+        P = rng.uniform(0, L, (npart, 3))
+        H = rng.uniform(0, L, (nhalo, 3))
+        H[:5] = [[0.3, 0.2, L - 0.4], [L - 0.1, L / 2, 0.2], [L / 2, 0.05, L / 2], [1.0, L - 1.0, 1.0], [L / 3, L / 3, 0.1]]
+        hM = 10 ** rng.uniform(13.0, 15.3, nhalo)
+        P[:200] = H[rng.integers(0, nhalo, 200)] + rng.normal(0, 0.3, (200, 3))      # particles close to halo centres
+        P %= L
+        redshift = 0.25
+        Cat = io.HaloNDCatalog(H[:, 0], H[:, 1], hM, redshift, COSMO, z=None if is2D else H[:, 2])
+        Part = io.ParticleSnapshot(x=P[:, 0], y=P[:, 1], z=None if is2D else P[:, 2], M=np.ones(npart), L=L,
+                                   redshift=redshift, cosmo=COSMO)
+        res = snap.BaryonifySnapshot(Cat, Part, epsilon_max=eps, model=disp, mass_def=mdef, verbose=False).process()
+        new = np.stack([res["x"], res["y"]] + ([] if is2D else [res["z"]]), axis=1)
+        old = P[:, :2] if is2D else P
+        out.update({f"{tag}_is2D": np.array(is2D), f"{tag}_L": np.array(L), f"{tag}_redshift": np.array(redshift),
+                    f"{tag}_P": old, f"{tag}_H": H[:, :2] if is2D else H, f"{tag}_hM": hM, f"{tag}_eps": np.array(eps),
+                    f"{tag}_eps_model": np.array(emod), f"{tag}_rdelta": np.array(rdelta), f"{tag}_zax": zd,
+                    f"{tag}_Max": Md, f"{tag}_rax": rd, f"{tag}_d": d, f"{tag}_P_new": new})
+        moved = np.abs(new - old); moved = np.minimum(moved, L - moved)
+        print("snapshot", tag, "moved particles", np.count_nonzero(moved.max(axis=1) > 0), "max shift", moved.max())
+    np.savez_compressed(os.path.join(HERE, "snapshot.npz"), **out)
 
 
 if __name__ == "__main__":

@@ -154,3 +154,16 @@ def test_oracle_anis_shell_matches_reference(golden, cosmo, tag):
     assert np.array_equal(got != 0, ref != 0)
     np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-300)
 
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_oracle_snapshot_matches_reference(golden, cosmo, tag):
+    """oracle restatement of BaryonifySnapshot.process vs the reference's own run (make_golden.py snapshot)"""
+    g = golden("snapshot.npz")
+    P, H, hM = g[f"{tag}_P"], g[f"{tag}_H"], g[f"{tag}_hM"]                    # the oracle narrows halo columns to float32
+    is2D = bool(g[f"{tag}_is2D"])
+    got = o.baryonify_snapshot(cosmo, float(g[f"{tag}_L"]), float(g[f"{tag}_redshift"]), P[:, 0], P[:, 1],
+                               None if is2D else P[:, 2], hM, H[:, 0], H[:, 1], None if is2D else H[:, 2],
+                               (g[f"{tag}_zax"], g[f"{tag}_Max"], g[f"{tag}_rax"]), g[f"{tag}_d"], float(g[f"{tag}_eps"]),
+                               float(g[f"{tag}_eps_model"]), bool(g[f"{tag}_rdelta"]))
+    np.testing.assert_allclose(got, g[f"{tag}_P_new"], rtol=0, atol=1e-11)
+
