@@ -1,1 +1,2 @@
 from .HealpixRunner import *  # noqa: F401,F403
+from .SnapshotRunner import *  # noqa: F401,F403

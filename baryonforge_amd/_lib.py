@@ -35,6 +35,7 @@ SYMBOLS = [
     "bfg_table_create", "bfg_table_destroy", "bfg_table_eval",
     "bfg_spline_create", "bfg_spline_destroy",
     "bfg_paint_shell", "bfg_baryonify_offsets", "bfg_regrid_shell", "bfg_reduce_absmax_sum",
+    "bfg_baryonify_snapshot",
     "bfg_stats_reset", "bfg_stats_read", "bfg_timing_enable", "bfg_timing_read",
 ]
 
@@ -50,6 +51,13 @@ class ShellArgs(C.Structure):
                 ("model_md", MassDefStruct), ("model_epsilon_max", _dbl),
                 ("rdelta_sampling", C.c_int32), ("include_pixel_size", C.c_int32),
                 ("variant", C.c_int32), ("reserved", C.c_int32)]
+
+
+class SnapshotArgs(C.Structure):
+    _fields_ = [("ndim", C.c_int32), ("rdelta_sampling", C.c_int32), ("n_part", _i64), ("n_halo", _i64),
+                ("L", _dbl), ("a", _dbl), ("d_part", _vp), ("d_halo", _vp), ("halo_stride", C.c_int32),
+                ("n_extra", C.c_int32), ("epsilon_max", _dbl), ("runner_md", MassDefStruct),
+                ("model_md", MassDefStruct), ("model_epsilon_max", _dbl)]
 
 
 class Stats(C.Structure):
@@ -113,6 +121,7 @@ def load(build_if_missing=True):
     L.bfg_spline_create.argtypes = [_vp, C.c_int, C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_vp)]
     L.bfg_spline_destroy.argtypes = [_vp, _vp]
     L.bfg_paint_shell.argtypes = [_vp, C.POINTER(ShellArgs), _vp, _vp, _vp]
+    L.bfg_baryonify_snapshot.argtypes = [_vp, C.POINTER(SnapshotArgs), _vp, _vp]
     L.bfg_baryonify_offsets.argtypes = [_vp, C.POINTER(ShellArgs), _vp, _vp, _vp]
     L.bfg_regrid_shell.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp]
     L.bfg_reduce_absmax_sum.argtypes = [_vp, _i64, _vp, C.POINTER(_dbl), C.POINTER(_dbl)]

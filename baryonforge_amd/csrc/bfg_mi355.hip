@@ -186,6 +186,8 @@ __device__ inline double massdef_radius(const bfg_massdef &md, double M, double 
     return cbrt(M / (4.18879020479 * md.Delta * rho));
 }
 
+#include "bfg_snapshot.hpp"
+
 // scipy PPoly evaluation of the not-a-knot CubicSpline of HealpixRunner.py:299 (extrapolates)
 __device__ inline double spline_eval(int n, const double *__restrict__ x, const double *__restrict__ c, double v)
 {
@@ -1565,6 +1567,68 @@ int bfg_reduce_absmax_sum(bfg_ctx *c, int64_t n, const double *d_x, double *absm
     }
     if (sum) *sum = h[0];
     if (absmax) *absmax = h[1];
+    return BFG_OK;
+}
+
+int bfg_baryonify_snapshot(bfg_ctx *c, const bfg_snapshot_args *a, const bfg_table *t, double *d_out)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    if (!a || !t || !d_out || (a->ndim != 2 && a->ndim != 3) || a->n_part < 0 || a->n_halo < 0 || !(a->L > 0) ||
+        !(a->a > 0) || a->n_part >= (1ll << 31) || a->n_extra < 0 || a->halo_stride < 5 + a->n_extra)
+        return BFG_ERR_INVALID;
+    if (t->dev.ndim != 3 + a->n_extra || t->dev.log_values) return BFG_ERR_INVALID;       // linear displacement table
+    if ((a->n_part > 0 && !a->d_part) || (a->n_halo > 0 && !a->d_halo)) return BFG_ERR_INVALID;
+    if (a->n_part == 0) return BFG_OK;
+    SnapParams P;
+    std::memset(&P, 0, sizeof(P));
+    P.ndim = a->ndim; P.rdelta = a->rdelta_sampling; P.n_part = a->n_part; P.n_halo = a->n_halo;
+    P.L = a->L; P.a = a->a; P.eps_run = a->epsilon_max; P.eps_model = a->model_epsilon_max;
+    P.md_run = a->runner_md; P.md_model = a->model_md;
+    P.part = a->d_part; P.halo = a->d_halo; P.halo_stride = a->halo_stride; P.n_extra = a->n_extra;
+    P.tab = t->dev; P.stats = c->d_stats; P.out = d_out;
+    // ~12 particles per cell, at most 256^3 / 4096^2 cells
+    const int nmax = (a->ndim == 3) ? 256 : 4096;
+    int ncell = (int)std::floor(std::pow((double)a->n_part / 12.0, 1.0 / a->ndim));
+    ncell = std::max(1, std::min(ncell, nmax));
+    P.ncell = ncell;
+    P.ncell_tot = (a->ndim == 3) ? (int64_t)ncell * ncell * ncell : (int64_t)ncell * ncell;
+    const int64_t nblk = (P.ncell_tot + 1023) / 1024;
+    int32_t *d_bsum = nullptr, *d_total = nullptr;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(P.cell_count); (void)hipFree(P.cell_start); (void)hipFree(P.order); (void)hipFree(P.hs);
+        (void)hipFree(P.hrow); (void)hipFree(P.off); (void)hipFree(d_bsum); (void)hipFree(d_total);
+    };
+#define SNAP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_last_error = std::string(#expr) + ": " + hipGetErrorString(e_); cleanup(); return BFG_ERR_HIP; } } while (0)
+    SNAP_TRY(hipMalloc((void **)&P.cell_count, (size_t)P.ncell_tot * sizeof(int32_t)));
+    SNAP_TRY(hipMalloc((void **)&P.cell_start, (size_t)(P.ncell_tot + 1) * sizeof(int32_t)));
+    SNAP_TRY(hipMalloc((void **)&P.order, (size_t)a->n_part * sizeof(int32_t)));
+    SNAP_TRY(hipMalloc((void **)&P.hs, (size_t)std::max<int64_t>(a->n_halo, 1) * sizeof(SnapHalo)));
+    SNAP_TRY(hipMalloc((void **)&P.hrow, (size_t)std::max<int64_t>(a->n_halo, 1) * t->dev.nr * sizeof(double)));
+    SNAP_TRY(hipMalloc((void **)&P.off, (size_t)a->n_part * a->ndim * sizeof(double)));
+    SNAP_TRY(hipMalloc((void **)&d_bsum, (size_t)nblk * sizeof(int32_t)));
+    SNAP_TRY(hipMalloc((void **)&d_total, sizeof(int32_t)));
+    SNAP_TRY(hipMemsetAsync(P.cell_count, 0, (size_t)P.ncell_tot * sizeof(int32_t), c->stream));
+    SNAP_TRY(hipMemsetAsync(P.off, 0, (size_t)a->n_part * a->ndim * sizeof(double), c->stream));
+    const unsigned pgrid = (unsigned)((a->n_part + 255) / 256);
+    hipLaunchKernelGGL(snap_count_kernel, dim3(pgrid), dim3(256), 0, c->stream, P);
+    hipLaunchKernelGGL(snap_scan_block_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, P.ncell_tot, P.cell_count,
+                       P.cell_start, d_bsum);
+    hipLaunchKernelGGL(snap_scan_sums_kernel, dim3(1), dim3(1024), 0, c->stream, (int)nblk, d_bsum, d_total);
+    hipLaunchKernelGGL(snap_scan_add_kernel, dim3((unsigned)((P.ncell_tot + 255) / 256)), dim3(256), 0, c->stream,
+                       P.ncell_tot, P.cell_start, d_bsum, P.cell_count, d_total);
+    hipLaunchKernelGGL(snap_fill_kernel, dim3(pgrid), dim3(256), 0, c->stream, P);
+    if (a->n_halo > 0) {
+        hipLaunchKernelGGL(snap_halo_kernel, dim3((unsigned)a->n_halo), dim3(64), 0, c->stream, P);
+        const unsigned hgrid = (unsigned)((a->n_halo + 3) / 4);
+        if (a->ndim == 3) hipLaunchKernelGGL(snap_displace_kernel<3>, dim3(hgrid), dim3(256), 0, c->stream, P);
+        else hipLaunchKernelGGL(snap_displace_kernel<2>, dim3(hgrid), dim3(256), 0, c->stream, P);
+    }
+    hipLaunchKernelGGL(snap_apply_kernel, dim3((unsigned)((a->n_part * a->ndim + 255) / 256)), dim3(256), 0, c->stream, P);
+    SNAP_TRY(hipGetLastError());
+#undef SNAP_TRY
+    cleanup();
     return BFG_OK;
 }
 

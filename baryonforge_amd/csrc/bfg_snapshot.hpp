@@ -1,0 +1,276 @@
+// bfg_snapshot.hpp -- BaryonifySnapshot (BaryonForge/Runners/SnapshotRunner.py:176-275) on the GPU.
+//
+// The reference finds, halo by halo, the particles inside R_q = min(eps R / a, L / 2) with a periodic scipy KDTree
+// (:99, :225 / :240), reads the radial displacement off the model's table and accumulates offset * unit-vector on
+// every particle found (:232 / :249); at the end positions are shifted and wrapped into the box once (:260-273).
+//
+// Here the particles are binned into a uniform periodic cell grid (counting sort: count -> scan -> fill, cell lists
+// of particle indices), each halo's table rows are blended once into a full radial row (hrow), and one wavefront per
+// halo walks the cells its sphere can touch (one lane per cell, cells that cannot intersect the sphere are skipped)
+// and adds the displacement to the particles' offset vectors with f64 global atomics.  A last kernel shifts and wraps.
+// Included by bfg_mi355.hip after DevTable / massdef_radius are defined.
+#pragma once
+
+namespace bfg {
+
+struct __align__(16) SnapHalo {      // per-halo constants (written by snap_halo_kernel)
+    double x, y, z, rq;              // centre [comoving Mpc], query radius
+    double xcut;                     // model.epsilon_max * R_model_com: no displacement at or beyond it
+    double lnshift;                  // ln(R_model_com) for Rdelta_sampling tables, else 0
+    int32_t flags, pad;              // HF_OOB: (z, M, extras) outside the table hull -> contributes nothing
+    double pad2;
+};
+
+struct SnapParams {
+    int ndim;                        // 2 or 3
+    int rdelta;
+    int64_t n_part, n_halo;
+    double L, a, eps_run, eps_model;
+    bfg_massdef md_run, md_model;
+    const double *part;              // [n_part][ndim]
+    const double *halo;              // [n_halo][stride]: M, lnM (table coordinate), x, y, z, extras...
+    int halo_stride, n_extra;
+    DevTable tab;
+    int ncell;                       // cells per dimension
+    int64_t ncell_tot;
+    int32_t *cell_count;             // [ncell_tot] (count, then fill cursor)
+    int32_t *cell_start;             // [ncell_tot + 1]
+    int32_t *order;                  // [n_part] particle indices grouped by cell
+    SnapHalo *hs;                    // [n_halo]
+    double *hrow;                    // [n_halo][tab.nr] blended radial rows
+    double *off;                     // [n_part][ndim] accumulated offsets
+    double *out;                     // [n_part][ndim] displaced, wrapped coordinates
+    bfg_stats *stats;
+};
+
+__device__ inline int snap_cell_of(double x, double inv_cell, int n)
+{
+    int i = (int)floor(x * inv_cell);
+    return min(max(i, 0), n - 1);    // x in [0, L]; x == L lands in the last cell
+}
+
+__global__ __launch_bounds__(256) void snap_count_kernel(const SnapParams P)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n_part) return;
+    const double inv_cell = (double)P.ncell / P.L;
+    int64_t c = 0;
+    for (int k = 0; k < P.ndim; ++k) c = c * P.ncell + snap_cell_of(P.part[i * P.ndim + k], inv_cell, P.ncell);
+    atomicAdd(&P.cell_count[c], 1);
+}
+
+__global__ __launch_bounds__(256) void snap_fill_kernel(const SnapParams P)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n_part) return;
+    const double inv_cell = (double)P.ncell / P.L;
+    int64_t c = 0;
+    for (int k = 0; k < P.ndim; ++k) c = c * P.ncell + snap_cell_of(P.part[i * P.ndim + k], inv_cell, P.ncell);
+    const int pos = atomicAdd(&P.cell_count[c], 1);
+    P.order[P.cell_start[c] + pos] = (int32_t)i;
+}
+
+// exclusive scan of n int32 in three phases (block sums -> scan of the sums -> add), 1024 elements per block
+__global__ __launch_bounds__(256) void snap_scan_block_kernel(int64_t n, const int32_t *in, int32_t *out, int32_t *bsum)
+{
+    __shared__ int32_t wsum[4];
+    const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x * 4;
+    int v[4], s = 0;
+    for (int k = 0; k < 4; ++k) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
+    int incl = s;
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if ((threadIdx.x & 63) >= d) incl += o; }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
+    int run = woff + incl - s;
+    for (int k = 0; k < 4; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
+    if (threadIdx.x == 255) bsum[blockIdx.x] = woff + incl;
+}
+
+__global__ __launch_bounds__(1024) void snap_scan_sums_kernel(int nb, int32_t *bsum, int32_t *total)
+{
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = (i < nb) ? bsum[i] : 0;
+        int incl = v;
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if ((threadIdx.x & 63) >= d) incl += o; }
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
+        const int c = carry;
+        if (i < nb) bsum[i] = c + woff + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(256) void snap_scan_add_kernel(int64_t n, int32_t *out, const int32_t *bsum, int32_t *count,
+                                                            const int32_t *total)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { out[i] += bsum[i >> 10]; count[i] = 0; }      // count becomes the fill cursor
+    if (i == 0) out[n] = *total;
+}
+
+// per halo: radii, table cell in the outer dimensions, full blended radial row
+__global__ __launch_bounds__(64) void snap_halo_kernel(const SnapParams P)
+{
+    const int64_t j = blockIdx.x;
+    const int lane = threadIdx.x;
+    const double *c = P.halo + j * P.halo_stride;
+    const double M = c[0], lnM = c[1];
+    const DevTable &T = P.tab;
+    __shared__ double s_w[kMaxCorner];
+    __shared__ int64_t s_off[kMaxCorner];
+    __shared__ int s_oob;
+    if (lane == 0) {
+        const double R = massdef_radius(P.md_run, M, P.a);                          // physical Mpc (:222)
+        double rq = P.eps_run * R / P.a;                                            // comoving (:223)
+        rq = fmin(fmax(rq, 0.0), 0.5 * P.L);                                        // :224 (NaN -> NaN: finds nothing)
+        const double Rm = massdef_radius(P.md_model, M, P.a) / P.a;                 // BaryonCorrection.py:399
+        bool oob = false;
+        uint32_t warn = 0;
+        int idx[BFG_MAX_DIM];
+        double wt[BFG_MAX_DIM];
+        for (int k = 0; k < T.nouter; ++k) {
+            const double x = (k == 0) ? log(1.0 / P.a) : (k == 1) ? lnM : c[5 + (k - 2)];
+            const double *g = T.oaxis[k];
+            const int n = T.oshape[k];
+            if (!(x >= g[0]) || !(x <= g[n - 1])) {
+                oob = true;
+                if (k == 0) warn |= BFG_WARN_Z_RANGE;
+                if (k == 1) warn |= BFG_WARN_M_RANGE;
+            }
+            idx[k] = find_interval(g, n, x);
+            wt[k] = (x - g[idx[k]]) / (g[idx[k] + 1] - g[idx[k]]);
+        }
+        const int ncorner = 1 << T.nouter;
+        for (int cc = 0; cc < ncorner; ++cc) {
+            double w = 1.0;
+            int64_t off = 0;
+            for (int k = 0; k < T.nouter; ++k) {
+                const int bit = (cc >> (T.nouter - 1 - k)) & 1;
+                w *= bit ? wt[k] : 1.0 - wt[k];
+                off += (int64_t)(idx[k] + bit) * T.ostride[k];
+            }
+            s_w[cc] = w; s_off[cc] = off;
+        }
+        s_oob = oob ? 1 : 0;
+        if (oob) {
+            atomicAdd((unsigned long long *)&P.stats->halos_out_of_table, 1ull);
+            atomicOr(&P.stats->warn_mask, warn);
+        }
+        SnapHalo h;
+        h.x = c[2]; h.y = c[3]; h.z = (P.ndim == 3) ? c[4] : 0.0; h.rq = rq;
+        h.xcut = P.eps_model * Rm;
+        h.lnshift = P.rdelta ? log(Rm) : 0.0;
+        h.flags = oob ? HF_OOB : 0; h.pad = 0; h.pad2 = 0.0;
+        P.hs[j] = h;
+    }
+    __syncthreads();
+    const int ncorner = 1 << T.nouter;
+    for (int i = lane; i < T.nr; i += 64) {
+        double b = 0.0;
+        for (int cc = 0; cc < ncorner; ++cc) b = fma(T.values[s_off[cc] + i], s_w[cc], b);
+        P.hrow[j * T.nr + i] = s_oob ? nan("") : b;
+    }
+}
+
+// one wavefront per halo; one lane per cell of the sphere's bounding box
+template <int NDIM>
+__global__ __launch_bounds__(256) void snap_displace_kernel(const SnapParams P)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= P.n_halo) return;
+    const SnapHalo h = P.hs[j];
+    if (h.flags & HF_OOB) return;                            // NaN displacement everywhere -> 0 (:231 / :248)
+    if (!(h.rq > 0.0)) return;
+    const DevTable &T = P.tab;
+    const double L = P.L, halfL = 0.5 * P.L;
+    const int n = P.ncell;
+    const double cell = L / (double)n, inv_cell = (double)n / L;
+    const double hc[3] = {h.x, h.y, h.z};
+    int lo[3] = {0, 0, 0}, cnt[3] = {1, 1, 1};
+    for (int k = 0; k < NDIM; ++k) {
+        const int a = (int)floor((hc[k] - h.rq) * inv_cell), b = (int)floor((hc[k] + h.rq) * inv_cell);
+        lo[k] = a; cnt[k] = min(b - a + 1, n);               // at most every cell once
+    }
+    const int64_t nbox = (int64_t)cnt[0] * cnt[1] * cnt[2];
+    const double rq2 = h.rq * h.rq;
+    const double *row = P.hrow + j * T.nr;
+    const double r_lo = T.raxis[0], r_hi = T.raxis[T.nr - 1];
+    unsigned long long hits = 0, n_oob = 0;
+    for (int64_t ci = lane; ci < nbox; ci += 64) {
+        int ic[3];
+        int64_t rem = ci;
+        for (int k = NDIM - 1; k >= 0; --k) { ic[k] = lo[k] + (int)(rem % cnt[k]); rem /= cnt[k]; }
+        // wrapped cell id, and the smallest possible squared distance from the halo to the (unwrapped) cell
+        int64_t cid = 0;
+        double dmin2 = 0.0;
+        for (int k = 0; k < NDIM; ++k) {
+            const double c0 = (double)ic[k] * cell, c1 = c0 + cell;
+            double gap = 0.0;
+            if (cnt[k] < n - 1) {                            // (nearly) full wrap: another image of the cell may be closer
+                if (hc[k] < c0) gap = c0 - hc[k]; else if (hc[k] > c1) gap = hc[k] - c1;
+            }
+            dmin2 += gap * gap;
+            int w = ic[k] % n; if (w < 0) w += n;
+            cid = cid * n + w;
+        }
+        if (dmin2 > rq2 * (1.0 + 1e-12)) continue;           // the sphere cannot reach this cell
+        const int p0 = P.cell_start[cid], p1 = P.cell_start[cid + 1];
+        for (int q = p0; q < p1; ++q) {
+            const int64_t ip = P.order[q];
+            double dd[3] = {0.0, 0.0, 0.0}, d2 = 0.0;
+            for (int k = 0; k < NDIM; ++k) {
+                double dx = P.part[ip * NDIM + k] - hc[k];
+                dx = (dx > halfL) ? dx - L : dx;               // compute_distance / enforce_periodicity (:104-158)
+                dx = (dx < -halfL) ? dx + L : dx;
+                dd[k] = dx; d2 += dx * dx;
+            }
+            const double d = sqrt(d2);
+            if (!(d <= h.rq)) continue;                        // KDTree.query_ball_point radius (:225 / :240)
+            ++hits;
+            // BaryonificationClass._readout (BaryonCorrection.py:331-419): linear table, NaN outside the hull,
+            // 0 at or beyond epsilon_max * R; non-finite offsets contribute nothing (:231 / :248)
+            const double rin = log(d) - h.lnshift;
+            if (!(rin >= r_lo) || !(rin <= r_hi)) { ++n_oob; continue; }
+            if (!(d < h.xcut)) continue;
+            const int i = find_interval(T.raxis, T.nr, rin);
+            const double f = (rin - T.raxis[i]) / (T.raxis[i + 1] - T.raxis[i]);
+            const double val = row[i] * (1.0 - f) + row[i + 1] * f;
+            if (!(fabs(val) < 1.0e300)) continue;
+            const double s = val / d;
+            for (int k = 0; k < NDIM; ++k) unsafeAtomicAdd(P.off + ip * NDIM + k, s * dd[k]);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { hits += __shfl_down(hits, o, 64); n_oob += __shfl_down(n_oob, o, 64); }
+    if (lane == 0) {
+        if (hits) atomicAdd((unsigned long long *)&P.stats->pixel_updates, hits);
+        if (n_oob) {
+            atomicAdd((unsigned long long *)&P.stats->pixels_out_of_table, n_oob);
+            if (!P.rdelta) atomicOr(&P.stats->warn_mask, BFG_WARN_R_RANGE);       // BaryonCorrection.py:391-394
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void snap_apply_kernel(const SnapParams P)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n_part * P.ndim) return;
+    double v = P.part[i] + P.off[i];                          // :262-265
+    v = (v > P.L) ? v - P.L : v;                              // :268-273
+    v = (v < 0.0) ? v + P.L : v;
+    P.out[i] = v;
+}
+
+}  // namespace bfg

@@ -188,6 +188,22 @@ class Context(object):
                                              C.c_void_p(d_sums.data_ptr()) if d_sums is not None else None),
                    "bfg_regrid_shell")
 
+    def baryonify_snapshot(self, d_part, d_halo, ndim, L, a, epsilon_max, runner_md, model_md, model_epsilon_max,
+                           rdelta_sampling, n_extra, table, d_out):
+        """bfg_baryonify_snapshot: d_part float64[n, ndim], d_halo float64[n_halo, 5 + n_extra] (M, lnM, x, y, z, extras)"""
+        args = _lib.SnapshotArgs()
+        args.ndim, args.rdelta_sampling = int(ndim), int(bool(rdelta_sampling))
+        args.n_part, args.n_halo = int(d_part.shape[0]), int(d_halo.shape[0])
+        args.L, args.a = float(L), float(a)
+        args.d_part = d_part.data_ptr() if args.n_part else None
+        args.d_halo = d_halo.data_ptr() if args.n_halo else None
+        args.halo_stride, args.n_extra = int(d_halo.shape[1]), int(n_extra)
+        args.epsilon_max = float(epsilon_max)
+        args.runner_md, args.model_md = runner_md, model_md
+        args.model_epsilon_max = float(model_epsilon_max)
+        _lib.check(self.lib.bfg_baryonify_snapshot(self.handle, C.byref(args), table.handle,
+                                                   C.c_void_p(d_out.data_ptr())), "bfg_baryonify_snapshot")
+
     def absmax_sum(self, d_x):
         amax, s = C.c_double(), C.c_double()
         _lib.check(self.lib.bfg_reduce_absmax_sum(self.handle, d_x.numel(), C.c_void_p(d_x.data_ptr()),

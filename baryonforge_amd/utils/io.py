@@ -10,7 +10,7 @@ import numpy as np
 
 from ..background import check_cosmology_dict
 
-__all__ = ["HaloLightConeCatalog", "LightconeShell", "npix2nside", "nside2npix"]
+__all__ = ["HaloLightConeCatalog", "LightconeShell", "HaloNDCatalog", "ParticleSnapshot", "npix2nside", "nside2npix"]
 
 
 def nside2npix(nside):
@@ -122,3 +122,80 @@ class LightconeShell(object):
     @property
     def cosmology(self):
         return self.cosmo
+
+
+class HaloNDCatalog(object):
+    """
+    Halo catalog in a periodic 2D or 3D box (io.py:143-287): `cat` with fields M, x, y, z (+extras) stored, as the
+    reference does, in big-endian float32 (io.py:204); `redshift`; `cosmology`.  z=None means a 2D field (z column 0).
+    """
+
+    def __init__(self, x, y, M, redshift, cosmo, z=None, **arrays):
+        dtype = [("M", ">f"), ("x", ">f"), ("y", ">f"), ("z", ">f")]
+        dtype = dtype + [(name, ">f", np.asarray(arr).shape[1:] if np.ndim(arr) > 1 else "") for name, arr in arrays.items()]
+        N = 1 if not isinstance(x, (list, np.ndarray, tuple)) else len(x)
+        cat = np.zeros(N, dtype)
+        cat["x"] = x
+        cat["y"] = y
+        cat["z"] = 0 if z is None else z
+        cat["M"] = M
+        for name, arr in arrays.items():
+            cat[name] = arr
+        self.cat = cat
+        self.redshift = redshift
+        check_cosmology_dict(cosmo)
+        self.cosmo = cosmo
+
+    def __str__(self):
+        return "HaloNDCatalog with %d halos at z = %s. Cosmology: %s" % (self.cat.size, str(self.redshift), str(self.cosmo))
+
+    __repr__ = __str__
+
+    @property
+    def data(self):
+        return self.cat
+
+    @property
+    def cosmology(self):
+        return self.cosmo
+
+
+class ParticleSnapshot(object):
+    """
+    Particle snapshot of a periodic box (io.py:497-677): `cat` (float64 fields M, x, y, z), box size `L` [comoving
+    Mpc], `redshift`, `is2D` (z=None), `cosmology`; `make_map(N_grid)` = nearest-grid-point mass histogram (:629-677).
+    """
+
+    def __init__(self, x=None, y=None, z=None, M=None, L=None, redshift=None, cosmo=None):
+        dtype = [("M", np.float64), ("x", np.float64), ("y", np.float64), ("z", np.float64)]
+        cat = np.zeros(len(x), dtype)
+        cat["x"] = x
+        cat["y"] = y
+        cat["z"] = 0 if z is None else z
+        cat["M"] = M
+        self.L = L
+        self.cat = cat
+        self.redshift = redshift
+        self.is2D = True if z is None else False
+        check_cosmology_dict(cosmo)
+        self.cosmo = cosmo
+
+    @property
+    def data(self):
+        return self.cat
+
+    @property
+    def cosmology(self):
+        return self.cosmo
+
+    def make_map(self, N_grid):
+        assert np.isnan(self.cat["M"]).sum() == 0, "If you want to make a map, provide a value for the particle mass"
+        bins = np.linspace(0, self.L, N_grid + 1)
+        if self.is2D:
+            coords = np.vstack([self.cat["x"], self.cat["y"]]).T
+            bins = (bins, bins)
+        else:
+            coords = np.vstack([self.cat["x"], self.cat["y"], self.cat["z"]]).T
+            bins = (bins, bins, bins)
+        return np.histogramdd(coords, bins=bins, weights=self.cat["M"])[0]
+

@@ -140,6 +140,30 @@ typedef struct {
 #define BFG_VARIANT_SCATTER_QUARTER 2  /* one 16-lane group per halo, global f64 atomics       */
 #define BFG_VARIANT_TILE_LDS 3         /* sky-tile privatised accumulation in LDS              */
 
+/* BaryonifySnapshot.process (Runners/SnapshotRunner.py:176-275): for every halo, the particles within
+ * min(epsilon_max R / a, L / 2) (periodic box) are displaced radially by model.displacement(d, M, a)
+ * (Profiles/BaryonCorrection.py:331-419, linear table as for bfg_baryonify_offsets); positions are shifted
+ * and wrapped into [0, L] once at the end.  Replaces the scipy KDTree + python halo loop.
+ * d_halo rows: (M, ln M as used for the table -- the reference's float32 catalogue gives a float32
+ * logarithm --, x, y, z [0 in 2D], extras...).  bfg_stats.pixel_updates counts (halo, particle) pairs.   */
+typedef struct {
+    int32_t ndim;              /* 2 or 3                                                          */
+    int32_t rdelta_sampling;   /* model.Rdelta_sampling (BaryonCorrection.py:406-408)             */
+    int64_t n_part, n_halo;
+    double L;                  /* box size, comoving Mpc                                          */
+    double a;                  /* scale factor of the snapshot                                    */
+    const double *d_part;      /* device, float64[n_part][ndim]                                   */
+    const double *d_halo;      /* device, float64[n_halo][halo_stride]                            */
+    int32_t halo_stride;       /* >= 5 + n_extra                                                  */
+    int32_t n_extra;           /* extra table coordinates per halo (p_keys)                       */
+    double epsilon_max;        /* runner cut in halo radii (SnapshotRunner.py:223)                */
+    bfg_massdef runner_md;     /* mass definition of the runner (:222)                            */
+    bfg_massdef model_md;      /* mass definition of the model (BaryonCorrection.py:399)          */
+    double model_epsilon_max;  /* model.epsilon_max (:410)                                        */
+} bfg_snapshot_args;
+int bfg_baryonify_snapshot(bfg_ctx *ctx, const bfg_snapshot_args *args, const bfg_table *table,
+                           double *d_out /* device, float64[n_part][ndim] */);
+
 /* Counters the kernels maintain (device side), fetched with bfg_stats_read. */
 typedef struct {
     uint64_t pixel_updates;   /* P_tot = sum_j |disc_j| (incl. the 4-neighbour fallback)  */

@@ -96,6 +96,73 @@ def test_paint_shell_golden(golden, cosmo, tag, variant):
     assert R.last_stats["pixel_updates"] >= np.count_nonzero(ref)
 
 
+def _snapshot_inputs(g, tag, cosmo):
+    is2D = bool(g[f"{tag}_is2D"])
+    P, H = g[f"{tag}_P"], g[f"{tag}_H"]
+    L, zs = float(g[f"{tag}_L"]), float(g[f"{tag}_redshift"])
+    Cat = bfg.HaloNDCatalog(H[:, 0], H[:, 1], g[f"{tag}_hM"], zs, cosmo, z=None if is2D else H[:, 2])
+    Part = bfg.ParticleSnapshot(x=P[:, 0], y=P[:, 1], z=None if is2D else P[:, 2], M=np.ones(P.shape[0]), L=L,
+                                redshift=zs, cosmo=cosmo)
+    model = bfg.Baryonification2D.from_arrays(g[f"{tag}_zax"], g[f"{tag}_Max"], g[f"{tag}_rax"], g[f"{tag}_d"], cosmo,
+                                              epsilon_max=float(g[f"{tag}_eps_model"]),
+                                              Rdelta_sampling=bool(g[f"{tag}_rdelta"]))
+    return Cat, Part, model, is2D, L
+
+
+def _periodic_close(got, ref, L, atol):
+    d = np.abs(got - ref)
+    d = np.minimum(d, L - d)                          # a particle that lands on the box edge may wrap either way
+    assert d.max() <= atol, f"max periodic deviation {d.max():.3e} > {atol:.1e}"
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_baryonify_snapshot_golden(golden, cosmo, tag):
+    """BaryonifySnapshot (SnapshotRunner.py:162-275) against the reference's own run; displacements are ~0.1 Mpc, so
+    1e-9 Mpc absolute is 1e-8 relative on the shift (tolerance of the path: 1e-5)"""
+    import warnings
+    g = golden("snapshot.npz")
+    Cat, Part, model, is2D, L = _snapshot_inputs(g, tag, cosmo)
+    R = bfg.BaryonifySnapshot(Cat, Part, epsilon_max=float(g[f"{tag}_eps"]), model=model, verbose=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        new = R.process()
+    assert new.dtype == Part.cat.dtype and new.size == Part.cat.size
+    got = np.stack([new["x"], new["y"]] + ([] if is2D else [new["z"]]), axis=1)
+    _periodic_close(got, g[f"{tag}_P_new"], L, 1e-9)
+    assert np.array_equal(new["M"], Part.cat["M"])
+    moved_ref = np.any(g[f"{tag}_P_new"] != g[f"{tag}_P"], axis=1)
+    moved_got = np.any(got != g[f"{tag}_P"], axis=1)
+    assert np.array_equal(moved_ref, moved_got)       # exactly the same particles are displaced
+
+
+@pytest.mark.parametrize("is2D", [False, True])
+def test_baryonify_snapshot_vs_oracle(cosmo, is2D):
+    """larger box than the golden cases, vs the oracle (KDTree restatement): many cells, halos on the box faces"""
+    import warnings
+    rng = np.random.default_rng(123 + int(is2D))
+    L, npart, nhalo = 300.0, 400000, 1500
+    nd = 2 if is2D else 3
+    P = rng.uniform(0, L, (npart, nd))
+    H = rng.uniform(0, L, (nhalo, nd))
+    H[:20] = np.where(rng.uniform(size=(20, nd)) < 0.5, rng.uniform(0, 0.5, (20, nd)), L - rng.uniform(0, 0.5, (20, nd)))
+    hM = 10 ** rng.uniform(13.0, 15.4, nhalo)
+    zax, Max, rax, d = syn.displacement_table()
+    zs = 0.3
+    Cat = bfg.HaloNDCatalog(H[:, 0], H[:, 1], hM, zs, cosmo, z=None if is2D else H[:, 2])
+    Part = bfg.ParticleSnapshot(x=P[:, 0], y=P[:, 1], z=None if is2D else P[:, 2], M=np.ones(npart), L=L, redshift=zs,
+                                cosmo=cosmo)
+    model = bfg.Baryonification2D.from_arrays(zax, Max, rax, d, cosmo, epsilon_max=20)
+    R = bfg.BaryonifySnapshot(Cat, Part, epsilon_max=10, model=model, verbose=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        new = R.process()
+        ref = orc.baryonify_snapshot(cosmo, L, zs, P[:, 0], P[:, 1], None if is2D else P[:, 2], hM, H[:, 0], H[:, 1],
+                                     None if is2D else H[:, 2], (zax, Max, rax), d, 10, 20)
+    got = np.stack([new["x"], new["y"]] + ([] if is2D else [new["z"]]), axis=1)
+    _periodic_close(got, ref, L, 1e-9)
+    assert R.last_stats["pixel_updates"] > 0
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_paint_anis_shell_golden(golden, cosmo, tag):
     """PaintProfilesAnisShell (HealpixRunner.py:486-640) against the reference's own run"""

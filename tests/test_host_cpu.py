@@ -283,3 +283,32 @@ def test_anis_runner_conventions(cosmo):
         with pytest.raises(Exception):
             R.process()
 
+
+def test_snapshot_containers_and_runner_conventions(cosmo):
+    """HaloNDCatalog keeps float32 big-endian columns (io.py:204), ParticleSnapshot float64 + NGP make_map (io.py:629-677)"""
+    rng = np.random.default_rng(2)
+    H = rng.uniform(0, 50, (7, 3))
+    Cat = bfg.HaloNDCatalog(H[:, 0], H[:, 1], 10 ** rng.uniform(13, 15, 7), 0.3, cosmo, z=H[:, 2], cdelta=np.arange(7.0))
+    assert Cat.cat.dtype["M"] == np.dtype(">f4") and Cat.cat.dtype["x"] == np.dtype(">f4") and "cdelta" in Cat.cat.dtype.names
+    assert Cat.cosmology is cosmo and Cat.redshift == 0.3 and Cat.data is Cat.cat
+    Cat2 = bfg.HaloNDCatalog(H[:, 0], H[:, 1], np.ones(7), 0.3, cosmo)
+    assert np.all(Cat2.cat["z"] == 0)
+    with pytest.raises(ValueError):
+        bfg.HaloNDCatalog(H[:, 0], H[:, 1], np.ones(7), 0.3, {"Omega_m": 0.3})
+    P = rng.uniform(0, 50, (1000, 3))
+    S = bfg.ParticleSnapshot(x=P[:, 0], y=P[:, 1], z=P[:, 2], M=np.full(1000, 2.0), L=50.0, redshift=0.3, cosmo=cosmo)
+    assert not S.is2D and S.cat.dtype["x"] == np.float64
+    m = S.make_map(8)
+    assert m.shape == (8, 8, 8) and np.isclose(m.sum(), 2000.0)
+    S2 = bfg.ParticleSnapshot(x=P[:, 0], y=P[:, 1], M=np.ones(1000), L=50.0, redshift=0.3, cosmo=cosmo)
+    assert S2.is2D and S2.make_map(4).shape == (4, 4)
+    zax, Max, rax, d = syn.displacement_table()
+    model = bfg.Baryonification2D.from_arrays(zax, Max, rax, d, cosmo, epsilon_max=20)
+    R = bfg.BaryonifySnapshot(Cat, S, epsilon_max=10, model=model, verbose=False)
+    assert R.cosmo is cosmo and R.epsilon_max == 10 and R.model is model
+    np.testing.assert_allclose(R.compute_distance(np.array([49.0]), np.array([0.0])), [1.0])
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception):
+            R.process()
+
