@@ -35,7 +35,7 @@ SYMBOLS = [
     "bfg_table_create", "bfg_table_destroy", "bfg_table_eval",
     "bfg_spline_create", "bfg_spline_destroy",
     "bfg_paint_shell", "bfg_baryonify_offsets", "bfg_regrid_shell", "bfg_reduce_absmax_sum",
-    "bfg_baryonify_snapshot",
+    "bfg_baryonify_snapshot", "bfg_deposit_grid",
     "bfg_stats_reset", "bfg_stats_read", "bfg_timing_enable", "bfg_timing_read",
 ]
 
@@ -122,6 +122,7 @@ def load(build_if_missing=True):
     L.bfg_spline_destroy.argtypes = [_vp, _vp]
     L.bfg_paint_shell.argtypes = [_vp, C.POINTER(ShellArgs), _vp, _vp, _vp]
     L.bfg_baryonify_snapshot.argtypes = [_vp, C.POINTER(SnapshotArgs), _vp, _vp]
+    L.bfg_deposit_grid.argtypes = [_vp, C.c_int, _i64, _vp, _vp, _dbl, C.c_int, C.c_int, _vp]
     L.bfg_baryonify_offsets.argtypes = [_vp, C.POINTER(ShellArgs), _vp, _vp, _vp]
     L.bfg_regrid_shell.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp]
     L.bfg_reduce_absmax_sum.argtypes = [_vp, _i64, _vp, C.POINTER(_dbl), C.POINTER(_dbl)]

@@ -1632,6 +1632,24 @@ int bfg_baryonify_snapshot(bfg_ctx *c, const bfg_snapshot_args *a, const bfg_tab
     return BFG_OK;
 }
 
+int bfg_deposit_grid(bfg_ctx *c, int ndim, int64_t n_part, const double *d_pos, const double *d_mass, double L,
+                     int n_grid, int mode, double *d_grid)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    if ((ndim != 2 && ndim != 3) || n_part < 0 || !(L > 0) || n_grid < 1 || (mode != BFG_DEPOSIT_NGP && mode != BFG_DEPOSIT_CIC) ||
+        !d_grid || (n_part > 0 && !d_pos))
+        return BFG_ERR_INVALID;
+    if (n_part == 0) return BFG_OK;
+    DepositParams P;
+    P.ndim = ndim; P.mode = mode; P.N = n_grid; P.n_part = n_part; P.L = L; P.pos = d_pos; P.mass = d_mass; P.grid = d_grid;
+    const unsigned grid = (unsigned)((n_part + 255) / 256);
+    if (ndim == 3) hipLaunchKernelGGL(deposit_kernel<3>, dim3(grid), dim3(256), 0, c->stream, P);
+    else hipLaunchKernelGGL(deposit_kernel<2>, dim3(grid), dim3(256), 0, c->stream, P);
+    HIP_TRY(hipGetLastError());
+    return BFG_OK;
+}
+
 int bfg_stats_reset(bfg_ctx *c)
 {
     int rc = ctx_enter(c);

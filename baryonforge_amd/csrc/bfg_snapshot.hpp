@@ -273,4 +273,67 @@ __global__ __launch_bounds__(256) void snap_apply_kernel(const SnapParams P)
     P.out[i] = v;
 }
 
+// Mass deposit of particles on a periodic N^ndim grid: mode 0 = nearest grid point with numpy.histogramdd's bin
+// rule on edges linspace(0, L, N + 1) (ParticleSnapshot.make_map, io.py:629-677: right-open bins, the last one
+// closed); mode 1 = cloud-in-cell on cell centres (i + 1/2) L / N with periodic wrap.  mass == nullptr: unit masses.
+struct DepositParams {
+    int ndim, mode, N;
+    int64_t n_part;
+    double L;
+    const double *pos;               // [n_part][ndim]
+    const double *mass;              // [n_part] or nullptr
+    double *grid;                    // [N^ndim], C order (x slowest), accumulated into
+};
+
+__device__ inline int ngp_bin(double x, double step, int N, double L)
+{
+    // np.histogramdd: searchsorted(edges, x, 'right') - 1, with x == edges[-1] put into the last bin; outside -> dropped
+    if (!(x >= 0.0) || !(x <= L)) return -1;
+    int i = (int)floor(x / step);
+    i = min(max(i, 0), N - 1);
+    // edges as numpy.linspace builds them: i * step, the last one exactly L
+    const double e0 = (double)i * step, e1 = (i + 1 == N) ? L : (double)(i + 1) * step;
+    if (x < e0) --i; else if (x >= e1 && i + 1 < N) ++i;
+    return i;
+}
+
+template <int NDIM>
+__global__ __launch_bounds__(256) void deposit_kernel(const DepositParams P)
+{
+    const int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= P.n_part) return;
+    const double m = P.mass ? P.mass[ip] : 1.0;
+    const double step = P.L / (double)P.N;
+    if (P.mode == 0) {
+        int64_t c = 0;
+        for (int k = 0; k < NDIM; ++k) {
+            const int i = ngp_bin(P.pos[ip * NDIM + k], step, P.N, P.L);
+            if (i < 0) return;
+            c = c * P.N + i;
+        }
+        unsafeAtomicAdd(P.grid + c, m);
+    } else {
+        int i0[NDIM];
+        double w1[NDIM];
+        for (int k = 0; k < NDIM; ++k) {
+            const double u = P.pos[ip * NDIM + k] / step - 0.5;     // in units of cells, relative to cell centres
+            const double f = floor(u);
+            w1[k] = u - f;
+            int i = (int)f % P.N; if (i < 0) i += P.N;
+            i0[k] = i;
+        }
+        for (int corner = 0; corner < (1 << NDIM); ++corner) {
+            double w = m;
+            int64_t c = 0;
+            for (int k = 0; k < NDIM; ++k) {
+                const int bit = (corner >> k) & 1;
+                w *= bit ? w1[k] : 1.0 - w1[k];
+                int i = i0[k] + bit; if (i >= P.N) i -= P.N;
+                c = c * P.N + i;
+            }
+            if (w != 0.0) unsafeAtomicAdd(P.grid + c, w);
+        }
+    }
+}
+
 }  // namespace bfg

@@ -204,6 +204,16 @@ class Context(object):
         _lib.check(self.lib.bfg_baryonify_snapshot(self.handle, C.byref(args), table.handle,
                                                    C.c_void_p(d_out.data_ptr())), "bfg_baryonify_snapshot")
 
+    def deposit_grid(self, d_pos, d_mass, L, n_grid, mode="ngp"):
+        """mass map float64[n_grid]*ndim of particles d_pos float64[n, ndim] (d_mass float64[n] or None)"""
+        ndim = int(d_pos.shape[1])
+        d_grid = self.zeros(*([int(n_grid)] * ndim))
+        _lib.check(self.lib.bfg_deposit_grid(self.handle, ndim, int(d_pos.shape[0]), C.c_void_p(d_pos.data_ptr()),
+                                             C.c_void_p(d_mass.data_ptr()) if d_mass is not None else None, float(L),
+                                             int(n_grid), {"ngp": 0, "cic": 1}[mode], C.c_void_p(d_grid.data_ptr())),
+                   "bfg_deposit_grid")
+        return d_grid
+
     def absmax_sum(self, d_x):
         amax, s = C.c_double(), C.c_double()
         _lib.check(self.lib.bfg_reduce_absmax_sum(self.handle, d_x.numel(), C.c_void_p(d_x.data_ptr()),

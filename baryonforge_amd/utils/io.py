@@ -188,8 +188,16 @@ class ParticleSnapshot(object):
     def cosmology(self):
         return self.cosmo
 
-    def make_map(self, N_grid):
+    def make_map(self, N_grid, mode="ngp", device=False):
+        """mode 'ngp' (the reference's histogram) or 'cic' (cloud-in-cell, periodic); device=True deposits on the GPU
+        (bfg_deposit_grid) -- the host path is numpy, as in the reference, and only does 'ngp'."""
         assert np.isnan(self.cat["M"]).sum() == 0, "If you want to make a map, provide a value for the particle mass"
+        if device or mode != "ngp":
+            from ..engine import get_context
+            ctx = get_context()
+            cols = ("x", "y") if self.is2D else ("x", "y", "z")
+            d_pos = ctx.to_device(np.stack([self.cat[c] for c in cols], axis=1))
+            return ctx.deposit_grid(d_pos, ctx.to_device(self.cat["M"]), self.L, N_grid, mode).cpu().numpy()
         bins = np.linspace(0, self.L, N_grid + 1)
         if self.is2D:
             coords = np.vstack([self.cat["x"], self.cat["y"]]).T

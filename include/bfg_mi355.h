@@ -164,6 +164,15 @@ typedef struct {
 int bfg_baryonify_snapshot(bfg_ctx *ctx, const bfg_snapshot_args *args, const bfg_table *table,
                            double *d_out /* device, float64[n_part][ndim] */);
 
+/* Mass map of a particle set on a periodic N^ndim grid, accumulated INTO d_grid (float64[N^ndim], C order):
+ * mode BFG_DEPOSIT_NGP = ParticleSnapshot.make_map (utils/io.py:629-677, numpy.histogramdd on
+ * linspace(0, L, N + 1)); BFG_DEPOSIT_CIC = cloud-in-cell on cell centres, periodic.
+ * d_mass may be NULL (unit masses).                                                          */
+#define BFG_DEPOSIT_NGP 0
+#define BFG_DEPOSIT_CIC 1
+int bfg_deposit_grid(bfg_ctx *ctx, int ndim, int64_t n_part, const double *d_pos, const double *d_mass,
+                     double L, int n_grid, int mode, double *d_grid);
+
 /* Counters the kernels maintain (device side), fetched with bfg_stats_read. */
 typedef struct {
     uint64_t pixel_updates;   /* P_tot = sum_j |disc_j| (incl. the 4-neighbour fallback)  */

@@ -440,3 +440,29 @@ def baryonify_snapshot(cosmo, L, redshift, px, py, pz, hM, hx, hy, hz, axes, val
     new = np.where(new < 0, new + L, new)
     return new
 
+
+def make_map(pos, mass, L, n_grid, mode="ngp"):
+    """Mass map of particles pos[n, ndim] on a periodic n_grid^ndim grid.  'ngp' = ParticleSnapshot.make_map
+    (io.py:629-677: numpy.histogramdd on linspace(0, L, n_grid + 1)); 'cic' = cloud-in-cell on the cell centres
+    (i + 1/2) L / n_grid with periodic wrap (the BASELINE config asks for CIC; the reference itself only has NGP)."""
+    pos = _f(pos)
+    ndim = pos.shape[1]
+    mass = np.ones(pos.shape[0]) if mass is None else _f(mass)
+    if mode == "ngp":
+        bins = np.linspace(0, L, n_grid + 1)
+        return np.histogramdd(pos, bins=(bins,) * ndim, weights=mass)[0]
+    u = pos / (L / n_grid) - 0.5
+    f = np.floor(u)
+    w1 = u - f
+    i0 = f.astype(np.int64) % n_grid
+    out = np.zeros((n_grid,) * ndim)
+    for corner in range(1 << ndim):
+        w = mass.copy()
+        idx = []
+        for k in range(ndim):
+            bit = (corner >> k) & 1
+            w = w * (w1[:, k] if bit else 1.0 - w1[:, k])
+            idx.append((i0[:, k] + bit) % n_grid)
+        np.add.at(out, tuple(idx), w)
+    return out
+

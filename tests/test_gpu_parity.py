@@ -163,6 +163,28 @@ def test_baryonify_snapshot_vs_oracle(cosmo, is2D):
     assert R.last_stats["pixel_updates"] > 0
 
 
+@pytest.mark.parametrize("ndim", [2, 3])
+@pytest.mark.parametrize("mode", ["ngp", "cic"])
+def test_deposit_grid_vs_oracle(cosmo, ndim, mode):
+    """bfg_deposit_grid: NGP = numpy.histogramdd of ParticleSnapshot.make_map (io.py:629-677), incl. particles exactly on
+    bin edges and on the box faces; CIC vs the oracle's numpy cloud-in-cell"""
+    rng = np.random.default_rng(17 + ndim)
+    L, N, n = 75.0, 48 if ndim == 3 else 200, 200000
+    P = rng.uniform(0, L, (n, ndim))
+    edges = np.linspace(0, L, N + 1)
+    P[:2000] = edges[rng.integers(0, N + 1, (2000, ndim))]          # exactly on edges, 0 and L included
+    M = rng.uniform(0.5, 2.0, n)
+    S = bfg.ParticleSnapshot(x=P[:, 0], y=P[:, 1], z=P[:, 2] if ndim == 3 else None, M=M, L=L, redshift=0.1, cosmo=cosmo)
+    got = S.make_map(N, mode=mode, device=True)
+    ref = orc.make_map(P, M, L, N, mode)
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12)
+    if mode == "ngp":
+        np.testing.assert_allclose(S.make_map(N), ref, rtol=1e-12, atol=1e-12)     # the host path is the reference's
+    else:
+        assert np.isclose(got.sum(), M.sum(), rtol=1e-12)
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_paint_anis_shell_golden(golden, cosmo, tag):
     """PaintProfilesAnisShell (HealpixRunner.py:486-640) against the reference's own run"""
