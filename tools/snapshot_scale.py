@@ -23,6 +23,8 @@ npart = n1 ** 3
 ax = (torch.arange(n1, device=dev, dtype=torch.float64) + 0.5) * (L / n1)
 P = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), dim=-1).reshape(-1, 3)
 P = (P + (torch.rand(P.shape, generator=g, device=dev, dtype=torch.float64) - 0.5) * (L / n1)) % L
+if os.environ.get('SNAP_SHUFFLE'):
+    P = P[torch.randperm(P.shape[0], device=dev, generator=g)].contiguous()      # arbitrary particle order
 rng = np.random.default_rng(3)
 H = rng.uniform(0, L, (nhalo, 3)).astype(">f4").astype(np.float64)
 hM = (10 ** rng.uniform(13.0, 15.3, nhalo)).astype(">f4")
