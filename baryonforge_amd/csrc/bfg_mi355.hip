@@ -101,6 +101,9 @@ struct bfg_ctx {
     int32_t *d_pairs;
     bfg::HaloDisp *d_hd;            // [cap_halo] baryonify tile path
     int32_t *d_left;                // [cap_halo + 1] tile variant: [0] = count, then the halos left to the scatter kernel
+    // bfg_baryonify_snapshot workspace (grow-only)
+    void *snap_buf[8];
+    size_t snap_cap[8];
     int64_t pair_cap;
     unsigned long long *d_pair_total;
     double *d_mathtab;              // logtab (256 doubles) | exptab (64 doubles)
@@ -1013,6 +1016,7 @@ int bfg_ctx_destroy(bfg_ctx *c)
     }
     if (c->d_hd) (void)hipFree(c->d_hd);
     if (c->d_left) (void)hipFree(c->d_left);
+    for (int k = 0; k < 8; ++k) if (c->snap_buf[k]) (void)hipFree(c->snap_buf[k]);
     if (c->d_pairs) (void)hipFree(c->d_pairs);
     (void)hipFree(c->d_mathtab); (void)hipFree(c->d_pair_total);
     for (int k = 0; k < 5; ++k) {
@@ -1594,21 +1598,24 @@ int bfg_baryonify_snapshot(bfg_ctx *c, const bfg_snapshot_args *a, const bfg_tab
     P.ncell = ncell;
     P.ncell_tot = (a->ndim == 3) ? (int64_t)ncell * ncell * ncell : (int64_t)ncell * ncell;
     const int64_t nblk = (P.ncell_tot + 1023) / 1024;
-    int32_t *d_bsum = nullptr, *d_total = nullptr;
-    auto cleanup = [&]() {
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipFree(P.cell_count); (void)hipFree(P.cell_start); (void)hipFree(P.order); (void)hipFree(P.hs);
-        (void)hipFree(P.hrow); (void)hipFree(P.off); (void)hipFree(d_bsum); (void)hipFree(d_total);
-    };
-#define SNAP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_last_error = std::string(#expr) + ": " + hipGetErrorString(e_); cleanup(); return BFG_ERR_HIP; } } while (0)
-    SNAP_TRY(hipMalloc((void **)&P.cell_count, (size_t)P.ncell_tot * sizeof(int32_t)));
-    SNAP_TRY(hipMalloc((void **)&P.cell_start, (size_t)(P.ncell_tot + 1) * sizeof(int32_t)));
-    SNAP_TRY(hipMalloc((void **)&P.order, (size_t)a->n_part * sizeof(int32_t)));
-    SNAP_TRY(hipMalloc((void **)&P.hs, (size_t)std::max<int64_t>(a->n_halo, 1) * sizeof(SnapHalo)));
-    SNAP_TRY(hipMalloc((void **)&P.hrow, (size_t)std::max<int64_t>(a->n_halo, 1) * t->dev.nr * sizeof(double)));
-    SNAP_TRY(hipMalloc((void **)&P.off, (size_t)a->n_part * a->ndim * sizeof(double)));
-    SNAP_TRY(hipMalloc((void **)&d_bsum, (size_t)nblk * sizeof(int32_t)));
-    SNAP_TRY(hipMalloc((void **)&d_total, sizeof(int32_t)));
+    // workspace kept in the context between calls (hipMalloc / hipFree of GBs per call costs 100+ ms)
+    const size_t want[8] = {(size_t)P.ncell_tot * sizeof(int32_t), (size_t)(P.ncell_tot + 1) * sizeof(int32_t),
+                            (size_t)a->n_part * sizeof(int32_t), (size_t)std::max<int64_t>(a->n_halo, 1) * sizeof(SnapHalo),
+                            (size_t)std::max<int64_t>(a->n_halo, 1) * t->dev.nr * sizeof(double),
+                            (size_t)a->n_part * a->ndim * sizeof(double), (size_t)nblk * sizeof(int32_t), sizeof(int32_t)};
+    for (int k = 0; k < 8; ++k) {
+        if (want[k] > c->snap_cap[k]) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->snap_buf[k]) (void)hipFree(c->snap_buf[k]);
+            c->snap_buf[k] = nullptr; c->snap_cap[k] = 0;
+            HIP_TRY(hipMalloc(&c->snap_buf[k], want[k]));
+            c->snap_cap[k] = want[k];
+        }
+    }
+    P.cell_count = (int32_t *)c->snap_buf[0]; P.cell_start = (int32_t *)c->snap_buf[1]; P.order = (int32_t *)c->snap_buf[2];
+    P.hs = (SnapHalo *)c->snap_buf[3]; P.hrow = (double *)c->snap_buf[4]; P.off = (double *)c->snap_buf[5];
+    int32_t *d_bsum = (int32_t *)c->snap_buf[6], *d_total = (int32_t *)c->snap_buf[7];
+#define SNAP_TRY(expr) HIP_TRY(expr)
     SNAP_TRY(hipMemsetAsync(P.cell_count, 0, (size_t)P.ncell_tot * sizeof(int32_t), c->stream));
     SNAP_TRY(hipMemsetAsync(P.off, 0, (size_t)a->n_part * a->ndim * sizeof(double), c->stream));
     const unsigned pgrid = (unsigned)((a->n_part + 255) / 256);
@@ -1628,7 +1635,6 @@ int bfg_baryonify_snapshot(bfg_ctx *c, const bfg_snapshot_args *a, const bfg_tab
     hipLaunchKernelGGL(snap_apply_kernel, dim3((unsigned)((a->n_part * a->ndim + 255) / 256)), dim3(256), 0, c->stream, P);
     SNAP_TRY(hipGetLastError());
 #undef SNAP_TRY
-    cleanup();
     return BFG_OK;
 }
 
