@@ -96,6 +96,45 @@ def test_paint_shell_golden(golden, cosmo, tag, variant):
     assert R.last_stats["pixel_updates"] >= np.count_nonzero(ref)
 
 
+def test_paint_headline_full_size_vs_oracle(cosmo):
+    """The headline workload itself (bench.py defaults: 1e6 halos, NSIDE 1024, eps 10, seed 42) against the oracle run
+    split-join over the host cores (Parallelize.py:255-318 analogue): every non-zero pixel within 1e-5 relative,
+    identical pixel-update count and identical non-zero pixel set."""
+    import os
+    nside, n = 1024, 1000000
+    ra, dec, M, z = syn.catalog(n, seed=42)
+    zax, Max, rax, T = syn.pressure_table()
+    a, R, D = orc.halo_scalars(cosmo, M, z)
+    njobs = max(1, min(32, (os.cpu_count() or 1)))
+    with np.errstate(all="ignore"):
+        ref, ptot = orc.paint_shell(nside, ra, dec, M, a, D, R, (zax, Max, rax), np.log(T), 10, njobs=njobs)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    Run = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), 10,
+                                 _paint_model(zax, Max, rax, T), verbose=False)
+    got = Run.process()
+    assert Run.last_stats["pixel_updates"] == ptot
+    assert np.array_equal(got != 0, ref != 0)
+    assert_maps_close(got, ref, RTOL, what="headline paint 1e6 halos")
+
+
+def test_baryonify_config2_full_size_vs_oracle(cosmo):
+    """BASELINE config[2] at full size (1e5 halos, NSIDE 1024, eps 10, model eps 20), the whole BaryonifyShell pipeline
+    (offsets + regrid) against the oracle; mass conserved as the reference asserts (HealpixRunner.py:368-370)"""
+    import warnings
+    nside, n = 1024, 100000
+    ra, dec, M, z = syn.catalog(n, seed=42)
+    zax, Max, rax, d = syn.displacement_table()
+    m_in = syn.mass_map(nside)
+    ref = oracle_baryonify(cosmo, ra, dec, M, z, (zax, Max, rax), d, nside, 10, 20, m_in)
+    model = bfg.Baryonification2D.from_arrays(zax, Max, rax, d, cosmo, epsilon_max=20)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo), 10, model, verbose=False).process()
+    assert np.isclose(got.sum(), m_in.sum(), rtol=1e-5, atol=1e-8)
+    assert_maps_close(got, ref, RTOL, floor=BFLOOR, what="baryonify config 2")
+
+
 def _snapshot_inputs(g, tag, cosmo):
     is2D = bool(g[f"{tag}_is2D"])
     P, H = g[f"{tag}_P"], g[f"{tag}_H"]
