@@ -466,3 +466,141 @@ def make_map(pos, mass, L, n_grid, mode="ngp"):
         np.add.at(out, tuple(idx), w)
     return out
 
+
+# --------------------------------------------------------------------------
+# Periodic Cartesian grids (BaryonForge/Runners/Map2DRunner.py)
+# --------------------------------------------------------------------------
+def _grid_cutout(bins, Npix, res, hpos, R_cut):
+    """the cut-out of one halo as Map2DRunner builds it (:485-505 / :720-742): even size, stretched linspace offsets,
+    nearest-bin centre, wrapped index ranges"""
+    Nsize = 2 * R_cut / res
+    Nsize = int(Nsize // 2) * 2
+    Nsize = int(np.clip(Nsize, 2, bins.size // 2))
+    x = np.linspace(-Nsize / 2, Nsize / 2, Nsize) * res
+    w = Nsize // 2
+    cen = [int(np.argmin(np.abs(bins - h))) for h in hpos]
+    inds = []
+    for c in cen:                                                            # pick_indices (:400-428)
+        i = np.arange(c - w, c + w)
+        i = np.where(i < 0, i + Npix, i)
+        i = np.where(i >= Npix, i - Npix, i)
+        inds.append(i)
+    d = [bins[c] - h for c, h in zip(cen, hpos)]
+    return x, inds, d
+
+
+def _grid_flat_and_r(x, inds, d, Npix):
+    """flat map indices of the cut-out and the offsets (x_grid + dx, y_grid + dy[, z_grid + dz]) paired with them, in the
+    reference's pairing: inds[x_inds, :][:, y_inds].flatten() against np.meshgrid(x, x, indexing='xy') (:507-516)"""
+    if len(inds) == 2:
+        flat = (inds[0][:, None] * Npix + inds[1][None, :]).ravel()
+        xg, yg = np.meshgrid(x, x, indexing="xy")
+        comps = [(xg + d[0]).ravel(), (yg + d[1]).ravel()]
+    else:
+        flat = ((inds[0][:, None, None] * Npix + inds[1][None, :, None]) * Npix + inds[2][None, None, :]).ravel()
+        xg, yg, zg = np.meshgrid(x, x, x, indexing="xy")
+        comps = [(xg + d[0]).ravel(), (yg + d[1]).ravel(), (zg + d[2]).ravel()]
+    return flat, comps
+
+
+def paint_grid(cosmo, bins, shape, redshift, hpos, hM, axes, T, eps_run, include_pixel_size=True, Delta=200,
+               rho_type="critical"):
+    """PaintProfilesGrid.process (Map2DRunner.py:676-829) without ellipticity.  hpos [n, ndim], T = the raw table the model
+    reads for this dimensionality (projected for 2D maps, real for 3D).  Halo columns are narrowed to float32 as in
+    HaloNDCatalog (io.py:204); ln M is a float32 logarithm (Tabulate.py:316)."""
+    bins = _f(bins)
+    Npix, nd = bins.size, len(shape)
+    res = bins[1] - bins[0]
+    a = 1 / (1 + redshift)
+    new_map = np.zeros(int(np.prod(shape)))
+    with np.errstate(all="ignore"):
+        lnT = np.log(_f(T))
+    hpos32 = np.asarray(hpos, dtype=np.float32).astype(np.float64)
+    for j in range(hpos32.shape[0]):
+        M32 = np.float32(hM[j])
+        R_j = float(get_radius(cosmo, float(M32), a, Delta, rho_type)) / a                  # comoving (:708)
+        x, inds, d = _grid_cutout(bins, Npix, res, hpos32[j, :nd], eps_run * R_j)
+        flat, comps = _grid_flat_and_r(x, inds, d, Npix)
+        r = np.sqrt(sum(c * c for c in comps))
+        with np.errstate(all="ignore"):
+            pts = np.stack([np.full(r.size, np.log(1 / a)), np.full(r.size, float(np.log(M32))), np.log(r)], axis=1)
+            P = np.exp(interp_linear(axes, lnT, pts))
+        mask = np.isfinite(P) & (r < R_j * eps_run)                                         # :812-815
+        if mask.sum() == 0:
+            continue
+        new_map[flat] += np.where(mask, P, 0)                                                # :820-823
+    if include_pixel_size:
+        new_map *= res ** nd                                                                  # :826
+    return new_map.reshape(shape)
+
+
+def regrid_pixels_grid(N, positions, values, nd):
+    """regrid_pixels_2D / regrid_pixels_3D (Map2DRunner.py:14-82, :86-162): every unit pixel displaced to `positions`
+    (pixel units) deposits value x overlap onto the periodic N^nd grid; grid[i, j(, k)] with i from the y-range, j from
+    the x-range (and k from z).  Vectorised over pixels, candidate cells as in the reference loops."""
+    start = np.mod(_f(positions), N)                                                          # :52 / :127
+    end = start + 1
+    out = np.zeros((N,) * nd)
+    offs = np.arange(-2, 4)                                                                    # int(start) - 2 ... int(end) + 1
+    base = start.astype(np.int64)                                                              # int() truncation, start >= 0
+
+    def overlaps(axis):
+        c = base[:, axis][:, None] + offs[None, :]                                             # candidate cells
+        valid = c < (end[:, axis].astype(np.int64) + 2)[:, None]                               # range(x_min, x_max)
+        c = np.where(c < 0, c + N, c)
+        c = np.where(c + 1 > N, c % N, c)
+        s, e = start[:, axis][:, None], end[:, axis][:, None]
+        dx = np.minimum(c + 1, e) - np.maximum(c, s)
+        dx = np.where(dx < 0, np.minimum(c + 1, e + N) - np.maximum(c, s + N), dx)
+        dx = np.where(dx < 0, np.minimum(c + 1, e - N) - np.maximum(c, s - N), dx)
+        return c, np.where(valid, dx, -1.0)
+
+    cx, dx = overlaps(0)
+    cy, dy = overlaps(1)
+    v = _f(values)
+    if nd == 2:
+        w = dy[:, :, None] * dx[:, None, :]
+        ok = (dy[:, :, None] > 0) & (dx[:, None, :] > 0)
+        ii = np.broadcast_to(cy[:, :, None], w.shape)
+        jj = np.broadcast_to(cx[:, None, :], w.shape)
+        np.add.at(out, (ii[ok], jj[ok]), (w * v[:, None, None])[ok])
+    else:
+        cz, dz = overlaps(2)
+        w = dy[:, :, None, None] * dx[:, None, :, None] * dz[:, None, None, :]
+        ok = (dy[:, :, None, None] > 0) & (dx[:, None, :, None] > 0) & (dz[:, None, None, :] > 0)
+        ii = np.broadcast_to(cy[:, :, None, None], w.shape)
+        jj = np.broadcast_to(cx[:, None, :, None], w.shape)
+        kk = np.broadcast_to(cz[:, None, None, :], w.shape)
+        np.add.at(out, (ii[ok], jj[ok], kk[ok]), (w * v[:, None, None, None])[ok])
+    return out
+
+
+def baryonify_grid(cosmo, bins, orig_map, redshift, hpos, hM, axes, d_table, eps_run, eps_model, rdelta_sampling=False,
+                   Delta=200, rho_type="critical"):
+    """BaryonifyGrid.process (Map2DRunner.py:431-621) without ellipticity: per-pixel offsets (in pixel widths) summed over
+    halos, then the overlap regrid; mass conserved (:617-619)."""
+    bins = _f(bins)
+    orig_map = _f(orig_map)
+    Npix, nd = bins.size, orig_map.ndim
+    res = bins[1] - bins[0]
+    a = 1 / (1 + redshift)
+    pix_offsets = np.zeros((orig_map.size, nd))
+    hpos32 = np.asarray(hpos, dtype=np.float32).astype(np.float64)
+    for j in range(hpos32.shape[0]):
+        M32 = np.float32(hM[j])
+        R_j = float(get_radius(cosmo, float(M32), a, Delta, rho_type))                     # physical (:471)
+        R_q = np.clip(eps_run * R_j / a, 0, np.max(bins) / 2)                               # :473-474
+        x, inds, d = _grid_cutout(bins, Npix, res, hpos32[j, :nd], R_q)
+        flat, comps = _grid_flat_and_r(x, inds, d, Npix)
+        r = np.sqrt(sum(c * c for c in comps))
+        with np.errstate(all="ignore"):
+            off = displacement_readout(cosmo, axes, d_table, r, float(M32), a, eps_model, rdelta_sampling, Delta, rho_type,
+                                       lnM=float(np.log(M32))) / res                        # :530 / :570
+            for k in range(nd):
+                pix_offsets[flat, k] += off * (comps[k] / r)
+    pix_offsets = np.where(np.isfinite(pix_offsets), pix_offsets, 0)                        # :591 / :603
+    grids = np.meshgrid(*([np.arange(Npix)] * nd), indexing="xy")
+    for k in range(nd):
+        pix_offsets[:, k] += grids[k].ravel()
+    return regrid_pixels_grid(Npix, pix_offsets, orig_map.ravel(), nd)
+

@@ -261,6 +261,8 @@ def main(only=None):
         return anis_section(ccl, io, run, make_tabulated, mdef)
     if only == "snapshot":
         return snapshot_section(io, make_disp, mdef)
+    if only == "grid":
+        return grid_section(io, make_tabulated, make_disp, mdef)
 
     # ---------------------------------------------------------------- 1. read-outs
     out = {}
@@ -402,6 +404,7 @@ def main(only=None):
 
     anis_section(ccl, io, run, make_tabulated, mdef)
     snapshot_section(io, make_disp, mdef)
+    grid_section(io, make_tabulated, make_disp, mdef)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
@@ -473,6 +476,55 @@ def snapshot_section(io, make_disp, mdef):
         moved = np.abs(new - old); moved = np.minimum(moved, L - moved)
         print("snapshot", tag, "moved particles", np.count_nonzero(moved.max(axis=1) > 0), "max shift", moved.max())
     np.savez_compressed(os.path.join(HERE, "snapshot.npz"), **out)
+
+
+def grid_section(io, make_tabulated, make_disp, mdef):
+    """8. PaintProfilesGrid.process / BaryonifyGrid.process (Map2DRunner.py:376-829) on periodic 2D / 3D grids, run
+    verbatim (numba.njit = identity, so regrid_pixels_2D/3D are the reference's own python loops)"""
+    m2d = load("BaryonForge.Runners.Map2DRunner", "Runners/Map2DRunner.py")
+    out = {}
+    for tag, is2D, Npix, L, nhalo, seed, eps, ips in (("p2", True, 96, 60.0, 40, 81, 4, True), ("p3", False, 24, 30.0, 25, 82, 3, False)):
+        rng = np.random.default_rng(seed)
+        res = L / Npix
+        bins = (np.arange(Npix) + 0.5) * res                 # pixel centres; GriddedMap.L = bins[-1] + res/2 (io.py:457)
+        nd = 2 if is2D else 3
+        H = rng.uniform(0, L, (nhalo, 3))
+        H[:4] = [[0.1, 0.2, L - 0.1], [L - 0.2, L / 2, 0.3], [L / 2, L - 0.05, L / 2], [res * 5.5, res * 7.5, res * 3.5]]
+        hM = 10 ** rng.uniform(13.0, 15.0, nhalo)
+        zax, Max, rax, T = paint_table(bad_block=(tag == "p3"))
+        prof = make_tabulated(zax, Max, rax, T, T3D=T * 1.7)
+        Cat = io.HaloNDCatalog(H[:, 0], H[:, 1], hM, 0.3, COSMO, z=None if is2D else H[:, 2])
+        Map = io.GriddedMap(map=np.zeros((Npix,) * nd), redshift=0.3, bins=bins, cosmo=COSMO)
+        resmap = m2d.PaintProfilesGrid(Cat, Map, epsilon_max=eps, model=prof, mass_def=mdef, include_pixel_size=ips,
+                                       verbose=False).process()
+        out.update({f"{tag}_is2D": np.array(is2D), f"{tag}_Npix": np.array(Npix), f"{tag}_bins": bins, f"{tag}_H": H[:, :nd],
+                    f"{tag}_hM": hM, f"{tag}_redshift": np.array(0.3), f"{tag}_eps": np.array(eps), f"{tag}_ips": np.array(ips),
+                    f"{tag}_zax": zax, f"{tag}_Max": Max, f"{tag}_rax": rax, f"{tag}_T2D": T, f"{tag}_T3D": T * 1.7,
+                    f"{tag}_map": resmap})
+        print("grid paint", tag, "sum", resmap.sum(), "nonzero", np.count_nonzero(resmap))
+    for tag, is2D, Npix, L, nhalo, seed, eps, rdelta, emod in (("b2", True, 64, 80.0, 30, 83, 5, False, 20),
+                                                               ("b3", False, 16, 40.0, 12, 84, 3, True, 4)):
+        rng = np.random.default_rng(seed)
+        res = L / Npix
+        bins = (np.arange(Npix) + 0.5) * res
+        nd = 2 if is2D else 3
+        H = rng.uniform(0, L, (nhalo, 3))
+        H[:3] = [[0.1, 0.2, L - 0.1], [L - 0.2, L / 2, 0.3], [res * 5.5, res * 7.5, res * 3.5]]
+        hM = 10 ** rng.uniform(13.5, 15.3, nhalo)
+        zd, Md, rd, d = disp_table(rdelta=rdelta)
+        d = d * 8.0                                            # displacements of a good fraction of a pixel
+        disp = make_disp(zd, Md, rd, d, rdelta=rdelta, eps=emod)
+        m_in = rng.uniform(0, 10, (Npix,) * nd)
+        m_in[rng.uniform(size=m_in.shape) < 0.1] = 0.0
+        Cat = io.HaloNDCatalog(H[:, 0], H[:, 1], hM, 0.3, COSMO, z=None if is2D else H[:, 2])
+        Map = io.GriddedMap(map=m_in, redshift=0.3, bins=bins, cosmo=COSMO)
+        resmap = m2d.BaryonifyGrid(Cat, Map, epsilon_max=eps, model=disp, mass_def=mdef, verbose=False).process()
+        out.update({f"{tag}_is2D": np.array(is2D), f"{tag}_Npix": np.array(Npix), f"{tag}_bins": bins, f"{tag}_H": H[:, :nd],
+                    f"{tag}_hM": hM, f"{tag}_redshift": np.array(0.3), f"{tag}_eps": np.array(eps),
+                    f"{tag}_eps_model": np.array(emod), f"{tag}_rdelta": np.array(rdelta), f"{tag}_zax": zd, f"{tag}_Max": Md,
+                    f"{tag}_rax": rd, f"{tag}_d": d, f"{tag}_map_in": m_in, f"{tag}_map_out": resmap})
+        print("grid baryonify", tag, "sum in/out", m_in.sum(), resmap.sum(), "changed", np.count_nonzero(~np.isclose(resmap, m_in)))
+    np.savez_compressed(os.path.join(HERE, "grid.npz"), **out)
 
 
 if __name__ == "__main__":

@@ -167,3 +167,28 @@ def test_oracle_snapshot_matches_reference(golden, cosmo, tag):
                                float(g[f"{tag}_eps_model"]), bool(g[f"{tag}_rdelta"]))
     np.testing.assert_allclose(got, g[f"{tag}_P_new"], rtol=0, atol=1e-11)
 
+
+@pytest.mark.parametrize("tag", ["p2", "p3"])
+def test_oracle_paint_grid_matches_reference(golden, cosmo, tag):
+    """oracle restatement of PaintProfilesGrid.process vs the reference's own run (make_golden.py grid)"""
+    g = golden("grid.npz")
+    is2D = bool(g[f"{tag}_is2D"])
+    N = int(g[f"{tag}_Npix"])
+    got = o.paint_grid(cosmo, g[f"{tag}_bins"], (N,) * (2 if is2D else 3), float(g[f"{tag}_redshift"]), g[f"{tag}_H"],
+                       g[f"{tag}_hM"], (g[f"{tag}_zax"], g[f"{tag}_Max"], g[f"{tag}_rax"]),
+                       g[f"{tag}_T2D"] if is2D else g[f"{tag}_T3D"], float(g[f"{tag}_eps"]), bool(g[f"{tag}_ips"]))
+    ref = g[f"{tag}_map"]
+    assert np.array_equal(got != 0, ref != 0)
+    np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-300)
+
+
+@pytest.mark.parametrize("tag", ["b2", "b3"])
+def test_oracle_baryonify_grid_matches_reference(golden, cosmo, tag):
+    """oracle restatement of BaryonifyGrid.process (incl. regrid_pixels_2D/3D) vs the reference's own run"""
+    g = golden("grid.npz")
+    got = o.baryonify_grid(cosmo, g[f"{tag}_bins"], g[f"{tag}_map_in"], float(g[f"{tag}_redshift"]), g[f"{tag}_H"],
+                           g[f"{tag}_hM"], (g[f"{tag}_zax"], g[f"{tag}_Max"], g[f"{tag}_rax"]), g[f"{tag}_d"],
+                           float(g[f"{tag}_eps"]), float(g[f"{tag}_eps_model"]), bool(g[f"{tag}_rdelta"]))
+    ref = g[f"{tag}_map_out"]
+    np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-10)
+
