@@ -1,0 +1,183 @@
+"""
+Periodic Cartesian-grid runners, mirroring BaryonForge/Runners/Map2DRunner.py: `DefaultRunnerGrid` (:170-373),
+`BaryonifyGrid` (:376-621), `PaintProfilesGrid` (:624-829) and the overlap regrid `regrid_pixels_2D/_3D` (:14-162).
+Same constructors, attributes and `process() -> ndarray` of the map's shape; the per-halo python loops and the numba
+regrid are replaced by bfg_paint_grid / bfg_baryonify_grid_offsets / bfg_regrid_grid (csrc/bfg_grid.hpp).  No CPU
+fallback.  Ellipticity (use_ellipticity=True) and PaintProfilesAnisGrid are not built.
+"""
+import numpy as np
+
+from ..background import Background, MassDef
+from ..engine import emit_range_warnings, get_context
+from ..utils.Tabulate import ParamTabulatedProfile
+from .HealpixRunner import _is_disp_table, _is_paint_table, _table_axes
+
+__all__ = ["DefaultRunnerGrid", "BaryonifyGrid", "PaintProfilesGrid", "regrid_pixels_2D", "regrid_pixels_3D"]
+
+
+def _regrid_host(grid, pix_positions, pix_values):
+    """host utility behind regrid_pixels_2D/_3D (API parity; the runners regrid on the GPU): the reference's candidate
+    cells and periodic overlap rules (Map2DRunner.py:48-82, :122-162), vectorised over pixels"""
+    N, nd = grid.shape[0], grid.ndim
+    start = np.mod(np.asarray(pix_positions, dtype=np.float64), N)
+    end = start + 1
+    offs = np.arange(-2, 4)
+    base = start.astype(np.int64)
+    cells, ov = [], []
+    for ax in range(nd):
+        c = base[:, ax][:, None] + offs[None, :]
+        valid = c < (end[:, ax].astype(np.int64) + 2)[:, None]
+        c = np.where(c < 0, c + N, c)
+        c = np.where(c + 1 > N, c % N, c)
+        s, e = start[:, ax][:, None], end[:, ax][:, None]
+        d = np.minimum(c + 1, e) - np.maximum(c, s)
+        d = np.where(d < 0, np.minimum(c + 1, e + N) - np.maximum(c, s + N), d)
+        d = np.where(d < 0, np.minimum(c + 1, e - N) - np.maximum(c, s - N), d)
+        cells.append(c)
+        ov.append(np.where(valid, d, -1.0))
+    v = np.asarray(pix_values, dtype=np.float64)
+    order = [1, 0] + ([2] if nd == 3 else [])                 # grid[i, j(, k)]: i from the y range, j from x, k from z
+    shape = (v.size,) + (offs.size,) * nd
+    w = v.reshape((-1,) + (1,) * nd) * np.ones(shape)
+    ok = np.ones(shape, dtype=bool)
+    idx = []
+    for pos, ax in enumerate(order):
+        sl = [slice(None)] + [None] * nd
+        sl[pos + 1] = slice(None)
+        w = w * ov[ax][tuple(sl)]
+        ok &= (ov[ax][tuple(sl)] > 0)
+        idx.append(np.broadcast_to(cells[ax][tuple(sl)], shape))
+    np.add.at(grid, tuple(i[ok] for i in idx), w[ok])
+    return grid
+
+
+def regrid_pixels_2D(grid, pix_positions, pix_values):
+    """grid[i, j] += overlap * value for every displaced unit pixel (Map2DRunner.py:14-82); modifies grid in place"""
+    _regrid_host(grid, pix_positions, pix_values)
+
+
+def regrid_pixels_3D(grid, pix_positions, pix_values):
+    """3D version (Map2DRunner.py:86-162)"""
+    _regrid_host(grid, pix_positions, pix_values)
+
+
+class DefaultRunnerGrid(object):
+    """Base class (Map2DRunner.py:170-373): catalog, gridded map, `epsilon_max`, `model`, mass definition."""
+
+    def __init__(self, HaloNDCatalog, GriddedMap, epsilon_max, model, use_ellipticity=False, mass_def=None,
+                 include_pixel_size=True, verbose=True):
+        self.HaloNDCatalog = HaloNDCatalog
+        self.GriddedMap = GriddedMap
+        self.cosmo = HaloNDCatalog.cosmology
+        self.model = model
+        self.epsilon_max = epsilon_max
+        self.mass_def = MassDef(200, "critical") if mass_def is None else mass_def
+        self.verbose = verbose
+        self.use_ellipticity = use_ellipticity
+        self.include_pixel_size = include_pixel_size
+        self.last_stats = None
+        if use_ellipticity:
+            raise NotImplementedError("use_ellipticity = True is not built on the MI355X grid path")
+
+    def coord_array(self, *args):
+        return np.vstack([a.flatten() for a in args]).T
+
+    def pick_indices(self, center, width, Npix):
+        """Map2DRunner.py:400-428"""
+        inds = np.arange(center - width, center + width)
+        inds = np.where(inds < 0, inds + Npix, inds)
+        inds = np.where(inds >= Npix, inds - Npix, inds)
+        return inds
+
+    # ---- shared set-up --------------------------------------------------------------------------
+    def _keys_checked(self):
+        keys = vars(self.model).get("p_keys", []) if self.model is not None else []
+        if len(keys) > 0:                                                   # :455-459 / :692-696
+            txt = (f"You asked to use {keys} properties in Baryonification. You must pass a ParamTabulatedProfile"
+                   f"as the model. You have passed {type(self.model)} instead")
+            assert isinstance(self.model, ParamTabulatedProfile) or type(self.model).__name__ == "ParamTabulatedProfile", txt
+        return list(keys)
+
+    def _device_inputs(self, ctx, keys):
+        hcat = self.HaloNDCatalog.cat
+        # float32 catalogue columns (io.py:204): exact widening, but ln M is a float32 logarithm (Tabulate.py:316)
+        with np.errstate(all="ignore"):
+            lnM = np.log(hcat["M"]).astype(np.float64)
+        cols = [hcat["M"].astype(np.float64), lnM, hcat["x"].astype(np.float64), hcat["y"].astype(np.float64),
+                hcat["z"].astype(np.float64)] + [np.asarray(hcat[k], dtype=np.float64) for k in keys]
+        halos = np.stack(cols, axis=1) if hcat.size else np.zeros((0, 5 + len(keys)))
+        return ctx.to_device(halos), ctx.to_device(np.asarray(self.GriddedMap.bins, dtype=np.float64))
+
+
+class PaintProfilesGrid(DefaultRunnerGrid):
+    """Paint a tabulated profile around every halo onto the periodic grid (Map2DRunner.py:624-829): `model.projected`
+    (raw_input_2D) on 2D maps, `model.real` (raw_input_3D) on 3D maps."""
+
+    def process(self):
+        assert self.model is not None, "You must provide a model"
+        keys = self._keys_checked()
+        if not _is_paint_table(self.model):
+            if hasattr(self.model, "setup_interpolator"):
+                raise NameError("No Table created. Run setup_interpolator() method first")
+            raise TypeError(f"PaintProfilesGrid on the MI355X path needs a tabulated model; got {type(self.model)}")
+        ctx = get_context()
+        gm = self.GriddedMap
+        ndim = 2 if gm.is2D else 3
+        raw = self.model.raw_input_2D if gm.is2D else self.model.raw_input_3D
+
+        def log_table():
+            with np.errstate(all="ignore"):
+                return np.log(np.asarray(raw, dtype=np.float64))
+        table = ctx.table(_table_axes(self.model, keys), log_table, log_values=True,
+                          cache_key=(id(self.model), "grid%dD" % ndim, id(raw)))
+        d_halo, d_bins = self._device_inputs(ctx, keys)
+        bg = Background(self.cosmo)
+        a = 1 / (1 + self.HaloNDCatalog.redshift)                          # :707
+        args = ctx.grid_args(ndim, gm.Npix, d_bins, d_halo, a, self.epsilon_max, ctx.massdef_struct(bg, self.mass_def),
+                             n_extra=len(keys))
+        d_map = ctx.zeros(int(np.prod(np.shape(gm.map))))                  # :685
+        ctx.stats_reset()
+        ctx.paint_grid(args, table, d_map)
+        self.last_stats = ctx.stats()
+        if self.include_pixel_size:
+            d_map *= float(np.power(gm.res, ndim))                         # :826
+        return d_map.cpu().numpy().reshape(np.shape(gm.map))
+
+
+class BaryonifyGrid(DefaultRunnerGrid):
+    """Baryonify a MASS grid with a tabulated displacement model (Map2DRunner.py:376-621)."""
+
+    def process(self):
+        keys = self._keys_checked()
+        if not _is_disp_table(self.model):
+            if self.model is not None and hasattr(self.model, "displacement"):
+                raise NameError("No Table created. Run setup_interpolator() method first")
+            raise TypeError(f"BaryonifyGrid needs a BaryonificationClass model with a displacement table; got {type(self.model)}")
+        ctx = get_context()
+        gm, model = self.GriddedMap, self.model
+        ndim = 2 if gm.is2D else 3
+        table = ctx.table(_table_axes(model, keys), lambda: np.asarray(model.raw_input_d, dtype=np.float64),
+                          log_values=False, cache_key=(id(model), "d", id(model.raw_input_d)))
+        d_halo, d_bins = self._device_inputs(ctx, keys)
+        bg = Background(self.cosmo)
+        model_bg = Background(model.cosmo) if getattr(model, "cosmo", None) is not None else bg
+        a = 1 / (1 + self.HaloNDCatalog.redshift)                          # :470
+        args = ctx.grid_args(ndim, gm.Npix, d_bins, d_halo, a, self.epsilon_max, ctx.massdef_struct(bg, self.mass_def),
+                             model_md=ctx.massdef_struct(model_bg, getattr(model, "mass_def", None)),
+                             model_epsilon_max=model.epsilon_max, rdelta_sampling=getattr(model, "Rdelta_sampling", False),
+                             n_extra=len(keys))
+        orig = np.ascontiguousarray(gm.map, dtype=np.float64)
+        npx = orig.size
+        d_off = ctx.zeros(npx, ndim)                                       # :450
+        ctx.stats_reset()
+        ctx.baryonify_grid_offsets(args, table, d_off)                     # :463-584
+        self.last_stats = ctx.stats()
+        emit_range_warnings(self.last_stats, "table")
+        d_in = ctx.to_device(orig.reshape(-1))
+        d_out = ctx.zeros(npx)
+        ctx.regrid_grid(ndim, gm.Npix, d_off, d_in, d_out)                 # :586-613
+        new_map = d_out.cpu().numpy().reshape(orig.shape)
+        new_sum, old_sum = np.sum(new_map), np.sum(orig)                   # :616-619
+        assert np.isclose(new_sum, old_sum), \
+            "ERROR in pixel regridding, sum(new_map) [%0.14e] != sum(oldmap) [%0.14e]" % (new_sum, old_sum)
+        return new_map

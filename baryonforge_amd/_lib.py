@@ -35,7 +35,7 @@ SYMBOLS = [
     "bfg_table_create", "bfg_table_destroy", "bfg_table_eval",
     "bfg_spline_create", "bfg_spline_destroy",
     "bfg_paint_shell", "bfg_baryonify_offsets", "bfg_regrid_shell", "bfg_reduce_absmax_sum",
-    "bfg_baryonify_snapshot", "bfg_deposit_grid",
+    "bfg_baryonify_snapshot", "bfg_deposit_grid", "bfg_paint_grid", "bfg_baryonify_grid_offsets", "bfg_regrid_grid",
     "bfg_stats_reset", "bfg_stats_read", "bfg_timing_enable", "bfg_timing_read",
 ]
 
@@ -56,6 +56,13 @@ class ShellArgs(C.Structure):
 class SnapshotArgs(C.Structure):
     _fields_ = [("ndim", C.c_int32), ("rdelta_sampling", C.c_int32), ("n_part", _i64), ("n_halo", _i64),
                 ("L", _dbl), ("a", _dbl), ("d_part", _vp), ("d_halo", _vp), ("halo_stride", C.c_int32),
+                ("n_extra", C.c_int32), ("epsilon_max", _dbl), ("runner_md", MassDefStruct),
+                ("model_md", MassDefStruct), ("model_epsilon_max", _dbl)]
+
+
+class GridArgs(C.Structure):
+    _fields_ = [("ndim", C.c_int32), ("rdelta_sampling", C.c_int32), ("n_halo", _i64), ("npix", C.c_int32),
+                ("reserved", C.c_int32), ("a", _dbl), ("d_bins", _vp), ("d_halo", _vp), ("halo_stride", C.c_int32),
                 ("n_extra", C.c_int32), ("epsilon_max", _dbl), ("runner_md", MassDefStruct),
                 ("model_md", MassDefStruct), ("model_epsilon_max", _dbl)]
 
@@ -122,6 +129,9 @@ def load(build_if_missing=True):
     L.bfg_spline_destroy.argtypes = [_vp, _vp]
     L.bfg_paint_shell.argtypes = [_vp, C.POINTER(ShellArgs), _vp, _vp, _vp]
     L.bfg_baryonify_snapshot.argtypes = [_vp, C.POINTER(SnapshotArgs), _vp, _vp]
+    L.bfg_paint_grid.argtypes = [_vp, C.POINTER(GridArgs), _vp, _vp]
+    L.bfg_baryonify_grid_offsets.argtypes = [_vp, C.POINTER(GridArgs), _vp, _vp]
+    L.bfg_regrid_grid.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _vp]
     L.bfg_deposit_grid.argtypes = [_vp, C.c_int, _i64, _vp, _vp, _dbl, C.c_int, C.c_int, _vp]
     L.bfg_baryonify_offsets.argtypes = [_vp, C.POINTER(ShellArgs), _vp, _vp, _vp]
     L.bfg_regrid_shell.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp]

@@ -1,0 +1,256 @@
+// bfg_grid.hpp -- periodic Cartesian grid runners (BaryonForge/Runners/Map2DRunner.py) on the GPU:
+// PaintProfilesGrid.process (:676-829), BaryonifyGrid.process (:431-621) and regrid_pixels_2D / _3D (:14-162).
+//
+// The reference cuts a (2w)^d window of pixels out of the periodic map around every halo (w from eps R / res, even,
+// clipped), evaluates radii on a *stretched* offset grid np.linspace(-w, w, 2w) * res shifted by the sub-pixel offset of
+// the halo from its nearest pixel centre, and pairs those offsets with the window's pixels in np.meshgrid(..., 'xy')
+// order against inds[x_inds, :][:, y_inds] -- so the first window axis carries the y offsets and the second the x
+// offsets.  All of that is reproduced literally (the oracle restates it line by line and is pinned by the reference's
+// own output).  One workgroup per halo walks its window; values / offsets go to the map with f64 global atomics.
+// Included by bfg_mi355.hip after DevTable / massdef_radius / SnapHalo helpers are defined.
+#pragma once
+
+namespace bfg {
+
+struct __align__(16) GridHalo {
+    double d[3];                     // bins[cen] - halo coordinate
+    double rmask;                    // paint: eps R_com (pixels at or beyond it are masked, :815)
+    double xcut;                     // baryonify: model.epsilon_max * R_model_com
+    double lnshift;                  // ln(R_model_com) for Rdelta_sampling tables, else 0
+    int32_t cen[3];
+    int32_t nsize, flags, pad;
+};
+
+struct GridParams {
+    int ndim, npix, mode, rdelta;    // mode: MODE_PAINT / MODE_BARYONIFY
+    int64_t n_halo;
+    double res, a, eps_run, eps_model;
+    bfg_massdef md_run, md_model;
+    const double *bins;              // [npix] pixel centres
+    const double *halo;              // [n_halo][stride]: M, lnM (table coordinate), x, y, z, extras...
+    int halo_stride, n_extra;
+    DevTable tab;
+    GridHalo *gh;                    // [n_halo]
+    double *hrow;                    // [n_halo][tab.nr] blended radial rows (ln T for paint, d for baryonify)
+    double *out;                     // paint: map [npix^ndim]; baryonify: offsets [npix^ndim][ndim] (pixel widths)
+    bfg_stats *stats;
+};
+
+// np.argmin(np.abs(bins - h)): nearest pixel centre, the lowest index on ties
+__device__ inline int grid_nearest_bin(const double *bins, int n, double res, double h)
+{
+    int i = (int)floor((h - bins[0]) / res + 0.5);
+    i = min(max(i, 0), n - 1);
+    int best = i;
+    double dbest = fabs(bins[i] - h);
+    for (int c = max(i - 1, 0); c <= min(i + 1, n - 1); ++c) {
+        const double dc = fabs(bins[c] - h);
+        if (dc < dbest || (dc == dbest && c < best)) { best = c; dbest = dc; }
+    }
+    return best;
+}
+
+__global__ __launch_bounds__(64) void grid_halo_kernel(const GridParams P)
+{
+    const int64_t j = blockIdx.x;
+    const int lane = threadIdx.x;
+    const double *c = P.halo + j * P.halo_stride;
+    const double M = c[0], lnM = c[1];
+    const DevTable &T = P.tab;
+    __shared__ double s_w[kMaxCorner];
+    __shared__ int64_t s_off[kMaxCorner];
+    __shared__ int s_oob;
+    if (lane == 0) {
+        const double R = massdef_radius(P.md_run, M, P.a);                          // physical Mpc (:471 / :708)
+        const double Rcom = R / P.a;
+        const double Rm = massdef_radius(P.md_model, M, P.a) / P.a;
+        double rcut;
+        if (P.mode == MODE_PAINT) rcut = P.eps_run * Rcom;                          // :718
+        else {
+            double bmax = P.bins[0];
+            bmax = fmax(bmax, P.bins[P.npix - 1]);
+            rcut = fmin(fmax(P.eps_run * R / P.a, 0.0), 0.5 * bmax);                // :473-474 (bins ascend: max = last)
+        }
+        double ns = 2.0 * rcut / P.res;                                             // :484-486 / :718-720
+        long long nsz = (long long)floor(ns / 2.0) * 2;
+        if (!(ns == ns)) nsz = 2;
+        nsz = std::min<long long>(std::max<long long>(nsz, 2), P.npix / 2);
+        GridHalo h;
+        h.nsize = (int)nsz; h.flags = 0; h.pad = 0;
+        for (int k = 0; k < 3; ++k) { h.cen[k] = 0; h.d[k] = 0.0; }
+        for (int k = 0; k < P.ndim; ++k) {
+            h.cen[k] = grid_nearest_bin(P.bins, P.npix, P.res, c[2 + k]);           // :492-494
+            h.d[k] = P.bins[h.cen[k]] - c[2 + k];                                   // :500-502
+        }
+        h.rmask = Rcom * P.eps_run;                                                 // :815
+        h.xcut = P.eps_model * Rm;                                                  // BaryonCorrection.py:410
+        h.lnshift = P.rdelta ? log(Rm) : 0.0;
+        bool oob = false;
+        uint32_t warn = 0;
+        int idx[BFG_MAX_DIM];
+        double wt[BFG_MAX_DIM];
+        for (int k = 0; k < T.nouter; ++k) {
+            const double x = (k == 0) ? log(1.0 / P.a) : (k == 1) ? lnM : c[5 + (k - 2)];
+            const double *g = T.oaxis[k];
+            const int n = T.oshape[k];
+            if (!(x >= g[0]) || !(x <= g[n - 1])) {
+                oob = true;
+                if (k == 0) warn |= BFG_WARN_Z_RANGE;
+                if (k == 1) warn |= BFG_WARN_M_RANGE;
+            }
+            idx[k] = find_interval(g, n, x);
+            wt[k] = (x - g[idx[k]]) / (g[idx[k] + 1] - g[idx[k]]);
+        }
+        const int ncorner = 1 << T.nouter;
+        for (int cc = 0; cc < ncorner; ++cc) {
+            double w = 1.0;
+            int64_t off = 0;
+            for (int k = 0; k < T.nouter; ++k) {
+                const int bit = (cc >> (T.nouter - 1 - k)) & 1;
+                w *= bit ? wt[k] : 1.0 - wt[k];
+                off += (int64_t)(idx[k] + bit) * T.ostride[k];
+            }
+            s_w[cc] = w; s_off[cc] = off;
+        }
+        s_oob = oob ? 1 : 0;
+        if (oob) {
+            h.flags = HF_OOB;
+            atomicAdd((unsigned long long *)&P.stats->halos_out_of_table, 1ull);
+            atomicOr(&P.stats->warn_mask, warn);
+        }
+        P.gh[j] = h;
+    }
+    __syncthreads();
+    const int ncorner = 1 << T.nouter;
+    for (int i = lane; i < T.nr; i += 64) {
+        double b = 0.0;
+        for (int cc = 0; cc < ncorner; ++cc) b = fma(T.values[s_off[cc] + i], s_w[cc], b);
+        P.hrow[j * T.nr + i] = s_oob ? nan("") : b;
+    }
+}
+
+// offset m of np.linspace(-n/2, n/2, n) * res  (numpy: arange(n) * step + start, the last element set to stop)
+__device__ inline double grid_linspace(int m, int n, double res)
+{
+    const double start = -0.5 * (double)n, stop = 0.5 * (double)n;
+    const double step = (stop - start) / (double)(n - 1);
+    const double v = (m == n - 1) ? stop : (double)m * step + start;
+    return v * res;
+}
+
+template <int NDIM, int MODE>
+__global__ __launch_bounds__(256) void grid_window_kernel(const GridParams P)
+{
+    const int64_t j = blockIdx.x;
+    const GridHalo h = P.gh[j];
+    const DevTable &T = P.tab;
+    const int n = h.nsize, w = n / 2, N = P.npix;
+    const int64_t ncell = (NDIM == 2) ? (int64_t)n * n : (int64_t)n * n * n;
+    const double *row = P.hrow + j * T.nr;
+    const double r_lo = T.raxis[0], r_hi = T.raxis[T.nr - 1];
+    unsigned long long cnt = 0, n_oob = 0;
+    for (int64_t q = threadIdx.x; q < ncell; q += blockDim.x) {
+        // window element (a, b[, c]) in C order: map pixel (x_inds[a], y_inds[b][, z_inds[c]]), offsets of the
+        // 'xy' meshgrid: x offset = x[b], y offset = x[a], z offset = x[c]   (:507-516 / :545-556)
+        int ia, ib, ic = 0;
+        if (NDIM == 2) { ia = (int)(q / n); ib = (int)(q % n); }
+        else { ia = (int)(q / ((int64_t)n * n)); ib = (int)((q / n) % n); ic = (int)(q % n); }
+        int pa = h.cen[0] - w + ia; pa = (pa < 0) ? pa + N : pa; pa = (pa >= N) ? pa - N : pa;          // pick_indices
+        int pb = h.cen[1] - w + ib; pb = (pb < 0) ? pb + N : pb; pb = (pb >= N) ? pb - N : pb;
+        int64_t flat = (int64_t)pa * N + pb;
+        double comp[3];
+        comp[0] = grid_linspace(ib, n, P.res) + h.d[0];
+        comp[1] = grid_linspace(ia, n, P.res) + h.d[1];
+        double r2 = comp[0] * comp[0] + comp[1] * comp[1];
+        if (NDIM == 3) {
+            int pc = h.cen[2] - w + ic; pc = (pc < 0) ? pc + N : pc; pc = (pc >= N) ? pc - N : pc;
+            flat = flat * N + pc;
+            comp[2] = grid_linspace(ic, n, P.res) + h.d[2];
+            r2 += comp[2] * comp[2];
+        }
+        const double r = sqrt(r2);
+        ++cnt;
+        // table read-out on the halo's blended row: NaN outside the radial hull
+        const double rin = log(r) - ((MODE == MODE_BARYONIFY) ? h.lnshift : 0.0);
+        double val = nan("");
+        if ((rin >= r_lo) && (rin <= r_hi)) {
+            const int i = find_interval(T.raxis, T.nr, rin);
+            const double f = (rin - T.raxis[i]) / (T.raxis[i + 1] - T.raxis[i]);
+            val = row[i] * (1.0 - f) + row[i + 1] * f;
+        } else if (!(h.flags & HF_OOB)) ++n_oob;
+        if (MODE == MODE_PAINT) {
+            const double Pv = exp(val);                                              // Tabulate.py:319
+            if ((fabs(Pv) <= 1.797e308) && (r < h.rmask)) unsafeAtomicAdd(P.out + flat, Pv);          // :812-823
+        } else {
+            // BaryonCorrection.py:410-411: 0 at or beyond eps R, else the (possibly NaN) table value; the reference adds
+            // NaN contributions too -- they poison the pixel's offset, which is zeroed before the regrid (:591 / :603)
+            const double off = (r < h.xcut) ? val / P.res : 0.0;                     // :530 / :570, in pixel widths
+            for (int k = 0; k < NDIM; ++k) unsafeAtomicAdd(P.out + flat * NDIM + k, off * (comp[k] / r));
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_down(cnt, o, 64); n_oob += __shfl_down(n_oob, o, 64); }
+    if ((threadIdx.x & 63) == 0) {
+        if (cnt) atomicAdd((unsigned long long *)&P.stats->pixel_updates, cnt);
+        if (n_oob) {
+            atomicAdd((unsigned long long *)&P.stats->pixels_out_of_table, n_oob);
+            if (!(MODE == MODE_BARYONIFY && P.rdelta)) atomicOr(&P.stats->warn_mask, BFG_WARN_R_RANGE);
+        }
+    }
+}
+
+// regrid_pixels_2D / _3D: one thread per source pixel
+template <int NDIM>
+__global__ __launch_bounds__(256) void grid_regrid_kernel(int N, const double *__restrict__ offsets,
+                                                          const double *__restrict__ in_map, double *__restrict__ out_map)
+{
+    const int64_t ntot = (NDIM == 2) ? (int64_t)N * N : (int64_t)N * N * N;
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= ntot) return;
+    const double val = in_map[q];
+    if (val == 0.0) return;                                   // overlap * 0 adds nothing
+    // np.meshgrid(arange, ..., indexing='xy') flattened: x = second index, y = first index, z = third (:588-606)
+    int gi, gj, gk = 0;
+    if (NDIM == 2) { gi = (int)(q / N); gj = (int)(q % N); }
+    else { gi = (int)(q / ((int64_t)N * N)); gj = (int)((q / N) % N); gk = (int)(q % N); }
+    const double g[3] = {(double)gj, (double)gi, (double)gk};
+    double start[3], end[3];
+    int base[3], last[3];
+    for (int k = 0; k < NDIM; ++k) {
+        double o = offsets[q * NDIM + k];
+        if (!(fabs(o) <= 1.797e308)) o = 0.0;                 // :591 / :603
+        double s = fmod(o + g[k], (double)N);                 // python %: result in [0, N)
+        if (s < 0.0) s += (double)N;
+        if (s >= (double)N) s -= (double)N;
+        start[k] = s; end[k] = s + 1.0;
+        base[k] = (int)s - 2;                                 // range(int(start) - 2, int(end) + 2)
+        last[k] = (int)end[k] + 2;
+    }
+    auto overlap = [&](int k, int cc, int &cell) -> double {
+        int c = cc;
+        if (c < 0) c += N;
+        if (c + 1 > N) c = c % N;
+        cell = c;
+        double d = fmin((double)c + 1.0, end[k]) - fmax((double)c, start[k]);
+        if (d < 0) d = fmin((double)c + 1.0, end[k] + N) - fmax((double)c, start[k] + N);
+        if (d < 0) d = fmin((double)c + 1.0, end[k] - N) - fmax((double)c, start[k] - N);
+        return d;
+    };
+    for (int ci = base[1]; ci < last[1]; ++ci) {              // i: y range
+        int ii; const double dy = overlap(1, ci, ii);
+        if (!(dy > 0)) continue;
+        for (int cj = base[0]; cj < last[0]; ++cj) {          // j: x range
+            int jj; const double dx = overlap(0, cj, jj);
+            if (!(dx > 0)) continue;
+            if (NDIM == 2) unsafeAtomicAdd(out_map + (int64_t)ii * N + jj, dx * dy * val);
+            else {
+                for (int ck = base[2]; ck < last[2]; ++ck) {
+                    int kk; const double dz = overlap(2, ck, kk);
+                    if (!(dz > 0)) continue;
+                    unsafeAtomicAdd(out_map + ((int64_t)ii * N + jj) * N + kk, dx * dy * dz * val);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace bfg

@@ -104,6 +104,8 @@ struct bfg_ctx {
     // bfg_baryonify_snapshot workspace (grow-only)
     void *snap_buf[8];
     size_t snap_cap[8];
+    void *grid_buf[2];              // grid runners: per-halo records, blended rows (grow-only)
+    size_t grid_cap[2];
     int64_t pair_cap;
     unsigned long long *d_pair_total;
     double *d_mathtab;              // logtab (256 doubles) | exptab (64 doubles)
@@ -190,6 +192,7 @@ __device__ inline double massdef_radius(const bfg_massdef &md, double M, double 
 }
 
 #include "bfg_snapshot.hpp"
+#include "bfg_grid.hpp"
 
 // scipy PPoly evaluation of the not-a-knot CubicSpline of HealpixRunner.py:299 (extrapolates)
 __device__ inline double spline_eval(int n, const double *__restrict__ x, const double *__restrict__ c, double v)
@@ -1017,6 +1020,7 @@ int bfg_ctx_destroy(bfg_ctx *c)
     if (c->d_hd) (void)hipFree(c->d_hd);
     if (c->d_left) (void)hipFree(c->d_left);
     for (int k = 0; k < 8; ++k) if (c->snap_buf[k]) (void)hipFree(c->snap_buf[k]);
+    for (int k = 0; k < 2; ++k) if (c->grid_buf[k]) (void)hipFree(c->grid_buf[k]);
     if (c->d_pairs) (void)hipFree(c->d_pairs);
     (void)hipFree(c->d_mathtab); (void)hipFree(c->d_pair_total);
     for (int k = 0; k < 5; ++k) {
@@ -1635,6 +1639,75 @@ int bfg_baryonify_snapshot(bfg_ctx *c, const bfg_snapshot_args *a, const bfg_tab
     hipLaunchKernelGGL(snap_apply_kernel, dim3((unsigned)((a->n_part * a->ndim + 255) / 256)), dim3(256), 0, c->stream, P);
     SNAP_TRY(hipGetLastError());
 #undef SNAP_TRY
+    return BFG_OK;
+}
+
+static int run_grid(bfg_ctx *c, const bfg_grid_args *a, const bfg_table *t, double *d_out, int mode)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    if (!a || !t || !d_out || (a->ndim != 2 && a->ndim != 3) || a->n_halo < 0 || a->npix < 4 || !(a->a > 0) ||
+        a->n_extra < 0 || a->halo_stride < 5 + a->n_extra || !a->d_bins)
+        return BFG_ERR_INVALID;
+    if (t->dev.ndim != 3 + a->n_extra) return BFG_ERR_INVALID;
+    if ((mode == MODE_PAINT) != (t->dev.log_values != 0)) return BFG_ERR_INVALID;          // paint: ln T; baryonify: linear d
+    if (a->n_halo == 0) return BFG_OK;
+    if (!a->d_halo) return BFG_ERR_INVALID;
+    const size_t want[2] = {(size_t)a->n_halo * sizeof(GridHalo), (size_t)a->n_halo * t->dev.nr * sizeof(double)};
+    for (int k = 0; k < 2; ++k) {
+        if (want[k] > c->grid_cap[k]) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->grid_buf[k]) (void)hipFree(c->grid_buf[k]);
+            c->grid_buf[k] = nullptr; c->grid_cap[k] = 0;
+            HIP_TRY(hipMalloc(&c->grid_buf[k], want[k]));
+            c->grid_cap[k] = want[k];
+        }
+    }
+    double b01[2];
+    HIP_TRY(hipMemcpyAsync(b01, a->d_bins, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    GridParams P;
+    std::memset(&P, 0, sizeof(P));
+    P.ndim = a->ndim; P.npix = a->npix; P.mode = mode; P.rdelta = a->rdelta_sampling; P.n_halo = a->n_halo;
+    P.res = b01[1] - b01[0];                                                               // GriddedMap.res (io.py:455)
+    if (!(P.res > 0)) return BFG_ERR_INVALID;
+    P.a = a->a; P.eps_run = a->epsilon_max; P.eps_model = a->model_epsilon_max;
+    P.md_run = a->runner_md; P.md_model = a->model_md;
+    P.bins = a->d_bins; P.halo = a->d_halo; P.halo_stride = a->halo_stride; P.n_extra = a->n_extra;
+    P.tab = t->dev; P.gh = (GridHalo *)c->grid_buf[0]; P.hrow = (double *)c->grid_buf[1]; P.out = d_out; P.stats = c->d_stats;
+    hipLaunchKernelGGL(grid_halo_kernel, dim3((unsigned)a->n_halo), dim3(64), 0, c->stream, P);
+    const dim3 g((unsigned)a->n_halo), b(256);
+    if (mode == MODE_PAINT) {
+        if (a->ndim == 2) hipLaunchKernelGGL((grid_window_kernel<2, MODE_PAINT>), g, b, 0, c->stream, P);
+        else hipLaunchKernelGGL((grid_window_kernel<3, MODE_PAINT>), g, b, 0, c->stream, P);
+    } else {
+        if (a->ndim == 2) hipLaunchKernelGGL((grid_window_kernel<2, MODE_BARYONIFY>), g, b, 0, c->stream, P);
+        else hipLaunchKernelGGL((grid_window_kernel<3, MODE_BARYONIFY>), g, b, 0, c->stream, P);
+    }
+    HIP_TRY(hipGetLastError());
+    return BFG_OK;
+}
+
+int bfg_paint_grid(bfg_ctx *c, const bfg_grid_args *a, const bfg_table *t, double *d_map)
+{
+    return run_grid(c, a, t, d_map, MODE_PAINT);
+}
+
+int bfg_baryonify_grid_offsets(bfg_ctx *c, const bfg_grid_args *a, const bfg_table *t, double *d_offsets)
+{
+    return run_grid(c, a, t, d_offsets, MODE_BARYONIFY);
+}
+
+int bfg_regrid_grid(bfg_ctx *c, int ndim, int npix, const double *d_offsets, const double *d_in_map, double *d_out_map)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    if ((ndim != 2 && ndim != 3) || npix < 1 || !d_offsets || !d_in_map || !d_out_map) return BFG_ERR_INVALID;
+    const int64_t ntot = (ndim == 2) ? (int64_t)npix * npix : (int64_t)npix * npix * npix;
+    const unsigned grid = (unsigned)((ntot + 255) / 256);
+    if (ndim == 2) hipLaunchKernelGGL(grid_regrid_kernel<2>, dim3(grid), dim3(256), 0, c->stream, npix, d_offsets, d_in_map, d_out_map);
+    else hipLaunchKernelGGL(grid_regrid_kernel<3>, dim3(grid), dim3(256), 0, c->stream, npix, d_offsets, d_in_map, d_out_map);
+    HIP_TRY(hipGetLastError());
     return BFG_OK;
 }
 

@@ -204,6 +204,33 @@ class Context(object):
         _lib.check(self.lib.bfg_baryonify_snapshot(self.handle, C.byref(args), table.handle,
                                                    C.c_void_p(d_out.data_ptr())), "bfg_baryonify_snapshot")
 
+    def grid_args(self, ndim, npix, d_bins, d_halo, a, epsilon_max, runner_md, model_md=None, model_epsilon_max=0.0,
+                  rdelta_sampling=False, n_extra=0):
+        g = _lib.GridArgs()
+        g.ndim, g.rdelta_sampling, g.n_halo, g.npix = int(ndim), int(bool(rdelta_sampling)), int(d_halo.shape[0]), int(npix)
+        g.a = float(a)
+        g.d_bins = d_bins.data_ptr()
+        g.d_halo = d_halo.data_ptr() if g.n_halo else None
+        g.halo_stride, g.n_extra = int(d_halo.shape[1]), int(n_extra)
+        g.epsilon_max = float(epsilon_max)
+        g.runner_md = runner_md
+        g.model_md = model_md if model_md is not None else runner_md
+        g.model_epsilon_max = float(model_epsilon_max)
+        return g
+
+    def paint_grid(self, args, table, d_map):
+        _lib.check(self.lib.bfg_paint_grid(self.handle, C.byref(args), table.handle, C.c_void_p(d_map.data_ptr())),
+                   "bfg_paint_grid")
+
+    def baryonify_grid_offsets(self, args, table, d_offsets):
+        _lib.check(self.lib.bfg_baryonify_grid_offsets(self.handle, C.byref(args), table.handle,
+                                                       C.c_void_p(d_offsets.data_ptr())), "bfg_baryonify_grid_offsets")
+
+    def regrid_grid(self, ndim, npix, d_offsets, d_in_map, d_out_map):
+        _lib.check(self.lib.bfg_regrid_grid(self.handle, int(ndim), int(npix), C.c_void_p(d_offsets.data_ptr()),
+                                            C.c_void_p(d_in_map.data_ptr()), C.c_void_p(d_out_map.data_ptr())),
+                   "bfg_regrid_grid")
+
     def deposit_grid(self, d_pos, d_mass, L, n_grid, mode="ngp"):
         """mass map float64[n_grid]*ndim of particles d_pos float64[n, ndim] (d_mass float64[n] or None)"""
         ndim = int(d_pos.shape[1])

@@ -10,7 +10,8 @@ import numpy as np
 
 from ..background import check_cosmology_dict
 
-__all__ = ["HaloLightConeCatalog", "LightconeShell", "HaloNDCatalog", "ParticleSnapshot", "npix2nside", "nside2npix"]
+__all__ = ["HaloLightConeCatalog", "LightconeShell", "HaloNDCatalog", "GriddedMap", "ParticleSnapshot", "npix2nside",
+           "nside2npix"]
 
 
 def nside2npix(nside):
@@ -154,6 +155,40 @@ class HaloNDCatalog(object):
     @property
     def data(self):
         return self.cat
+
+    @property
+    def cosmology(self):
+        return self.cosmo
+
+
+class GriddedMap(object):
+    """
+    Periodic 2D / 3D mass or density grid (io.py:382-495): `map` (square / cubic), `bins` (the Npix pixel centres),
+    `res`, `L` (centre of the last bin + res / 2), `Npix`, `is2D`, `grid` (np.meshgrid of the bins, 'xy') and `inds`.
+    """
+
+    def __init__(self, map=None, redshift=None, bins=None, cosmo=None):
+        self.map = map
+        self.redshift = redshift
+        self.Npix = self.map.shape[0]
+        self.res = bins[1] - bins[0]
+        self.bins = bins
+        self.L = bins[-1] + self.res / 2
+        self.is2D = True if len(self.map.shape) == 2 else False
+        if self.is2D:
+            assert self.map.shape[0] == self.map.shape[1]
+            self.grid = np.meshgrid(bins, bins, indexing="xy")
+        else:
+            assert (self.map.shape[0] == self.map.shape[1]) & (self.map.shape[1] == self.map.shape[2])
+            self.grid = np.meshgrid(bins, bins, bins, indexing="xy")
+        assert self.Npix == self.bins.size, f"Map has {self.Npix} pixels a side, but you passed {self.bins.size} bins"
+        self.inds = np.arange(self.grid[0].size).reshape(self.grid[0].shape)
+        check_cosmology_dict(cosmo)
+        self.cosmo = cosmo
+
+    @property
+    def data(self):
+        return self.map
 
     @property
     def cosmology(self):

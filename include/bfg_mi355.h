@@ -164,6 +164,37 @@ typedef struct {
 int bfg_baryonify_snapshot(bfg_ctx *ctx, const bfg_snapshot_args *args, const bfg_table *table,
                            double *d_out /* device, float64[n_part][ndim] */);
 
+/* Periodic Cartesian grid runners (Runners/Map2DRunner.py), no ellipticity.  d_halo rows as for
+ * bfg_baryonify_snapshot: (M, ln M as used for the table, x, y, z [0 in 2D], extras...); d_bins = the npix pixel
+ * centres of GriddedMap.bins (utils/io.py:450-470).
+ * bfg_paint_grid            the halo loop of PaintProfilesGrid.process (:700-823): d_map[npix^ndim] += profile in every
+ *                           halo's cut-out window (log table: raw_input_2D for 2D maps, raw_input_3D for 3D maps); the
+ *                           pixel-size factor (:826) is left to the caller.
+ * bfg_baryonify_grid_offsets the halo loop of BaryonifyGrid.process (:463-584): d_offsets[npix^ndim][ndim] += radial
+ *                           displacement / res; non-finite contributions are added as the reference adds them.
+ * bfg_regrid_grid           :586-613 + regrid_pixels_2D/_3D (:14-162): non-finite offsets -> 0, pixel positions
+ *                           index + offset, overlap-weighted deposit of d_in_map INTO d_out_map.                     */
+typedef struct {
+    int32_t ndim;              /* 2 or 3                                                          */
+    int32_t rdelta_sampling;
+    int64_t n_halo;
+    int32_t npix;              /* pixels per side                                                 */
+    int32_t reserved;
+    double a;                  /* scale factor of the map                                         */
+    const double *d_bins;      /* device, float64[npix] ascending, uniform                        */
+    const double *d_halo;      /* device, float64[n_halo][halo_stride]                            */
+    int32_t halo_stride;       /* >= 5 + n_extra                                                  */
+    int32_t n_extra;
+    double epsilon_max;
+    bfg_massdef runner_md;
+    bfg_massdef model_md;
+    double model_epsilon_max;
+} bfg_grid_args;
+int bfg_paint_grid(bfg_ctx *ctx, const bfg_grid_args *args, const bfg_table *table, double *d_map);
+int bfg_baryonify_grid_offsets(bfg_ctx *ctx, const bfg_grid_args *args, const bfg_table *table, double *d_offsets);
+int bfg_regrid_grid(bfg_ctx *ctx, int ndim, int npix, const double *d_offsets, const double *d_in_map,
+                    double *d_out_map);
+
 /* Mass map of a particle set on a periodic N^ndim grid, accumulated INTO d_grid (float64[N^ndim], C order):
  * mode BFG_DEPOSIT_NGP = ParticleSnapshot.make_map (utils/io.py:629-677, numpy.histogramdd on
  * linspace(0, L, N + 1)); BFG_DEPOSIT_CIC = cloud-in-cell on cell centres, periodic.

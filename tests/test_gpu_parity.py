@@ -135,6 +135,71 @@ def test_baryonify_config2_full_size_vs_oracle(cosmo):
     assert_maps_close(got, ref, RTOL, floor=BFLOOR, what="baryonify config 2")
 
 
+def _grid_inputs(g, tag, cosmo):
+    is2D = bool(g[f"{tag}_is2D"])
+    N, bins, H = int(g[f"{tag}_Npix"]), g[f"{tag}_bins"], g[f"{tag}_H"]
+    Cat = bfg.HaloNDCatalog(H[:, 0], H[:, 1], g[f"{tag}_hM"], float(g[f"{tag}_redshift"]), cosmo, z=None if is2D else H[:, 2])
+    return is2D, N, bins, Cat
+
+
+@pytest.mark.parametrize("tag", ["p2", "p3"])
+def test_paint_grid_golden(golden, cosmo, tag):
+    """PaintProfilesGrid (Map2DRunner.py:624-829) against the reference's own run"""
+    g = golden("grid.npz")
+    is2D, N, bins, Cat = _grid_inputs(g, tag, cosmo)
+    model = bfg.TabulatedProfile.from_arrays(g[f"{tag}_zax"], g[f"{tag}_Max"], g[f"{tag}_rax"], g[f"{tag}_T2D"], g[f"{tag}_T3D"])
+    Map = bfg.GriddedMap(map=np.zeros((N,) * (2 if is2D else 3)), redshift=float(g[f"{tag}_redshift"]), bins=bins, cosmo=cosmo)
+    got = bfg.PaintProfilesGrid(Cat, Map, float(g[f"{tag}_eps"]), model, include_pixel_size=bool(g[f"{tag}_ips"]),
+                                verbose=False).process()
+    ref = g[f"{tag}_map"]
+    assert got.shape == ref.shape and got.dtype == np.float64
+    assert np.array_equal(got != 0, ref != 0)
+    assert_maps_close(got, ref, RTOL, what=f"grid paint {tag}")
+
+
+@pytest.mark.parametrize("tag", ["b2", "b3"])
+def test_baryonify_grid_golden(golden, cosmo, tag):
+    """BaryonifyGrid (Map2DRunner.py:376-621, incl. regrid_pixels_2D/_3D) against the reference's own run"""
+    import warnings
+    g = golden("grid.npz")
+    is2D, N, bins, Cat = _grid_inputs(g, tag, cosmo)
+    model = bfg.Baryonification2D.from_arrays(g[f"{tag}_zax"], g[f"{tag}_Max"], g[f"{tag}_rax"], g[f"{tag}_d"], cosmo,
+                                              epsilon_max=float(g[f"{tag}_eps_model"]), Rdelta_sampling=bool(g[f"{tag}_rdelta"]))
+    Map = bfg.GriddedMap(map=g[f"{tag}_map_in"].copy(), redshift=float(g[f"{tag}_redshift"]), bins=bins, cosmo=cosmo)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = bfg.BaryonifyGrid(Cat, Map, float(g[f"{tag}_eps"]), model, verbose=False).process()
+    assert_maps_close(got, g[f"{tag}_map_out"], RTOL, floor=BFLOOR, what=f"grid baryonify {tag}")
+
+
+@pytest.mark.parametrize("is2D", [True, False])
+def test_grid_runners_vs_oracle(cosmo, is2D):
+    """larger grids than the golden cases (2D 512^2, 3D 64^3), against the oracle"""
+    import warnings
+    rng = np.random.default_rng(31 + int(is2D))
+    N, L, nhalo = (512, 400.0, 300) if is2D else (64, 120.0, 120)
+    nd = 2 if is2D else 3
+    bins = (np.arange(N) + 0.5) * (L / N)
+    H = rng.uniform(0, L, (nhalo, 3))
+    hM = 10 ** rng.uniform(13.0, 15.2, nhalo)
+    Cat = bfg.HaloNDCatalog(H[:, 0], H[:, 1], hM, 0.2, cosmo, z=None if is2D else H[:, 2])
+    zax, Max, rax, T = syn.pressure_table()
+    model = bfg.TabulatedProfile.from_arrays(zax, Max, rax, T, T * 0.5)
+    Map = bfg.GriddedMap(map=np.zeros((N,) * nd), redshift=0.2, bins=bins, cosmo=cosmo)
+    got = bfg.PaintProfilesGrid(Cat, Map, 6, model, verbose=False).process()
+    ref = orc.paint_grid(cosmo, bins, (N,) * nd, 0.2, H[:, :nd], hM, (zax, Max, rax), T if is2D else T * 0.5, 6, True)
+    assert_maps_close(got, ref, RTOL, what="grid paint vs oracle")
+    zax, Max, rax, d = syn.displacement_table()
+    dm = bfg.Baryonification2D.from_arrays(zax, Max, rax, d * 5, cosmo, epsilon_max=20)
+    m_in = rng.uniform(0, 10, (N,) * nd)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gotb = bfg.BaryonifyGrid(Cat, bfg.GriddedMap(map=m_in.copy(), redshift=0.2, bins=bins, cosmo=cosmo), 6, dm,
+                                 verbose=False).process()
+        refb = orc.baryonify_grid(cosmo, bins, m_in, 0.2, H[:, :nd], hM, (zax, Max, rax), d * 5, 6, 20)
+    assert_maps_close(gotb, refb, RTOL, floor=BFLOOR, what="grid baryonify vs oracle")
+
+
 def _snapshot_inputs(g, tag, cosmo):
     is2D = bool(g[f"{tag}_is2D"])
     P, H = g[f"{tag}_P"], g[f"{tag}_H"]

@@ -312,3 +312,28 @@ def test_snapshot_containers_and_runner_conventions(cosmo):
         with pytest.raises(Exception):
             R.process()
 
+
+def test_grid_containers_and_host_regrid(golden, cosmo):
+    """GriddedMap mirrors io.py:450-470; the host regrid_pixels_2D/_3D utilities reproduce the reference's overlap rule"""
+    bins = (np.arange(16) + 0.5) * 2.0
+    G = bfg.GriddedMap(map=np.zeros((16, 16)), redshift=0.1, bins=bins, cosmo=cosmo)
+    assert G.is2D and G.Npix == 16 and G.res == 2.0 and G.L == 32.0 and G.inds.shape == (16, 16) and G.inds[2, 3] == 35
+    G3 = bfg.GriddedMap(map=np.zeros((8, 8, 8)), redshift=0.1, bins=bins[:8], cosmo=cosmo)
+    assert not G3.is2D and G3.inds.shape == (8, 8, 8)
+    with pytest.raises(AssertionError):
+        bfg.GriddedMap(map=np.zeros((16, 16)), redshift=0.1, bins=bins[:8], cosmo=cosmo)
+    from oracle import oracle as orc_
+    rng = np.random.default_rng(0)
+    for nd, N in ((2, 12), (3, 7)):
+        pos = rng.uniform(-3, N + 3, (200, nd))
+        val = rng.uniform(0, 2, 200)
+        a = np.zeros((N,) * nd)
+        (bfg.regrid_pixels_2D if nd == 2 else bfg.regrid_pixels_3D)(a, pos, val)
+        np.testing.assert_allclose(a, orc_.regrid_pixels_grid(N, pos, val, nd), rtol=1e-13, atol=1e-13)
+        assert np.isclose(a.sum(), val.sum())
+    Cat = bfg.HaloNDCatalog([1.0], [2.0], [1e14], 0.1, cosmo)
+    with pytest.raises(NotImplementedError):
+        bfg.PaintProfilesGrid(Cat, G, 4, None, use_ellipticity=True)
+    R = bfg.BaryonifyGrid(Cat, G, 4, None, verbose=False)
+    np.testing.assert_array_equal(R.pick_indices(1, 2, 16), [15, 0, 1, 2])
+
