@@ -135,6 +135,49 @@ def test_baryonify_config2_full_size_vs_oracle(cosmo):
     assert_maps_close(got, ref, RTOL, floor=BFLOOR, what="baryonify config 2")
 
 
+def test_geometry_fuzz_against_oracle(cosmo):
+    """Randomised geometry: odd and even NSIDE from 8 to 700, halos drawn towards the poles, the phi = 0 seam and the
+    equatorial-belt / polar-cap transition, discs from sub-pixel to larger than a hemisphere (eps up to 400); every case
+    must give the oracle's pixel-update count, non-zero pixel set and values for paint and baryonify, on all variants."""
+    import warnings
+    rng = np.random.default_rng(2024)
+    zax, Max, rax, T = syn.pressure_table()
+    zd, Md, rd, d = syn.displacement_table()
+    for case in range(14):
+        nside = int(rng.choice([8, 11, 16, 29, 64, 100, 255, 256, 513, 700]))
+        n = 60
+        ra = rng.uniform(0, 360, n)
+        u = rng.uniform(-1, 1, n)
+        dec = np.degrees(np.arcsin(u))
+        k = n // 6
+        dec[:k] = 90 - np.abs(rng.normal(0, 0.7, k))                       # north cap, some almost on the pole
+        dec[k:2 * k] = -90 + np.abs(rng.normal(0, 0.7, k))
+        ra[2 * k:3 * k] = rng.normal(0, 0.3, k) % 360                       # seam
+        dec[3 * k:4 * k] = np.degrees(np.arcsin(2 / 3)) + rng.normal(0, 0.5, k)   # belt / cap transition
+        dec[4 * k:5 * k] = rng.normal(0, 0.5, k)                            # equator
+        M = 10 ** rng.uniform(12.5, 15.5, n)
+        z = rng.uniform(0.02, 0.9, n)
+        eps = float(rng.choice([0.5, 3, 10, 40, 400]))
+        ref, ptot = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax), T, nside, eps)
+        Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+        for variant in VARIANTS:
+            R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), eps,
+                                       _paint_model(zax, Max, rax, T), verbose=False, variant=variant)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                got = R.process()
+            assert R.last_stats["pixel_updates"] == ptot, (case, nside, eps, variant)
+            assert np.array_equal(got != 0, ref != 0), (case, nside, eps, variant)
+            assert_maps_close(got, ref, RTOL, what=f"fuzz paint case {case} nside {nside} eps {eps} {variant}")
+        m_in = syn.mass_map(nside)
+        refb = oracle_baryonify(cosmo, ra, dec, M, z, (zd, Md, rd), d, nside, eps, 20, m_in)
+        model = bfg.Baryonification2D.from_arrays(zd, Md, rd, d, cosmo, epsilon_max=20)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            gotb = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo), eps, model, verbose=False).process()
+        assert_maps_close(gotb, refb, RTOL, floor=BFLOOR, what=f"fuzz baryonify case {case} nside {nside} eps {eps}")
+
+
 def _grid_inputs(g, tag, cosmo):
     is2D = bool(g[f"{tag}_is2D"])
     N, bins, H = int(g[f"{tag}_Npix"]), g[f"{tag}_bins"], g[f"{tag}_H"]
