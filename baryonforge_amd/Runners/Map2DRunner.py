@@ -9,10 +9,11 @@ import numpy as np
 
 from ..background import Background, MassDef
 from ..engine import emit_range_warnings, get_context
-from ..utils.Tabulate import ParamTabulatedProfile
+from ..utils.Tabulate import ParamTabulatedProfile, _get_parameter
 from .HealpixRunner import _is_disp_table, _is_paint_table, _table_axes
 
-__all__ = ["DefaultRunnerGrid", "BaryonifyGrid", "PaintProfilesGrid", "regrid_pixels_2D", "regrid_pixels_3D"]
+__all__ = ["DefaultRunnerGrid", "BaryonifyGrid", "PaintProfilesGrid", "PaintProfilesAnisGrid", "regrid_pixels_2D",
+           "regrid_pixels_3D"]
 
 
 def _regrid_host(grid, pix_positions, pix_values):
@@ -76,8 +77,59 @@ class DefaultRunnerGrid(object):
         self.use_ellipticity = use_ellipticity
         self.include_pixel_size = include_pixel_size
         self.last_stats = None
-        if use_ellipticity:
-            raise NotImplementedError("use_ellipticity = True is not built on the MI355X grid path")
+        if use_ellipticity:                                                 # :272-278
+            names = HaloNDCatalog.cat.dtype.names
+            assert "q_ell" in names, "The 'q_ell' column is missing, but you set use_ellipticity = True"
+            if not GriddedMap.is2D:
+                assert "c_ell" in names, "The 'c_ell' column is missing, but you set use_ellipticity = True"
+            assert "A_ell" in names, "The 'A_ell' column is missing, but you set use_ellipticity = True"
+
+    def build_Rmat(self, A, q):
+        """2D shear matrix of a halo with major-axis direction A and axis ratio q (Map2DRunner.py:281-350)"""
+        A = np.array(A)
+        A /= np.linalg.norm(A)
+        if len(A) == 1:
+            raise ValueError("Can't rotate a 1-dimensional vector")
+        elif len(A) == 2:
+            ref = np.array([1., 0.])
+            beta = np.arccos(np.dot(A, ref))
+            eta = -np.log(q)
+            if eta > 1e-4:
+                eta2g = np.tanh(0.5 * eta) / eta
+            else:
+                etasq = eta * eta
+                eta2g = 0.5 + etasq * ((-1 / 24) + etasq * (1 / 240))
+            g = eta2g * eta * np.exp(2j * beta)
+            g1, g2 = g.real, g.imag
+            det = np.sqrt(1 - np.abs(g) ** 2)
+            return np.array([[1 + g1, g2], [g2, 1 - g1]]) / det
+        raise NotImplementedError("This method has not yet been verified. Use 2D ellipticity method instead")
+
+    def _rmat_device(self, ctx):
+        """build_Rmat of every halo, vectorised with the reference's dtypes (float32 catalogue columns); None if
+        ellipticity is off.  3D maps: the reference raises inside its halo loop (:558 / :797)."""
+        if not self.use_ellipticity:
+            return None
+        if not self.GriddedMap.is2D:
+            if isinstance(self, PaintProfilesGrid):
+                raise ValueError("use_ellipticity is not implemented for 3D maps")
+            raise NotImplementedError("Currently not able to ellipticities with 3D maps.")
+        cat = self.HaloNDCatalog.cat
+        q = np.asarray(cat["q_ell"])
+        assert np.all(q > 0), "The axis ratio in halo %d is not positive" % int(np.argmin(q))
+        A = np.asarray(cat["A_ell"])
+        A = A / np.sqrt(np.sum(A ** 2, axis=1))[:, None]                    # :478-480
+        A = A / np.linalg.norm(A, axis=1)[:, None]                          # build_Rmat: A /= norm(A)
+        beta = np.arccos(A[:, 0].astype(np.float64) * 1.0 + A[:, 1].astype(np.float64) * 0.0)
+        with np.errstate(all="ignore"):
+            eta = -np.log(q)
+            etasq = eta * eta
+            eta2g = np.where(eta > 1e-4, np.tanh(0.5 * eta) / np.where(eta == 0, 1, eta),
+                             0.5 + etasq * ((-1 / 24) + etasq * (1 / 240))).astype(eta.dtype)
+        g = (eta2g * eta) * np.exp(2j * beta)
+        det = np.sqrt(1 - np.abs(g) ** 2)
+        R = np.stack([(1 + g.real) / det, g.imag / det, g.imag / det, (1 - g.real) / det], axis=1)
+        return ctx.to_device(R)
 
     def coord_array(self, *args):
         return np.vstack([a.flatten() for a in args]).T
@@ -130,18 +182,26 @@ class PaintProfilesGrid(DefaultRunnerGrid):
                 return np.log(np.asarray(raw, dtype=np.float64))
         table = ctx.table(_table_axes(self.model, keys), log_table, log_values=True,
                           cache_key=(id(self.model), "grid%dD" % ndim, id(raw)))
+        d_map = self._paint_device(ctx, table, keys)
+        if self.include_pixel_size:
+            d_map *= float(np.power(gm.res, ndim))                         # :826
+        return d_map.cpu().numpy().reshape(np.shape(gm.map))
+
+    def _paint_device(self, ctx, table, keys):
+        """sum over halos of the table's profile in every cut-out window (:700-823), on the device"""
+        gm = self.GriddedMap
+        ndim = 2 if gm.is2D else 3
         d_halo, d_bins = self._device_inputs(ctx, keys)
         bg = Background(self.cosmo)
         a = 1 / (1 + self.HaloNDCatalog.redshift)                          # :707
+        d_rmat = self._rmat_device(ctx)            # keep the tensor alive until the kernels have been enqueued
         args = ctx.grid_args(ndim, gm.Npix, d_bins, d_halo, a, self.epsilon_max, ctx.massdef_struct(bg, self.mass_def),
-                             n_extra=len(keys))
+                             n_extra=len(keys), d_rmat=d_rmat)
         d_map = ctx.zeros(int(np.prod(np.shape(gm.map))))                  # :685
         ctx.stats_reset()
         ctx.paint_grid(args, table, d_map)
         self.last_stats = ctx.stats()
-        if self.include_pixel_size:
-            d_map *= float(np.power(gm.res, ndim))                         # :826
-        return d_map.cpu().numpy().reshape(np.shape(gm.map))
+        return d_map
 
 
 class BaryonifyGrid(DefaultRunnerGrid):
@@ -162,10 +222,11 @@ class BaryonifyGrid(DefaultRunnerGrid):
         bg = Background(self.cosmo)
         model_bg = Background(model.cosmo) if getattr(model, "cosmo", None) is not None else bg
         a = 1 / (1 + self.HaloNDCatalog.redshift)                          # :470
+        d_rmat = self._rmat_device(ctx)            # keep the tensor alive until the kernels have been enqueued
         args = ctx.grid_args(ndim, gm.Npix, d_bins, d_halo, a, self.epsilon_max, ctx.massdef_struct(bg, self.mass_def),
                              model_md=ctx.massdef_struct(model_bg, getattr(model, "mass_def", None)),
                              model_epsilon_max=model.epsilon_max, rdelta_sampling=getattr(model, "Rdelta_sampling", False),
-                             n_extra=len(keys))
+                             n_extra=len(keys), d_rmat=d_rmat)
         orig = np.ascontiguousarray(gm.map, dtype=np.float64)
         npx = orig.size
         d_off = ctx.zeros(npx, ndim)                                       # :450
@@ -181,3 +242,62 @@ class BaryonifyGrid(DefaultRunnerGrid):
         assert np.isclose(new_sum, old_sum), \
             "ERROR in pixel regridding, sum(new_map) [%0.14e] != sum(oldmap) [%0.14e]" % (new_sum, old_sum)
         return new_map
+
+
+class PaintProfilesAnisGrid(PaintProfilesGrid):
+    """
+    Tracer-weighted painting on a 2D grid (Map2DRunner.py:833-1015): as `PaintProfilesAnisShell`, the per-pixel weights
+    factor out of the halo sum -- two launches of the grid paint kernel (`Mtot_model` without pixel size; the ln-space
+    product table of `model` x `Tracer_model`) and element-wise work on the GPU.
+    """
+
+    def __init__(self, HaloNDCatalog, GriddedMap, epsilon_max, model, Tracer_model, Mtot_model, background_val,
+                 global_tracer_fraction, mass_def=None, include_pixel_size=True, use_ellipticity=False, verbose=True):
+        self.Tracer_model = Tracer_model
+        self.Mtot_model = Mtot_model
+        self.background_val = background_val
+        self.global_tracer_fraction = global_tracer_fraction
+        super().__init__(HaloNDCatalog, GriddedMap, epsilon_max, model, use_ellipticity, mass_def, include_pixel_size, verbose)
+
+    def process(self):
+        import torch
+        from .HealpixRunner import _ProductTable
+        assert self.GriddedMap.is2D == True, "Can only paint tSZ on 2D maps. You have passed a 3D Map"   # noqa: E712 (:849)
+        assert self.model is not None, "You must provide a model"
+        keys = self._keys_checked()
+        for m in (self.model, self.Tracer_model, self.Mtot_model):
+            if not _is_paint_table(m):
+                if hasattr(m, "setup_interpolator"):
+                    raise NameError("No Table created. Run setup_interpolator() method first")
+                raise TypeError(f"PaintProfilesAnisGrid on the MI355X path needs tabulated models; got {type(m)}")
+        ctx = get_context()
+        gm = self.GriddedMap
+        res = gm.res
+        with np.errstate(all="ignore"):
+            mt = ctx.table(_table_axes(self.Mtot_model, keys), np.log(np.asarray(self.Mtot_model.raw_input_2D, dtype=np.float64)),
+                           log_values=True)
+        d_mtot = self._paint_device(ctx, mt, keys)                          # :866-871 (include_pixel_size = False)
+        dL = 2 * _get_parameter(self.Mtot_model, "proj_cutoff")            # :876-878
+        dV = np.power(res, 2) * dL
+        rho_halos = float(d_mtot.mean().item()) / dL
+        rho_m = float(Background(self.cosmo).rho_x(1.0, "matter"))          # comoving matter density (:886)
+        drho_m = float(np.clip(rho_m - rho_halos, 0, None))
+        d_mtot += dV * drho_m
+        if self.verbose:
+            print(f"Inputted halos contribute {100*(rho_halos/rho_m):0.2f}% of the total matter density.")
+            print("Remaining density is assigned to a uniform background.")
+        if rho_halos > rho_m:
+            warnings.warn("Inputted halos contribute more mass than is available for this mean matter density."
+                          "Your Mtot_model profiles are either too extended or you are using the wrong cosmology.")
+        prod = _ProductTable(self.model, self.Tracer_model, keys)
+        d_sum = self._paint_device(ctx, ctx.table(_table_axes(prod, keys), prod.ln_product, log_values=True), keys)
+        d_orig = ctx.to_device(np.ascontiguousarray(gm.map, dtype=np.float64).reshape(-1))
+        pos = d_mtot > 0
+        safe = torch.where(pos, d_mtot, torch.ones_like(d_mtot))
+        new_map = d_sum * torch.where(pos, d_orig / safe, torch.zeros_like(d_orig))
+        new_map += (self.background_val * self.global_tracer_fraction) * \
+            torch.where(pos, (dV * drho_m) / safe, torch.zeros_like(safe)) * d_orig
+        if self.include_pixel_size:
+            new_map *= float(np.power(res, 2))                             # :1009-1010
+        return new_map.cpu().numpy().reshape(np.shape(gm.map))
+

@@ -64,7 +64,7 @@ class GridArgs(C.Structure):
     _fields_ = [("ndim", C.c_int32), ("rdelta_sampling", C.c_int32), ("n_halo", _i64), ("npix", C.c_int32),
                 ("reserved", C.c_int32), ("a", _dbl), ("d_bins", _vp), ("d_halo", _vp), ("halo_stride", C.c_int32),
                 ("n_extra", C.c_int32), ("epsilon_max", _dbl), ("runner_md", MassDefStruct),
-                ("model_md", MassDefStruct), ("model_epsilon_max", _dbl)]
+                ("model_md", MassDefStruct), ("model_epsilon_max", _dbl), ("d_rmat", _vp)]
 
 
 class Stats(C.Structure):

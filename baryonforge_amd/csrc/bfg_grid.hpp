@@ -28,6 +28,7 @@ struct GridParams {
     bfg_massdef md_run, md_model;
     const double *bins;              // [npix] pixel centres
     const double *halo;              // [n_halo][stride]: M, lnM (table coordinate), x, y, z, extras...
+    const double *rmat;              // [n_halo][4] shear matrices of the 2D ellipticity option, or nullptr
     int halo_stride, n_extra;
     DevTable tab;
     GridHalo *gh;                    // [n_halo]
@@ -168,10 +169,16 @@ __global__ __launch_bounds__(256) void grid_window_kernel(const GridParams P)
             comp[2] = grid_linspace(ic, n, P.res) + h.d[2];
             r2 += comp[2] * comp[2];
         }
-        const double r = sqrt(r2);
+        const double r = sqrt(r2);                              // circular radius: the unit vectors always use it
+        double rm = r;                                          // radius handed to the model
+        if (NDIM == 2 && P.rmat) {                              // (x, y) @ Rmat  (:520-524 / :753-757)
+            const double *Rm = P.rmat + j * 4;
+            const double xe = comp[0] * Rm[0] + comp[1] * Rm[2], ye = comp[0] * Rm[1] + comp[1] * Rm[3];
+            rm = sqrt(xe * xe + ye * ye);
+        }
         ++cnt;
         // table read-out on the halo's blended row: NaN outside the radial hull
-        const double rin = log(r) - ((MODE == MODE_BARYONIFY) ? h.lnshift : 0.0);
+        const double rin = log(rm) - ((MODE == MODE_BARYONIFY) ? h.lnshift : 0.0);
         double val = nan("");
         if ((rin >= r_lo) && (rin <= r_hi)) {
             const int i = find_interval(T.raxis, T.nr, rin);
@@ -180,11 +187,11 @@ __global__ __launch_bounds__(256) void grid_window_kernel(const GridParams P)
         } else if (!(h.flags & HF_OOB)) ++n_oob;
         if (MODE == MODE_PAINT) {
             const double Pv = exp(val);                                              // Tabulate.py:319
-            if ((fabs(Pv) <= 1.797e308) && (r < h.rmask)) unsafeAtomicAdd(P.out + flat, Pv);          // :812-823
+            if ((fabs(Pv) <= 1.797e308) && (rm < h.rmask)) unsafeAtomicAdd(P.out + flat, Pv);         // :812-823
         } else {
             // BaryonCorrection.py:410-411: 0 at or beyond eps R, else the (possibly NaN) table value; the reference adds
             // NaN contributions too -- they poison the pixel's offset, which is zeroed before the regrid (:591 / :603)
-            const double off = (r < h.xcut) ? val / P.res : 0.0;                     // :530 / :570, in pixel widths
+            const double off = (rm < h.xcut) ? val / P.res : 0.0;                    // :530 / :570, in pixel widths
             for (int k = 0; k < NDIM; ++k) unsafeAtomicAdd(P.out + flat * NDIM + k, off * (comp[k] / r));
         }
     }

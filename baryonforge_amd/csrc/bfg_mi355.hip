@@ -1674,6 +1674,7 @@ static int run_grid(bfg_ctx *c, const bfg_grid_args *a, const bfg_table *t, doub
     P.a = a->a; P.eps_run = a->epsilon_max; P.eps_model = a->model_epsilon_max;
     P.md_run = a->runner_md; P.md_model = a->model_md;
     P.bins = a->d_bins; P.halo = a->d_halo; P.halo_stride = a->halo_stride; P.n_extra = a->n_extra;
+    P.rmat = (a->ndim == 2) ? a->d_rmat : nullptr;
     P.tab = t->dev; P.gh = (GridHalo *)c->grid_buf[0]; P.hrow = (double *)c->grid_buf[1]; P.out = d_out; P.stats = c->d_stats;
     hipLaunchKernelGGL(grid_halo_kernel, dim3((unsigned)a->n_halo), dim3(64), 0, c->stream, P);
     const dim3 g((unsigned)a->n_halo), b(256);

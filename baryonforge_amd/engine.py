@@ -205,7 +205,7 @@ class Context(object):
                                                    C.c_void_p(d_out.data_ptr())), "bfg_baryonify_snapshot")
 
     def grid_args(self, ndim, npix, d_bins, d_halo, a, epsilon_max, runner_md, model_md=None, model_epsilon_max=0.0,
-                  rdelta_sampling=False, n_extra=0):
+                  rdelta_sampling=False, n_extra=0, d_rmat=None):
         g = _lib.GridArgs()
         g.ndim, g.rdelta_sampling, g.n_halo, g.npix = int(ndim), int(bool(rdelta_sampling)), int(d_halo.shape[0]), int(npix)
         g.a = float(a)
@@ -216,6 +216,7 @@ class Context(object):
         g.runner_md = runner_md
         g.model_md = model_md if model_md is not None else runner_md
         g.model_epsilon_max = float(model_epsilon_max)
+        g.d_rmat = d_rmat.data_ptr() if d_rmat is not None else None
         return g
 
     def paint_grid(self, args, table, d_map):

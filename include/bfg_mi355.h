@@ -189,6 +189,8 @@ typedef struct {
     bfg_massdef runner_md;
     bfg_massdef model_md;
     double model_epsilon_max;
+    const double *d_rmat;      /* device, float64[n_halo][4] = build_Rmat(A_ell, q_ell) row-major (Map2DRunner.py:281-350):
+                                * 2D use_ellipticity; NULL = circular                                               */
 } bfg_grid_args;
 int bfg_paint_grid(bfg_ctx *ctx, const bfg_grid_args *args, const bfg_table *table, double *d_map);
 int bfg_baryonify_grid_offsets(bfg_ctx *ctx, const bfg_grid_args *args, const bfg_table *table, double *d_offsets);

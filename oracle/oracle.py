@@ -489,6 +489,33 @@ def _grid_cutout(bins, Npix, res, hpos, R_cut):
     return x, inds, d
 
 
+def build_Rmat(A, q):
+    """DefaultRunnerGrid.build_Rmat (Map2DRunner.py:281-350), 2D branch, with the dtypes the runner hands it: A is the
+    float32 'A_ell' row already divided by its norm (:478-480), q the float32 'q_ell'."""
+    A = np.array(A)
+    A /= np.linalg.norm(A)
+    ref = np.array([1., 0.])
+    beta = np.arccos(np.dot(A, ref))
+    eta = -np.log(q)
+    if eta > 1e-4:
+        eta2g = np.tanh(0.5 * eta) / eta
+    else:
+        etasq = eta * eta
+        eta2g = 0.5 + etasq * ((-1 / 24) + etasq * (1 / 240))
+    g = eta2g * eta * np.exp(2j * beta)
+    g1, g2 = g.real, g.imag
+    det = np.sqrt(1 - np.abs(g) ** 2)
+    return np.array([[1 + g1, g2], [g2, 1 - g1]]) / det
+
+
+def _grid_r(comps, Rmat=None):
+    """radius handed to the model: circular, or after the shear of the 2D ellipticity option (:520-524)"""
+    if Rmat is None:
+        return np.sqrt(sum(c * c for c in comps))
+    xy = np.vstack([comps[0], comps[1]]).T @ Rmat
+    return np.sqrt(xy[:, 0] ** 2 + xy[:, 1] ** 2)
+
+
 def _grid_flat_and_r(x, inds, d, Npix):
     """flat map indices of the cut-out and the offsets (x_grid + dx, y_grid + dy[, z_grid + dz]) paired with them, in the
     reference's pairing: inds[x_inds, :][:, y_inds].flatten() against np.meshgrid(x, x, indexing='xy') (:507-516)"""
@@ -504,7 +531,7 @@ def _grid_flat_and_r(x, inds, d, Npix):
 
 
 def paint_grid(cosmo, bins, shape, redshift, hpos, hM, axes, T, eps_run, include_pixel_size=True, Delta=200,
-               rho_type="critical"):
+               rho_type="critical", q_ell=None, A_ell=None):
     """PaintProfilesGrid.process (Map2DRunner.py:676-829) without ellipticity.  hpos [n, ndim], T = the raw table the model
     reads for this dimensionality (projected for 2D maps, real for 3D).  Halo columns are narrowed to float32 as in
     HaloNDCatalog (io.py:204); ln M is a float32 logarithm (Tabulate.py:316)."""
@@ -521,7 +548,11 @@ def paint_grid(cosmo, bins, shape, redshift, hpos, hM, axes, T, eps_run, include
         R_j = float(get_radius(cosmo, float(M32), a, Delta, rho_type)) / a                  # comoving (:708)
         x, inds, d = _grid_cutout(bins, Npix, res, hpos32[j, :nd], eps_run * R_j)
         flat, comps = _grid_flat_and_r(x, inds, d, Npix)
-        r = np.sqrt(sum(c * c for c in comps))
+        Rmat = None
+        if q_ell is not None:                                                               # :710-713, :753-757
+            A = np.asarray(A_ell[j], dtype=np.float32)
+            Rmat = build_Rmat(A / np.sqrt(np.sum(A ** 2)), np.float32(q_ell[j]))
+        r = _grid_r(comps, Rmat)
         with np.errstate(all="ignore"):
             pts = np.stack([np.full(r.size, np.log(1 / a)), np.full(r.size, float(np.log(M32))), np.log(r)], axis=1)
             P = np.exp(interp_linear(axes, lnT, pts))
@@ -576,7 +607,7 @@ def regrid_pixels_grid(N, positions, values, nd):
 
 
 def baryonify_grid(cosmo, bins, orig_map, redshift, hpos, hM, axes, d_table, eps_run, eps_model, rdelta_sampling=False,
-                   Delta=200, rho_type="critical"):
+                   Delta=200, rho_type="critical", q_ell=None, A_ell=None):
     """BaryonifyGrid.process (Map2DRunner.py:431-621) without ellipticity: per-pixel offsets (in pixel widths) summed over
     halos, then the overlap regrid; mass conserved (:617-619)."""
     bins = _f(bins)
@@ -592,9 +623,13 @@ def baryonify_grid(cosmo, bins, orig_map, redshift, hpos, hM, axes, d_table, eps
         R_q = np.clip(eps_run * R_j / a, 0, np.max(bins) / 2)                               # :473-474
         x, inds, d = _grid_cutout(bins, Npix, res, hpos32[j, :nd], R_q)
         flat, comps = _grid_flat_and_r(x, inds, d, Npix)
-        r = np.sqrt(sum(c * c for c in comps))
+        r = np.sqrt(sum(c * c for c in comps))                                              # unit vectors use the circular radius
+        r_mod = r
+        if q_ell is not None:
+            A = np.asarray(A_ell[j], dtype=np.float32)
+            r_mod = _grid_r(comps, build_Rmat(A / np.sqrt(np.sum(A ** 2)), np.float32(q_ell[j])))
         with np.errstate(all="ignore"):
-            off = displacement_readout(cosmo, axes, d_table, r, float(M32), a, eps_model, rdelta_sampling, Delta, rho_type,
+            off = displacement_readout(cosmo, axes, d_table, r_mod, float(M32), a, eps_model, rdelta_sampling, Delta, rho_type,
                                        lnM=float(np.log(M32))) / res                        # :530 / :570
             for k in range(nd):
                 pix_offsets[flat, k] += off * (comps[k] / r)
@@ -603,4 +638,54 @@ def baryonify_grid(cosmo, bins, orig_map, redshift, hpos, hM, axes, d_table, eps
     for k in range(nd):
         pix_offsets[:, k] += grids[k].ravel()
     return regrid_pixels_grid(Npix, pix_offsets, orig_map.ravel(), nd)
+
+
+def paint_anis_grid(cosmo, bins, orig_map, redshift, hpos, hM, axes, T_paint, T_tracer, T_mtot, proj_cutoff, background_val,
+                    global_tracer_fraction, eps_run, include_pixel_size=True, q_ell=None, A_ell=None):
+    """PaintProfilesAnisGrid.process (Map2DRunner.py:847-1015), 2D maps only (:849)."""
+    bins = _f(bins)
+    orig = _f(orig_map)
+    assert orig.ndim == 2
+    Npix = bins.size
+    res = bins[1] - bins[0]
+    a = 1 / (1 + redshift)
+    Mtot = paint_grid(cosmo, bins, orig.shape, redshift, hpos, hM, axes, T_mtot, eps_run, include_pixel_size=False,
+                      q_ell=q_ell, A_ell=A_ell).ravel()                                       # :866-871
+    dL = 2 * proj_cutoff                                                                      # :876-878
+    dV = res ** 2 * dL
+    rho_halos = np.average(Mtot) / dL
+    rho_m = rho_x(cosmo, 1.0, "matter")                                                       # comoving matter density (:886)
+    drho_m = np.clip(rho_m - rho_halos, 0, None)
+    Mtot = Mtot + dV * drho_m
+    with np.errstate(all="ignore"):
+        lnP, lnC = np.log(_f(T_paint)), np.log(_f(T_tracer))
+    new_map = np.zeros(orig.size)
+    of = orig.ravel()
+    hpos32 = np.asarray(hpos, dtype=np.float32).astype(np.float64)
+    for j in range(hpos32.shape[0]):                                                          # :901-1000
+        M32 = np.float32(hM[j])
+        R_j = float(get_radius(cosmo, float(M32), a)) / a
+        x, inds, d = _grid_cutout(bins, Npix, res, hpos32[j, :2], eps_run * R_j)
+        flat, comps = _grid_flat_and_r(x, inds, d, Npix)
+        Rmat = None
+        if q_ell is not None:
+            A = np.asarray(A_ell[j], dtype=np.float32)
+            Rmat = build_Rmat(A / np.sqrt(np.sum(A ** 2)), np.float32(q_ell[j]))
+        r = _grid_r(comps, Rmat)
+        with np.errstate(all="ignore"):
+            pts = np.stack([np.full(r.size, np.log(1 / a)), np.full(r.size, float(np.log(M32))), np.log(r)], axis=1)
+            Painting = np.exp(interp_linear(axes, lnP, pts))
+            Canvas = np.exp(interp_linear(axes, lnC, pts))
+        Canvas = np.where(np.isfinite(Canvas), Canvas, 0)
+        Mfrac = np.divide(Canvas, Mtot[flat], out=np.zeros_like(Canvas), where=Mtot[flat] > 0) * of[flat]
+        mask = np.isfinite(Painting) & (r < R_j * eps_run)
+        if mask.sum() == 0:
+            continue
+        new_map[flat] += np.where(mask, Painting, 0) * Mfrac
+    Mfrac = np.divide(dV * drho_m, Mtot, out=np.zeros_like(Mtot), where=Mtot > 0) * of
+    new_map += background_val * global_tracer_fraction * Mfrac
+    new_map = new_map.reshape(orig.shape)
+    if include_pixel_size:
+        new_map = new_map * res ** 2
+    return new_map
 

@@ -78,8 +78,8 @@ def install_stubs():
             pass
 
         def rho_x(self, a, species, is_comoving=False):
-            assert species == "matter" and not is_comoving
-            return orc.rho_x(self.d, a, "matter")
+            assert species == "matter"
+            return orc.rho_x(self.d, 1.0 if is_comoving else a, "matter")      # comoving = physical * a^3
 
     def angular_diameter_distance(cosmo, a):
         return orc.angular_diameter_distance(cosmo.d, a)
@@ -524,6 +524,42 @@ def grid_section(io, make_tabulated, make_disp, mdef):
                     f"{tag}_eps_model": np.array(emod), f"{tag}_rdelta": np.array(rdelta), f"{tag}_zax": zd, f"{tag}_Max": Md,
                     f"{tag}_rax": rd, f"{tag}_d": d, f"{tag}_map_in": m_in, f"{tag}_map_out": resmap})
         print("grid baryonify", tag, "sum in/out", m_in.sum(), resmap.sum(), "changed", np.count_nonzero(~np.isclose(resmap, m_in)))
+    # ellipticity (2D only, :518-524 / :753-757) and PaintProfilesAnisGrid (:833-1015)
+    rng = np.random.default_rng(90)
+    Npix, L, nhalo = 80, 70.0, 30
+    res = L / Npix
+    bins = (np.arange(Npix) + 0.5) * res
+    H = rng.uniform(0, L, (nhalo, 2))
+    hM = 10 ** rng.uniform(13.3, 15.0, nhalo)
+    q = rng.uniform(0.4, 1.0, nhalo)
+    q[:3] = [1.0, 0.99995, 0.5]                                # eta below / above the series switch (:303-307)
+    A = rng.normal(size=(nhalo, 2))
+    Cat = io.HaloNDCatalog(H[:, 0], H[:, 1], hM, 0.3, COSMO, q_ell=q, A_ell=A)
+    zax, Max, rax, T = paint_table()
+    zz, MM, rr = np.meshgrid(np.exp(zax) - 1, np.exp(Max), np.exp(rax), indexing="ij")
+    Rc = r200c_com(MM, zz)
+    Ttr = 3.0 * (MM / 1e14) ** 0.8 * (1 + (rr / (0.5 * Rc)) ** 2) ** -1.0 / (1 + zz)
+    Tm = MM / (2 * np.pi * (0.3 * Rc) ** 2) * (1 + (rr / (0.3 * Rc)) ** 2) ** -1.5 / (1 + zz)
+    paint, tracer, mtot = (make_tabulated(zax, Max, rax, t) for t in (T, Ttr, Tm))
+    mtot.proj_cutoff = 25.0
+    m_in = rng.uniform(0, 3, (Npix, Npix))
+    m_in[rng.uniform(size=m_in.shape) < 0.1] = 0.0
+    zd, Md, rd, dd = disp_table()
+    disp = make_disp(zd, Md, rd, dd * 8.0, eps=20)
+    mk = lambda m: io.GriddedMap(map=m, redshift=0.3, bins=bins, cosmo=COSMO)
+    e_paint = m2d.PaintProfilesGrid(Cat, mk(np.zeros((Npix, Npix))), epsilon_max=4, model=paint, use_ellipticity=True,
+                                    mass_def=mdef, verbose=False).process()
+    e_bary = m2d.BaryonifyGrid(Cat, mk(m_in.copy()), epsilon_max=4, model=disp, use_ellipticity=True, mass_def=mdef,
+                               verbose=False).process()
+    anis = m2d.PaintProfilesAnisGrid(Cat, mk(m_in.copy()), 4, paint, tracer, mtot, 0.7, 0.35, mass_def=mdef,
+                                     include_pixel_size=True, use_ellipticity=False, verbose=False).process()
+    anis_e = m2d.PaintProfilesAnisGrid(Cat, mk(m_in.copy()), 4, paint, tracer, mtot, 0.7, 0.35, mass_def=mdef,
+                                       include_pixel_size=False, use_ellipticity=True, verbose=False).process()
+    out.update(e_Npix=np.array(Npix), e_bins=bins, e_H=H, e_hM=hM, e_q=q, e_A=A, e_redshift=np.array(0.3), e_eps=np.array(4),
+               e_zax=zax, e_Max=Max, e_rax=rax, e_T_paint=T, e_T_tracer=Ttr, e_T_mtot=Tm, e_proj_cutoff=np.array(25.0),
+               e_map_in=m_in, e_zd=zd, e_Md=Md, e_rd=rd, e_d=dd * 8.0, e_background_val=np.array(0.7),
+               e_global_tracer_fraction=np.array(0.35), e_paint_ell=e_paint, e_bary_ell=e_bary, e_anis=anis, e_anis_ell=anis_e)
+    print("grid ellipticity / anis sums", e_paint.sum(), e_bary.sum(), anis.sum(), anis_e.sum())
     np.savez_compressed(os.path.join(HERE, "grid.npz"), **out)
 
 

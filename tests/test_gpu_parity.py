@@ -215,6 +215,38 @@ def test_baryonify_grid_golden(golden, cosmo, tag):
     assert_maps_close(got, g[f"{tag}_map_out"], RTOL, floor=BFLOOR, what=f"grid baryonify {tag}")
 
 
+def test_grid_ellipticity_and_anis_golden(golden, cosmo):
+    """2D ellipticity (Map2DRunner.py:281-350) in PaintProfilesGrid / BaryonifyGrid and PaintProfilesAnisGrid (:833-1015)
+    against the reference's own run"""
+    import warnings
+    g = golden("grid.npz")
+    N, bins, H = int(g["e_Npix"]), g["e_bins"], g["e_H"]
+    zs, eps = float(g["e_redshift"]), float(g["e_eps"])
+    Cat = bfg.HaloNDCatalog(H[:, 0], H[:, 1], g["e_hM"], zs, cosmo, q_ell=g["e_q"], A_ell=g["e_A"])
+    axes = (g["e_zax"], g["e_Max"], g["e_rax"])
+    mk = lambda m: bfg.GriddedMap(map=m, redshift=zs, bins=bins, cosmo=cosmo)
+    paint, tracer, mtot = (bfg.TabulatedProfile.from_arrays(*axes, g[k]) for k in ("e_T_paint", "e_T_tracer", "e_T_mtot"))
+    mtot.proj_cutoff = float(g["e_proj_cutoff"])
+    got = bfg.PaintProfilesGrid(Cat, mk(np.zeros((N, N))), eps, paint, use_ellipticity=True, verbose=False).process()
+    assert_maps_close(got, g["e_paint_ell"], RTOL, what="grid paint ellipticity")
+    disp = bfg.Baryonification2D.from_arrays(g["e_zd"], g["e_Md"], g["e_rd"], g["e_d"], cosmo, epsilon_max=20)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = bfg.BaryonifyGrid(Cat, mk(g["e_map_in"].copy()), eps, disp, use_ellipticity=True, verbose=False).process()
+    assert_maps_close(got, g["e_bary_ell"], RTOL, floor=BFLOOR, what="grid baryonify ellipticity")
+    bv, gf = float(g["e_background_val"]), float(g["e_global_tracer_fraction"])
+    got = bfg.PaintProfilesAnisGrid(Cat, mk(g["e_map_in"].copy()), eps, paint, tracer, mtot, bv, gf, include_pixel_size=True,
+                                    verbose=False).process()
+    assert_maps_close(got, g["e_anis"], RTOL, what="anis grid")
+    got = bfg.PaintProfilesAnisGrid(Cat, mk(g["e_map_in"].copy()), eps, paint, tracer, mtot, bv, gf, include_pixel_size=False,
+                                    use_ellipticity=True, verbose=False).process()
+    assert_maps_close(got, g["e_anis_ell"], RTOL, what="anis grid ellipticity")
+    G3 = bfg.GriddedMap(map=np.zeros((8, 8, 8)), redshift=zs, bins=bins[:8], cosmo=cosmo)
+    Cat3 = bfg.HaloNDCatalog(H[:, 0], H[:, 1], g["e_hM"], zs, cosmo, z=H[:, 0], q_ell=g["e_q"], A_ell=g["e_A"], c_ell=g["e_q"])
+    with pytest.raises(ValueError):
+        bfg.PaintProfilesGrid(Cat3, G3, eps, paint, use_ellipticity=True, verbose=False).process()
+
+
 @pytest.mark.parametrize("is2D", [True, False])
 def test_grid_runners_vs_oracle(cosmo, is2D):
     """larger grids than the golden cases (2D 512^2, 3D 64^3), against the oracle"""

@@ -36,13 +36,14 @@ def test_header_is_plain_c(tmp_path):
     import subprocess
     src = tmp_path / "t.c"
     src.write_text('#include "bfg_mi355.h"\n#include <stdio.h>\n'
-                   'int main(void){printf("%zu %zu %zu %d\\n", sizeof(bfg_massdef), sizeof(bfg_shell_args), '
-                   'sizeof(bfg_stats), BFG_ABI_VERSION); return 0;}\n')
+                   'int main(void){printf("%zu %zu %zu %d %zu %zu\\n", sizeof(bfg_massdef), sizeof(bfg_shell_args), '
+                   'sizeof(bfg_stats), BFG_ABI_VERSION, sizeof(bfg_snapshot_args), sizeof(bfg_grid_args)); return 0;}\n')
     exe = tmp_path / "t"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)])
     out = subprocess.check_output([str(exe)]).decode().split()
     assert [int(x) for x in out] == [ctypes.sizeof(_lib.MassDefStruct), ctypes.sizeof(_lib.ShellArgs),
-                                     ctypes.sizeof(_lib.Stats), 1]
+                                     ctypes.sizeof(_lib.Stats), 1, ctypes.sizeof(_lib.SnapshotArgs),
+                                     ctypes.sizeof(_lib.GridArgs)]
 
 
 def test_struct_layouts_match_header():
@@ -332,8 +333,12 @@ def test_grid_containers_and_host_regrid(golden, cosmo):
         np.testing.assert_allclose(a, orc_.regrid_pixels_grid(N, pos, val, nd), rtol=1e-13, atol=1e-13)
         assert np.isclose(a.sum(), val.sum())
     Cat = bfg.HaloNDCatalog([1.0], [2.0], [1e14], 0.1, cosmo)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AssertionError):                       # no q_ell / A_ell columns (Map2DRunner.py:272-278)
         bfg.PaintProfilesGrid(Cat, G, 4, None, use_ellipticity=True)
     R = bfg.BaryonifyGrid(Cat, G, 4, None, verbose=False)
+    from oracle import oracle as orc2
+    Rm = R.build_Rmat(np.array([0.6, 0.8], dtype=np.float32), np.float32(0.7))
+    np.testing.assert_allclose(Rm, orc2.build_Rmat(np.array([0.6, 0.8], dtype=np.float32), np.float32(0.7)), rtol=1e-12)
+    assert np.isclose(np.linalg.det(Rm), 1.0)
     np.testing.assert_array_equal(R.pick_indices(1, 2, 16), [15, 0, 1, 2])
 

@@ -192,3 +192,24 @@ def test_oracle_baryonify_grid_matches_reference(golden, cosmo, tag):
     ref = g[f"{tag}_map_out"]
     np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-10)
 
+
+def test_oracle_grid_ellipticity_and_anis_match_reference(golden, cosmo):
+    """2D ellipticity option of the grid runners and PaintProfilesAnisGrid (Map2DRunner.py:281-350, :833-1015)"""
+    g = golden("grid.npz")
+    N, bins, H, hM, q, A = int(g["e_Npix"]), g["e_bins"], g["e_H"], g["e_hM"], g["e_q"], g["e_A"]
+    axes = (g["e_zax"], g["e_Max"], g["e_rax"])
+    zs, eps = float(g["e_redshift"]), float(g["e_eps"])
+    got = o.paint_grid(cosmo, bins, (N, N), zs, H, hM, axes, g["e_T_paint"], eps, True, q_ell=q, A_ell=A)
+    np.testing.assert_allclose(got, g["e_paint_ell"], rtol=1e-10, atol=1e-300)
+    got = o.baryonify_grid(cosmo, bins, g["e_map_in"], zs, H, hM, (g["e_zd"], g["e_Md"], g["e_rd"]), g["e_d"], eps, 20,
+                           q_ell=q, A_ell=A)
+    np.testing.assert_allclose(got, g["e_bary_ell"], rtol=1e-9, atol=1e-9)
+    kw = dict(proj_cutoff=float(g["e_proj_cutoff"]), background_val=float(g["e_background_val"]),
+              global_tracer_fraction=float(g["e_global_tracer_fraction"]), eps_run=eps)
+    got = o.paint_anis_grid(cosmo, bins, g["e_map_in"], zs, H, hM, axes, g["e_T_paint"], g["e_T_tracer"], g["e_T_mtot"],
+                            include_pixel_size=True, **kw)
+    np.testing.assert_allclose(got, g["e_anis"], rtol=1e-10, atol=1e-300)
+    got = o.paint_anis_grid(cosmo, bins, g["e_map_in"], zs, H, hM, axes, g["e_T_paint"], g["e_T_tracer"], g["e_T_mtot"],
+                            include_pixel_size=False, q_ell=q, A_ell=A, **kw)
+    np.testing.assert_allclose(got, g["e_anis_ell"], rtol=1e-10, atol=1e-300)
+
