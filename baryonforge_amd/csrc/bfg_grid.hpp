@@ -195,8 +195,13 @@ __global__ __launch_bounds__(256) void grid_window_kernel(const GridParams P)
             for (int k = 0; k < NDIM; ++k) unsafeAtomicAdd(P.out + flat * NDIM + k, off * (comp[k] / r));
         }
     }
+    __shared__ unsigned long long s_red[2][4];
     for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_down(cnt, o, 64); n_oob += __shfl_down(n_oob, o, 64); }
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = cnt; s_red[1][threadIdx.x >> 6] = n_oob; }
+    __syncthreads();
+    if (threadIdx.x == 0) {                                    // one pair of same-address atomics per workgroup (= halo)
+        cnt = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+        n_oob = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
         if (cnt) atomicAdd((unsigned long long *)&P.stats->pixel_updates, cnt);
         if (n_oob) {
             atomicAdd((unsigned long long *)&P.stats->pixels_out_of_table, n_oob);

@@ -1595,50 +1595,61 @@ int bfg_baryonify_snapshot(bfg_ctx *c, const bfg_snapshot_args *a, const bfg_tab
     P.md_run = a->runner_md; P.md_model = a->model_md;
     P.part = a->d_part; P.halo = a->d_halo; P.halo_stride = a->halo_stride; P.n_extra = a->n_extra;
     P.tab = t->dev; P.stats = c->d_stats; P.out = d_out;
-    // ~12 particles per cell, at most 256^3 / 4096^2 cells
-    const int nmax = (a->ndim == 3) ? 256 : 4096;
-    int ncell = (int)std::floor(std::pow((double)a->n_part / 12.0, 1.0 / a->ndim));
-    ncell = std::max(1, std::min(ncell, nmax));
+    // coarse cell grid for the halo-overlap lists: a few candidate halos per cell
+    const int nmax = (a->ndim == 3) ? 128 : 2048;
+    int ncell = (int)std::floor(std::pow(4.0 * (double)std::max<int64_t>(a->n_halo, 1), 1.0 / a->ndim));
+    ncell = std::max(4, std::min(ncell, nmax));
     P.ncell = ncell;
     P.ncell_tot = (a->ndim == 3) ? (int64_t)ncell * ncell * ncell : (int64_t)ncell * ncell;
     const int64_t nblk = (P.ncell_tot + 1023) / 1024;
-    // workspace kept in the context between calls (hipMalloc / hipFree of GBs per call costs 100+ ms)
+    // workspace kept in the context between calls; the candidate list is sized after the count pass
     const size_t want[8] = {(size_t)P.ncell_tot * sizeof(int32_t), (size_t)(P.ncell_tot + 1) * sizeof(int32_t),
-                            (size_t)a->n_part * sizeof(int32_t), (size_t)std::max<int64_t>(a->n_halo, 1) * sizeof(SnapHalo),
+                            (size_t)(std::max<int64_t>(a->n_halo, 1) + 1) * sizeof(int32_t),
+                            (size_t)std::max<int64_t>(a->n_halo, 1) * sizeof(SnapHalo),
                             (size_t)std::max<int64_t>(a->n_halo, 1) * t->dev.nr * sizeof(double),
-                            (size_t)a->n_part * a->ndim * sizeof(double), (size_t)nblk * sizeof(int32_t), sizeof(int32_t)};
-    for (int k = 0; k < 8; ++k) {
-        if (want[k] > c->snap_cap[k]) {
+                            c->snap_cap[5], (size_t)nblk * sizeof(int32_t), sizeof(int32_t)};
+    auto ensure = [&](int k, size_t bytes) -> int {
+        if (bytes > c->snap_cap[k]) {
             HIP_TRY(hipStreamSynchronize(c->stream));
             if (c->snap_buf[k]) (void)hipFree(c->snap_buf[k]);
             c->snap_buf[k] = nullptr; c->snap_cap[k] = 0;
-            HIP_TRY(hipMalloc(&c->snap_buf[k], want[k]));
-            c->snap_cap[k] = want[k];
+            HIP_TRY(hipMalloc(&c->snap_buf[k], bytes));
+            c->snap_cap[k] = bytes;
         }
-    }
-    P.cell_count = (int32_t *)c->snap_buf[0]; P.cell_start = (int32_t *)c->snap_buf[1]; P.order = (int32_t *)c->snap_buf[2];
-    P.hs = (SnapHalo *)c->snap_buf[3]; P.hrow = (double *)c->snap_buf[4]; P.off = (double *)c->snap_buf[5];
+        return BFG_OK;
+    };
+    for (int k = 0; k < 8; ++k) { rc = ensure(k, want[k]); if (rc) return rc; }
+    P.cell_count = (int32_t *)c->snap_buf[0]; P.cell_start = (int32_t *)c->snap_buf[1]; P.big = (int32_t *)c->snap_buf[2];
+    P.hs = (SnapHalo *)c->snap_buf[3]; P.hrow = (double *)c->snap_buf[4];
     int32_t *d_bsum = (int32_t *)c->snap_buf[6], *d_total = (int32_t *)c->snap_buf[7];
-#define SNAP_TRY(expr) HIP_TRY(expr)
-    SNAP_TRY(hipMemsetAsync(P.cell_count, 0, (size_t)P.ncell_tot * sizeof(int32_t), c->stream));
-    SNAP_TRY(hipMemsetAsync(P.off, 0, (size_t)a->n_part * a->ndim * sizeof(double), c->stream));
-    const unsigned pgrid = (unsigned)((a->n_part + 255) / 256);
-    hipLaunchKernelGGL(snap_count_kernel, dim3(pgrid), dim3(256), 0, c->stream, P);
-    hipLaunchKernelGGL(snap_scan_block_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, P.ncell_tot, P.cell_count,
-                       P.cell_start, d_bsum);
-    hipLaunchKernelGGL(snap_scan_sums_kernel, dim3(1), dim3(1024), 0, c->stream, (int)nblk, d_bsum, d_total);
-    hipLaunchKernelGGL(snap_scan_add_kernel, dim3((unsigned)((P.ncell_tot + 255) / 256)), dim3(256), 0, c->stream,
-                       P.ncell_tot, P.cell_start, d_bsum, P.cell_count, d_total);
-    hipLaunchKernelGGL(snap_fill_kernel, dim3(pgrid), dim3(256), 0, c->stream, P);
+    HIP_TRY(hipMemsetAsync(P.cell_count, 0, (size_t)P.ncell_tot * sizeof(int32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(P.big, 0, sizeof(int32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(P.cell_start, 0, (size_t)(P.ncell_tot + 1) * sizeof(int32_t), c->stream));
     if (a->n_halo > 0) {
+        const unsigned hgrid = (unsigned)((a->n_halo + 255) / 256);
         hipLaunchKernelGGL(snap_halo_kernel, dim3((unsigned)a->n_halo), dim3(64), 0, c->stream, P);
-        const unsigned hgrid = (unsigned)((a->n_halo + 3) / 4);
-        if (a->ndim == 3) hipLaunchKernelGGL(snap_displace_kernel<3>, dim3(hgrid), dim3(256), 0, c->stream, P);
-        else hipLaunchKernelGGL(snap_displace_kernel<2>, dim3(hgrid), dim3(256), 0, c->stream, P);
+        if (a->ndim == 3) hipLaunchKernelGGL(snap_overlap_kernel<3>, dim3(hgrid), dim3(256), 0, c->stream, P, 0);
+        else hipLaunchKernelGGL(snap_overlap_kernel<2>, dim3(hgrid), dim3(256), 0, c->stream, P, 0);
+        hipLaunchKernelGGL(snap_scan_block_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, P.ncell_tot, P.cell_count,
+                           P.cell_start, d_bsum);
+        hipLaunchKernelGGL(snap_scan_sums_kernel, dim3(1), dim3(1024), 0, c->stream, (int)nblk, d_bsum, d_total);
+        hipLaunchKernelGGL(snap_scan_add_kernel, dim3((unsigned)((P.ncell_tot + 255) / 256)), dim3(256), 0, c->stream,
+                           P.ncell_tot, P.cell_start, d_bsum, P.cell_count, d_total);
+        int32_t total = 0;                                      // size of the candidate list (a few entries per halo)
+        HIP_TRY(hipMemcpyAsync(&total, d_total, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        rc = ensure(5, (size_t)std::max<int32_t>(total, 1) * sizeof(SnapCand));
+        if (rc) return rc;
+        P.cand = (SnapCand *)c->snap_buf[5]; P.cand_cap = total;
+        if (a->ndim == 3) hipLaunchKernelGGL(snap_overlap_kernel<3>, dim3(hgrid), dim3(256), 0, c->stream, P, 1);
+        else hipLaunchKernelGGL(snap_overlap_kernel<2>, dim3(hgrid), dim3(256), 0, c->stream, P, 1);
+    } else {
+        P.cand = (SnapCand *)c->snap_buf[5]; P.cand_cap = 0;
     }
-    hipLaunchKernelGGL(snap_apply_kernel, dim3((unsigned)((a->n_part * a->ndim + 255) / 256)), dim3(256), 0, c->stream, P);
-    SNAP_TRY(hipGetLastError());
-#undef SNAP_TRY
+    const unsigned pgrid = (unsigned)std::min<int64_t>((a->n_part + 255) / 256, 8192);       // grid-stride
+    if (a->ndim == 3) hipLaunchKernelGGL(snap_particle_kernel<3>, dim3(pgrid), dim3(256), 0, c->stream, P);
+    else hipLaunchKernelGGL(snap_particle_kernel<2>, dim3(pgrid), dim3(256), 0, c->stream, P);
+    HIP_TRY(hipGetLastError());
     return BFG_OK;
 }
 

@@ -4,14 +4,19 @@
 // (:99, :225 / :240), reads the radial displacement off the model's table and accumulates offset * unit-vector on
 // every particle found (:232 / :249); at the end positions are shifted and wrapped into the box once (:260-273).
 //
-// Here the particles are binned into a uniform periodic cell grid (counting sort: count -> scan -> fill, cell lists
-// of particle indices), each halo's table rows are blended once into a full radial row (hrow), and one wavefront per
-// halo walks the cells its sphere can touch (one lane per cell, cells that cannot intersect the sphere are skipped)
-// and adds the displacement to the particles' offset vectors with f64 global atomics.  A last kernel shifts and wraps.
+// Here the search is turned around (particles outnumber halos by 10^3): a coarse periodic cell grid holds, per cell,
+// the list of halos whose sphere can reach the cell (built halo by halo: count -> scan -> fill over each sphere's
+// bounding box; spheres spanning more than kSnapBigCells cells go to one global list instead).  Then ONE pass over the
+// particles, one thread per particle in whatever order they come: look up the particle's cell, test its handful of
+// candidate halos (+ the global list), read the displacement off the halo's blended radial row (hrow), sum the
+// offsets in registers, shift, wrap, write.  No particle sort, no atomics on particle data, one read and one write of
+// every particle.
 // Included by bfg_mi355.hip after DevTable / massdef_radius are defined.
 #pragma once
 
 namespace bfg {
+
+constexpr int kSnapBigCells = 4096;
 
 struct __align__(16) SnapHalo {      // per-halo constants (written by snap_halo_kernel)
     double x, y, z, rq;              // centre [comoving Mpc], query radius
@@ -19,6 +24,11 @@ struct __align__(16) SnapHalo {      // per-halo constants (written by snap_halo
     double lnshift;                  // ln(R_model_com) for Rdelta_sampling tables, else 0
     int32_t flags, pad;              // HF_OOB: (z, M, extras) outside the table hull -> contributes nothing
     double pad2;
+};
+
+struct __align__(16) SnapCand {      // one (cell, halo) entry of the overlap lists
+    double x, y, z, rq;
+    int32_t halo, pad[3];
 };
 
 struct SnapParams {
@@ -35,10 +45,11 @@ struct SnapParams {
     int64_t ncell_tot;
     int32_t *cell_count;             // [ncell_tot] (count, then fill cursor)
     int32_t *cell_start;             // [ncell_tot + 1]
-    int32_t *order;                  // [n_part] particle indices grouped by cell
+    SnapCand *cand;                  // [cand_cap] candidates grouped by cell: test data inline, no second indirection
+    int64_t cand_cap;
+    int32_t *big;                    // [0] = count, [1..] halos whose sphere spans too many cells (tested by every particle)
     SnapHalo *hs;                    // [n_halo]
     double *hrow;                    // [n_halo][tab.nr] blended radial rows
-    double *off;                     // [n_part][ndim] accumulated offsets
     double *out;                     // [n_part][ndim] displaced, wrapped coordinates
     bfg_stats *stats;
 };
@@ -47,27 +58,6 @@ __device__ inline int snap_cell_of(double x, double inv_cell, int n)
 {
     int i = (int)floor(x * inv_cell);
     return min(max(i, 0), n - 1);    // x in [0, L]; x == L lands in the last cell
-}
-
-__global__ __launch_bounds__(256) void snap_count_kernel(const SnapParams P)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n_part) return;
-    const double inv_cell = (double)P.ncell / P.L;
-    int64_t c = 0;
-    for (int k = 0; k < P.ndim; ++k) c = c * P.ncell + snap_cell_of(P.part[i * P.ndim + k], inv_cell, P.ncell);
-    atomicAdd(&P.cell_count[c], 1);
-}
-
-__global__ __launch_bounds__(256) void snap_fill_kernel(const SnapParams P)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n_part) return;
-    const double inv_cell = (double)P.ncell / P.L;
-    int64_t c = 0;
-    for (int k = 0; k < P.ndim; ++k) c = c * P.ncell + snap_cell_of(P.part[i * P.ndim + k], inv_cell, P.ncell);
-    const int pos = atomicAdd(&P.cell_count[c], 1);
-    P.order[P.cell_start[c] + pos] = (int32_t)i;
 }
 
 // exclusive scan of n int32 in three phases (block sums -> scan of the sums -> add), 1024 elements per block
@@ -184,93 +174,143 @@ __global__ __launch_bounds__(64) void snap_halo_kernel(const SnapParams P)
     }
 }
 
-// one wavefront per halo; one lane per cell of the sphere's bounding box
+// cells of the (periodic) grid a halo's sphere can reach: count pass (fill = false) / list fill (fill = true);
+// spheres spanning more than kSnapBigCells cells are appended to the global list in the count pass
 template <int NDIM>
-__global__ __launch_bounds__(256) void snap_displace_kernel(const SnapParams P)
+__global__ __launch_bounds__(256) void snap_overlap_kernel(const SnapParams P, int fill)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= P.n_halo) return;
     const SnapHalo h = P.hs[j];
-    if (h.flags & HF_OOB) return;                            // NaN displacement everywhere -> 0 (:231 / :248)
-    if (!(h.rq > 0.0)) return;
-    const DevTable &T = P.tab;
-    const double L = P.L, halfL = 0.5 * P.L;
+    if ((h.flags & HF_OOB) || !(h.rq > 0.0)) return;           // NaN displacement everywhere -> 0 (:231 / :248)
     const int n = P.ncell;
-    const double cell = L / (double)n, inv_cell = (double)n / L;
+    const double cell = P.L / (double)n, inv_cell = (double)n / P.L;
     const double hc[3] = {h.x, h.y, h.z};
     int lo[3] = {0, 0, 0}, cnt[3] = {1, 1, 1};
     for (int k = 0; k < NDIM; ++k) {
-        const int a = (int)floor((hc[k] - h.rq) * inv_cell), b = (int)floor((hc[k] + h.rq) * inv_cell);
-        lo[k] = a; cnt[k] = min(b - a + 1, n);               // at most every cell once
+        // 1e-9 cells of slack: a particle's own cell index is floor(x / cell) of its wrapped coordinate
+        const int a = (int)floor((hc[k] - h.rq) * inv_cell - 1e-9), b = (int)floor((hc[k] + h.rq) * inv_cell + 1e-9);
+        lo[k] = a; cnt[k] = min(b - a + 1, n);                 // at most every cell once
     }
     const int64_t nbox = (int64_t)cnt[0] * cnt[1] * cnt[2];
-    const double rq2 = h.rq * h.rq;
-    const double *row = P.hrow + j * T.nr;
-    const double r_lo = T.raxis[0], r_hi = T.raxis[T.nr - 1];
-    unsigned long long hits = 0, n_oob = 0;
-    for (int64_t ci = lane; ci < nbox; ci += 64) {
+    if (nbox > kSnapBigCells) {
+        if (!fill) P.big[1 + atomicAdd(&P.big[0], 1)] = (int32_t)j;
+        return;
+    }
+    const double rq2 = h.rq * h.rq * (1.0 + 1e-12);
+    for (int64_t ci = 0; ci < nbox; ++ci) {
+        int64_t rem = ci, cid = 0;
         int ic[3];
-        int64_t rem = ci;
         for (int k = NDIM - 1; k >= 0; --k) { ic[k] = lo[k] + (int)(rem % cnt[k]); rem /= cnt[k]; }
-        // wrapped cell id, and the smallest possible squared distance from the halo to the (unwrapped) cell
-        int64_t cid = 0;
         double dmin2 = 0.0;
         for (int k = 0; k < NDIM; ++k) {
             const double c0 = (double)ic[k] * cell, c1 = c0 + cell;
             double gap = 0.0;
-            if (cnt[k] < n - 1) {                            // (nearly) full wrap: another image of the cell may be closer
+            if (cnt[k] < n - 1) {                              // (nearly) full wrap: another image of the cell may be closer
                 if (hc[k] < c0) gap = c0 - hc[k]; else if (hc[k] > c1) gap = hc[k] - c1;
             }
             dmin2 += gap * gap;
             int w = ic[k] % n; if (w < 0) w += n;
             cid = cid * n + w;
         }
-        if (dmin2 > rq2 * (1.0 + 1e-12)) continue;           // the sphere cannot reach this cell
-        const int p0 = P.cell_start[cid], p1 = P.cell_start[cid + 1];
-        for (int q = p0; q < p1; ++q) {
-            const int64_t ip = P.order[q];
-            double dd[3] = {0.0, 0.0, 0.0}, d2 = 0.0;
+        if (dmin2 > rq2) continue;                             // the sphere cannot reach this cell
+        if (!fill) atomicAdd(&P.cell_count[cid], 1);
+        else {
+            const int64_t pos = (int64_t)P.cell_start[cid] + atomicAdd(&P.cell_count[cid], 1);
+            if (pos < P.cand_cap) {
+                SnapCand e;
+                e.x = h.x; e.y = h.y; e.z = h.z; e.rq = h.rq; e.halo = (int32_t)j; e.pad[0] = e.pad[1] = e.pad[2] = 0;
+                P.cand[pos] = e;
+            }
+        }
+    }
+}
+
+// one thread per particle: candidates of its cell (+ the global list) -> summed offset -> shift, wrap, write
+template <int NDIM>
+__global__ __launch_bounds__(256) void snap_particle_kernel(const SnapParams P)
+{
+    // grid-stride over the particles: a few thousand fat workgroups, so that the two statistics counters see a few
+    // thousand same-address atomics instead of one per wavefront (2e6 of those cost 20 ms)
+    unsigned long long hits = 0, n_oob = 0;
+    for (int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ip < P.n_part; ip += (int64_t)gridDim.x * blockDim.x) {
+        const DevTable &T = P.tab;
+        const double L = P.L, halfL = 0.5 * P.L;
+        const int n = P.ncell;
+        const double inv_cell = (double)n / L;
+        double p[3] = {0.0, 0.0, 0.0}, off[3] = {0.0, 0.0, 0.0};
+        int64_t cid = 0;
+        for (int k = 0; k < NDIM; ++k) { p[k] = P.part[ip * NDIM + k]; cid = cid * n + snap_cell_of(p[k], inv_cell, n); }
+        const double r_lo = T.raxis[0], r_hi = T.raxis[T.nr - 1];
+        // a candidate: periodic distance test (compute_distance / enforce_periodicity, :104-158; KDTree radius :225 / :240)
+        auto test = [&](double hx_, double hy_, double hz_, double rq_, double *dd, double &d) -> bool {
+            const double hc[3] = {hx_, hy_, hz_};
+            double d2 = 0.0;
             for (int k = 0; k < NDIM; ++k) {
-                double dx = P.part[ip * NDIM + k] - hc[k];
-                dx = (dx > halfL) ? dx - L : dx;               // compute_distance / enforce_periodicity (:104-158)
+                double dx = p[k] - hc[k];
+                dx = (dx > halfL) ? dx - L : dx;
                 dx = (dx < -halfL) ? dx + L : dx;
                 dd[k] = dx; d2 += dx * dx;
             }
-            const double d = sqrt(d2);
-            if (!(d <= h.rq)) continue;                        // KDTree.query_ball_point radius (:225 / :240)
+            d = sqrt(d2);
+            return d <= rq_;
+        };
+        // a hit: BaryonificationClass._readout (BaryonCorrection.py:331-419): linear table, NaN outside the hull, 0 at or
+        // beyond epsilon_max * R; non-finite offsets contribute nothing (:231 / :248)
+        auto apply = [&](int j, const double *dd, double d) {
             ++hits;
-            // BaryonificationClass._readout (BaryonCorrection.py:331-419): linear table, NaN outside the hull,
-            // 0 at or beyond epsilon_max * R; non-finite offsets contribute nothing (:231 / :248)
-            const double rin = log(d) - h.lnshift;
-            if (!(rin >= r_lo) || !(rin <= r_hi)) { ++n_oob; continue; }
-            if (!(d < h.xcut)) continue;
-            const int i = find_interval(T.raxis, T.nr, rin);
+            const double rin = log(d) - P.hs[j].lnshift;
+            if (!(rin >= r_lo) || !(rin <= r_hi)) { ++n_oob; return; }
+            if (!(d < P.hs[j].xcut)) return;
+            const double *row = P.hrow + (int64_t)j * T.nr;
+            int i;
+            if (T.r_uniform) {                                 // geomspace radial axis: the cell by arithmetic, then one fix-up
+                i = min(max((int)((rin - T.r0) * T.inv_dr), 0), T.nr - 2);
+                if (rin < T.raxis[i]) --i; else if (rin >= T.raxis[i + 1] && i < T.nr - 2) ++i;
+            } else i = find_interval(T.raxis, T.nr, rin);
             const double f = (rin - T.raxis[i]) / (T.raxis[i + 1] - T.raxis[i]);
             const double val = row[i] * (1.0 - f) + row[i + 1] * f;
-            if (!(fabs(val) < 1.0e300)) continue;
+            if (!(fabs(val) < 1.0e300)) return;
             const double s = val / d;
-            for (int k = 0; k < NDIM; ++k) unsafeAtomicAdd(P.off + ip * NDIM + k, s * dd[k]);
+            for (int k = 0; k < NDIM; ++k) off[k] += s * dd[k];
+        };
+        const int c0 = P.cell_start[cid], c1 = (int)min((int64_t)P.cell_start[cid + 1], P.cand_cap);
+        for (int q = c0; q < c1; q += 2) {                     // two candidates per trip: their loads are independent
+            const SnapCand ea = P.cand[q];
+            const SnapCand eb = P.cand[min(q + 1, c1 - 1)];
+            double da[3] = {0, 0, 0}, db[3] = {0, 0, 0}, ra, rb;
+            const bool ha = test(ea.x, ea.y, ea.z, ea.rq, da, ra);
+            const bool hb = (q + 1 < c1) && test(eb.x, eb.y, eb.z, eb.rq, db, rb);
+            if (ha) apply(ea.halo, da, ra);
+            if (hb) apply(eb.halo, db, rb);
+        }
+        const int nbig = P.big[0];
+        for (int q = 0; q < nbig; ++q) {
+            const int j = P.big[1 + q];
+            const double4 hx = *reinterpret_cast<const double4 *>(&P.hs[j]);
+            double dd[3] = {0, 0, 0}, d;
+            if (test(hx.x, hx.y, hx.z, hx.w, dd, d)) apply(j, dd, d);
+        }
+        for (int k = 0; k < NDIM; ++k) {
+            double v = p[k] + off[k];                          // :262-265
+            v = (v > L) ? v - L : v;                           // :268-273
+            v = (v < 0.0) ? v + L : v;
+            P.out[ip * NDIM + k] = v;
         }
     }
+    __shared__ unsigned long long s_red[2][4];
     for (int o = 32; o > 0; o >>= 1) { hits += __shfl_down(hits, o, 64); n_oob += __shfl_down(n_oob, o, 64); }
-    if (lane == 0) {
+    if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = hits; s_red[1][threadIdx.x >> 6] = n_oob; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        hits = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+        n_oob = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
         if (hits) atomicAdd((unsigned long long *)&P.stats->pixel_updates, hits);
         if (n_oob) {
             atomicAdd((unsigned long long *)&P.stats->pixels_out_of_table, n_oob);
             if (!P.rdelta) atomicOr(&P.stats->warn_mask, BFG_WARN_R_RANGE);       // BaryonCorrection.py:391-394
         }
     }
-}
-
-__global__ __launch_bounds__(256) void snap_apply_kernel(const SnapParams P)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n_part * P.ndim) return;
-    double v = P.part[i] + P.off[i];                          // :262-265
-    v = (v > P.L) ? v - P.L : v;                              // :268-273
-    v = (v < 0.0) ? v + P.L : v;
-    P.out[i] = v;
 }
 
 // Mass deposit of particles on a periodic N^ndim grid: mode 0 = nearest grid point with numpy.histogramdd's bin
