@@ -106,6 +106,8 @@ struct bfg_ctx {
     size_t snap_cap[8];
     void *grid_buf[2];              // grid runners: per-halo records, blended rows (grow-only)
     size_t grid_cap[2];
+    void *dep_buf[5];               // tiled deposit: keys, permutation, tile counts, tile starts, scan scratch (grow-only)
+    size_t dep_cap[5];
     int64_t pair_cap;
     unsigned long long *d_pair_total;
     double *d_mathtab;              // logtab (256 doubles) | exptab (64 doubles)
@@ -1021,6 +1023,7 @@ int bfg_ctx_destroy(bfg_ctx *c)
     if (c->d_left) (void)hipFree(c->d_left);
     for (int k = 0; k < 8; ++k) if (c->snap_buf[k]) (void)hipFree(c->snap_buf[k]);
     for (int k = 0; k < 2; ++k) if (c->grid_buf[k]) (void)hipFree(c->grid_buf[k]);
+    for (int k = 0; k < 5; ++k) if (c->dep_buf[k]) (void)hipFree(c->dep_buf[k]);
     if (c->d_pairs) (void)hipFree(c->d_pairs);
     (void)hipFree(c->d_mathtab); (void)hipFree(c->d_pair_total);
     for (int k = 0; k < 5; ++k) {
@@ -1578,6 +1581,23 @@ int bfg_reduce_absmax_sum(bfg_ctx *c, int64_t n, const double *d_x, double *absm
     return BFG_OK;
 }
 
+} // extern C (helper below has C++ linkage)
+// grow-only workspace of the particle-grouping passes (tiled deposit, cell-grouped snapshot pass)
+static int dep_workspace(bfg_ctx *c, const size_t want[5])
+{
+    for (int k = 0; k < 5; ++k) {
+        if (want[k] > c->dep_cap[k]) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->dep_buf[k]) (void)hipFree(c->dep_buf[k]);
+            c->dep_buf[k] = nullptr; c->dep_cap[k] = 0;
+            HIP_TRY(hipMalloc(&c->dep_buf[k], want[k]));
+            c->dep_cap[k] = want[k];
+        }
+    }
+    return BFG_OK;
+}
+
+extern "C" {
 int bfg_baryonify_snapshot(bfg_ctx *c, const bfg_snapshot_args *a, const bfg_table *t, double *d_out)
 {
     int rc = ctx_enter(c);
@@ -1595,6 +1615,7 @@ int bfg_baryonify_snapshot(bfg_ctx *c, const bfg_snapshot_args *a, const bfg_tab
     P.md_run = a->runner_md; P.md_model = a->model_md;
     P.part = a->d_part; P.halo = a->d_halo; P.halo_stride = a->halo_stride; P.n_extra = a->n_extra;
     P.tab = t->dev; P.stats = c->d_stats; P.out = d_out;
+    P.logtab = reinterpret_cast<const double2 *>(c->d_mathtab);
     // coarse cell grid for the halo-overlap lists: a few candidate halos per cell
     const int nmax = (a->ndim == 3) ? 128 : 2048;
     int ncell = (int)std::floor(std::pow(4.0 * (double)std::max<int64_t>(a->n_halo, 1), 1.0 / a->ndim));
@@ -1646,9 +1667,40 @@ int bfg_baryonify_snapshot(bfg_ctx *c, const bfg_snapshot_args *a, const bfg_tab
     } else {
         P.cand = (SnapCand *)c->snap_buf[5]; P.cand_cap = 0;
     }
-    const unsigned pgrid = (unsigned)std::min<int64_t>((a->n_part + 255) / 256, 8192);       // grid-stride
-    if (a->ndim == 3) hipLaunchKernelGGL(snap_particle_kernel<3>, dim3(pgrid), dim3(256), 0, c->stream, P);
-    else hipLaunchKernelGGL(snap_particle_kernel<2>, dim3(pgrid), dim3(256), 0, c->stream, P);
+    // default: one thread per particle in the caller's order.  BFG_SNAPSHOT=cell: group the particle indices by cell,
+    // then one wavefront per cell with wave-uniform candidate lists (measured equal at 512^3: 7.1 vs 6.2 ms; kept as the
+    // variant for particle orders without any spatial coherence)
+    bool grouped = false;
+    if (const char *e = std::getenv("BFG_SNAPSHOT"))
+        if (!std::strcmp(e, "cell")) grouped = a->n_part < (int64_t)0x7fffffff;
+    if (!grouped) {
+        const unsigned pgrid = (unsigned)std::min<int64_t>((a->n_part + 255) / 256, 8192);       // grid-stride
+        if (a->ndim == 3) hipLaunchKernelGGL(snap_particle_kernel<3>, dim3(pgrid), dim3(256), 0, c->stream, P);
+        else hipLaunchKernelGGL(snap_particle_kernel<2>, dim3(pgrid), dim3(256), 0, c->stream, P);
+        HIP_TRY(hipGetLastError());
+        return BFG_OK;
+    }
+    const size_t dwant[5] = {(size_t)a->n_part * sizeof(int32_t), (size_t)a->n_part * sizeof(int32_t),
+                             (size_t)P.ncell_tot * sizeof(int32_t), (size_t)(P.ncell_tot + 1) * sizeof(int32_t),
+                             (size_t)(nblk + 1) * sizeof(int32_t)};
+    rc = dep_workspace(c, dwant);
+    if (rc) return rc;
+    P.pkey = (int32_t *)c->dep_buf[0]; P.perm = (int32_t *)c->dep_buf[1]; P.pcount = (int32_t *)c->dep_buf[2];
+    int32_t *d_pstart = (int32_t *)c->dep_buf[3], *d_pbsum = (int32_t *)c->dep_buf[4], *d_ptotal = d_pbsum + nblk;
+    P.pstart = d_pstart;
+    HIP_TRY(hipMemsetAsync(P.pcount, 0, (size_t)P.ncell_tot * sizeof(int32_t), c->stream));
+    const unsigned kgrid = (unsigned)std::min<int64_t>((a->n_part + 255) / 256, 16384);         // grid-stride
+    if (a->ndim == 3) hipLaunchKernelGGL(snap_key_kernel<3>, dim3(kgrid), dim3(256), 0, c->stream, P);
+    else hipLaunchKernelGGL(snap_key_kernel<2>, dim3(kgrid), dim3(256), 0, c->stream, P);
+    hipLaunchKernelGGL(snap_scan_block_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, P.ncell_tot, P.pcount, d_pstart,
+                       d_pbsum);
+    hipLaunchKernelGGL(snap_scan_sums_kernel, dim3(1), dim3(1024), 0, c->stream, (int)nblk, d_pbsum, d_ptotal);
+    hipLaunchKernelGGL(snap_scan_add_kernel, dim3((unsigned)((P.ncell_tot + 255) / 256)), dim3(256), 0, c->stream, P.ncell_tot,
+                       d_pstart, d_pbsum, P.pcount, d_ptotal);
+    hipLaunchKernelGGL(group_fill_kernel, dim3(kgrid), dim3(256), 0, c->stream, a->n_part, P.pkey, P.pcount, P.pstart, P.perm);
+    const unsigned cgrid = (unsigned)std::min<int64_t>((P.ncell_tot + 3) / 4, 8192);             // 4 cells per workgroup trip
+    if (a->ndim == 3) hipLaunchKernelGGL(snap_cell_kernel<3>, dim3(cgrid), dim3(256), 0, c->stream, P);
+    else hipLaunchKernelGGL(snap_cell_kernel<2>, dim3(cgrid), dim3(256), 0, c->stream, P);
     HIP_TRY(hipGetLastError());
     return BFG_OK;
 }
@@ -1734,9 +1786,57 @@ int bfg_deposit_grid(bfg_ctx *c, int ndim, int64_t n_part, const double *d_pos, 
     if (n_part == 0) return BFG_OK;
     DepositParams P;
     P.ndim = ndim; P.mode = mode; P.N = n_grid; P.n_part = n_part; P.L = L; P.pos = d_pos; P.mass = d_mass; P.grid = d_grid;
-    const unsigned grid = (unsigned)((n_part + 255) / 256);
-    if (ndim == 3) hipLaunchKernelGGL(deposit_kernel<3>, dim3(grid), dim3(256), 0, c->stream, P);
-    else hipLaunchKernelGGL(deposit_kernel<2>, dim3(grid), dim3(256), 0, c->stream, P);
+    // large particle sets go through the tile-privatised path (BFG_DEPOSIT=direct / tile forces either one)
+    const int T = (ndim == 3) ? DepTile<3>::T : DepTile<2>::T;
+    const int nt = (n_grid + T - 1) / T;
+    const int64_t ntile = (ndim == 3) ? (int64_t)nt * nt * nt : (int64_t)nt * nt;
+    bool tiled = n_part >= (1 << 18) && n_part < (int64_t)0x7fffffff && ntile < (1 << 26);
+    if (const char *e = std::getenv("BFG_DEPOSIT")) {
+        if (!std::strcmp(e, "direct")) tiled = false;
+        else if (!std::strcmp(e, "tile")) tiled = n_part < (int64_t)0x7fffffff && ntile < (1 << 26);
+    }
+    if (!tiled) {
+        const unsigned grid = (unsigned)((n_part + 255) / 256);
+        if (ndim == 3) hipLaunchKernelGGL(deposit_kernel<3>, dim3(grid), dim3(256), 0, c->stream, P);
+        else hipLaunchKernelGGL(deposit_kernel<2>, dim3(grid), dim3(256), 0, c->stream, P);
+        HIP_TRY(hipGetLastError());
+        return BFG_OK;
+    }
+    const int64_t nblk = (ntile + 1023) / 1024;
+    const size_t want[5] = {(size_t)n_part * sizeof(int32_t), (size_t)n_part * sizeof(int32_t), (size_t)ntile * sizeof(int32_t),
+                            (size_t)(ntile + 1) * sizeof(int32_t), (size_t)(nblk + 1) * sizeof(int32_t)};
+    rc = dep_workspace(c, want);
+    if (rc) return rc;
+    DepSortParams S;
+    S.d = P; S.nt = nt;
+    S.key = (int32_t *)c->dep_buf[0]; S.perm = (int32_t *)c->dep_buf[1]; S.count = (int32_t *)c->dep_buf[2];
+    int32_t *d_start = (int32_t *)c->dep_buf[3], *d_bsum = (int32_t *)c->dep_buf[4], *d_total = d_bsum + nblk;
+    S.start = d_start;
+    HIP_TRY(hipMemsetAsync(S.count, 0, (size_t)ntile * sizeof(int32_t), c->stream));
+    const unsigned pgrid = (unsigned)std::min<int64_t>((n_part + 255) / 256, 16384);          // grid-stride
+#define BFG_DEP_LAUNCH(KERNEL, GRID)                                                                              \
+    do {                                                                                                           \
+        if (ndim == 3 && mode == BFG_DEPOSIT_CIC) hipLaunchKernelGGL((KERNEL<3, BFG_DEPOSIT_CIC>), dim3(GRID), dim3(256), 0, c->stream, S); \
+        else if (ndim == 3) hipLaunchKernelGGL((KERNEL<3, BFG_DEPOSIT_NGP>), dim3(GRID), dim3(256), 0, c->stream, S);                       \
+        else if (mode == BFG_DEPOSIT_CIC) hipLaunchKernelGGL((KERNEL<2, BFG_DEPOSIT_CIC>), dim3(GRID), dim3(256), 0, c->stream, S);         \
+        else hipLaunchKernelGGL((KERNEL<2, BFG_DEPOSIT_NGP>), dim3(GRID), dim3(256), 0, c->stream, S);                                      \
+    } while (0)
+    BFG_DEP_LAUNCH(dep_key_kernel, pgrid);
+    hipLaunchKernelGGL(snap_scan_block_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, ntile, S.count, d_start, d_bsum);
+    hipLaunchKernelGGL(snap_scan_sums_kernel, dim3(1), dim3(1024), 0, c->stream, (int)nblk, d_bsum, d_total);
+    hipLaunchKernelGGL(snap_scan_add_kernel, dim3((unsigned)((ntile + 255) / 256)), dim3(256), 0, c->stream, ntile, d_start,
+                       d_bsum, S.count, d_total);
+    hipLaunchKernelGGL(group_fill_kernel, dim3(pgrid), dim3(256), 0, c->stream, n_part, S.key, S.count, S.start, S.perm);
+#undef BFG_DEP_LAUNCH
+#define BFG_DEP_LAUNCH(KERNEL, GRID)                                                                              \
+    do {                                                                                                           \
+        if (ndim == 3 && mode == BFG_DEPOSIT_CIC) hipLaunchKernelGGL((KERNEL<3, BFG_DEPOSIT_CIC>), dim3(GRID), dim3(kDepThreads), 0, c->stream, S); \
+        else if (ndim == 3) hipLaunchKernelGGL((KERNEL<3, BFG_DEPOSIT_NGP>), dim3(GRID), dim3(kDepThreads), 0, c->stream, S);                       \
+        else if (mode == BFG_DEPOSIT_CIC) hipLaunchKernelGGL((KERNEL<2, BFG_DEPOSIT_CIC>), dim3(GRID), dim3(kDepThreads), 0, c->stream, S);         \
+        else hipLaunchKernelGGL((KERNEL<2, BFG_DEPOSIT_NGP>), dim3(GRID), dim3(kDepThreads), 0, c->stream, S);                                      \
+    } while (0)
+    BFG_DEP_LAUNCH(dep_tile_kernel, (unsigned)ntile);
+#undef BFG_DEP_LAUNCH
     HIP_TRY(hipGetLastError());
     return BFG_OK;
 }

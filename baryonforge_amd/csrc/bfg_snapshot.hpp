@@ -26,8 +26,9 @@ struct __align__(16) SnapHalo {      // per-halo constants (written by snap_halo
     double pad2;
 };
 
-struct __align__(16) SnapCand {      // one (cell, halo) entry of the overlap lists
+struct __align__(16) SnapCand {      // one (cell, halo) entry of the overlap lists (64 B)
     double x, y, z, rq;
+    double xcut, lnshift;            // copies of SnapHalo's: a hit needs no second per-halo record
     int32_t halo, pad[3];
 };
 
@@ -52,6 +53,12 @@ struct SnapParams {
     double *hrow;                    // [n_halo][tab.nr] blended radial rows
     double *out;                     // [n_part][ndim] displaced, wrapped coordinates
     bfg_stats *stats;
+    const double2 *logtab;           // [kLogTab] {1/c, ln c} of fast_log (bfg_tile.hpp), staged in LDS
+    // cell-grouped pass: particle indices grouped by cell (counting sort of 4-byte indices)
+    int32_t *pkey;                   // [n_part] cell of every particle
+    int32_t *pcount;                 // [ncell_tot] counts, then fill cursors
+    const int32_t *pstart;           // [ncell_tot + 1]
+    int32_t *perm;                   // [n_part]
 };
 
 __device__ inline int snap_cell_of(double x, double inv_cell, int n)
@@ -108,6 +115,44 @@ __global__ __launch_bounds__(256) void snap_scan_add_kernel(int64_t n, int32_t *
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) { out[i] += bsum[i >> 10]; count[i] = 0; }      // count becomes the fill cursor
     if (i == 0) out[n] = *total;
+}
+
+// ---- grouping particle indices by an integer key (cell / tile): counting sort of 4-byte indices --------------------
+// keys[] -> counts (wave-aggregated atomics) -> exclusive scan (kernels above) -> slots (wave-aggregated atomics).
+// wave_group_slot adds 1 to count[key] for every active lane and returns the lane's slot in its key's range.  Lanes of
+// a wavefront that share a key are merged into ONE atomic: up to 16 groups are found with ballots (spatially coherent
+// particle orders have 1-4 keys per wavefront), the rest stay singletons; every group leader then issues its atomic in
+// the same instruction, so a wavefront waits for one atomic round trip, not one per group.
+__device__ inline int wave_group_slot(int32_t *count, int key, bool active)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(active);
+    unsigned long long mine = 1ull << lane;
+    int leader = lane;
+    for (int round = 0; round < 16 && todo; ++round) {
+        const int l0 = __ffsll((long long)todo) - 1;
+        const int k0 = __shfl(key, l0, 64);
+        const unsigned long long same = __ballot(active && key == k0) & todo;
+        if ((same >> lane) & 1ull) { mine = same; leader = l0; }
+        todo &= ~same;
+    }
+    int base = 0;
+    if (active && lane == leader) base = atomicAdd(&count[key], __popcll(mine));
+    base = __shfl(base, leader, 64);
+    return base + __popcll(mine & ((1ull << lane) - 1ull));
+}
+
+// perm[start[key] + slot] = particle index, for every particle with key >= 0 (count[] holds the fill cursors, zeroed)
+__global__ __launch_bounds__(256) void group_fill_kernel(int64_t n, const int32_t *key, int32_t *count, const int32_t *start,
+                                                         int32_t *perm)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < n; base += stride) {          // wave-uniform trip count
+        const int64_t ip = base + threadIdx.x;
+        const int k = (ip < n) ? key[ip] : -1;
+        const int slot = wave_group_slot(count, k, k >= 0);
+        if (k >= 0) perm[(int64_t)start[k] + slot] = (int32_t)ip;
+    }
 }
 
 // per halo: radii, table cell in the outer dimensions, full blended radial row
@@ -219,11 +264,63 @@ __global__ __launch_bounds__(256) void snap_overlap_kernel(const SnapParams P, i
             const int64_t pos = (int64_t)P.cell_start[cid] + atomicAdd(&P.cell_count[cid], 1);
             if (pos < P.cand_cap) {
                 SnapCand e;
-                e.x = h.x; e.y = h.y; e.z = h.z; e.rq = h.rq; e.halo = (int32_t)j; e.pad[0] = e.pad[1] = e.pad[2] = 0;
+                e.x = h.x; e.y = h.y; e.z = h.z; e.rq = h.rq; e.xcut = h.xcut; e.lnshift = h.lnshift;
+                e.halo = (int32_t)j; e.pad[0] = e.pad[1] = e.pad[2] = 0;
                 P.cand[pos] = e;
             }
         }
     }
+}
+
+// One (halo, particle) hit: BaryonificationClass._readout (BaryonCorrection.py:331-419) on the halo's blended radial
+// row -- linear table in ln r, NaN outside the hull (contributes nothing, :231 / :248), 0 at or beyond
+// epsilon_max * R -- and the radial unit vector.  d2 = squared periodic distance (<= rq^2, checked by the caller).
+// Lean arithmetic: 1/sqrt by v_rsq_f64 + two coupled Newton steps (d and 1/d to ~1 ulp, no sqrt / division),
+// ln d = ln(d2)/2 from the table-driven fast_log (abs err < 6e-11; libm within 1e-9 of the axis ends so that the
+// in / out-of-table decision is the reference's), the cell on a geomspace axis by arithmetic.
+struct SnapHit {
+    const DevTable *T;
+    const double *hrow;
+    const double2 *logtab;           // LDS
+    double r_lo, r_hi;
+};
+
+__device__ inline void snap_hit(const SnapHit &H, double d2, const double *dd, int ndim, int j, double xcut, double lnshift,
+                                double *off, unsigned long long &n_oob)
+{
+    const DevTable &T = *H.T;
+    double rin, d, rinv;
+    if (d2 >= 1e-290 && d2 <= 1e290) {
+        double y = __builtin_amdgcn_rsq(d2);
+        double g = d2 * y, h = 0.5 * y;
+        double r = fma(-h, g, 0.5);
+        g = fma(g, r, g); h = fma(h, r, h);
+        r = fma(-h, g, 0.5);
+        g = fma(g, r, g); h = fma(h, r, h);
+        d = g; rinv = h + h;
+        rin = 0.5 * fast_log(d2, H.logtab) - lnshift;
+        if (fabs(rin - H.r_lo) < 1e-9 || fabs(rin - H.r_hi) < 1e-9) rin = log(sqrt(d2)) - lnshift;
+    } else {
+        d = sqrt(d2); rinv = 1.0 / d;
+        rin = log(d) - lnshift;
+    }
+    if (!(rin >= H.r_lo) || !(rin <= H.r_hi)) { ++n_oob; return; }
+    if (!(d < xcut)) return;
+    const double *row = H.hrow + (int64_t)j * T.nr;
+    int i;
+    double f;
+    if (T.r_uniform) {
+        const double t = (rin - T.r0) * T.inv_dr;
+        i = min(max((int)t, 0), T.nr - 2);
+        f = t - (double)i;
+    } else {
+        i = find_interval(T.raxis, T.nr, rin);
+        f = (rin - T.raxis[i]) / (T.raxis[i + 1] - T.raxis[i]);
+    }
+    const double val = row[i] * (1.0 - f) + row[i + 1] * f;
+    if (!(fabs(val) < 1.0e300)) return;
+    const double sc = val * rinv;
+    for (int k = 0; k < ndim; ++k) off[k] += sc * dd[k];
 }
 
 // one thread per particle: candidates of its cell (+ the global list) -> summed offset -> shift, wrap, write
@@ -232,6 +329,10 @@ __global__ __launch_bounds__(256) void snap_particle_kernel(const SnapParams P)
 {
     // grid-stride over the particles: a few thousand fat workgroups, so that the two statistics counters see a few
     // thousand same-address atomics instead of one per wavefront (2e6 of those cost 20 ms)
+    __shared__ double2 s_logtab[kLogTab];
+    if (threadIdx.x < kLogTab) s_logtab[threadIdx.x] = P.logtab[threadIdx.x];
+    __syncthreads();
+    const SnapHit H = {&P.tab, P.hrow, s_logtab, P.tab.raxis[0], P.tab.raxis[P.tab.nr - 1]};
     unsigned long long hits = 0, n_oob = 0;
     for (int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ip < P.n_part; ip += (int64_t)gridDim.x * blockDim.x) {
         const DevTable &T = P.tab;
@@ -241,61 +342,151 @@ __global__ __launch_bounds__(256) void snap_particle_kernel(const SnapParams P)
         double p[3] = {0.0, 0.0, 0.0}, off[3] = {0.0, 0.0, 0.0};
         int64_t cid = 0;
         for (int k = 0; k < NDIM; ++k) { p[k] = P.part[ip * NDIM + k]; cid = cid * n + snap_cell_of(p[k], inv_cell, n); }
-        const double r_lo = T.raxis[0], r_hi = T.raxis[T.nr - 1];
         // a candidate: periodic distance test (compute_distance / enforce_periodicity, :104-158; KDTree radius :225 / :240)
-        auto test = [&](double hx_, double hy_, double hz_, double rq_, double *dd, double &d) -> bool {
+        auto test = [&](double hx_, double hy_, double hz_, double rq_, double *dd, double &d2) -> bool {
             const double hc[3] = {hx_, hy_, hz_};
-            double d2 = 0.0;
+            d2 = 0.0;
             for (int k = 0; k < NDIM; ++k) {
                 double dx = p[k] - hc[k];
                 dx = (dx > halfL) ? dx - L : dx;
                 dx = (dx < -halfL) ? dx + L : dx;
                 dd[k] = dx; d2 += dx * dx;
             }
-            d = sqrt(d2);
-            return d <= rq_;
-        };
-        // a hit: BaryonificationClass._readout (BaryonCorrection.py:331-419): linear table, NaN outside the hull, 0 at or
-        // beyond epsilon_max * R; non-finite offsets contribute nothing (:231 / :248)
-        auto apply = [&](int j, const double *dd, double d) {
-            ++hits;
-            const double rin = log(d) - P.hs[j].lnshift;
-            if (!(rin >= r_lo) || !(rin <= r_hi)) { ++n_oob; return; }
-            if (!(d < P.hs[j].xcut)) return;
-            const double *row = P.hrow + (int64_t)j * T.nr;
-            int i;
-            if (T.r_uniform) {                                 // geomspace radial axis: the cell by arithmetic, then one fix-up
-                i = min(max((int)((rin - T.r0) * T.inv_dr), 0), T.nr - 2);
-                if (rin < T.raxis[i]) --i; else if (rin >= T.raxis[i + 1] && i < T.nr - 2) ++i;
-            } else i = find_interval(T.raxis, T.nr, rin);
-            const double f = (rin - T.raxis[i]) / (T.raxis[i + 1] - T.raxis[i]);
-            const double val = row[i] * (1.0 - f) + row[i + 1] * f;
-            if (!(fabs(val) < 1.0e300)) return;
-            const double s = val / d;
-            for (int k = 0; k < NDIM; ++k) off[k] += s * dd[k];
+            return d2 <= rq_ * rq_;
         };
         const int c0 = P.cell_start[cid], c1 = (int)min((int64_t)P.cell_start[cid + 1], P.cand_cap);
-        for (int q = c0; q < c1; q += 2) {                     // two candidates per trip: their loads are independent
-            const SnapCand ea = P.cand[q];
-            const SnapCand eb = P.cand[min(q + 1, c1 - 1)];
-            double da[3] = {0, 0, 0}, db[3] = {0, 0, 0}, ra, rb;
-            const bool ha = test(ea.x, ea.y, ea.z, ea.rq, da, ra);
-            const bool hb = (q + 1 < c1) && test(eb.x, eb.y, eb.z, eb.rq, db, rb);
-            if (ha) apply(ea.halo, da, ra);
-            if (hb) apply(eb.halo, db, rb);
+        // two phases per batch of 64 candidates, so that the expensive read-out runs on the lanes' own hits only
+        // (a lane hits ~2 of its ~8 candidates; done inline, every trip of the test loop would pay for the read-out
+        // because some lane of the wavefront hits): (1) distance tests -> hit mask, (2) the set bits in ascending order
+        for (int qb = c0; qb < c1; qb += 64) {
+            const int qe = min(qb + 64, c1);
+            unsigned long long mask = 0;
+            for (int q = qb; q < qe; q += 4) {                 // four independent record loads in flight per trip
+                double4 e[4];
+                for (int u = 0; u < 4; ++u) e[u] = *reinterpret_cast<const double4 *>(&P.cand[min(q + u, qe - 1)]);   // x, y, z, rq
+                for (int u = 0; u < 4; ++u) {
+                    double dd[3], d2;
+                    if (test(e[u].x, e[u].y, e[u].z, e[u].w, dd, d2) && q + u < qe) mask |= 1ull << (q + u - qb);
+                }
+            }
+            while (mask) {
+                const int q = qb + __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const SnapCand e = P.cand[q];
+                double dd[3] = {0, 0, 0}, d2;
+                (void)test(e.x, e.y, e.z, e.rq, dd, d2);
+                ++hits;
+                snap_hit(H, d2, dd, NDIM, e.halo, e.xcut, e.lnshift, off, n_oob);
+            }
         }
         const int nbig = P.big[0];
         for (int q = 0; q < nbig; ++q) {
             const int j = P.big[1 + q];
-            const double4 hx = *reinterpret_cast<const double4 *>(&P.hs[j]);
-            double dd[3] = {0, 0, 0}, d;
-            if (test(hx.x, hx.y, hx.z, hx.w, dd, d)) apply(j, dd, d);
+            const SnapHalo h = P.hs[j];
+            double dd[3] = {0, 0, 0}, d2;
+            if (test(h.x, h.y, h.z, h.rq, dd, d2)) { ++hits; snap_hit(H, d2, dd, NDIM, j, h.xcut, h.lnshift, off, n_oob); }
         }
         for (int k = 0; k < NDIM; ++k) {
             double v = p[k] + off[k];                          // :262-265
             v = (v > L) ? v - L : v;                           // :268-273
             v = (v < 0.0) ? v + L : v;
             P.out[ip * NDIM + k] = v;
+        }
+    }
+    __shared__ unsigned long long s_red[2][4];
+    for (int o = 32; o > 0; o >>= 1) { hits += __shfl_down(hits, o, 64); n_oob += __shfl_down(n_oob, o, 64); }
+    if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = hits; s_red[1][threadIdx.x >> 6] = n_oob; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        hits = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+        n_oob = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+        if (hits) atomicAdd((unsigned long long *)&P.stats->pixel_updates, hits);
+        if (n_oob) {
+            atomicAdd((unsigned long long *)&P.stats->pixels_out_of_table, n_oob);
+            if (!P.rdelta) atomicOr(&P.stats->warn_mask, BFG_WARN_R_RANGE);       // BaryonCorrection.py:391-394
+        }
+    }
+}
+
+// ---- cell-grouped pass ----------------------------------------------------------------------------------------------
+// The one-thread-per-particle kernel above reads its candidate records lane by lane: a wavefront of 64 consecutive
+// particles straddles several cells, so every trip of the candidate loop is a divergent 64-byte gather (8 tests per
+// particle on average: ~70 GB of L2 -> CU traffic for 512^3 particles).  Here the particle indices are grouped by cell
+// first (key -> count -> scan -> fill, 4 bytes per particle), then one wavefront works on one cell: the cell's
+// candidate list is wave-uniform (scalar loads, one per candidate for 64 particles), every lane tests its own
+// particle, and results go to out[] in the caller's particle order.
+template <int NDIM>
+__global__ __launch_bounds__(256) void snap_key_kernel(const SnapParams P)
+{
+    const int n = P.ncell;
+    const double inv_cell = (double)n / P.L;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < P.n_part; base += stride) {
+        const int64_t ip = base + threadIdx.x;
+        int key = -1;
+        if (ip < P.n_part) {
+            key = 0;
+            for (int k = 0; k < NDIM; ++k) key = key * n + snap_cell_of(P.part[ip * NDIM + k], inv_cell, n);
+            P.pkey[ip] = key;
+        }
+        (void)wave_group_slot(P.pcount, key, key >= 0);
+    }
+}
+
+template <int NDIM>
+__global__ __launch_bounds__(256) void snap_cell_kernel(const SnapParams P)
+{
+    __shared__ double2 s_logtab[kLogTab];
+    if (threadIdx.x < kLogTab) s_logtab[threadIdx.x] = P.logtab[threadIdx.x];
+    __syncthreads();
+    const SnapHit H = {&P.tab, P.hrow, s_logtab, P.tab.raxis[0], P.tab.raxis[P.tab.nr - 1]};
+    const int lane = threadIdx.x & 63;
+    const double L = P.L, halfL = 0.5 * P.L;
+    const int nbig = P.big[0];
+    unsigned long long hits = 0, n_oob = 0;
+    for (int64_t cell = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); cell < P.ncell_tot; cell += (int64_t)gridDim.x * 4) {
+        const int64_t cid = __builtin_amdgcn_readfirstlane((int)cell);                       // wave-uniform
+        const int p0 = __builtin_amdgcn_readfirstlane(P.pstart[cid]), p1 = __builtin_amdgcn_readfirstlane(P.pstart[cid + 1]);
+        if (p0 == p1) continue;
+        const int c0 = __builtin_amdgcn_readfirstlane(P.cell_start[cid]);
+        const int c1 = __builtin_amdgcn_readfirstlane((int)min((int64_t)P.cell_start[cid + 1], P.cand_cap));
+        for (int qb = p0; qb < p1; qb += 64) {
+            const bool valid = qb + lane < p1;
+            const int64_t ip = P.perm[valid ? qb + lane : p1 - 1];
+            double p[3] = {0.0, 0.0, 0.0}, off[3] = {0.0, 0.0, 0.0};
+            for (int k = 0; k < NDIM; ++k) p[k] = P.part[ip * NDIM + k];
+            // one candidate against this lane's particle: periodic distance (compute_distance / enforce_periodicity,
+            // :104-158; KDTree radius :225 / :240), then the read-out
+            auto visit = [&](double hx_, double hy_, double hz_, double rq_, double xcut_, double lnshift_, int j) {
+                const double hc[3] = {hx_, hy_, hz_};
+                double dd[3] = {0.0, 0.0, 0.0}, d2 = 0.0;
+                for (int k = 0; k < NDIM; ++k) {
+                    double dx = p[k] - hc[k];
+                    dx = (dx > halfL) ? dx - L : dx;
+                    dx = (dx < -halfL) ? dx + L : dx;
+                    dd[k] = dx; d2 += dx * dx;
+                }
+                if (!valid || !(d2 <= rq_ * rq_)) return;
+                ++hits;
+                snap_hit(H, d2, dd, NDIM, j, xcut_, lnshift_, off, n_oob);
+            };
+            for (int q = c0; q < c1; ++q) {                                                  // wave-uniform: scalar loads
+                const SnapCand &e = P.cand[q];
+                visit(e.x, e.y, e.z, e.rq, e.xcut, e.lnshift, e.halo);
+            }
+            for (int q = 0; q < nbig; ++q) {
+                const int j = P.big[1 + q];
+                const SnapHalo &h = P.hs[j];
+                visit(h.x, h.y, h.z, h.rq, h.xcut, h.lnshift, j);
+            }
+            if (valid) {
+                for (int k = 0; k < NDIM; ++k) {
+                    double v = p[k] + off[k];                  // :262-265
+                    v = (v > L) ? v - L : v;                   // :268-273
+                    v = (v < 0.0) ? v + L : v;
+                    P.out[ip * NDIM + k] = v;
+                }
+            }
         }
     }
     __shared__ unsigned long long s_red[2][4];
@@ -373,6 +564,140 @@ __global__ __launch_bounds__(256) void deposit_kernel(const DepositParams P)
             }
             if (w != 0.0) unsafeAtomicAdd(P.grid + c, w);
         }
+    }
+}
+
+
+// ---- tile-privatised deposit ------------------------------------------------------------------------------------
+// The direct kernel above issues 2^ndim scattered f64 atomics per particle (1.1e9 for 512^3 particles: 24 ms, bound
+// by the L2 atomic rate of ~4.5e10/s).  Here the particles are first grouped by the grid tile (16^3 / 64^2 cells)
+// of their lower CIC corner with a counting sort that moves 4-byte particle indices only (keys -> wave-aggregated
+// counts -> scan -> wave-aggregated slots), then one workgroup per tile accumulates its particles in LDS
+// (ds_add_f64, ~2e12/s) and flushes the (T + 1)^ndim block once: cells no other tile can touch by a plain
+// read-add-write, the shared faces by global atomics.  Weights are computed exactly as in deposit_kernel.
+template <int NDIM> struct DepTile {
+    static constexpr int T = (NDIM == 3) ? 16 : 64;
+    static constexpr int E = T + 1;
+    static constexpr int NE = (NDIM == 3) ? E * E * E : E * E;
+};
+
+struct DepSortParams {
+    DepositParams d;
+    int nt;                          // tiles per dimension = ceil(N / T)
+    int32_t *key;                    // [n_part] tile of every particle, -1 = dropped (NGP, outside the box)
+    int32_t *count;                  // [ntile] counts, then fill cursors
+    const int32_t *start;            // [ntile + 1]
+    int32_t *perm;                   // [n_part] particle indices grouped by tile
+};
+
+// lower corner (CIC) / bin (NGP) of a particle along one axis; false = dropped
+template <int MODE>
+__device__ inline bool dep_cell(double x, double step, int N, double L, int &i0, double &w1)
+{
+    if (MODE == BFG_DEPOSIT_NGP) {
+        i0 = ngp_bin(x, step, N, L); w1 = 0.0;
+        return i0 >= 0;
+    }
+    const double u = x / step - 0.5;
+    const double f = floor(u);
+    w1 = u - f;
+    int i = (int)f % N; if (i < 0) i += N;
+    i0 = i;
+    return true;
+}
+
+template <int NDIM, int MODE>
+__global__ __launch_bounds__(256) void dep_key_kernel(const DepSortParams S)
+{
+    const DepositParams &P = S.d;
+    constexpr int T = DepTile<NDIM>::T;
+    const double step = P.L / (double)P.N;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < P.n_part; base += stride) {     // wave-uniform trip count
+        const int64_t ip = base + threadIdx.x;
+        int key = -1;
+        if (ip < P.n_part) {
+            key = 0;
+            for (int k = 0; k < NDIM; ++k) {
+                int i0; double w1;
+                if (!dep_cell<MODE>(P.pos[ip * NDIM + k], step, P.N, P.L, i0, w1)) { key = -1; break; }
+                key = key * S.nt + i0 / T;
+            }
+            S.key[ip] = key;
+        }
+        (void)wave_group_slot(S.count, key, key >= 0);
+    }
+}
+
+constexpr int kDepThreads = 512;
+
+template <int NDIM, int MODE>
+__global__ __launch_bounds__(kDepThreads) void dep_tile_kernel(const DepSortParams S)
+{
+    const DepositParams &P = S.d;
+    constexpr int T = DepTile<NDIM>::T, E = DepTile<NDIM>::E, NE = DepTile<NDIM>::NE;
+    __shared__ double acc[NE];
+    const int tile = blockIdx.x;
+    const int q0 = S.start[tile], q1 = S.start[tile + 1];
+    if (q0 == q1) return;
+    int tc[3] = {0, 0, 0};
+    { int rem = tile; for (int k = NDIM - 1; k >= 0; --k) { tc[k] = rem % S.nt; rem /= S.nt; } }
+    for (int e = threadIdx.x; e < NE; e += kDepThreads) acc[e] = 0.0;
+    __syncthreads();
+    const double step = P.L / (double)P.N;
+    constexpr int U = 2;                                       // particles per thread and trip: independent gathers
+    for (int qb = q0 + threadIdx.x; qb < q1; qb += U * kDepThreads) {
+        int64_t ip[U];
+        double x[U][NDIM], m[U];
+        for (int u = 0; u < U; ++u) ip[u] = (qb + u * kDepThreads < q1) ? S.perm[qb + u * kDepThreads] : -1;
+        for (int u = 0; u < U; ++u) {
+            if (ip[u] < 0) continue;
+            for (int k = 0; k < NDIM; ++k) x[u][k] = P.pos[ip[u] * NDIM + k];
+            m[u] = P.mass ? P.mass[ip[u]] : 1.0;
+        }
+        for (int u = 0; u < U; ++u) {
+            if (ip[u] < 0) continue;
+            int l0[NDIM];
+            double w1[NDIM];
+            for (int k = 0; k < NDIM; ++k) {
+                int i0;
+                (void)dep_cell<MODE>(x[u][k], step, P.N, P.L, i0, w1[k]);
+                l0[k] = i0 - tc[k] * T;
+            }
+            if (MODE == BFG_DEPOSIT_NGP) {
+                int e = 0;
+                for (int k = 0; k < NDIM; ++k) e = e * E + l0[k];
+                unsafeAtomicAdd(&acc[e], m[u]);
+            } else {
+                for (int corner = 0; corner < (1 << NDIM); ++corner) {
+                    double w = m[u];
+                    int e = 0;
+                    for (int k = 0; k < NDIM; ++k) {
+                        const int bit = (corner >> k) & 1;
+                        w *= bit ? w1[k] : 1.0 - w1[k];
+                        e = e * E + l0[k] + bit;
+                    }
+                    if (w != 0.0) unsafeAtomicAdd(&acc[e], w);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NE; e += kDepThreads) {
+        const double v = acc[e];
+        if (v == 0.0) continue;
+        int rem = e;
+        int64_t c = 0, mul = 1;
+        bool own = true;
+        for (int k = NDIM - 1; k >= 0; --k) {
+            const int l = rem % E; rem /= E;
+            int g = tc[k] * T + l;
+            own = own && (l >= 1) && (l <= T - 1) && (g < P.N);
+            if (g >= P.N) g -= P.N;                            // only g == N carries weight (the periodic +1 neighbour)
+            c += (int64_t)g * mul; mul *= P.N;
+        }
+        if (own) P.grid[c] += v;                               // no other tile writes this cell
+        else unsafeAtomicAdd(P.grid + c, v);
     }
 }
 

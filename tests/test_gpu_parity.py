@@ -294,10 +294,12 @@ def _periodic_close(got, ref, L, atol):
     assert d.max() <= atol, f"max periodic deviation {d.max():.3e} > {atol:.1e}"
 
 
+@pytest.mark.parametrize("path", ["direct", "cell"])
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
-def test_baryonify_snapshot_golden(golden, cosmo, tag):
+def test_baryonify_snapshot_golden(golden, cosmo, tag, path, monkeypatch):
     """BaryonifySnapshot (SnapshotRunner.py:162-275) against the reference's own run; displacements are ~0.1 Mpc, so
     1e-9 Mpc absolute is 1e-8 relative on the shift (tolerance of the path: 1e-5)"""
+    monkeypatch.setenv("BFG_SNAPSHOT", path)      # one thread per particle / particle indices grouped by cell
     import warnings
     g = golden("snapshot.npz")
     Cat, Part, model, is2D, L = _snapshot_inputs(g, tag, cosmo)
@@ -314,9 +316,11 @@ def test_baryonify_snapshot_golden(golden, cosmo, tag):
     assert np.array_equal(moved_ref, moved_got)       # exactly the same particles are displaced
 
 
+@pytest.mark.parametrize("path", ["direct", "cell"])
 @pytest.mark.parametrize("is2D", [False, True])
-def test_baryonify_snapshot_vs_oracle(cosmo, is2D):
+def test_baryonify_snapshot_vs_oracle(cosmo, is2D, path, monkeypatch):
     """larger box than the golden cases, vs the oracle (KDTree restatement): many cells, halos on the box faces"""
+    monkeypatch.setenv("BFG_SNAPSHOT", path)
     import warnings
     rng = np.random.default_rng(123 + int(is2D))
     L, npart, nhalo = 300.0, 400000, 1500
@@ -342,16 +346,20 @@ def test_baryonify_snapshot_vs_oracle(cosmo, is2D):
     assert R.last_stats["pixel_updates"] > 0
 
 
-@pytest.mark.parametrize("ndim", [2, 3])
+@pytest.mark.parametrize("path", ["direct", "tile"])
+@pytest.mark.parametrize("ndim,N", [(2, 200), (3, 48), (3, 50), (2, 40), (3, 9)])
 @pytest.mark.parametrize("mode", ["ngp", "cic"])
-def test_deposit_grid_vs_oracle(cosmo, ndim, mode):
+def test_deposit_grid_vs_oracle(cosmo, ndim, N, mode, path, monkeypatch):
     """bfg_deposit_grid: NGP = numpy.histogramdd of ParticleSnapshot.make_map (io.py:629-677), incl. particles exactly on
-    bin edges and on the box faces; CIC vs the oracle's numpy cloud-in-cell"""
+    bin edges and on the box faces; CIC vs the oracle's numpy cloud-in-cell.  Both device paths: direct global atomics
+    and the tile-privatised one (grids that are / are not a multiple of the tile size, a grid smaller than one tile)"""
+    monkeypatch.setenv("BFG_DEPOSIT", path)
     rng = np.random.default_rng(17 + ndim)
-    L, N, n = 75.0, 48 if ndim == 3 else 200, 200000
+    L, n = 75.0, 200000
     P = rng.uniform(0, L, (n, ndim))
     edges = np.linspace(0, L, N + 1)
     P[:2000] = edges[rng.integers(0, N + 1, (2000, ndim))]          # exactly on edges, 0 and L included
+    P[2000:3000] = rng.normal(L / 3, L / 500, (1000, ndim))          # a clump: many particles in one cell
     M = rng.uniform(0.5, 2.0, n)
     S = bfg.ParticleSnapshot(x=P[:, 0], y=P[:, 1], z=P[:, 2] if ndim == 3 else None, M=M, L=L, redshift=0.1, cosmo=cosmo)
     got = S.make_map(N, mode=mode, device=True)
@@ -362,6 +370,35 @@ def test_deposit_grid_vs_oracle(cosmo, ndim, mode):
         np.testing.assert_allclose(S.make_map(N), ref, rtol=1e-12, atol=1e-12)     # the host path is the reference's
     else:
         assert np.isclose(got.sum(), M.sum(), rtol=1e-12)
+
+
+@pytest.mark.parametrize("mode", ["ngp", "cic"])
+def test_deposit_grid_paths_agree_outside_the_box(mode, monkeypatch):
+    """positions outside [0, L]: NGP drops them (histogramdd), CIC wraps them; unit masses (d_mass = NULL); the deposit
+    accumulates INTO the grid.  Direct and tiled paths must agree to rounding."""
+    import torch
+    from baryonforge_amd.engine import get_context
+    ctx = get_context(0)
+    rng = np.random.default_rng(5)
+    L, N, n = 40.0, 70, 300000
+    P = rng.uniform(-0.3 * L, 1.3 * L, (n, 3))
+    d_pos = ctx.to_device(P)
+    out = {}
+    for path in ("direct", "tile"):
+        monkeypatch.setenv("BFG_DEPOSIT", path)
+        g = ctx.deposit_grid(d_pos, None, L, N, mode)
+        out[path] = g.cpu().numpy()
+    np.testing.assert_allclose(out["tile"], out["direct"], rtol=1e-12, atol=1e-12)
+    inside = np.all((P >= 0) & (P <= L), axis=1).sum()
+    assert np.isclose(out["tile"].sum(), inside if mode == "ngp" else n, rtol=1e-12)
+    np.testing.assert_allclose(out["tile"], orc.make_map(P, None, L, N, mode), rtol=1e-12, atol=1e-12)
+    monkeypatch.setenv("BFG_DEPOSIT", "tile")                       # accumulates INTO the grid
+    import ctypes as C
+    g = ctx.to_device(np.full((N, N, N), 2.5))
+    from baryonforge_amd import _lib
+    _lib.check(ctx.lib.bfg_deposit_grid(ctx.handle, 3, n, C.c_void_p(d_pos.data_ptr()), None, L, N,
+                                        {"ngp": 0, "cic": 1}[mode], C.c_void_p(g.data_ptr())), "bfg_deposit_grid")
+    np.testing.assert_allclose(g.cpu().numpy(), out["tile"] + 2.5, rtol=1e-12, atol=1e-12)
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])
