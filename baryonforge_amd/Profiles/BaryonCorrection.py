@@ -134,8 +134,11 @@ class BaryonificationClass(object):
                            M_min=1e12, M_max=1e16, N_samples_Mass=30,
                            R_min=1e-3, R_max=1e2, N_samples_R=100,
                            Rdelta_min=1e-3, Rdelta_max=10, Rdelta_sampling=False,
-                           other_params={}, verbose=True):
-        """BaryonCorrection.py:142-328"""
+                           other_params={}, verbose=True, device=False):
+        """BaryonCorrection.py:142-328.  device=True evaluates the DMO / DMB densities on the integration grid for
+        every (z, params) slice on the host (the profile models are the caller's) and runs everything downstream of them
+        -- Simpson, the PCHIPs, the monotonic mask, the inversion -- for all rows in one GPU launch
+        (bfg_build_displacement_table)."""
         if z_min <= 0:
             assert z_linear_sampling, (f"Geometric series not possible for {z_min} < z < {z_max}. "
                                        "Set z_linear_sampling = True, or z_min > 0")
@@ -147,7 +150,9 @@ class BaryonificationClass(object):
         d_interp = np.zeros([z_range.size, M_range.size, r.size] + [np.size(other_params[k]) for k in p_keys])
         rdelta_range = np.geomspace(Rdelta_min, Rdelta_max, N_samples_R) if Rdelta_sampling else None
         combos = [p for p in product(*[np.arange(np.size(other_params[k])) for k in p_keys])]
-        for j in range(z_range.size):
+        if device:
+            d_interp = self._build_on_device(r, M_range, a_range, p_keys, other_params, combos, rdelta_range, d_interp)
+        for j in range(z_range.size if not device else 0):
             for c in combos:
                 for k_i, key in enumerate(p_keys):
                     _set_parameter(self.DMO, key, other_params[key][c[k_i]])
@@ -163,6 +168,42 @@ class BaryonificationClass(object):
         input_rad = np.log(r) if not Rdelta_sampling else np.log(rdelta_range)
         self._set_table(np.log(1 + z_range), np.log(M_range), input_rad, d_interp, Rdelta_sampling,
                         {k: np.asarray(other_params[k], dtype=np.float64) for k in p_keys})
+
+    def _build_on_device(self, r, M_range, a_range, p_keys, other_params, combos, rdelta_range, d_interp):
+        from ..engine import get_context
+        r_int, _ = _integration_grid(r, self.r_min_int, self.r_max_int, self.N_int)
+        dens = {"DMO": [], "DMB": []}
+        rdelta, where = [], []
+        for j in range(a_range.size):
+            for c in combos:
+                for k_i, key in enumerate(p_keys):
+                    _set_parameter(self.DMO, key, other_params[key][c[k_i]])
+                    _set_parameter(self.DMB, key, other_params[key][c[k_i]])
+                for name, model in (("DMO", self.DMO), ("DMB", self.DMB)):
+                    dd = np.asarray(self._density(model, r_int, M_range, a_range[j]), dtype=np.float64)
+                    dens[name].append(np.broadcast_to(dd, (M_range.size, r_int.size)))
+                for i in range(M_range.size):
+                    where.append(tuple([j, i, slice(None)] + list(c)))
+                    if rdelta_range is not None:
+                        rdelta.append(self.mass_def.get_radius(self.cosmo, M_range[i], a_range[j]) / a_range[j])
+        d, status = get_context().build_displacement_table(
+            self._geometry, r_int, np.concatenate(dens["DMO"], axis=0), np.concatenate(dens["DMB"], axis=0), r,
+            np.asarray(rdelta) if rdelta_range is not None else None, rdelta_range)
+        for row, index in enumerate(where):
+            log10M = np.log10(M_range[index[1]])
+            if status[row] & 8:
+                raise ValueError(f"PchipInterpolator: unusable points in the mass profile of log10(M) = {log10M}")
+            if status[row] & 1:
+                warnings.warn(f"Mass profile of log10(M) = {log10M} is nearly constant over radius. Suggests density is "
+                              "negative or zero for most of the range.", UserWarning)
+            if status[row] & 2:
+                warnings.warn(f"Mass profile of log10(M) = {log10M} is nearly constant over radius. Or it is broken. "
+                              "Less than 5 datapoints are usable.", UserWarning)
+            if status[row] & 4:
+                warnings.warn(f"Displacement function for halo with log10(M) = {log10M} failed to compute. "
+                              "Defaulting to d = 0.", UserWarning)
+            d_interp[index] = d[row]
+        return d_interp
 
     # ---- read-out ------------------------------------------------------------------------
     def _model_radius_com(self, M, a):
@@ -217,13 +258,18 @@ class BaryonificationClass(object):
         return self._readout(r, M, a, **kwargs)
 
 
-def _enclosed_mass(r, integrand_of_rint, density, r_min_int, r_max_int, N_int):
-    """cumulative Simpson in ln r of a non-negative density, then log-log PCHIP onto r
-    (shared by the 2D / 3D get_masses, BaryonCorrection.py:669-691 / :552-575)."""
+def _integration_grid(r, r_min_int, r_max_int, N_int):
+    """the integration radii of get_masses (:669-675): the table range widened to [r_min_int, r_max_int] and by 20 %"""
     r_min = np.min([np.min(r), r_min_int])
     r_max = np.max([np.max(r), r_max_int])
     r_int = np.geomspace(r_min / 1.2, r_max * 1.2, N_int)
-    dlnr = np.log(r_int[1] / r_int[0])
+    return r_int, np.log(r_int[1] / r_int[0])
+
+
+def _enclosed_mass(r, integrand_of_rint, density, r_min_int, r_max_int, N_int):
+    """cumulative Simpson in ln r of a non-negative density, then log-log PCHIP onto r
+    (shared by the 2D / 3D get_masses, BaryonCorrection.py:669-691 / :552-575)."""
+    r_int, dlnr = _integration_grid(r, r_min_int, r_max_int, N_int)
     dens = density(r_int)
     dens = np.where(dens < 0, 0, dens)
     scalar = dens.ndim == 1
@@ -244,18 +290,25 @@ def _enclosed_mass(r, integrand_of_rint, density, r_min_int, r_max_int, N_int):
 class Baryonification2D(BaryonificationClass):
     """Projected (2D) displacement model: enclosed mass from Sigma(r) (BaryonCorrection.py:581-695)."""
 
-    def get_masses(self, model, r, M, a):
+    _geometry = 2
+
+    def _density(self, model, r_int, M, a):
         # Sigma * a: ccl projects in comoving, not physical, coordinates (:676)
-        M_f = _enclosed_mass(r, lambda x: 2 * np.pi * x ** 2,
-                             lambda x: np.asarray(model.projected(self.cosmo, x, M, a)) * a,
-                             self.r_min_int, self.r_max_int, self.N_int)
-        return M_f
+        return np.asarray(model.projected(self.cosmo, r_int, M, a)) * a
+
+    def get_masses(self, model, r, M, a):
+        return _enclosed_mass(r, lambda x: 2 * np.pi * x ** 2, lambda x: self._density(model, x, M, a),
+                              self.r_min_int, self.r_max_int, self.N_int)
 
 
 class Baryonification3D(BaryonificationClass):
     """3D displacement model: enclosed mass from rho(r) (BaryonCorrection.py:464-578)."""
 
+    _geometry = 3
+
+    def _density(self, model, r_int, M, a):
+        return np.asarray(model.real(self.cosmo, r_int, M, a))
+
     def get_masses(self, model, r, M, a):
-        return _enclosed_mass(r, lambda x: 4 * np.pi * x ** 3,
-                              lambda x: np.asarray(model.real(self.cosmo, x, M, a)),
+        return _enclosed_mass(r, lambda x: 4 * np.pi * x ** 3, lambda x: self._density(model, x, M, a),
                               self.r_min_int, self.r_max_int, self.N_int)

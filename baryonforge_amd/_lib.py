@@ -36,6 +36,7 @@ SYMBOLS = [
     "bfg_spline_create", "bfg_spline_destroy",
     "bfg_paint_shell", "bfg_baryonify_offsets", "bfg_regrid_shell", "bfg_reduce_absmax_sum",
     "bfg_baryonify_snapshot", "bfg_deposit_grid", "bfg_paint_grid", "bfg_baryonify_grid_offsets", "bfg_regrid_grid",
+    "bfg_build_displacement_table",
     "bfg_stats_reset", "bfg_stats_read", "bfg_timing_enable", "bfg_timing_read",
 ]
 
@@ -133,6 +134,9 @@ def load(build_if_missing=True):
     L.bfg_baryonify_grid_offsets.argtypes = [_vp, C.POINTER(GridArgs), _vp, _vp]
     L.bfg_regrid_grid.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _vp]
     L.bfg_deposit_grid.argtypes = [_vp, C.c_int, _i64, _vp, _vp, _dbl, C.c_int, C.c_int, _vp]
+    L.bfg_build_displacement_table.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(_dbl), _vp, _vp, C.c_int,
+                                               C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_dbl), _vp,
+                                               C.POINTER(C.c_int32)]
     L.bfg_baryonify_offsets.argtypes = [_vp, C.POINTER(ShellArgs), _vp, _vp, _vp]
     L.bfg_regrid_shell.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp]
     L.bfg_reduce_absmax_sum.argtypes = [_vp, _i64, _vp, C.POINTER(_dbl), C.POINTER(_dbl)]

@@ -195,6 +195,7 @@ __device__ inline double massdef_radius(const bfg_massdef &md, double M, double 
 
 #include "bfg_snapshot.hpp"
 #include "bfg_grid.hpp"
+#include "bfg_tablebuild.hpp"
 
 // scipy PPoly evaluation of the not-a-knot CubicSpline of HealpixRunner.py:299 (extrapolates)
 __device__ inline double spline_eval(int n, const double *__restrict__ x, const double *__restrict__ c, double v)
@@ -1838,6 +1839,54 @@ int bfg_deposit_grid(bfg_ctx *c, int ndim, int64_t n_part, const double *d_pos, 
     BFG_DEP_LAUNCH(dep_tile_kernel, (unsigned)ntile);
 #undef BFG_DEP_LAUNCH
     HIP_TRY(hipGetLastError());
+    return BFG_OK;
+}
+
+int bfg_build_displacement_table(bfg_ctx *c, int geometry, int n_rows, int n_int, const double *r_int,
+                                 const double *d_dens_dmo, const double *d_dens_dmb, int nr, const double *r,
+                                 const double *rdelta, const double *rdelta_range, double *d_out, int32_t *status)
+{
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    if ((geometry != 2 && geometry != 3) || n_rows < 0 || n_int < 3 || nr < 2 || !r_int || !r || !d_out || !status ||
+        (n_rows > 0 && (!d_dens_dmo || !d_dens_dmb)) || ((rdelta != nullptr) != (rdelta_range != nullptr)))
+        return BFG_ERR_INVALID;
+    if (n_rows == 0) return BFG_OK;
+    const size_t lds = build_lds_bytes(n_int, nr);
+    if (lds > c->max_dyn_lds) return BFG_ERR_UNSUPPORTED;
+    // small host arrays -> one device blob: r_int | ln r_int | r | ln r | rdelta | rdelta_range
+    std::vector<double> blob;
+    blob.reserve((size_t)2 * n_int + 3 * nr + n_rows);
+    for (int k = 0; k < n_int; ++k) blob.push_back(r_int[k]);
+    for (int k = 0; k < n_int; ++k) blob.push_back(std::log(r_int[k]));
+    for (int k = 0; k < nr; ++k) blob.push_back(r[k]);
+    for (int k = 0; k < nr; ++k) blob.push_back(std::log(r[k]));
+    if (rdelta) {
+        for (int k = 0; k < n_rows; ++k) blob.push_back(rdelta[k]);
+        for (int k = 0; k < nr; ++k) blob.push_back(rdelta_range[k]);
+    }
+    double *d_blob = nullptr;
+    int32_t *d_status = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_blob, blob.size() * sizeof(double)));
+    if (hipMalloc((void **)&d_status, (size_t)n_rows * sizeof(int32_t)) != hipSuccess) { (void)hipFree(d_blob); return BFG_ERR_NOMEM; }
+    BuildParams P;
+    P.n_rows = n_rows; P.n_int = n_int; P.nr = nr; P.geometry = geometry;
+    P.dens_dmo = d_dens_dmo; P.dens_dmb = d_dens_dmb;
+    P.r_int = d_blob; P.lnr_int = d_blob + n_int; P.r = d_blob + 2 * n_int; P.lnr = P.r + nr;
+    P.dlnr = std::log(r_int[1] / r_int[0]);                                                // get_masses :675
+    P.rdelta = rdelta ? P.lnr + nr : nullptr; P.rdelta_range = rdelta ? P.rdelta + n_rows : nullptr;
+    P.out = d_out; P.status = d_status;
+    hipError_t e = hipMemcpyAsync(d_blob, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && lds > 64 * 1024)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(table_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(table_build_kernel, dim3((unsigned)n_rows), dim3(256), lds, c->stream, P);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(status, d_status, (size_t)n_rows * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_blob); (void)hipFree(d_status);
+    if (e != hipSuccess) { g_last_error = std::string("bfg_build_displacement_table: ") + hipGetErrorString(e); return BFG_ERR_HIP; }
     return BFG_OK;
 }
 

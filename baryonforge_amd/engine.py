@@ -242,6 +242,27 @@ class Context(object):
                    "bfg_deposit_grid")
         return d_grid
 
+    def build_displacement_table(self, geometry, r_int, dens_dmo, dens_dmb, r, rdelta=None, rdelta_range=None):
+        """bfg_build_displacement_table: dens_* float64[n_rows, n_int] (host), returns (d[n_rows, nr], status[n_rows])"""
+        r_int = np.ascontiguousarray(r_int, dtype=np.float64)
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        d_dmo, d_dmb = self.to_device(dens_dmo), self.to_device(dens_dmb)
+        n_rows, n_int = d_dmo.shape
+        assert d_dmb.shape == d_dmo.shape and r_int.size == n_int
+        d_out = self.zeros(n_rows, r.size)
+        status = np.zeros(n_rows, dtype=np.int32)
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        if rdelta is not None:
+            rdelta = np.ascontiguousarray(rdelta, dtype=np.float64)
+            rdelta_range = np.ascontiguousarray(rdelta_range, dtype=np.float64)
+            assert rdelta.size == n_rows and rdelta_range.size == r.size
+        _lib.check(self.lib.bfg_build_displacement_table(
+            self.handle, int(geometry), int(n_rows), int(n_int), dp(r_int), C.c_void_p(d_dmo.data_ptr()),
+            C.c_void_p(d_dmb.data_ptr()), int(r.size), dp(r), dp(rdelta) if rdelta is not None else None,
+            dp(rdelta_range) if rdelta is not None else None, C.c_void_p(d_out.data_ptr()),
+            status.ctypes.data_as(C.POINTER(C.c_int32))), "bfg_build_displacement_table")
+        return d_out.cpu().numpy(), status
+
     def absmax_sum(self, d_x):
         amax, s = C.c_double(), C.c_double()
         _lib.check(self.lib.bfg_reduce_absmax_sum(self.handle, d_x.numel(), C.c_void_p(d_x.data_ptr()),

@@ -206,6 +206,28 @@ int bfg_regrid_grid(bfg_ctx *ctx, int ndim, int npix, const double *d_offsets, c
 int bfg_deposit_grid(bfg_ctx *ctx, int ndim, int64_t n_part, const double *d_pos, const double *d_mass,
                      double L, int n_grid, int mode, double *d_grid);
 
+/* Displacement-table builder on the device: the arithmetic of BaryonificationClass.setup_interpolator
+ * (Profiles/BaryonCorrection.py:225-304) with get_masses (:669-691 Baryonification2D, :552-575 Baryonification3D)
+ * inlined, for n_rows = all (z, params, M) rows of a table in one launch.  The DMO / DMB profile models stay with the
+ * caller (they are the reference's pyccl profile zoo): it supplies their densities on the integration grid,
+ *   d_dens_dmo / d_dens_dmb   device float64[n_rows][n_int]: Sigma(r_int) * a (geometry 2) or rho(r_int) (geometry 3),
+ *   r_int                     host float64[n_int], the geomspace grid of :672 (n_int >= 3),
+ *   r                         host float64[nr], the table radii (:209),
+ *   rdelta, rdelta_range      host float64[n_rows] R_delta (comoving) per row and float64[nr] r / R_delta axis for
+ *                             Rdelta_sampling tables (:293-295), or both NULL,
+ * and receives d_out = device float64[n_rows][nr] displacements and status = host int32[n_rows] with BFG_BUILD_* bits
+ * (the reference's UserWarnings; BFG_BUILD_ERROR where scipy's PchipInterpolator would raise ValueError).
+ * Synchronous.  Steps: clip negative densities, integrand * dlnr, scipy cumulative_simpson + first term, log-log PCHIP
+ * onto r (extrapolate = False), iterative monotonic mask, r(ln M_DMB) and ln M_DMO(ln r) PCHIPs, exp(...) - r,
+ * non-finite -> 0, optional np.interp onto rdelta_range.                                                          */
+#define BFG_BUILD_CONSTANT 1
+#define BFG_BUILD_FEW 2
+#define BFG_BUILD_ZERO 4
+#define BFG_BUILD_ERROR 8
+int bfg_build_displacement_table(bfg_ctx *ctx, int geometry, int n_rows, int n_int, const double *r_int,
+                                 const double *d_dens_dmo, const double *d_dens_dmb, int nr, const double *r,
+                                 const double *rdelta, const double *rdelta_range, double *d_out, int32_t *status);
+
 /* Counters the kernels maintain (device side), fetched with bfg_stats_read. */
 typedef struct {
     uint64_t pixel_updates;   /* P_tot = sum_j |disc_j| (incl. the 4-neighbour fallback)  */

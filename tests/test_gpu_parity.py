@@ -728,3 +728,89 @@ def test_error_conventions(cosmo):
     f.p_keys = ["cdelta"]
     with pytest.raises(AssertionError):
         bfg.PaintProfilesShell(Cat, Shell, 10, f, verbose=False).process()
+
+
+# ------------------------------------------------------------------ displacement-table builder on the device (a6)
+class _Profile(object):
+    """analytic density stand-in for the (out-of-scope) profile zoo; `ring` adds an oscillating, partly NEGATIVE tail
+    (what FFTLog ringing does to the reference's projected profiles) and `hole` zeroes a band of radii"""
+
+    def __init__(self, core, slope, ring=0.0, hole=None, cdelta=1.0):
+        self.core, self.slope, self.ring, self.hole, self.cdelta, self.cutoff = core, slope, ring, hole, cdelta, None
+
+    def set_parameter(self, k, v):
+        setattr(self, k, v)
+
+    def projected(self, cosmo, r, M, a):
+        M = np.atleast_1d(M)
+        r = np.atleast_1d(r)
+        R = (orc.get_radius(syn.COSMO, M, a) / a)[:, None]
+        x = r[None, :] / (self.core * self.cdelta * R)
+        S = M[:, None] / (2 * np.pi * (self.core * R) ** 2) * (1 + x * x) ** (-self.slope)
+        S = S * np.exp(-r[None, :] / (30 * R))
+        if self.ring:
+            S = S * (1 + self.ring * np.sin(6 * np.log(r))[None, :] * (r[None, :] / R) ** 1.5)
+        if self.hole is not None:
+            S = np.where((r[None, :] > self.hole[0]) & (r[None, :] < self.hole[1]), 0.0, S)
+        return S
+
+    real = projected
+
+
+def test_table_builder_device_vs_reference_golden(golden):
+    """bfg_build_displacement_table on the Sigma arrays of the golden file against the table the reference's own
+    Baryonification2D.setup_interpolator built from them (BaryonCorrection.py:142-328)"""
+    from baryonforge_amd.engine import get_context
+    g = golden("table_builder.npz")
+    Sd, Sb = g["tb_Sigma_DMO_z"], g["tb_Sigma_DMB_z"]                 # [Nz][NM][N_int]
+    nz, nm, nint = Sd.shape
+    d, status = get_context(0).build_displacement_table(2, g["tb_rint"], Sd.reshape(nz * nm, nint),
+                                                        Sb.reshape(nz * nm, nint), g["tb_r"])
+    assert np.all(status == 0)
+    ref = g["tb_d_interp"]
+    np.testing.assert_allclose(d.reshape(ref.shape), ref, rtol=1e-9, atol=1e-12)
+    assert np.abs(ref).max() > 1e-3                                       # a non-trivial table
+
+
+@pytest.mark.parametrize("case", ["smooth2d", "ringing2d", "hole3d", "rdelta", "params", "flat"])
+def test_table_builder_device_vs_host(case):
+    """setup_interpolator(device=True) against the host builder (the reference's scipy calls, pinned by the golden
+    file in tests/test_host_cpu.py) on profiles that exercise the masks: negative / zero densities, nearly flat mass
+    profiles (iterative mask, warnings, d = 0 rows), Rdelta_sampling, an extra table dimension, the 3D variant"""
+    import warnings
+    kw = dict(z_min=0.1, z_max=0.6, N_samples_z=3, M_min=1e12, M_max=1e16, N_samples_Mass=6, R_min=1e-3, R_max=1e2,
+              N_samples_R=60, verbose=False)
+    cls = bfg.Baryonification2D
+    if case == "smooth2d":
+        mk = lambda: (_Profile(0.25, 1.6), _Profile(0.45, 1.6))
+    elif case == "ringing2d":
+        mk = lambda: (_Profile(0.25, 1.6, ring=0.9), _Profile(0.45, 1.5, ring=1.4))
+    elif case == "hole3d":
+        cls = bfg.Baryonification3D
+        mk = lambda: (_Profile(0.25, 1.9, hole=(0.02, 0.05)), _Profile(0.4, 1.9, hole=(0.3, 0.9)))
+    elif case == "rdelta":
+        mk = lambda: (_Profile(0.25, 1.6), _Profile(0.45, 1.6, ring=0.5))
+        kw.update(Rdelta_sampling=True, Rdelta_min=1e-2, Rdelta_max=20)
+    elif case == "params":
+        mk = lambda: (_Profile(0.25, 1.6), _Profile(0.45, 1.6))
+        kw.update(other_params={"cdelta": np.array([0.7, 1.0, 1.6])})
+    else:                                                                 # DMB == DMO almost everywhere: rows default to 0
+        mk = lambda: (_Profile(0.25, 1.6), _Profile(0.25, 1.6, hole=(50.0, 60.0)))
+    out, warned = {}, {}
+    for dev in (False, True):
+        DMO, DMB = mk()
+        B = cls(DMO, DMB, dict(syn.COSMO), epsilon_max=20, N_int=400)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            B.setup_interpolator(device=dev, **kw)
+        out[dev] = B.raw_input_d
+        warned[dev] = sorted(str(x.message)[:70] for x in w if issubclass(x.category, UserWarning))
+        assert B.Rdelta_sampling == bool(kw.get("Rdelta_sampling", False))
+    assert out[True].shape == out[False].shape
+    scale = np.abs(out[False]).max()
+    np.testing.assert_allclose(out[True], out[False], rtol=1e-8, atol=1e-11 * max(scale, 1.0))
+    assert warned[True] == warned[False]
+    if case == "flat":
+        assert len(warned[True]) > 0 and np.count_nonzero(out[True]) < out[True].size
+    else:
+        assert scale > 1e-4
