@@ -210,6 +210,209 @@ __global__ __launch_bounds__(256) void grid_window_kernel(const GridParams P)
     }
 }
 
+// ---- tile-privatised window pass --------------------------------------------------------------------------------------
+// grid_window_kernel pays one global f64 atomic per window pixel (1 per pixel for paint, ndim for the offsets) plus libm
+// sqrt / log / exp and a bisection of the radial axis.  Here the map is cut into tiles of 64^2 / 16^3 pixels; the halos
+// are binned to the tiles their window touches (count -> scan -> fill, as the shell path does for sky tiles), one
+// workgroup per tile accumulates in LDS (ds_add_f64) -- each of its 4 wavefronts takes one (halo, tile) pair at a
+// time and walks the intersection of the halo's window with the tile -- and the tile is added to the map once with
+// plain coalesced read-add-writes (every pixel belongs to exactly one tile).  Same per-pixel formulas as above
+// (stretched linspace offsets, 'xy' pairing, pick_indices wrap); ln / exp from the shell kernels' LDS tables.
+// Needs npix >= 2 tile sides (a window, at most npix / 2 wide, then meets a tile in at most one interval per axis).
+template <int NDIM> struct GridTile {
+    static constexpr int TS = (NDIM == 2) ? 64 : 16;                 // production tile side
+    static constexpr int TS_SMALL = (NDIM == 2) ? 16 : 8;            // BFG_GRID=small: the same kernels on the small
+                                                                     // maps of the golden fixtures (test hook)
+};
+
+struct GridBin {
+    int nt;                          // tiles per axis = ceil(npix / TS)
+    int fill;                        // 0: count pass, 1: fill pass
+    int32_t *count;                  // [nt^ndim] counts, then fill cursors
+    const int32_t *start;            // [nt^ndim + 1]
+    int32_t *pairs;                  // [pair_cap] halo ids grouped by tile
+    int64_t pair_cap;
+    const double2 *logtab;           // [kLogTab]
+    const double *exptab;            // [kExpTab]
+    unsigned long long *winpix;      // count pass: sum of window sizes n^ndim over the halos
+};
+
+template <int NDIM, int TS>
+__global__ __launch_bounds__(256) void grid_bin_kernel(const GridParams P, const GridBin B)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P.n_halo) return;
+    const GridHalo h = P.gh[j];
+    const int N = P.npix, n = h.nsize, w = n / 2;
+    int lo[NDIM][2], cnt[NDIM][2], tot[NDIM];
+    int64_t total = 1;
+    for (int k = 0; k < NDIM; ++k) {
+        int s = (h.cen[k] - w) % N; if (s < 0) s += N;          // first window pixel (pick_indices wrap)
+        const int e = s + n;
+        lo[k][0] = s / TS; cnt[k][0] = (min(e, N) - 1) / TS - lo[k][0] + 1;
+        lo[k][1] = 0; cnt[k][1] = (e > N) ? (e - N - 1) / TS + 1 : 0;
+        tot[k] = cnt[k][0] + cnt[k][1];
+        total *= tot[k];
+    }
+    if (!B.fill) {                                             // window pixels of this wavefront's halos -> one atomic
+        unsigned long long wp = (NDIM == 2) ? (unsigned long long)n * n : (unsigned long long)n * n * n;
+        for (int o = 32; o > 0; o >>= 1) wp += __shfl_down(wp, o, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(B.winpix, wp);
+    }
+    for (int64_t q = 0; q < total; ++q) {
+        int64_t rem = q, tile = 0, mul = 1;
+        for (int k = NDIM - 1; k >= 0; --k) {
+            const int i = (int)(rem % tot[k]); rem /= tot[k];
+            const int t = (i < cnt[k][0]) ? lo[k][0] + i : lo[k][1] + (i - cnt[k][0]);
+            tile += (int64_t)t * mul; mul *= B.nt;
+        }
+        if (!B.fill) atomicAdd(&B.count[tile], 1);
+        else {
+            const int64_t pos = (int64_t)B.start[tile] + atomicAdd(&B.count[tile], 1);
+            if (pos < B.pair_cap) B.pairs[pos] = (int32_t)j;
+        }
+    }
+}
+
+template <int NDIM, int MODE, int TS>
+__global__ __launch_bounds__(256) void grid_tile_kernel(const GridParams P, const GridBin B)
+{
+    constexpr int NC = (NDIM == 2) ? TS * TS : TS * TS * TS;
+    constexpr int NA = (MODE == MODE_PAINT) ? 1 : NDIM;
+    extern __shared__ double smem_gt[];
+    double *acc = smem_gt;                                               // [NC][NA]
+    double2 *logtab = reinterpret_cast<double2 *>(acc + NC * NA);
+    double *exptab = reinterpret_cast<double *>(logtab + kLogTab);
+    const int tile = blockIdx.x;
+    const int p0 = B.start[tile], p1 = (int)min((int64_t)B.start[tile + 1], B.pair_cap);
+    if (p0 >= p1) return;                                                // nothing lands in this tile
+    const DevTable &T = P.tab;
+    const int N = P.npix;
+    int t0[NDIM], tlen[NDIM];
+    { int rem = tile; for (int k = NDIM - 1; k >= 0; --k) { t0[k] = (rem % B.nt) * TS; rem /= B.nt; tlen[k] = min(TS, N - t0[k]); } }
+    for (int e = threadIdx.x; e < NC * NA; e += 256) acc[e] = 0.0;
+    if (threadIdx.x < kLogTab) logtab[threadIdx.x] = B.logtab[threadIdx.x];
+    if (threadIdx.x < kExpTab) exptab[threadIdx.x] = B.exptab[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const double r_lo = T.raxis[0], r_hi = T.raxis[T.nr - 1];
+    unsigned long long cnt = 0, n_oob = 0;
+    for (int pi = p0 + (int)(threadIdx.x >> 6); pi < p1; pi += 4) {
+        const int j = __builtin_amdgcn_readfirstlane(B.pairs[pi]);
+        const GridHalo &h = P.gh[j];                                     // wave-uniform: scalar loads
+        const int n = h.nsize, w = n / 2;
+        int ia0[NDIM], l0[NDIM], len[NDIM];
+        int ncell = 1;
+        for (int k = 0; k < NDIM; ++k) {
+            int s = (h.cen[k] - w) % N; if (s < 0) s += N;
+            int a0 = t0[k] - s; if (a0 < 0) a0 += N;                     // window index of the tile's first pixel
+            if (a0 < n) { ia0[k] = a0; l0[k] = 0; len[k] = min(n - a0, tlen[k]); }
+            else {
+                int b0 = s - t0[k]; if (b0 < 0) b0 += N;                 // tile-local index of the window's first pixel
+                if (b0 < tlen[k]) { ia0[k] = 0; l0[k] = b0; len[k] = min(n, tlen[k] - b0); }
+                else { ia0[k] = 0; l0[k] = 0; len[k] = 0; }
+            }
+            ncell *= len[k];
+        }
+        const double *row = P.hrow + (int64_t)j * T.nr;
+        const float inv_last = 1.0f / (float)max(len[NDIM - 1], 1);
+        const float inv_mid = (NDIM == 3) ? 1.0f / (float)max(len[1], 1) : 0.0f;
+        for (int q = lane; q < ncell; q += 64) {
+            // (qa, qb[, qc]) = position inside the intersection, last axis fastest; quotients by float reciprocal
+            // (q < 4096: (q + 0.5) / len is at least 0.5 / 64 away from an integer)
+            int qa, qb, qc = 0;
+            if (NDIM == 2) {
+                qa = (int)(((float)q + 0.5f) * inv_last);
+                qb = q - qa * len[1];
+            } else {
+                const int qab = (int)(((float)q + 0.5f) * inv_last);
+                qc = q - qab * len[2];
+                qa = (int)(((float)qab + 0.5f) * inv_mid);
+                qb = qab - qa * len[1];
+            }
+            const int ia = ia0[0] + qa, ib = ia0[1] + qb;
+            int e = (l0[0] + qa) * TS + (l0[1] + qb);
+            // offsets of the 'xy' meshgrid: x offset = x[b], y offset = x[a], z offset = x[c]   (:507-516 / :545-556)
+            double comp[3];
+            comp[0] = grid_linspace(ib, n, P.res) + h.d[0];
+            comp[1] = grid_linspace(ia, n, P.res) + h.d[1];
+            double r2 = comp[0] * comp[0] + comp[1] * comp[1];
+            if (NDIM == 3) {
+                const int ic = ia0[2] + qc;
+                e = e * TS + (l0[2] + qc);
+                comp[2] = grid_linspace(ic, n, P.res) + h.d[2];
+                r2 += comp[2] * comp[2];
+            }
+            const double r = sqrt(r2);                                   // circular radius: the unit vectors always use it
+            double rm = r, rm2 = r2;                                     // radius handed to the model
+            if (NDIM == 2 && P.rmat) {                                   // (x, y) @ Rmat  (:520-524 / :753-757)
+                const double *Rm = P.rmat + (int64_t)j * 4;
+                const double xe = comp[0] * Rm[0] + comp[1] * Rm[2], ye = comp[0] * Rm[1] + comp[1] * Rm[3];
+                rm2 = xe * xe + ye * ye;
+                rm = sqrt(rm2);
+            }
+            ++cnt;
+            double rin;
+            if (rm2 >= 1e-290 && rm2 <= 1e290) {
+                rin = 0.5 * fast_log(rm2, logtab);
+                if (MODE == MODE_BARYONIFY) rin -= h.lnshift;
+                if (fabs(rin - r_lo) < 1e-9 || fabs(rin - r_hi) < 1e-9) rin = log(rm) - ((MODE == MODE_BARYONIFY) ? h.lnshift : 0.0);
+            } else rin = log(rm) - ((MODE == MODE_BARYONIFY) ? h.lnshift : 0.0);
+            double val = nan("");
+            if ((rin >= r_lo) && (rin <= r_hi)) {
+                int i;
+                double f;
+                if (T.r_uniform) {
+                    const double t = (rin - T.r0) * T.inv_dr;
+                    i = min(max((int)t, 0), T.nr - 2);
+                    f = t - (double)i;
+                } else {
+                    i = find_interval(T.raxis, T.nr, rin);
+                    f = (rin - T.raxis[i]) / (T.raxis[i + 1] - T.raxis[i]);
+                }
+                val = row[i] * (1.0 - f) + row[i + 1] * f;
+            } else if (!(h.flags & HF_OOB)) ++n_oob;
+            if (MODE == MODE_PAINT) {
+                const double Pv = (T.hot || !(fabs(val) < 700.0)) ? exp(val) : fast_exp(val, exptab);      // Tabulate.py:319
+                if ((fabs(Pv) <= 1.797e308) && (rm < h.rmask)) unsafeAtomicAdd(&acc[e], Pv);               // :812-823
+            } else {
+                const double off = (rm < h.xcut) ? val / P.res : 0.0;                                      // :530 / :570
+                const double s = off / r;
+                for (int k = 0; k < NDIM; ++k) unsafeAtomicAdd(&acc[e * NDIM + k], s * comp[k]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NC; e += 256) {
+        int rem = e;
+        int64_t flat = 0, mul = 1;
+        bool inside = true;
+        for (int k = NDIM - 1; k >= 0; --k) {
+            const int l = rem % TS; rem /= TS;
+            inside = inside && (l < tlen[k]);
+            flat += (int64_t)(t0[k] + l) * mul; mul *= N;
+        }
+        if (!inside) continue;
+        for (int k = 0; k < NA; ++k) {
+            const double v = acc[e * NA + k];
+            if (v != 0.0) P.out[flat * NA + k] += v;                     // this tile owns the pixel; NaN != 0 is added too
+        }
+    }
+    __shared__ unsigned long long s_red[2][4];
+    for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_down(cnt, o, 64); n_oob += __shfl_down(n_oob, o, 64); }
+    if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = cnt; s_red[1][threadIdx.x >> 6] = n_oob; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cnt = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+        n_oob = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+        if (cnt) atomicAdd((unsigned long long *)&P.stats->pixel_updates, cnt);
+        if (n_oob) {
+            atomicAdd((unsigned long long *)&P.stats->pixels_out_of_table, n_oob);
+            if (!(MODE == MODE_BARYONIFY && P.rdelta)) atomicOr(&P.stats->warn_mask, BFG_WARN_R_RANGE);
+        }
+    }
+}
+
 // regrid_pixels_2D / _3D: one thread per source pixel
 template <int NDIM>
 __global__ __launch_bounds__(256) void grid_regrid_kernel(int N, const double *__restrict__ offsets,

@@ -104,8 +104,9 @@ struct bfg_ctx {
     // bfg_baryonify_snapshot workspace (grow-only)
     void *snap_buf[8];
     size_t snap_cap[8];
-    void *grid_buf[2];              // grid runners: per-halo records, blended rows (grow-only)
-    size_t grid_cap[2];
+    void *grid_buf[6];              // grid runners: per-halo records, blended rows, tile counts / starts / pairs / scan scratch
+    size_t grid_cap[6];
+    bool grid_attr_set;             // MaxDynamicSharedMemorySize raised for the grid tile kernels
     void *dep_buf[5];               // tiled deposit: keys, permutation, tile counts, tile starts, scan scratch (grow-only)
     size_t dep_cap[5];
     int64_t pair_cap;
@@ -1023,7 +1024,7 @@ int bfg_ctx_destroy(bfg_ctx *c)
     if (c->d_hd) (void)hipFree(c->d_hd);
     if (c->d_left) (void)hipFree(c->d_left);
     for (int k = 0; k < 8; ++k) if (c->snap_buf[k]) (void)hipFree(c->snap_buf[k]);
-    for (int k = 0; k < 2; ++k) if (c->grid_buf[k]) (void)hipFree(c->grid_buf[k]);
+    for (int k = 0; k < 6; ++k) if (c->grid_buf[k]) (void)hipFree(c->grid_buf[k]);
     for (int k = 0; k < 5; ++k) if (c->dep_buf[k]) (void)hipFree(c->dep_buf[k]);
     if (c->d_pairs) (void)hipFree(c->d_pairs);
     (void)hipFree(c->d_mathtab); (void)hipFree(c->d_pair_total);
@@ -1741,14 +1742,99 @@ static int run_grid(bfg_ctx *c, const bfg_grid_args *a, const bfg_table *t, doub
     P.rmat = (a->ndim == 2) ? a->d_rmat : nullptr;
     P.tab = t->dev; P.gh = (GridHalo *)c->grid_buf[0]; P.hrow = (double *)c->grid_buf[1]; P.out = d_out; P.stats = c->d_stats;
     hipLaunchKernelGGL(grid_halo_kernel, dim3((unsigned)a->n_halo), dim3(64), 0, c->stream, P);
-    const dim3 g((unsigned)a->n_halo), b(256);
-    if (mode == MODE_PAINT) {
-        if (a->ndim == 2) hipLaunchKernelGGL((grid_window_kernel<2, MODE_PAINT>), g, b, 0, c->stream, P);
-        else hipLaunchKernelGGL((grid_window_kernel<3, MODE_PAINT>), g, b, 0, c->stream, P);
-    } else {
-        if (a->ndim == 2) hipLaunchKernelGGL((grid_window_kernel<2, MODE_BARYONIFY>), g, b, 0, c->stream, P);
-        else hipLaunchKernelGGL((grid_window_kernel<3, MODE_BARYONIFY>), g, b, 0, c->stream, P);
+    // tile-privatised pass when the map has at least two tiles per axis (BFG_GRID=direct forces the atomic kernel,
+    // BFG_GRID=small the small-tile instantiation used by the tests on the golden fixtures' small maps)
+    bool small = false;
+    bool direct = false;
+    if (const char *e = std::getenv("BFG_GRID")) { direct = !std::strcmp(e, "direct"); small = !std::strcmp(e, "small"); }
+    const int TS = (a->ndim == 2) ? (small ? GridTile<2>::TS_SMALL : GridTile<2>::TS) : (small ? GridTile<3>::TS_SMALL : GridTile<3>::TS);
+    bool tiled = !direct && a->npix >= 2 * TS && a->n_halo < (int64_t)0x7fffffff;
+    auto launch_direct = [&]() -> int {
+        const dim3 g((unsigned)a->n_halo), b(256);
+        if (mode == MODE_PAINT) {
+            if (a->ndim == 2) hipLaunchKernelGGL((grid_window_kernel<2, MODE_PAINT>), g, b, 0, c->stream, P);
+            else hipLaunchKernelGGL((grid_window_kernel<3, MODE_PAINT>), g, b, 0, c->stream, P);
+        } else {
+            if (a->ndim == 2) hipLaunchKernelGGL((grid_window_kernel<2, MODE_BARYONIFY>), g, b, 0, c->stream, P);
+            else hipLaunchKernelGGL((grid_window_kernel<3, MODE_BARYONIFY>), g, b, 0, c->stream, P);
+        }
+        HIP_TRY(hipGetLastError());
+        return BFG_OK;
+    };
+    if (!tiled) return launch_direct();
+    GridBin B;
+    std::memset(&B, 0, sizeof(B));
+    B.nt = (a->npix + TS - 1) / TS;
+    const int64_t ntile = (a->ndim == 2) ? (int64_t)B.nt * B.nt : (int64_t)B.nt * B.nt * B.nt;
+    const int64_t nblk = (ntile + 1023) / 1024;
+    auto ensure = [&](int k, size_t bytes) -> int {
+        if (bytes > c->grid_cap[k]) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->grid_buf[k]) (void)hipFree(c->grid_buf[k]);
+            c->grid_buf[k] = nullptr; c->grid_cap[k] = 0;
+            HIP_TRY(hipMalloc(&c->grid_buf[k], bytes));
+            c->grid_cap[k] = bytes;
+        }
+        return BFG_OK;
+    };
+    if ((rc = ensure(2, (size_t)ntile * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(3, (size_t)(ntile + 1) * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(5, (size_t)(nblk + 1) * sizeof(int32_t)))) return rc;
+    B.count = (int32_t *)c->grid_buf[2];
+    int32_t *d_start = (int32_t *)c->grid_buf[3], *d_bsum = (int32_t *)c->grid_buf[5], *d_total = d_bsum + nblk;
+    B.start = d_start;
+    B.logtab = reinterpret_cast<const double2 *>(c->d_mathtab);
+    B.exptab = c->d_mathtab + 2 * kLogTab;
+    HIP_TRY(hipMemsetAsync(B.count, 0, (size_t)ntile * sizeof(int32_t), c->stream));
+    B.winpix = c->d_pair_total;
+    HIP_TRY(hipMemsetAsync(B.winpix, 0, sizeof(unsigned long long), c->stream));
+    const unsigned hgrid = (unsigned)((a->n_halo + 255) / 256);
+    auto launch_bin = [&]() {
+        if (a->ndim == 2 && !small) hipLaunchKernelGGL((grid_bin_kernel<2, GridTile<2>::TS>), dim3(hgrid), dim3(256), 0, c->stream, P, B);
+        else if (a->ndim == 2) hipLaunchKernelGGL((grid_bin_kernel<2, GridTile<2>::TS_SMALL>), dim3(hgrid), dim3(256), 0, c->stream, P, B);
+        else if (!small) hipLaunchKernelGGL((grid_bin_kernel<3, GridTile<3>::TS>), dim3(hgrid), dim3(256), 0, c->stream, P, B);
+        else hipLaunchKernelGGL((grid_bin_kernel<3, GridTile<3>::TS_SMALL>), dim3(hgrid), dim3(256), 0, c->stream, P, B);
+    };
+    B.fill = 0;
+    launch_bin();
+    hipLaunchKernelGGL(snap_scan_block_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, ntile, B.count, d_start, d_bsum);
+    hipLaunchKernelGGL(snap_scan_sums_kernel, dim3(1), dim3(1024), 0, c->stream, (int)nblk, d_bsum, d_total);
+    hipLaunchKernelGGL(snap_scan_add_kernel, dim3((unsigned)((ntile + 255) / 256)), dim3(256), 0, c->stream, ntile, d_start,
+                       d_bsum, B.count, d_total);
+    int32_t total = 0;                                            // (halo, tile) pairs: a few per halo
+    unsigned long long winpix = 0;
+    HIP_TRY(hipMemcpyAsync(&total, d_total, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&winpix, B.winpix, sizeof(winpix), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // every touched tile costs an LDS clear and a sweep of its pixels, so tiles only pay when the windows cover the map
+    // a few times over (2D 4096^2, 1e5 halos: 24x -> 2.1x / 3.4x faster; 3D 512^3, 2e4 halos: 0.08x -> 1.4x / 2.6x slower)
+    const double npix_tot = std::pow((double)a->npix, a->ndim);
+    if (!small && !std::getenv("BFG_GRID") && (double)winpix < 2.0 * npix_tot) return launch_direct();
+    if ((rc = ensure(4, (size_t)std::max<int32_t>(total, 1) * sizeof(int32_t)))) return rc;
+    B.pairs = (int32_t *)c->grid_buf[4]; B.pair_cap = total;
+    B.fill = 1;
+    launch_bin();
+    const int na = (mode == MODE_PAINT) ? 1 : a->ndim;
+    const int nc = (a->ndim == 2) ? TS * TS : TS * TS * TS;
+    const size_t lds = (size_t)nc * na * sizeof(double) + kLogTab * sizeof(double2) + kExpTab * sizeof(double);
+    if (!c->grid_attr_set) {
+        const int big = 128 * 1024;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(grid_tile_kernel<2, MODE_BARYONIFY, GridTile<2>::TS>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(grid_tile_kernel<3, MODE_BARYONIFY, GridTile<3>::TS>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        c->grid_attr_set = true;
     }
+    const dim3 g((unsigned)ntile), b(256);
+#define BFG_GRID_LAUNCH(ND, MD)                                                                                          \
+    do {                                                                                                                  \
+        if (!small) hipLaunchKernelGGL((grid_tile_kernel<ND, MD, GridTile<ND>::TS>), g, b, lds, c->stream, P, B);         \
+        else hipLaunchKernelGGL((grid_tile_kernel<ND, MD, GridTile<ND>::TS_SMALL>), g, b, lds, c->stream, P, B);          \
+    } while (0)
+    if (mode == MODE_PAINT) {
+        if (a->ndim == 2) BFG_GRID_LAUNCH(2, MODE_PAINT); else BFG_GRID_LAUNCH(3, MODE_PAINT);
+    } else {
+        if (a->ndim == 2) BFG_GRID_LAUNCH(2, MODE_BARYONIFY); else BFG_GRID_LAUNCH(3, MODE_BARYONIFY);
+    }
+#undef BFG_GRID_LAUNCH
     HIP_TRY(hipGetLastError());
     return BFG_OK;
 }

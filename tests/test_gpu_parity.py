@@ -185,9 +185,15 @@ def _grid_inputs(g, tag, cosmo):
     return is2D, N, bins, Cat
 
 
+GRID_PATHS = ["direct", "small"]      # BFG_GRID: one workgroup per halo + global atomics / tile-privatised (small tiles,
+                                      # so that the golden fixtures' 16..96-pixel maps are cut into several tiles)
+
+
+@pytest.mark.parametrize("path", GRID_PATHS)
 @pytest.mark.parametrize("tag", ["p2", "p3"])
-def test_paint_grid_golden(golden, cosmo, tag):
+def test_paint_grid_golden(golden, cosmo, tag, path, monkeypatch):
     """PaintProfilesGrid (Map2DRunner.py:624-829) against the reference's own run"""
+    monkeypatch.setenv("BFG_GRID", path)
     g = golden("grid.npz")
     is2D, N, bins, Cat = _grid_inputs(g, tag, cosmo)
     model = bfg.TabulatedProfile.from_arrays(g[f"{tag}_zax"], g[f"{tag}_Max"], g[f"{tag}_rax"], g[f"{tag}_T2D"], g[f"{tag}_T3D"])
@@ -200,9 +206,11 @@ def test_paint_grid_golden(golden, cosmo, tag):
     assert_maps_close(got, ref, RTOL, what=f"grid paint {tag}")
 
 
+@pytest.mark.parametrize("path", GRID_PATHS)
 @pytest.mark.parametrize("tag", ["b2", "b3"])
-def test_baryonify_grid_golden(golden, cosmo, tag):
+def test_baryonify_grid_golden(golden, cosmo, tag, path, monkeypatch):
     """BaryonifyGrid (Map2DRunner.py:376-621, incl. regrid_pixels_2D/_3D) against the reference's own run"""
+    monkeypatch.setenv("BFG_GRID", path)
     import warnings
     g = golden("grid.npz")
     is2D, N, bins, Cat = _grid_inputs(g, tag, cosmo)
@@ -215,9 +223,11 @@ def test_baryonify_grid_golden(golden, cosmo, tag):
     assert_maps_close(got, g[f"{tag}_map_out"], RTOL, floor=BFLOOR, what=f"grid baryonify {tag}")
 
 
-def test_grid_ellipticity_and_anis_golden(golden, cosmo):
+@pytest.mark.parametrize("path", GRID_PATHS)
+def test_grid_ellipticity_and_anis_golden(golden, cosmo, path, monkeypatch):
     """2D ellipticity (Map2DRunner.py:281-350) in PaintProfilesGrid / BaryonifyGrid and PaintProfilesAnisGrid (:833-1015)
     against the reference's own run"""
+    monkeypatch.setenv("BFG_GRID", path)
     import warnings
     g = golden("grid.npz")
     N, bins, H = int(g["e_Npix"]), g["e_bins"], g["e_H"]
@@ -247,9 +257,11 @@ def test_grid_ellipticity_and_anis_golden(golden, cosmo):
         bfg.PaintProfilesGrid(Cat3, G3, eps, paint, use_ellipticity=True, verbose=False).process()
 
 
+@pytest.mark.parametrize("path", ["direct", "small", "tile"])
 @pytest.mark.parametrize("is2D", [True, False])
-def test_grid_runners_vs_oracle(cosmo, is2D):
-    """larger grids than the golden cases (2D 512^2, 3D 64^3), against the oracle"""
+def test_grid_runners_vs_oracle(cosmo, is2D, path, monkeypatch):
+    """larger grids than the golden cases (2D 512^2, 3D 64^3), against the oracle; "tile" = the production tile size"""
+    monkeypatch.setenv("BFG_GRID", path)
     import warnings
     rng = np.random.default_rng(31 + int(is2D))
     N, L, nhalo = (512, 400.0, 300) if is2D else (64, 120.0, 120)
@@ -273,6 +285,43 @@ def test_grid_runners_vs_oracle(cosmo, is2D):
                                  verbose=False).process()
         refb = orc.baryonify_grid(cosmo, bins, m_in, 0.2, H[:, :nd], hM, (zax, Max, rax), d * 5, 6, 20)
     assert_maps_close(gotb, refb, RTOL, floor=BFLOOR, what="grid baryonify vs oracle")
+
+
+@pytest.mark.parametrize("ndim,N", [(2, 150), (2, 333), (3, 40), (3, 53)])
+def test_grid_tile_pass_matches_direct_pass(cosmo, ndim, N, monkeypatch):
+    """tile-privatised window pass against the one-workgroup-per-halo pass on maps that are not a multiple of the tile
+    side, with halos on the box faces (windows that wrap) and windows at the npix / 2 clip: same maps, same counters"""
+    from baryonforge_amd.background import Background
+    from baryonforge_amd.engine import get_context
+    ctx = get_context(0)
+    md = ctx.massdef_struct(Background(cosmo), None)
+    rng = np.random.default_rng(70 + N)
+    L, nhalo, a = 300.0, 400, 1 / 1.2
+    H = rng.uniform(0, L, (nhalo, 3))
+    H[:60] = np.where(rng.uniform(size=(60, 3)) < 0.5, rng.uniform(0, 1.0, (60, 3)), L - rng.uniform(0, 1.0, (60, 3)))
+    hM = 10 ** rng.uniform(12.5, 15.6, nhalo)                      # the heaviest windows hit the npix / 2 clip
+    halos = ctx.to_device(np.stack([hM, np.log(hM), H[:, 0], H[:, 1], H[:, 2]], axis=1))
+    bins = ctx.to_device((np.arange(N) + 0.5) * (L / N))
+    zax, Max, rax, T = syn.pressure_table()
+    ptab = ctx.table([zax, Max, rax], np.log(T), log_values=True)
+    zd, Md, rd, d = syn.displacement_table()
+    dtab = ctx.table([zd, Md, rd], d, log_values=False)
+    pa = ctx.grid_args(ndim, N, bins, halos, a, 8.0, md)
+    ba = ctx.grid_args(ndim, N, bins, halos, a, 8.0, md, model_md=md, model_epsilon_max=20.0)
+    res = {}
+    for path in ("direct", "tile"):
+        monkeypatch.setenv("BFG_GRID", path)
+        d_map, d_off = ctx.to_device(np.full(N ** ndim, 0.25)), ctx.zeros(N ** ndim, ndim)      # accumulates INTO the map
+        ctx.stats_reset()
+        ctx.paint_grid(pa, ptab, d_map)
+        ctx.baryonify_grid_offsets(ba, dtab, d_off)
+        res[path] = (d_map.cpu().numpy(), d_off.cpu().numpy(), ctx.stats())
+    np.testing.assert_allclose(res["tile"][0], res["direct"][0], rtol=1e-8, atol=1e-300)
+    scale = np.abs(res["direct"][1]).max()
+    assert scale > 0
+    np.testing.assert_allclose(res["tile"][1], res["direct"][1], rtol=1e-7, atol=1e-9 * scale)
+    for key in ("pixel_updates", "pixels_out_of_table", "halos_out_of_table", "warn_mask"):
+        assert res["tile"][2][key] == res["direct"][2][key], key
 
 
 def _snapshot_inputs(g, tag, cosmo):
