@@ -72,17 +72,18 @@ class SplitJoinParallel(object):
     Runner : PaintProfilesShell or BaryonifyShell
     njobs : ignored when a process group exists (the world size is used); kept for API parity
     seed : kept for API parity (the sky-patch split is deterministic and needs no shuffle)
-    nside_patch : coarse NSIDE of the sky patches used for sharding
+    nside_patch, layout : NSIDE of the sky patches and how they are dealt to the ranks (sharding.shard_by_sky_patch)
     local_process : test seam -- callable(runner_for_this_rank) -> np.ndarray replacing the GPU
         process() of the per-rank paint runner, so the shard + all-reduce logic can be
         exercised with the gloo backend on CPU-only machines.
     """
 
-    def __init__(self, Runner, njobs=-1, seed=42, nside_patch=8, local_process=None):
+    def __init__(self, Runner, njobs=-1, seed=42, nside_patch=64, local_process=None, layout="interleaved"):
         self.Runner = Runner
         self.seed = seed
         self.njobs = njobs
         self.nside_patch = nside_patch
+        self.layout = layout
         self.local_process = local_process
         dist = _dist()
         self.rank = dist.get_rank() if dist else 0
@@ -98,7 +99,7 @@ class SplitJoinParallel(object):
             return [Runner]
         w = estimate_disc_pixels(Runner.cosmo, cat["M"], cat["z"], Runner.epsilon_max, Runner.LightconeShell.NSIDE,
                                  Runner.mass_def)
-        shards = shard_by_sky_patch(cat["ra"], cat["dec"], w, self.world, self.nside_patch)
+        shards = shard_by_sky_patch(cat["ra"], cat["dec"], w, self.world, self.nside_patch, layout=self.layout)
         self.shard_indices = shards[self.rank]
         New_HaloCatalog = HaloCat[self.shard_indices]
         New_Runner = type(Runner)(New_HaloCatalog, Runner.LightconeShell, Runner.epsilon_max, Runner.model,

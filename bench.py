@@ -10,7 +10,7 @@ halos/s + achieved HBM GB/s, NSIDE = 1024 shell, 1e6 halos, at 1/2/4/8 GPUs).
 One "step" = one full pass of the hot path over one synthetic catalog that is already
 resident in HBM as float64 (M, z, ra, dec) records: zero the map, halo preparation kernel,
 shell paint kernel, and -- for N > 1 -- the RCCL all-reduce of the per-rank maps.
-Weak scaling: every rank paints its own sky-patch shard of `--halos` halos PER GPU
+Weak scaling: every rank paints its own sky-patch shard (sharding.shard_by_sky_patch) of `--halos` halos PER GPU
 (N x halos in total); value = all halos painted by all ranks / max-over-ranks time.
 
 Rank 0 prints ONE JSON line (see the contract in the task statement) with two extra objects:
@@ -282,7 +282,7 @@ def main():
                                f"table {shape[0]}x{shape[1]}x{shape[2]}, catalog "
                                f"{'dn/dlnM~M^-0.9' if args.steep else 'log10M~U(12,15.5)'}, z~U(0.4,0.5), seed 42",
                    "variant": args.variant, "halos_per_gpu": args.halos, "nside": nside,
-                   "sharding": "sky patch (NEST nside 8) + RCCL all-reduce of the map, overlapped with the next shell (two map buffers)" if world > 1 else "none",
+                   "sharding": "sky patches (NEST nside 64, dealt round-robin) + RCCL all-reduce of the map, overlapped with the next shell (two map buffers)" if world > 1 else "none",
                    "pixel_updates_total_per_step": ptot_all},
         "roofline": roofline,
     }

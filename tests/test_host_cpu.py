@@ -235,11 +235,11 @@ def test_ang2pix_nest_is_a_consistent_spatial_key():
 
 
 @pytest.mark.parametrize("world", [1, 2, 4, 8])
-def test_shard_by_sky_patch_partitions_and_balances(world):
+def test_shard_by_sky_patch_contiguous_partitions_and_balances(world):
     ra, dec, M, z = syn.catalog(20000, seed=3)
     w = sharding.estimate_disc_pixels(syn.COSMO, M, z, 10, 1024)
     assert np.all(w > 16) and np.isfinite(w).all()
-    shards = sharding.shard_by_sky_patch(ra, dec, w, world)
+    shards = sharding.shard_by_sky_patch(ra, dec, w, world, nside_patch=8, layout="contiguous")
     assert len(shards) == world
     allidx = np.concatenate(shards)
     assert np.array_equal(np.sort(allidx), np.arange(20000))            # disjoint and complete
@@ -251,6 +251,25 @@ def test_shard_by_sky_patch_partitions_and_balances(world):
         assert all(lo[i + 1] > hi[i] for i in range(len(hi) - 1))
     fine = sharding.ang2pix_nest(1024, ra[shards[0]], dec[shards[0]])
     assert np.all(np.diff(fine) >= 0)                                   # sorted for locality inside a shard
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_shard_by_sky_patch_interleaved_covers_the_sky_on_every_rank(world):
+    ra, dec, M, z = syn.catalog(40000, seed=4)
+    w = sharding.estimate_disc_pixels(syn.COSMO, M, z, 10, 1024)
+    shards = sharding.shard_by_sky_patch(ra, dec, w, world)             # the default layout
+    assert len(shards) == world
+    assert np.array_equal(np.sort(np.concatenate(shards)), np.arange(40000))      # disjoint and complete
+    loads = np.array([w[s].sum() for s in shards])
+    assert loads.max() / loads.mean() < 1.1
+    patch = sharding.ang2pix_nest(64, ra, dec)
+    for r, s in enumerate(shards):
+        assert np.all(np.diff(s) > 0)                                   # the caller's halo order is kept
+        if world > 1:
+            assert np.all(patch[s] % world == r)                        # whole patches, dealt round-robin
+            assert np.unique(sharding.ang2pix_nest(2, ra[s], dec[s])).size == 48   # every rank sees the whole sky
+    with pytest.raises(ValueError):
+        sharding.shard_by_sky_patch(ra, dec, w, world, layout="random")
 
 
 def test_estimate_disc_pixels_tracks_the_oracle_count():
