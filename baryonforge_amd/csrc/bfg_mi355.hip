@@ -97,6 +97,8 @@ struct bfg_ctx {
         TileGeom geo;
         int32_t *d_geo;             // band_ns | band_tile0 | band_nrmin | tile_band
         int32_t *d_tile_count, *d_tile_start;
+        int4 *d_work;               // [ntiles + kWorkExtra] work items of the tile kernel + [1] their number
+        int32_t *d_nwork;
     } tiles[2];                     // [MODE_PAINT], [MODE_BARYONIFY]
     int32_t *d_pairs;
     bfg::HaloDisp *d_hd;            // [cap_halo] baryonify tile path
@@ -1020,6 +1022,8 @@ int bfg_ctx_destroy(bfg_ctx *c)
         if (c->tiles[m].d_geo) (void)hipFree(c->tiles[m].d_geo);
         if (c->tiles[m].d_tile_count) (void)hipFree(c->tiles[m].d_tile_count);
         if (c->tiles[m].d_tile_start) (void)hipFree(c->tiles[m].d_tile_start);
+        if (c->tiles[m].d_work) (void)hipFree(c->tiles[m].d_work);
+        if (c->tiles[m].d_nwork) (void)hipFree(c->tiles[m].d_nwork);
     }
     if (c->d_hd) (void)hipFree(c->d_hd);
     if (c->d_left) (void)hipFree(c->d_left);
@@ -1295,8 +1299,8 @@ static int ensure_tiles(bfg_ctx *c, int mode, int tr, int64_t nside, int64_t n_h
     bfg_ctx::TileSet &ts = c->tiles[mode];
     if (ts.nside != nside || ts.geo.tr != tr) {
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (ts.d_geo) { (void)hipFree(ts.d_geo); (void)hipFree(ts.d_tile_count); (void)hipFree(ts.d_tile_start); }
-        ts.d_geo = nullptr; ts.d_tile_count = nullptr; ts.d_tile_start = nullptr; ts.nside = 0;
+        if (ts.d_geo) { (void)hipFree(ts.d_geo); (void)hipFree(ts.d_tile_count); (void)hipFree(ts.d_tile_start); (void)hipFree(ts.d_work); (void)hipFree(ts.d_nwork); }
+        ts.d_geo = nullptr; ts.d_tile_count = nullptr; ts.d_tile_start = nullptr; ts.d_work = nullptr; ts.d_nwork = nullptr; ts.nside = 0;
         const int64_t nrings = 4 * nside - 1;
         const int nbands = (int)((nrings + tr - 1) / tr);
         std::vector<int32_t> ns(nbands), t0(nbands + 1), nrmin(nbands);
@@ -1324,6 +1328,8 @@ static int ensure_tiles(bfg_ctx *c, int mode, int tr, int64_t nside, int64_t n_h
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipMalloc((void **)&ts.d_tile_count, (size_t)ntiles * sizeof(int32_t)));
         HIP_TRY(hipMalloc((void **)&ts.d_tile_start, (size_t)(ntiles + 1) * sizeof(int32_t)));
+        HIP_TRY(hipMalloc((void **)&ts.d_work, (size_t)(ntiles + kWorkExtra) * sizeof(int4)));
+        HIP_TRY(hipMalloc((void **)&ts.d_nwork, sizeof(int32_t)));
         ts.geo.tr = tr; ts.geo.nbands = nbands; ts.geo.ntiles = ntiles;
         ts.geo.band_ns = ts.d_geo;
         ts.geo.band_tile0 = ts.d_geo + nbands;
@@ -1442,7 +1448,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         timing_begin(c, 3);
         const bfg_ctx::TileSet &ts = c->tiles[mode];
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, ts.geo.ntiles, ts.d_tile_count,
-                           ts.d_tile_start);
+                           ts.d_tile_start, ts.d_work, ts.d_nwork);
         FillParams fp;
         std::memset(&fp, 0, sizeof(fp));
         fp.n_halo = a->n_halo; fp.cap = c->cap_halo; fp.rec = c->d_rec; fp.irec = c->d_irec; fp.ht = c->d_ht; fp.bin = pp.bin;
@@ -1466,6 +1472,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         tp.hpx = pp.hpx; tp.n_halo = a->n_halo; tp.cap = c->cap_halo;
         tp.ht = c->d_ht; tp.cidx = c->d_cidx; tp.cw = c->d_cw;
         tp.tab = t->dev; tp.geo = ts.geo; tp.tile_start = ts.d_tile_start; tp.pairs = c->d_pairs;
+        tp.work = ts.d_work; tp.n_work = ts.d_nwork;
         tp.hd = c->d_hd;
         tp.hwin = c->d_hwin; tp.win_nodes = win_nodes; tp.pair_cap = c->pair_cap;
         tp.out = d_out; tp.stats = c->d_stats;
@@ -1484,7 +1491,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lb));
             c->tile_attr_set = true;
         }
-        const dim3 tgrid((unsigned)ts.geo.ntiles), tblock(kTileThreads);
+        const dim3 tgrid((unsigned)(ts.geo.ntiles + kWorkExtra)), tblock(kTileThreads);   // work items; the surplus exits at once
         const bool wl = win_nodes <= kWinLds;
         timing_begin(c, 1);
         if (mode == MODE_PAINT) {

@@ -168,6 +168,8 @@ struct TileParams {
     DevTable tab;
     TileGeom geo;
     const int32_t *tile_start;       // [ntiles+1]
+    const int4 *work;                // [n_work] (tile, first pair, last pair + 1, shared) -- see tile_scan_kernel
+    const int32_t *n_work;
     const int32_t *pairs;            // halo ids grouped by tile
     const double *hwin;              // [n_halo][win_nodes] blended row values B_i, i = win_lo + e
     int win_nodes;
@@ -284,8 +286,14 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const FillParams P)
                   P.rec[F_PPHI * cap + j], P.rec[F_RADIUS * cap + j]);
 }
 
-// exclusive scan of tile_count into tile_start[ntiles+1]; single workgroup
-__global__ __launch_bounds__(1024) void tile_scan_kernel(int ntiles, int32_t *count, int32_t *start)
+// exclusive scan of tile_count into tile_start[ntiles+1], then the work list of the tile kernel; single workgroup.
+// A work item is (tile, first pair, last pair + 1, shared): tiles with more than S pairs are cut into equal slices of at most S pairs that
+// different workgroups accumulate separately (shared = 1: the write-back uses atomics).  S = max(256, total / 4096), so a
+// full-sky catalog gives one item per tile while a catalog that crowds into part of the sky (an octant light cone, a
+// compact multi-GPU shard: 1/8 of the tiles with 8x the pairs) still yields a few thousand items of similar size instead of
+// 784 heavy ones on 512 workgroup slots.
+constexpr int kWorkExtra = 4096;
+__global__ __launch_bounds__(1024) void tile_scan_kernel(int ntiles, int32_t *count, int32_t *start, int4 *work, int32_t *n_work)
 {
     __shared__ int32_t wsum[16];
     __shared__ int32_t carry;
@@ -306,7 +314,29 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int ntiles, int32_t *co
         if (threadIdx.x == 1023) carry = c + woff + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) start[ntiles] = carry;
+    const int total = carry;
+    if (threadIdx.x == 0) { start[ntiles] = total; carry = 0; }
+    __syncthreads();
+    const int S = max(256, (total + kWorkExtra - 1) / kWorkExtra);
+    for (int base = 0; base < ntiles; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int n = (i < ntiles) ? start[i + 1] - start[i] : 0;
+        const int v = (n + S - 1) / S;
+        int incl = v;
+        for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(incl, d, 64); if ((threadIdx.x & 63) >= d) incl += o; }
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
+        const int c = carry;
+        int o = c + woff + incl - v;
+        const int slice = (v > 0) ? (n + v - 1) / v : 0;                    // equal slices within a tile
+        for (int m = 0; m < v; ++m, ++o) work[o] = make_int4(i, m * slice, min(n, (m + 1) * slice), v > 1 ? 1 : 0);
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_work = carry;
 }
 
 // Per-halo blended radial row: hwin[j][e] = B_i, i = win_lo_j + e, where
@@ -588,9 +618,10 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
     static_assert(sizeof(RingRow) % 16 == 0 && sizeof(Pair) % 16 == 0, "16-byte aligned LDS records");
     static_assert(ctl_off + 8 * sizeof(int32_t) == tile_lds_bytes<MODE>(), "layout and tile_lds_bytes() must agree");
 
-    const int tile = blockIdx.x;
-    const int n_pairs = P.tile_start[tile + 1] - P.tile_start[tile];
-    if (n_pairs == 0 || (long long)P.tile_start[P.geo.ntiles] > P.pair_cap) return;
+    if ((int)blockIdx.x >= *P.n_work || (long long)P.tile_start[P.geo.ntiles] > P.pair_cap) return;
+    const int4 wk = P.work[blockIdx.x];
+    const int tile = wk.x;
+    const int n_pairs = wk.z - wk.y;
     const Hpx &hp = P.hpx;
     const DevTable &T = P.tab;
     const int band = P.geo.tile_band[tile];
@@ -634,7 +665,7 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
     const int W = P.win_nodes;
     constexpr bool win_in_lds = WIN_LDS;     // row windows of <= kWinLds nodes live in LDS, longer ones stay in HBM/L2
     unsigned long long my_pixels = 0;
-    const int32_t *plist = P.pairs + P.tile_start[tile];
+    const int32_t *plist = P.pairs + P.tile_start[tile] + wk.y;
 
     // Wave 0 runs the pair pipeline two chunks deep, so that no stage waits for a dependent pair -> halo record load:
     //   pjA / pjB  the pair list entries [base, base + 128) of the current chunk's first pair (issued one chunk ago);
@@ -1045,7 +1076,8 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
 #if BFG_STAGE_TIMING
     if (tid == 64) for (int i = 0; i < 8; ++i) atomicAdd(&g_stage_cycles[i], (unsigned long long)st_acc[i]);
 #endif
-    // write the tile back: every pixel belongs to exactly one tile -> plain read-modify-write
+    // write the tile back: every pixel belongs to exactly one tile -> plain read-modify-write (unless the tile's pair list
+    // was cut into several work items)
     for (int i = tid; i < TR * TW; i += NT) {
         const int row = i / TW, col = i % TW;
         const int ring = ring_lo + row;
@@ -1056,7 +1088,10 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
 #pragma unroll
         for (int c = 0; c < NACC; ++c) {
             const double v = acc[NACC * i + c];
-            if (v != 0.0) P.out[NACC * pix + c] += v;
+            if (v != 0.0) {
+                if (wk.w) unsafeAtomicAdd(P.out + NACC * pix + c, v);      // the tile is shared with other workgroups
+                else P.out[NACC * pix + c] += v;
+            }
         }
     }
 }

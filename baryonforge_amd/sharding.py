@@ -4,10 +4,11 @@ Sky-patch sharding of a halo catalog across the GPUs of a node.
 The reference's only parallel path (utils/Parallelize.py:218-275, SplitJoinParallel)
 shuffles the catalog and cuts it into equal-count slices, one loky process each.
 On a multi-GPU node the cut is spatial: every halo gets the HEALPix NEST index of
-its centre at a patch NSIDE and whole patches go to ranks -- dealt round-robin
-(every rank covers the whole sky thinly; the default, see shard_by_sky_patch for
-the measurements) or as contiguous NEST ranges balanced by the ESTIMATED PIXEL
-WORK of their halos.  The per-rank maps / offset fields are then summed with one
+its centre at a patch NSIDE and whole patches go to ranks -- as contiguous NEST
+ranges balanced by the ESTIMATED PIXEL WORK of their halos (one compact region per
+rank, halos sorted by a fine NEST index inside it; the default, see
+shard_by_sky_patch for the measurements) or dealt round-robin (every rank covers
+the whole sky thinly).  The per-rank maps / offset fields are then summed with one
 RCCL all-reduce.
 """
 import numpy as np
@@ -79,20 +80,23 @@ def estimate_disc_pixels(cosmo, M, z, epsilon_max, nside, mass_def=None, overhea
     return np.where(np.isfinite(est), est, 0.0) + overhead
 
 
-def shard_by_sky_patch(ra_deg, dec_deg, weights, world_size, nside_patch=64, nside_order=1024, layout="interleaved"):
+def shard_by_sky_patch(ra_deg, dec_deg, weights, world_size, nside_patch=8, nside_order=1024, layout="contiguous"):
     """
     Returns a list of `world_size` index arrays that partition the catalog by sky patch (= NEST pixel of the halo
     centre at `nside_patch`); every halo appears exactly once, all halos of a patch go to the same rank.  Deterministic.
 
-    layout "interleaved" (default): the patches are dealt to the ranks round-robin in NEST order, so every rank's shard
-        covers the whole sky at 1/world_size of the density and keeps the caller's halo order.  With the map summed by
-        an all-reduce this is the fast decomposition: the per-rank kernels see the single-GPU workload.  Measured
-        (tools/shard_scale.py, 1e6 halos per rank, NSIDE 1024): 1.65 ms per step at any world size.
-    layout "contiguous": contiguous NEST ranges of patches with ~equal total weight (one compact region per rank),
-        sorted by fine NEST index inside a shard.  The compact shard crowds its halos into 1/world_size of the map
-        tiles -- fewer, fuller tiles for the tile kernel and same-address atomics in the binning passes: 2.6 / 3.3 /
-        4.4 ms per step at world size 2 / 4 / 8 -- so it only pays with an exchange that sends patch borders instead
-        of the whole map.
+    layout "contiguous" (default): contiguous NEST ranges of patches with ~equal total weight (one compact region per
+        rank), sorted by fine NEST index inside a shard.
+    layout "interleaved": the patches are dealt to the ranks round-robin in NEST order (use a fine nside_patch, e.g.
+        64), so every rank's shard covers the whole sky at 1/world_size of the density and keeps the caller's order.
+
+    Measured per rank, 1e6 halos per rank at NSIDE 1024 (tools/shard_scale.py; ms per step at world size 1 / 2 / 4 / 8):
+        contiguous, first version of the kernels     1.65 / 2.6 / 3.3 / 4.4   the compact shard crowds into 1/N of the map
+                                                      tiles (784 eight-fold tiles on 512 workgroup slots) and its sorted
+                                                      halos hit the same tile counters from neighbouring lanes
+        interleaved (NSIDE-64 patches)                1.67 / 1.69 / 1.64-1.72 / 1.75-1.84   the single-GPU workload
+        contiguous, with wave-merged binning atomics and heavy tiles cut into work items
+                                                      1.67 / 1.55-1.59 / 1.51-1.53 / 1.55-1.58   sorted halos now help
     """
     ra_deg = np.asarray(ra_deg, dtype=np.float64)
     n = ra_deg.size

@@ -78,7 +78,7 @@ class SplitJoinParallel(object):
         exercised with the gloo backend on CPU-only machines.
     """
 
-    def __init__(self, Runner, njobs=-1, seed=42, nside_patch=64, local_process=None, layout="interleaved"):
+    def __init__(self, Runner, njobs=-1, seed=42, nside_patch=8, local_process=None, layout="contiguous"):
         self.Runner = Runner
         self.seed = seed
         self.njobs = njobs

@@ -282,7 +282,7 @@ def main():
                                f"table {shape[0]}x{shape[1]}x{shape[2]}, catalog "
                                f"{'dn/dlnM~M^-0.9' if args.steep else 'log10M~U(12,15.5)'}, z~U(0.4,0.5), seed 42",
                    "variant": args.variant, "halos_per_gpu": args.halos, "nside": nside,
-                   "sharding": "sky patches (NEST nside 64, dealt round-robin) + RCCL all-reduce of the map, overlapped with the next shell (two map buffers)" if world > 1 else "none",
+                   "sharding": "sky patch (contiguous NEST ranges of nside-8 patches, balanced by pixel work) + RCCL all-reduce of the map, overlapped with the next shell (two map buffers)" if world > 1 else "none",
                    "pixel_updates_total_per_step": ptot_all},
         "roofline": roofline,
     }

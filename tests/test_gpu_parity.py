@@ -178,6 +178,42 @@ def test_geometry_fuzz_against_oracle(cosmo):
         assert_maps_close(gotb, refb, RTOL, floor=BFLOOR, what=f"fuzz baryonify case {case} nside {nside} eps {eps}")
 
 
+@pytest.mark.parametrize("order", ["random", "sorted"])
+def test_crowded_sky_patch_splits_tiles(cosmo, order):
+    """a catalog crowded into a few degrees of sky (an octant light cone or a compact multi-GPU shard in the small):
+    the heavy tiles' pair lists are cut into several work items whose workgroups add to the same map tile with
+    atomics, and -- sorted by position -- neighbouring lanes of the binning passes hit the same tile counter
+    (wave_merged_inc); paint and baryonify against the oracle"""
+    import warnings
+    rng = np.random.default_rng(77)
+    nside, n, eps = 512, 6000, 6.0
+    ra = (40.0 + rng.normal(0, 2.0, n)) % 360
+    dec = 25.0 + rng.normal(0, 2.0, n)
+    M = 10 ** rng.uniform(13.0, 14.8, n)
+    z = rng.uniform(0.3, 0.5, n)
+    if order == "sorted":
+        from baryonforge_amd import sharding
+        o = np.argsort(sharding.ang2pix_nest(1024, ra, dec), kind="stable")
+        ra, dec, M, z = ra[o], dec[o], M[o], z[o]
+    zax, Max, rax, T = syn.pressure_table()
+    ref, ptot = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax), T, nside, eps)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), eps,
+                               _paint_model(zax, Max, rax, T), verbose=False)
+    got = R.process()
+    assert R.last_stats["pixel_updates"] == ptot
+    assert np.array_equal(got != 0, ref != 0)
+    assert_maps_close(got, ref, RTOL, what="crowded paint")
+    zd, Md, rd, d = syn.displacement_table()
+    m_in = syn.mass_map(nside)
+    refb = oracle_baryonify(cosmo, ra, dec, M, z, (zd, Md, rd), d, nside, eps, 20, m_in)
+    model = bfg.Baryonification2D.from_arrays(zd, Md, rd, d, cosmo, epsilon_max=20)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gotb = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo), eps, model, verbose=False).process()
+    assert_maps_close(gotb, refb, RTOL, floor=BFLOOR, what="crowded baryonify")
+
+
 def _grid_inputs(g, tag, cosmo):
     is2D = bool(g[f"{tag}_is2D"])
     N, bins, H = int(g[f"{tag}_Npix"]), g[f"{tag}_bins"], g[f"{tag}_H"]

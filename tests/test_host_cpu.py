@@ -239,7 +239,7 @@ def test_shard_by_sky_patch_contiguous_partitions_and_balances(world):
     ra, dec, M, z = syn.catalog(20000, seed=3)
     w = sharding.estimate_disc_pixels(syn.COSMO, M, z, 10, 1024)
     assert np.all(w > 16) and np.isfinite(w).all()
-    shards = sharding.shard_by_sky_patch(ra, dec, w, world, nside_patch=8, layout="contiguous")
+    shards = sharding.shard_by_sky_patch(ra, dec, w, world)               # the default layout
     assert len(shards) == world
     allidx = np.concatenate(shards)
     assert np.array_equal(np.sort(allidx), np.arange(20000))            # disjoint and complete
@@ -257,7 +257,7 @@ def test_shard_by_sky_patch_contiguous_partitions_and_balances(world):
 def test_shard_by_sky_patch_interleaved_covers_the_sky_on_every_rank(world):
     ra, dec, M, z = syn.catalog(40000, seed=4)
     w = sharding.estimate_disc_pixels(syn.COSMO, M, z, 10, 1024)
-    shards = sharding.shard_by_sky_patch(ra, dec, w, world)             # the default layout
+    shards = sharding.shard_by_sky_patch(ra, dec, w, world, nside_patch=64, layout="interleaved")
     assert len(shards) == world
     assert np.array_equal(np.sort(np.concatenate(shards)), np.arange(40000))      # disjoint and complete
     loads = np.array([w[s].sum() for s in shards])

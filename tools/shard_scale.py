@@ -25,11 +25,11 @@ for world in (1, 2, 4, 8):
     spline = ctx.da_spline(bg, float(np.max(z)))
     if world > 1:
         w = sharding.estimate_disc_pixels(cosmo, M, z, eps, nside)
-        kw = {"layout": os.environ.get("LAYOUT", "interleaved")}
+        kw = {"layout": os.environ.get("LAYOUT", "contiguous")}
         if os.environ.get("PATCH"):
             kw["nside_patch"] = int(os.environ["PATCH"])
-        elif kw["layout"] == "contiguous":
-            kw["nside_patch"] = 8
+        elif kw["layout"] == "interleaved":
+            kw["nside_patch"] = 64
         shards = sharding.shard_by_sky_patch(ra, dec, w, world, **kw)
     else:
         shards = [np.arange(halos)]
