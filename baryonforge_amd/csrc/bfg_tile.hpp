@@ -207,12 +207,15 @@ __device__ inline int wave_merged_inc(int32_t *counter, int idx)
     unsigned long long todo = __ballot(1);
     unsigned long long mine = 1ull << lane;
     int leader = lane;
+    bool merged = false;
     for (int round = 0; round < 8 && todo; ++round) {
         const int l0 = __ffsll((long long)todo) - 1;
         const int k0 = __shfl(idx, l0, 64);
         const unsigned long long same = __ballot(idx == k0) & todo;
         if ((same >> lane) & 1ull) { mine = same; leader = l0; }
         todo &= ~same;
+        merged = merged || (same & (same - 1)) != 0;
+        if (round == 1 && !merged) break;          // two singleton groups in a row: an unsorted catalog, stop looking
     }
     int base = 0;
     if (lane == leader) base = atomicAdd(&counter[idx], __popcll(mine));
