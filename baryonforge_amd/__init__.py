@@ -9,8 +9,10 @@ paint / baryonify hot path behind the reference's `bfg.Runners` / `bfg.Profiles`
     model = bfg.utils.TabulatedProfile.from_arrays(ln1pz, lnM, lnr, table_2D)
     new   = bfg.Runners.PaintProfilesShell(Cat, Shell, epsilon_max=10, model=model).process()
 
-Everything outside that path (profile zoo, FFTLog pixel windows, grid/snapshot
-runners, halo-model utilities) is out of scope; see DESIGN.md.
+Widened along SURVEY 8f: PaintProfilesAnisShell, BaryonifySnapshot (+ HaloNDCatalog,
+ParticleSnapshot with NGP / CIC mass maps), the periodic-grid runners (+ GriddedMap)
+and the device-side displacement-table builder.  The profile zoo, FFTLog pixel
+windows and halo-model utilities are out of scope; see DESIGN.md.
 """
 from . import Profiles, Runners, utils  # noqa: F401
 from .Profiles import *  # noqa: F401,F403

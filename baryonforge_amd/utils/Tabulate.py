@@ -19,7 +19,7 @@ from itertools import product
 
 import numpy as np
 
-__all__ = ["_set_parameter", "_get_parameter", "TabulatedProfile", "ParamTabulatedProfile"]
+__all__ = ["_set_parameter", "_get_parameter", "TabulatedProfile", "ParamTabulatedProfile", "TabulatedCorrelation3D"]
 
 
 def _is_profile_like(obj):
@@ -239,3 +239,69 @@ class ParamTabulatedProfile(_TabulatedBase):
         for k in self.p_keys:
             assert k in kwargs.keys(), "Need to provide %s as input into `projected'. Table was built with this." % k
         return self._readout(r, M, a, "2D", **kwargs)
+
+
+class TabulatedCorrelation3D(object):
+    """
+    Tabulated matter correlation function xi(r, a).  Mirrors Tabulate.py:733-784: a (ln(1+z), ln r) table of
+    ccl.correlation_3d, read out as exp(bilinear(ln xi)) with NaN outside the table (RegularGridInterpolator,
+    bounds_error=False).  The read-out runs on the GPU (bfg_table_eval); the table itself comes from
+    `setup_interpolator` -- which needs a correlation function, pyccl's when it is installed or any
+    `correlation_3d(cosmo, a, r)` callable -- or from `from_arrays`.
+    """
+
+    def __init__(self, cosmo, R_range=[1e-3, 1e3], N_samples=500, correlation_3d=None):
+        self.cosmo = cosmo
+        self.R_range = R_range
+        self.N_samples = N_samples
+        self.correlation_3d = correlation_3d
+
+    @classmethod
+    def from_arrays(cls, ln1pz, lnr, raw_input_3D, cosmo=None):
+        self = cls(cosmo)
+        self._set_table(ln1pz, lnr, raw_input_3D)
+        return self
+
+    def _set_table(self, ln1pz, lnr, xi):
+        self.raw_input_z_range = np.ascontiguousarray(ln1pz, dtype=np.float64)
+        self.raw_input_r_range = np.ascontiguousarray(lnr, dtype=np.float64)
+        self.raw_input_3D = np.ascontiguousarray(xi, dtype=np.float64)
+        if self.raw_input_3D.shape != (self.raw_input_z_range.size, self.raw_input_r_range.size):
+            raise ValueError(f"table shape {self.raw_input_3D.shape} does not match its axes")
+
+    def setup_interpolator(self, z_min=0, z_max=5, N_samples_z=10, verbose=False):
+        """Tabulate.py:744-768"""
+        xi_of = self.correlation_3d
+        if xi_of is None:
+            try:
+                import pyccl as ccl
+                xi_of = ccl.correlation_3d
+            except ImportError as e:
+                raise ImportError("TabulatedCorrelation3D.setup_interpolator needs pyccl.correlation_3d, or pass "
+                                  "correlation_3d=callable(cosmo, a, r)") from e
+        r = np.geomspace(self.R_range[0], self.R_range[1], self.N_samples)
+        z_range = np.linspace(z_min, z_max, N_samples_z)
+        interp3D = np.zeros([z_range.size, r.size]) + np.nan
+        for j in range(z_range.size):
+            interp3D[j, :] = xi_of(self.cosmo, 1 / (1 + z_range[j]), r)
+        self._set_table(np.log(1 + z_range), np.log(r), interp3D)
+
+    def device_table(self, ctx):
+        """the (z, r) table as a (z, M, r) bfg_table with a two-node dummy mass axis (the read-out sits at its first node)"""
+        def log_table():
+            with np.errstate(all="ignore"):
+                lnxi = np.log(self.raw_input_3D)
+            return np.ascontiguousarray(np.repeat(lnxi[:, None, :], 2, axis=1))
+        axes = [self.raw_input_z_range, np.array([0.0, 1.0]), self.raw_input_r_range]
+        return ctx.table(axes, log_table, log_values=True, cache_key=(id(self), "xi", id(self.raw_input_3D)))
+
+    def __call__(self, r, a):
+        """Tabulate.py:771-784"""
+        if not hasattr(self, "raw_input_3D"):
+            raise NameError("No Table created. Run setup_interpolator() method first")
+        from ..engine import get_context
+        r_use = np.atleast_1d(r).astype(np.float64)
+        with np.errstate(all="ignore"):
+            z_in = np.log(1 / a) * np.ones_like(r_use)               # log(1 + z)
+            coords = np.stack([z_in, np.zeros_like(r_use), np.log(r_use)], axis=1)
+        return self.device_table(get_context()).eval(coords)

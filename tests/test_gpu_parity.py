@@ -899,3 +899,29 @@ def test_table_builder_device_vs_host(case):
         assert len(warned[True]) > 0 and np.count_nonzero(out[True]) < out[True].size
     else:
         assert scale > 1e-4
+
+
+def test_tabulated_correlation3d_matches_scipy():
+    """TabulatedCorrelation3D (Tabulate.py:733-784): exp of the bilinear ln xi table, NaN outside the table and wherever
+    a node of the cell is non-positive -- against the scipy RegularGridInterpolator the reference builds"""
+    from scipy import interpolate
+    xi_of = lambda cosmo, a, r: a ** 2 * (r / 5.0) ** -1.8 * (1 + 0.05 * np.sin(r / 15.0)) - 2e-4     # < 0 at large r
+    X = bfg.utils.TabulatedCorrelation3D(dict(syn.COSMO), R_range=[1e-2, 3e2], N_samples=120, correlation_3d=xi_of)
+    with pytest.raises(NameError):
+        X(1.0, 0.8)
+    X.setup_interpolator(z_min=0, z_max=2, N_samples_z=7)
+    assert X.raw_input_3D.shape == (7, 120)
+    with np.errstate(all="ignore"):
+        rgi = interpolate.RegularGridInterpolator((X.raw_input_z_range, X.raw_input_r_range), np.log(X.raw_input_3D),
+                                                  bounds_error=False)
+        rng = np.random.default_rng(4)
+        r = np.concatenate([10 ** rng.uniform(-2.3, 2.7, 4000), np.exp(X.raw_input_r_range[[0, 5, -1]])])
+        for a in (1.0, 0.71, 1 / 3.0, 0.3):                                  # the last one lies outside the z range
+            got = X(r, a)
+            ref = np.exp(rgi((np.log(1 / a) * np.ones_like(r), np.log(r))))
+            assert np.array_equal(np.isnan(got), np.isnan(ref))
+            ok = ~np.isnan(ref)
+            np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-12)
+        assert np.isnan(X(r, 0.3)).all() and np.isnan(got).any()
+    Y = bfg.utils.TabulatedCorrelation3D.from_arrays(X.raw_input_z_range, X.raw_input_r_range, X.raw_input_3D)
+    np.testing.assert_array_equal(Y(r[:50], 0.9), X(r[:50], 0.9))

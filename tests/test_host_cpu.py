@@ -361,3 +361,13 @@ def test_grid_containers_and_host_regrid(golden, cosmo):
     assert np.isclose(np.linalg.det(Rm), 1.0)
     np.testing.assert_array_equal(R.pick_indices(1, 2, 16), [15, 0, 1, 2])
 
+
+
+def test_tabulated_correlation3d_host_side():
+    X = bfg.utils.TabulatedCorrelation3D(dict(syn.COSMO))
+    with pytest.raises(NameError):
+        X(1.0, 0.5)
+    with pytest.raises(ImportError):                       # no pyccl here and no callable given
+        X.setup_interpolator()
+    with pytest.raises(ValueError):
+        bfg.utils.TabulatedCorrelation3D.from_arrays(np.zeros(3), np.zeros(5), np.ones((3, 4)))
