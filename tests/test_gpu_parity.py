@@ -135,6 +135,37 @@ def test_baryonify_config2_full_size_vs_oracle(cosmo):
     assert_maps_close(got, ref, RTOL, floor=BFLOOR, what="baryonify config 2")
 
 
+def test_paint_nside4096_and_offsets_nside2048_vs_oracle(cosmo):
+    """large maps: paint at NSIDE 4096 (2.0e8 pixels, discs of ~4400 pixels) and the baryonify offset field at NSIDE 2048
+    (BASELINE config[3]'s resolution) against the oracle, halos on both poles and on the phi = 0 seam"""
+    nside, n, eps = 4096, 2500, 10.0
+    ra, dec, M, z = syn.catalog(n, seed=12)
+    dec[:40] = 90 - np.abs(np.random.default_rng(1).normal(0, 0.3, 40))
+    dec[40:80] = -90 + np.abs(np.random.default_rng(2).normal(0, 0.3, 40))
+    ra[80:120] = np.random.default_rng(3).normal(0, 0.05, 40) % 360
+    zax, Max, rax, T = syn.pressure_table()
+    ref, ptot = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax), T, nside, eps)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    Run = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), eps,
+                                 _paint_model(zax, Max, rax, T), verbose=False)
+    got = Run.process()
+    assert Run.last_stats["pixel_updates"] == ptot
+    assert np.array_equal(got != 0, ref != 0)
+    assert_maps_close(got, ref, RTOL, what="paint nside 4096")
+    del got, ref
+    nside = 2048                                                   # the offset field has 3 doubles per pixel: 1.2 GB here
+    zd, Md, rd, d = syn.displacement_table()
+    refo, ptot = oracle_baryonify(cosmo, ra, dec, M, z, (zd, Md, rd), d, nside, eps, 20, None, offsets_only=True)
+    model = bfg.Baryonification2D.from_arrays(zd, Md, rd, d, cosmo, epsilon_max=20)
+    R = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=np.ones(12 * nside * nside), cosmo=cosmo), eps, model, verbose=False)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        goto = R.offsets_device().cpu().numpy()
+    assert R.last_stats["pixel_updates"] == ptot
+    assert_maps_close(goto, refo, RTOL, floor=1e-10, what="offsets nside 2048")
+
+
 def test_geometry_fuzz_against_oracle(cosmo):
     """Randomised geometry: odd and even NSIDE from 8 to 700, halos drawn towards the poles, the phi = 0 seam and the
     equatorial-belt / polar-cap transition, discs from sub-pixel to larger than a hemisphere (eps up to 400); every case
