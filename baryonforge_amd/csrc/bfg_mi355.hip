@@ -209,15 +209,28 @@ __device__ inline double spline_eval(int n, const double *__restrict__ x, const 
     return ((c[i] * s + c[m + i]) * s + c[2 * m + i]) * s + c[3 * m + i];
 }
 
+constexpr int kPrepKnots = 1024;     // D_A spline knots staged in LDS (the reference uses 1000, HealpixRunner.py:297)
+constexpr int kPrepAxis = 64;        // nodes of a non-radial table axis staged in LDS
+
 __global__ __launch_bounds__(256) void halo_prep_kernel(const PrepParams P)
 {
+    // the bisections below (spline knots: 10 steps; table axes: 4-5 steps each) are chains of dependent loads: from L2 they
+    // cost ~10 us per wavefront, from LDS well under 1 us.  Same comparisons on the same values, so the same cells.
+    __shared__ double s_knots[kPrepKnots];
+    __shared__ double s_axis[BFG_MAX_DIM - 1][kPrepAxis];
+    const bool knots_lds = P.spl_n <= kPrepKnots;
+    if (knots_lds) for (int i = threadIdx.x; i < P.spl_n; i += blockDim.x) s_knots[i] = P.spl_knots[i];
+    for (int k = 0; k < P.tab.nouter; ++k)
+        if (P.tab.oshape[k] <= kPrepAxis)
+            for (int i = threadIdx.x; i < P.tab.oshape[k]; i += blockDim.x) s_axis[k][i] = P.tab.oaxis[k][i];
+    __syncthreads();
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= P.n_halo) return;
     const double *c = P.cat + j * (int64_t)P.cat_stride;
     const double M = c[0], zred = c[1], ra = c[2], dec = c[3];
     const double a = 1.0 / (1.0 + zred);                                   // HealpixRunner.py:319/:453
     const double R = massdef_radius(P.md_run, M, a);                        // :320/:454
-    const double D = spline_eval(P.spl_n, P.spl_knots, P.spl_coef, zred);   // :321/:455
+    const double D = spline_eval(P.spl_n, knots_lds ? s_knots : P.spl_knots, P.spl_coef, zred);   // :321/:455
     // hp.ang2vec(ra, dec, lonlat=True)                                      // :327/:460
     const double theta = kHalfPi - dec * kDeg2Rad, phi = ra * kDeg2Rad;
     double st, ct, sp, cp;
@@ -266,8 +279,8 @@ __global__ __launch_bounds__(256) void halo_prep_kernel(const PrepParams P)
     uint32_t warn = 0;
     for (int k = 0; k < P.tab.nouter; ++k) {
         double x = (k == 0) ? lnz : (k == 1) ? lnM : c[4 + (k - 2)];
-        const double *g = P.tab.oaxis[k];
         int n = P.tab.oshape[k];
+        const double *g = (n <= kPrepAxis) ? s_axis[k] : P.tab.oaxis[k];
         if (!(x >= g[0]) || !(x <= g[n - 1])) {
             oob = true;
             if (k == 0) warn |= BFG_WARN_Z_RANGE;
