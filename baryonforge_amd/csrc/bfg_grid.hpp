@@ -450,15 +450,22 @@ __global__ __launch_bounds__(256) void grid_regrid_kernel(int N, const double *_
         if (d < 0) d = fmin((double)c + 1.0, end[k] - N) - fmax((double)c, start[k] - N);
         return d;
     };
-    for (int ci = base[1]; ci < last[1]; ++ci) {              // i: y range
+    // The reference scans range(int(start) - 2, int(end) + 2) on every axis (5-6 cells, 6^d overlap evaluations).  A unit
+    // cube starting at s in [0, N) can only overlap cells int(s) and int(s) + 1, and for N >= 7 the scanned range never
+    // visits a cell twice through the periodic wrap, so evaluating the SAME overlap expression on just those two cells
+    // gives the same deposits bit for bit; smaller grids keep the literal scan (with its double visits).
+    const bool narrow = N >= 7;
+    int lo[3], hi[3];
+    for (int k = 0; k < NDIM; ++k) { lo[k] = narrow ? (int)start[k] : base[k]; hi[k] = narrow ? (int)start[k] + 2 : last[k]; }
+    for (int ci = lo[1]; ci < hi[1]; ++ci) {                  // i: y range
         int ii; const double dy = overlap(1, ci, ii);
         if (!(dy > 0)) continue;
-        for (int cj = base[0]; cj < last[0]; ++cj) {          // j: x range
+        for (int cj = lo[0]; cj < hi[0]; ++cj) {              // j: x range
             int jj; const double dx = overlap(0, cj, jj);
             if (!(dx > 0)) continue;
             if (NDIM == 2) unsafeAtomicAdd(out_map + (int64_t)ii * N + jj, dx * dy * val);
             else {
-                for (int ck = base[2]; ck < last[2]; ++ck) {
+                for (int ck = lo[2]; ck < hi[2]; ++ck) {
                     int kk; const double dz = overlap(2, ck, kk);
                     if (!(dz > 0)) continue;
                     unsafeAtomicAdd(out_map + ((int64_t)ii * N + jj) * N + kk, dx * dy * dz * val);

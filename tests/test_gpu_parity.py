@@ -391,6 +391,37 @@ def test_grid_tile_pass_matches_direct_pass(cosmo, ndim, N, monkeypatch):
         assert res["tile"][2][key] == res["direct"][2][key], key
 
 
+@pytest.mark.parametrize("ndim,N", [(2, 6), (2, 7), (2, 45), (3, 5), (3, 7), (3, 20)])
+def test_regrid_grid_kernel_vs_host_rule(ndim, N):
+    """bfg_regrid_grid (regrid_pixels_2D/_3D, Map2DRunner.py:14-162) on random offsets of up to several pixels -- exact
+    integers, the periodic faces, non-finite entries (zeroed, :591 / :603) -- against the host restatement of the
+    reference's candidate-cell scan (pinned by the golden file in tests/test_host_cpu.py).  N < 7: the literal scan
+    (cells visited twice through the wrap), N >= 7: the two-cell form."""
+    from baryonforge_amd.engine import get_context
+    ctx = get_context(0)
+    rng = np.random.default_rng(100 * ndim + N)
+    npx = N ** ndim
+    off = rng.normal(0, 1.5, (npx, ndim))
+    off[rng.uniform(size=npx) < 0.2] = 0.0
+    k = rng.integers(0, npx, 30)
+    off[k] = np.round(off[k])                                           # exact pixel shifts
+    off[rng.integers(0, npx, 10), 0] = np.nan
+    off[rng.integers(0, npx, 10), ndim - 1] = np.inf
+    val = rng.uniform(0, 3, npx)
+    val[rng.uniform(size=npx) < 0.1] = 0.0
+    out = ctx.zeros(npx)
+    ctx.regrid_grid(ndim, N, ctx.to_device(off), ctx.to_device(val), out)
+    got = out.cpu().numpy().reshape((N,) * ndim)
+    idx = np.indices((N,) * ndim).reshape(ndim, -1).T.astype(np.float64)       # (i, j[, k]) of every pixel, C order
+    g = idx[:, [1, 0] + ([2] if ndim == 3 else [])]                             # x = second index, y = first, z = third
+    clean = np.where(np.isfinite(off), off, 0.0)
+    ref = np.zeros((N,) * ndim)
+    (bfg.regrid_pixels_2D if ndim == 2 else bfg.regrid_pixels_3D)(ref, g + clean, val)
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-13)
+    if N >= 7:
+        assert np.isclose(got.sum(), val.sum(), rtol=1e-12)
+
+
 def _snapshot_inputs(g, tag, cosmo):
     is2D = bool(g[f"{tag}_is2D"])
     P, H = g[f"{tag}_P"], g[f"{tag}_H"]
