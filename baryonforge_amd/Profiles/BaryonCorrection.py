@@ -124,7 +124,7 @@ class BaryonificationClass(object):
 
     def device_table(self, ctx):
         """bfg_table holding the LINEAR displacement table (interp_d of :322)"""
-        return ctx.table(self._axes(), self.raw_input_d, log_values=False, cache_key=(id(self), "d", id(self.raw_input_d)))
+        return ctx.table(self._axes(), self.raw_input_d, log_values=False, cache_key=(self, "d", self.raw_input_d))
 
     def get_masses(self, model, r, M, a):
         raise NotImplementedError("Implement a get_masses() method first")

@@ -134,7 +134,7 @@ class PaintProfilesShell(DefaultRunner):
             with np.errstate(all="ignore"):
                 return np.log(np.asarray(self.model.raw_input_2D, dtype=np.float64))
         table = ctx.table(_table_axes(self.model, keys), log_table, log_values=True,
-                          cache_key=(id(self.model), "2D", id(self.model.raw_input_2D)))
+                          cache_key=(self.model, "2D", self.model.raw_input_2D))
         if d_map is None:
             d_map = ctx.zeros(12 * NSIDE * NSIDE)                         # :424
         args = ctx.shell_args(NSIDE, d_cat, d_cat.shape[0], stride, len(keys), self.epsilon_max,
@@ -265,7 +265,7 @@ class BaryonifyShell(DefaultRunner):
         bg, spline, d_cat, stride = self._device_inputs(ctx, keys)
         model = self.model
         table = ctx.table(_table_axes(model, keys), lambda: np.asarray(model.raw_input_d, dtype=np.float64),
-                          log_values=False, cache_key=(id(model), "d", id(model.raw_input_d)))
+                          log_values=False, cache_key=(model, "d", model.raw_input_d))
         model_bg = Background(model.cosmo) if getattr(model, "cosmo", None) is not None else bg
         model_md = ctx.massdef_struct(model_bg, getattr(model, "mass_def", None))
         args = ctx.shell_args(NSIDE, d_cat, d_cat.shape[0], stride, len(keys), self.epsilon_max,

@@ -181,7 +181,7 @@ class PaintProfilesGrid(DefaultRunnerGrid):
             with np.errstate(all="ignore"):
                 return np.log(np.asarray(raw, dtype=np.float64))
         table = ctx.table(_table_axes(self.model, keys), log_table, log_values=True,
-                          cache_key=(id(self.model), "grid%dD" % ndim, id(raw)))
+                          cache_key=(self.model, "grid%dD" % ndim, raw))
         d_map = self._paint_device(ctx, table, keys)
         if self.include_pixel_size:
             d_map *= float(np.power(gm.res, ndim))                         # :826
@@ -217,7 +217,7 @@ class BaryonifyGrid(DefaultRunnerGrid):
         gm, model = self.GriddedMap, self.model
         ndim = 2 if gm.is2D else 3
         table = ctx.table(_table_axes(model, keys), lambda: np.asarray(model.raw_input_d, dtype=np.float64),
-                          log_values=False, cache_key=(id(model), "d", id(model.raw_input_d)))
+                          log_values=False, cache_key=(model, "d", model.raw_input_d))
         d_halo, d_bins = self._device_inputs(ctx, keys)
         bg = Background(self.cosmo)
         model_bg = Background(model.cosmo) if getattr(model, "cosmo", None) is not None else bg

@@ -85,7 +85,7 @@ class BaryonifySnapshot(DefaultRunnerSnapshot):
         bg = Background(self.cosmo)
         model = self.model
         table = ctx.table(_table_axes(model, list(keys)), lambda: np.asarray(model.raw_input_d, dtype=np.float64),
-                          log_values=False, cache_key=(id(model), "d", id(model.raw_input_d)))
+                          log_values=False, cache_key=(model, "d", model.raw_input_d))
         model_bg = Background(model.cosmo) if getattr(model, "cosmo", None) is not None else bg
         d_part, d_halo = ctx.to_device(part), ctx.to_device(halos)
         d_out = ctx.zeros(part.shape[0], ndim)

@@ -1399,15 +1399,19 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     const bool tile = (variant == BFG_VARIANT_TILE_LDS);
     // row window of the tile path: ~3.5 e-folds of radius below the disc edge (r_max/33 .. r_max)
     int win_nodes = 0;
+    bool win_table = false;      // finely sampled radial axis: no row windows, the pixel stage reads the table (bfg_tile.hpp)
     if (tile) {
         win_nodes = (int)std::ceil(3.5 * t->dev.inv_dr) + 2;
         win_nodes = std::max(8, std::min(win_nodes, 256));
         if (win_nodes <= kWinLds + kWinLds / 4) win_nodes = std::min(win_nodes, kWinLds);   // fits the LDS staging
         win_nodes = (int)std::min<int64_t>(win_nodes, t->dev.nr);
+        win_table = win_nodes > kWinLds && t->dev.nouter == 2;
+        if (const char *e = std::getenv("BFG_WINDOWS")) if (!std::strcmp(e, "hbm")) win_table = false;   // A/B: windows in HBM
+        if (win_table) win_nodes = (int)t->dev.nr;                   // the "window" is the whole axis
         rc = ensure_tiles(c, mode, mode == MODE_PAINT ? TileCfg<MODE_PAINT>::TR : TileCfg<MODE_BARYONIFY>::TR, a->nside,
                           a->n_halo);
         if (rc) return rc;
-        const int64_t want = a->n_halo * (int64_t)win_nodes;
+        const int64_t want = win_table ? 0 : a->n_halo * (int64_t)win_nodes;
         if (want > c->hwin_cap) {
             HIP_TRY(hipStreamSynchronize(c->stream));
             if (c->d_hwin) (void)hipFree(c->d_hwin);
@@ -1470,7 +1474,9 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         std::memset(&rp, 0, sizeof(rp));
         rp.n_halo = a->n_halo; rp.cap = c->cap_halo; rp.ht = c->d_ht; rp.cidx = c->d_cidx; rp.cw = c->d_cw;
         rp.tab = t->dev; rp.win_nodes = win_nodes; rp.hwin = c->d_hwin;
-        if (win_nodes % 4 == 0 && win_nodes >= 8) {
+        if (win_table) {
+            // no row windows
+        } else if (win_nodes % 4 == 0 && win_nodes >= 8) {
             const int hpb = std::min(256 / (win_nodes / 4), 64);
             hipLaunchKernelGGL(halo_row4_kernel, dim3((unsigned)((a->n_halo + hpb - 1) / hpb)), dim3(256), 0, c->stream, rp);
         } else {
@@ -1487,7 +1493,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         tp.tab = t->dev; tp.geo = ts.geo; tp.tile_start = ts.d_tile_start; tp.pairs = c->d_pairs;
         tp.work = ts.d_work; tp.n_work = ts.d_nwork;
         tp.hd = c->d_hd;
-        tp.hwin = c->d_hwin; tp.win_nodes = win_nodes; tp.pair_cap = c->pair_cap;
+        tp.hwin = c->d_hwin; tp.win_nodes = win_nodes; tp.win_table = win_table ? 1 : 0; tp.pair_cap = c->pair_cap;
         tp.out = d_out; tp.stats = c->d_stats;
         tp.logtab = reinterpret_cast<const double2 *>(c->d_mathtab);
         tp.exptab = c->d_mathtab + 2 * kLogTab;

@@ -173,6 +173,8 @@ struct TileParams {
     const int32_t *pairs;            // halo ids grouped by tile
     const double *hwin;              // [n_halo][win_nodes] blended row values B_i, i = win_lo + e
     int win_nodes;
+    int win_table;                   // 1: no per-halo row windows at all -- the pixel stage blends the halo's 4 corner rows
+                                     // straight from the (L2-resident) table; for finely sampled radial axes (see below)
     double *out;
     bfg_stats *stats;
     const double2 *logtab;           // [128] {1/c, ln c}
@@ -318,6 +320,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int ntiles, int32_t *co
         __syncthreads();
     }
     const int total = carry;
+    __syncthreads();                                   // every thread has read the total before carry is reused
     if (threadIdx.x == 0) { start[ntiles] = total; carry = 0; }
     __syncthreads();
     const int S = max(256, (total + kWorkExtra - 1) / kWorkExtra);
@@ -755,6 +758,23 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
         if constexpr (win_in_lds) {
             const lds_double *wp = lds_ptr<double>(lds_base + sg.wbyte + 8 * ic);
             B0 = wp[0]; B1 = wp[1];
+        } else if (P.win_table) {
+            // Finely sampled radial axes (the reference's examples use 2000 nodes: 174 per e-fold of radius) need ~600 nodes
+            // per halo, more than the halo has pixels, so pre-blended windows cost more than they save (4.8 KB per halo
+            // written and read back through HBM).  Blend the 4 corner rows of the halo's (z, M) cell per pixel instead:
+            // the table stays in L2.  Same corner order and the same + ln(pixarea D^2) as halo_row_kernel: same bits.
+            const double *cw4 = pwin + pidx * kWinLds;                     // [0..3] weights, [4..7] row offsets (as int64)
+            const int64_t *co4 = reinterpret_cast<const int64_t *>(cw4 + 4);
+            B0 = 0.0; B1 = 0.0;
+            if (in) {                                  // a cell outside the axis is the caller's business; never read there
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double *row = T.values + co4[c] + (ic - 1);
+                    const double w = cw4[c];
+                    B0 = fma(row[0], w, B0); B1 = fma(row[1], w, B1);
+                }
+                if constexpr (MODE == MODE_PAINT) { const double add = pinfo[pidx].lnpf; B0 += add; B1 += add; }
+            }
         } else {
             const double *wp = P.hwin + pinfo[pidx].hoff + (ic - wl1);
             B0 = wp[0]; B1 = wp[1];
@@ -897,6 +917,21 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
                 for (int idx = tid; idx < n_take * W; idx += NT) {
                     const int p = idx / W, e = idx - p * W;
                     pwin[p * kWinLds + e] = P.hwin[pinfo[p].hoff + e];
+                }
+            }
+        }
+        if constexpr (!win_in_lds) {
+            if (P.win_table && wave == kTileWaves - 1 && lane < n_take) {   // corner rows of the pair's halo (2 outer axes)
+                const int64_t j = pinfo[lane].halo;
+                const double y0 = P.cw[j], y1 = P.cw[P.cap + j];
+                const int64_t o0 = (int64_t)P.cidx[j] * T.ostride[0], o1 = (int64_t)P.cidx[P.cap + j] * T.ostride[1];
+                double *cw4 = pwin + lane * kWinLds;
+                int64_t *co4 = reinterpret_cast<int64_t *>(cw4 + 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int b0 = (c >> 1) & 1, b1 = c & 1;                // corner order of halo_row_kernel
+                    cw4[c] = (b0 ? y0 : 1.0 - y0) * (b1 ? y1 : 1.0 - y1);
+                    co4[c] = o0 + b0 * T.ostride[0] + o1 + b1 * T.ostride[1];
                 }
             }
         }

@@ -26,6 +26,14 @@ def _torch():
     return torch
 
 
+def _fingerprint(arr):
+    """cheap content stamp of an array: shape, a strided sample of <= 4096 elements and the two ends"""
+    a = np.asarray(arr)
+    flat = a.reshape(-1)
+    step = max(1, flat.size // 4096)
+    return (a.shape, a.dtype.str, flat[::step].tobytes(), flat[-1:].tobytes())
+
+
 def require_gpu():
     torch = _torch()
     if not torch.cuda.is_available():
@@ -130,16 +138,27 @@ class Context(object):
         return torch.zeros(*shape, dtype=torch.float64, device=self.device)
 
     def table(self, axes, values, log_values, cache_key=None):
-        """values: ndarray, or a zero-argument callable producing it (only called on a cache miss)"""
-        if cache_key is not None and cache_key in self._table_cache:
-            return self._table_cache[cache_key]
+        """values: ndarray, or a zero-argument callable producing it (only called on a cache miss).
+
+        cache_key: a tuple of the objects the table was made from (model, tag string, raw table array).  The entry
+        keeps those objects alive and is only reused for the very same objects (`is`) with unchanged contents (a
+        fingerprint of the array and of the axes): keys made of bare id() values would hand a stale table to a new model
+        that happens to be allocated where a collected one used to live."""
+        axes = [np.ascontiguousarray(a, dtype=np.float64) for a in axes]
+        if cache_key is not None:
+            ident = tuple(k if isinstance(k, str) else id(k) for k in cache_key)
+            stamp = tuple(_fingerprint(k) for k in cache_key if isinstance(k, np.ndarray)) + \
+                tuple(_fingerprint(a) for a in axes) + (bool(log_values),)
+            hit = self._table_cache.get(ident)
+            if hit is not None and hit[2] == stamp and all(a is b for a, b in zip(hit[1], cache_key)):
+                return hit[0]
         if callable(values):
             values = values()
         t = Table(self, axes, values, log_values)
         if cache_key is not None:
             if len(self._table_cache) > 8:
                 self._table_cache.clear()
-            self._table_cache[cache_key] = t
+            self._table_cache[ident] = (t, tuple(cache_key), stamp)
         return t
 
     def da_spline(self, background, z_max):

@@ -79,7 +79,7 @@ class _TabulatedBase(object):
     def device_table(self, ctx, which="2D"):
         """bfg_table holding ln(raw_input_<which>) -- what the reference's interp2D/interp3D hold (Tabulate.py:270-271)"""
         raw = self.raw_input_2D if which == "2D" else self.raw_input_3D
-        key = (id(self), which, id(raw))
+        key = (self, which, raw)
         def log_table():
             with np.errstate(all="ignore"):
                 return np.log(raw)
@@ -293,7 +293,7 @@ class TabulatedCorrelation3D(object):
                 lnxi = np.log(self.raw_input_3D)
             return np.ascontiguousarray(np.repeat(lnxi[:, None, :], 2, axis=1))
         axes = [self.raw_input_z_range, np.array([0.0, 1.0]), self.raw_input_r_range]
-        return ctx.table(axes, log_table, log_values=True, cache_key=(id(self), "xi", id(self.raw_input_3D)))
+        return ctx.table(axes, log_table, log_values=True, cache_key=(self, "xi", self.raw_input_3D))
 
     def __call__(self, r, a):
         """Tabulate.py:771-784"""

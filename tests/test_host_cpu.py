@@ -371,3 +371,38 @@ def test_tabulated_correlation3d_host_side():
         X.setup_interpolator()
     with pytest.raises(ValueError):
         bfg.utils.TabulatedCorrelation3D.from_arrays(np.zeros(3), np.zeros(5), np.ones((3, 4)))
+
+
+def test_table_cache_never_hands_out_a_stale_table(monkeypatch):
+    """engine.Context.table: entries are reused only for the very same model / array objects with unchanged contents.
+    (A cache keyed by bare id() values returned the table of a collected model to a new one allocated at the same
+    address: intermittently wrong maps.)"""
+    from baryonforge_amd import engine
+
+    class FakeTable(object):
+        made = 0
+
+        def __init__(self, ctx, axes, values, log_values):
+            FakeTable.made += 1
+            self.values = np.array(values, copy=True)
+
+    monkeypatch.setattr(engine, "Table", FakeTable)
+    ctx = engine.Context.__new__(engine.Context)          # no GPU needed for the cache logic
+    ctx._table_cache = {}
+    axes = [np.arange(3.0), np.arange(4.0), np.arange(5.0)]
+
+    class Model(object):
+        pass
+    m, raw = Model(), np.ones((3, 4, 5))
+    t1 = ctx.table(axes, raw, True, cache_key=(m, "2D", raw))
+    assert ctx.table(axes, raw, True, cache_key=(m, "2D", raw)) is t1 and FakeTable.made == 1
+    raw[1, 2, 3] = 7.0                                    # same objects, contents changed in place
+    t2 = ctx.table(axes, raw, True, cache_key=(m, "2D", raw))
+    assert t2 is not t1 and t2.values[1, 2, 3] == 7.0
+    raw2 = raw.copy()                                     # equal contents, another array object
+    assert ctx.table(axes, raw2, True, cache_key=(m, "2D", raw2)) is not t2
+    # entries keep their key objects alive, so an id can never be recycled while its entry exists
+    key_ids = {k[0] for k in ctx._table_cache}
+    assert id(m) in key_ids and all(v[1][0] is m for v in ctx._table_cache.values())
+    assert ctx.table(axes, raw, True, cache_key=(m, "3D", raw)) is not t2      # the tag is part of the key
+    assert ctx.table(axes, lambda: raw, False, cache_key=None) is not None     # uncached
