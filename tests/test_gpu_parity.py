@@ -641,7 +641,7 @@ def test_paint_config0_nside256_1e3(cosmo, variant):
 
 @pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("shape", [(10, 30, 100), (2, 30, 2000)])
-def test_paint_nside1024_vs_oracle(cosmo, variant, shape):
+def test_paint_nside1024_vs_oracle(cosmo, variant, shape, monkeypatch):
     """BASELINE config[1] geometry (NSIDE = 1024, eps = 10) on a 2e4-halo sample the oracle finishes in seconds;
     default table shape and the notebooks' 2 x 30 x 2000 stress shape; one table with non-finite nodes."""
     ra, dec, M, z = syn.catalog(20000, seed=42)
@@ -653,6 +653,14 @@ def test_paint_nside1024_vs_oracle(cosmo, variant, shape):
     got = R.process()
     assert R.last_stats["pixel_updates"] == ptot
     assert_maps_close(got, ref, RTOL, what=f"paint 1024 {shape}")
+    if variant == "tile_lds" and shape[2] == 2000:
+        # the fine axis takes the table-direct read-out; the row-windows-in-HBM form (what tables with extra dimensions
+        # and a fine axis still use) must agree with it bit for bit
+        monkeypatch.setenv("BFG_WINDOWS", "hbm")
+        got2 = R.process()
+        assert R.last_stats["pixel_updates"] == ptot
+        assert np.array_equal(got2 != 0, got != 0)
+        assert_maps_close(got2, got, 1e-13, what="row windows in HBM vs table-direct")
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
