@@ -302,45 +302,51 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int ntiles, int32_t *co
 {
     __shared__ int32_t wsum[16];
     __shared__ int32_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < ntiles; base += 1024) {
-        const int i = base + threadIdx.x;
-        int v = (i < ntiles) ? count[i] : 0;
-        int incl = v;
+    // block-wide exclusive scan of 4 values per thread (4096 tiles per trip); returns the offset of the thread's first value
+    auto scan4 = [&](const int v[4], int &running) -> int {
+        const int s = v[0] + v[1] + v[2] + v[3];
+        int incl = s;
         for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(incl, d, 64); if ((threadIdx.x & 63) >= d) incl += o; }
         if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
         __syncthreads();
         int woff = 0;
         for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
         const int c = carry;
-        if (i < ntiles) { start[i] = c + woff + incl - v; count[i] = 0; }   // count becomes the fill cursor
         __syncthreads();
         if (threadIdx.x == 1023) carry = c + woff + incl;
         __syncthreads();
+        running = c + woff + incl;
+        return c + woff + incl - s;
+    };
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < ntiles; base += 4096) {
+        const int i0 = base + 4 * threadIdx.x;
+        int v[4], run;
+        for (int k = 0; k < 4; ++k) v[k] = (i0 + k < ntiles) ? count[i0 + k] : 0;
+        int o = scan4(v, run);
+        for (int k = 0; k < 4; ++k) if (i0 + k < ntiles) { start[i0 + k] = o; o += v[k]; count[i0 + k] = 0; }   // count becomes the fill cursor
     }
     const int total = carry;
     __syncthreads();                                   // every thread has read the total before carry is reused
     if (threadIdx.x == 0) { start[ntiles] = total; carry = 0; }
     __syncthreads();
     const int S = max(256, (total + kWorkExtra - 1) / kWorkExtra);
-    for (int base = 0; base < ntiles; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int n = (i < ntiles) ? start[i + 1] - start[i] : 0;
-        const int v = (n + S - 1) / S;
-        int incl = v;
-        for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(incl, d, 64); if ((threadIdx.x & 63) >= d) incl += o; }
-        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
-        __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
-        const int c = carry;
-        int o = c + woff + incl - v;
-        const int slice = (v > 0) ? (n + v - 1) / v : 0;                    // equal slices within a tile
-        for (int m = 0; m < v; ++m, ++o) work[o] = make_int4(i, m * slice, min(n, (m + 1) * slice), v > 1 ? 1 : 0);
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = c + woff + incl;
-        __syncthreads();
+    for (int base = 0; base < ntiles; base += 4096) {
+        const int i0 = base + 4 * threadIdx.x;
+        int n[4], v[4], run;
+        for (int k = 0; k < 4; ++k) {
+            const int a0 = (i0 + k < ntiles) ? start[i0 + k] : total;
+            const int a1 = (i0 + k + 1 < ntiles) ? start[i0 + k + 1] : total;
+            n[k] = a1 - a0;
+            v[k] = (n[k] + S - 1) / S;
+        }
+        int o = scan4(v, run);
+        for (int k = 0; k < 4; ++k) {
+            const int slice = (v[k] > 0) ? (n[k] + v[k] - 1) / v[k] : 0;                    // equal slices within a tile
+            for (int m = 0; m < v[k]; ++m, ++o)
+                work[o] = make_int4(i0 + k, m * slice, min(n[k], (m + 1) * slice), v[k] > 1 ? 1 : 0);
+        }
     }
     if (threadIdx.x == 0) *n_work = carry;
 }
