@@ -1405,7 +1405,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         win_nodes = std::max(8, std::min(win_nodes, 256));
         if (win_nodes <= kWinLds + kWinLds / 4) win_nodes = std::min(win_nodes, kWinLds);   // fits the LDS staging
         win_nodes = (int)std::min<int64_t>(win_nodes, t->dev.nr);
-        win_table = win_nodes > kWinLds && t->dev.nouter == 2;
+        win_table = win_nodes > kWinLds && (2 << t->dev.nouter) <= kWinLds;         // weights + offsets fit the pair's LDS slot
         if (const char *e = std::getenv("BFG_WINDOWS")) if (!std::strcmp(e, "hbm")) win_table = false;   // A/B: windows in HBM
         if (win_table) win_nodes = (int)t->dev.nr;                   // the "window" is the whole axis
         rc = ensure_tiles(c, mode, mode == MODE_PAINT ? TileCfg<MODE_PAINT>::TR : TileCfg<MODE_BARYONIFY>::TR, a->nside,

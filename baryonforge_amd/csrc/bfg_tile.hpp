@@ -173,7 +173,7 @@ struct TileParams {
     const int32_t *pairs;            // halo ids grouped by tile
     const double *hwin;              // [n_halo][win_nodes] blended row values B_i, i = win_lo + e
     int win_nodes;
-    int win_table;                   // 1: no per-halo row windows at all -- the pixel stage blends the halo's 4 corner rows
+    int win_table;                   // 1: no per-halo row windows at all -- the pixel stage blends the halo's corner rows
                                      // straight from the (L2-resident) table; for finely sampled radial axes (see below)
     double *out;
     bfg_stats *stats;
@@ -767,16 +767,17 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
         } else if (P.win_table) {
             // Finely sampled radial axes (the reference's examples use 2000 nodes: 174 per e-fold of radius) need ~600 nodes
             // per halo, more than the halo has pixels, so pre-blended windows cost more than they save (4.8 KB per halo
-            // written and read back through HBM).  Blend the 4 corner rows of the halo's (z, M) cell per pixel instead:
+            // written and read back through HBM).  Blend the corner rows of the halo's (z, M[, params]) cell per pixel instead:
             // the table stays in L2.  Same corner order and the same + ln(pixarea D^2) as halo_row_kernel: same bits.
-            const double *cw4 = pwin + pidx * kWinLds;                     // [0..3] weights, [4..7] row offsets (as int64)
-            const int64_t *co4 = reinterpret_cast<const int64_t *>(cw4 + 4);
+            const int ncorner = 1 << T.nouter;                             // <= kWinLds / 2 (host-checked)
+            const double *cwn = pwin + pidx * kWinLds;                     // [0 .. nc) weights, [nc .. 2 nc) row offsets (int64)
+            const int64_t *con = reinterpret_cast<const int64_t *>(cwn + ncorner);
             B0 = 0.0; B1 = 0.0;
             if (in) {                                  // a cell outside the axis is the caller's business; never read there
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const double *row = T.values + co4[c] + (ic - 1);
-                    const double w = cw4[c];
+#pragma unroll 4
+                for (int c = 0; c < ncorner; ++c) {
+                    const double *row = T.values + con[c] + (ic - 1);
+                    const double w = cwn[c];
                     B0 = fma(row[0], w, B0); B1 = fma(row[1], w, B1);
                 }
                 if constexpr (MODE == MODE_PAINT) { const double add = pinfo[pidx].lnpf; B0 += add; B1 += add; }
@@ -927,17 +928,21 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
             }
         }
         if constexpr (!win_in_lds) {
-            if (P.win_table && wave == kTileWaves - 1 && lane < n_take) {   // corner rows of the pair's halo (2 outer axes)
+            if (P.win_table && wave == kTileWaves - 1 && lane < n_take) {   // corner rows of the pair's halo
                 const int64_t j = pinfo[lane].halo;
-                const double y0 = P.cw[j], y1 = P.cw[P.cap + j];
-                const int64_t o0 = (int64_t)P.cidx[j] * T.ostride[0], o1 = (int64_t)P.cidx[P.cap + j] * T.ostride[1];
-                double *cw4 = pwin + lane * kWinLds;
-                int64_t *co4 = reinterpret_cast<int64_t *>(cw4 + 4);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int b0 = (c >> 1) & 1, b1 = c & 1;                // corner order of halo_row_kernel
-                    cw4[c] = (b0 ? y0 : 1.0 - y0) * (b1 ? y1 : 1.0 - y1);
-                    co4[c] = o0 + b0 * T.ostride[0] + o1 + b1 * T.ostride[1];
+                const int ncorner = 1 << T.nouter;
+                double *cwn = pwin + lane * kWinLds;
+                int64_t *con = reinterpret_cast<int64_t *>(cwn + ncorner);
+                for (int c = 0; c < ncorner; ++c) {                        // corner order and products of halo_row_kernel
+                    double w = 1.0;
+                    int64_t off = 0;
+                    for (int k = 0; k < T.nouter; ++k) {
+                        const int bit = (c >> (T.nouter - 1 - k)) & 1;
+                        const double y = P.cw[k * P.cap + j];
+                        w = w * (bit ? y : 1.0 - y);
+                        off += (int64_t)(P.cidx[k * P.cap + j] + bit) * T.ostride[k];
+                    }
+                    cwn[c] = w; con[c] = off;
                 }
             }
         }

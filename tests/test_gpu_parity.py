@@ -603,6 +603,29 @@ def test_paint_shell_golden_param(golden, cosmo, variant):
     assert np.array_equal(got != 0, g["p_map"] != 0)
 
 
+@pytest.mark.parametrize("windows", ["table", "hbm"])
+def test_paint_fine_radial_axis_with_extra_dimension(cosmo, windows, monkeypatch):
+    """a finely sampled radial axis (1500 nodes) on a table with an extra p_keys dimension: the tile kernel reads the 8
+    corner rows of every halo straight from the table (or, BFG_WINDOWS=hbm, pre-blended row windows from HBM) -- against
+    the oracle's N-linear read-out"""
+    if windows == "hbm":
+        monkeypatch.setenv("BFG_WINDOWS", "hbm")
+    nside, n, eps = 512, 6000, 10.0
+    ra, dec, M, z = syn.catalog(n, seed=314)
+    cdelta = np.random.default_rng(5).uniform(0.65, 1.45, n)
+    zax, Max, rax, T = syn.pressure_table(3, 12, 1500)
+    pax = np.array([0.6, 0.9, 1.2, 1.5])
+    T4 = T[..., None] * (1.0 + 0.3 * (pax - 1.0)[None, None, None, :] * np.tanh(np.exp(rax))[None, None, :, None])
+    ref, ptot = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax, pax), T4, nside, eps, extra=cdelta[:, None])
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo, cdelta=cdelta)
+    R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), eps,
+                               _paint_model(zax, Max, rax, T4, pax), verbose=False)
+    got = R.process()
+    assert R.last_stats["pixel_updates"] == ptot
+    assert np.array_equal(got != 0, ref != 0)
+    assert_maps_close(got, ref, RTOL, what=f"fine axis + p_keys ({windows})")
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_baryonify_shell_golden(golden, cosmo, tag, variant):
