@@ -8,8 +8,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "bfg_mi355.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "bfg_device.hpp"),
-        os.path.join(os.path.dirname(HERE), "include", "bfg_mi355.h")]
+DEPS = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))
+              if f.endswith((".hip", ".hpp"))) + [os.path.join(os.path.dirname(HERE), "include", "bfg_mi355.h")]
 SO = os.path.join(HERE, "libbfg_mi355.so")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",

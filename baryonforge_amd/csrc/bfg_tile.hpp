@@ -168,7 +168,7 @@ struct TileParams {
     DevTable tab;
     TileGeom geo;
     const int32_t *tile_start;       // [ntiles+1]
-    const int4 *work;                // [n_work] (tile, first pair, last pair + 1, shared) -- see tile_scan_kernel
+    const int4 *work;                // [n_work] (tile, first pair, last pair + 1 [positions in pairs], shared) -- see tile_scan_kernel
     const int32_t *n_work;
     const int32_t *pairs;            // halo ids grouped by tile
     const double *hwin;              // [n_halo][win_nodes] blended row values B_i, i = win_lo + e
@@ -292,7 +292,8 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const FillParams P)
 }
 
 // exclusive scan of tile_count into tile_start[ntiles+1], then the work list of the tile kernel; single workgroup.
-// A work item is (tile, first pair, last pair + 1, shared): tiles with more than S pairs are cut into equal slices of at most S pairs that
+// A work item is (tile, first pair, last pair + 1 -- positions in pairs[], so the tile kernel needs no tile_start lookup
+// on its start-up chain --, shared): tiles with more than S pairs are cut into equal slices of at most S pairs that
 // different workgroups accumulate separately (shared = 1: the write-back uses atomics).  S = max(256, total / 4096), so a
 // full-sky catalog gives one item per tile while a catalog that crowds into part of the sky (an octant light cone, a
 // compact multi-GPU shard: 1/8 of the tiles with 8x the pairs) still yields a few thousand items of similar size instead of
@@ -344,8 +345,9 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int ntiles, int32_t *co
         int o = scan4(v, run);
         for (int k = 0; k < 4; ++k) {
             const int slice = (v[k] > 0) ? (n[k] + v[k] - 1) / v[k] : 0;                    // equal slices within a tile
+            const int a0 = (i0 + k < ntiles) ? start[i0 + k] : total;                       // absolute positions in pairs[]
             for (int m = 0; m < v[k]; ++m, ++o)
-                work[o] = make_int4(i0 + k, m * slice, min(n[k], (m + 1) * slice), v[k] > 1 ? 1 : 0);
+                work[o] = make_int4(i0 + k, a0 + m * slice, a0 + min(n[k], (m + 1) * slice), v[k] > 1 ? 1 : 0);
         }
     }
     if (threadIdx.x == 0) *n_work = carry;
@@ -642,6 +644,9 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
     const int ring_lo = 1 + band * TR;
     const int ring_hi = min((int)(4 * hp.nside - 1), ring_lo + TR - 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#if BFG_STAGE_TIMING
+    long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = clock64();
+#endif
 
     for (int i = tid; i < TR * TW * NACC; i += NT) acc[i] = 0.0;
     if (tid == 0) ctl[5] = 0;
@@ -677,7 +682,7 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
     const int W = P.win_nodes;
     constexpr bool win_in_lds = WIN_LDS;     // row windows of <= kWinLds nodes live in LDS, longer ones stay in HBM/L2
     unsigned long long my_pixels = 0;
-    const int32_t *plist = P.pairs + P.tile_start[tile] + wk.y;
+    const int32_t *plist = P.pairs + wk.y;
 
     // Wave 0 runs the pair pipeline two chunks deep, so that no stage waits for a dependent pair -> halo record load:
     //   pjA / pjB  the pair list entries [base, base + 128) of the current chunk's first pair (issued one chunk ago);
@@ -875,7 +880,7 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
     };
 
 #if BFG_STAGE_TIMING
-    long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = clock64();
+    BFG_TICK(6);                                       // prologue: LDS clear, tables, ring rows, first pair records
 #endif
     for (int base = 0; base < n_pairs;) {
         // ---- stage a: one lane per pair of the chunk (wave 0) ---------------------------------------
@@ -1083,9 +1088,8 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
         const int nseg = min(nslots + ctl[2], kSegMax);
         const int ptotal = (P.debug & 2) ? 0 : ctl[3];
         my_pixels += (tid == 0) ? (unsigned long long)ctl[3] : 0ull;
-        BFG_TICK(6);
         if (wave == 0) { load_records(); load_list_windows(base + n_take); }   // in flight during the pixel stage
-        BFG_TICK(7);
+        BFG_TICK(2);
 
         // ---- stage c: one thread per pixel of the flattened list (rounds of kPixMax pixels; the first round's
         //      pixel -> segment table was filled by stage b) -------------------------------------------------
@@ -1116,33 +1120,53 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
         base += n_take;
         if constexpr (kQCap > 0) { if (ctl[5] >= qcap / 2) drain(); }     // uniform: ctl[5] is stable between the barriers
     }
-    if constexpr (kQCap > 0) { if (ctl[5] > 0) drain(); }
     if (my_pixels) atomicAdd((unsigned long long *)&P.stats->pixel_updates, my_pixels);
     if (n_oob32) {
         atomicAdd((unsigned long long *)&P.stats->pixels_out_of_table, (unsigned long long)n_oob32);
         atomicOr(&P.stats->warn_mask, BFG_WARN_R_RANGE);
     }
-#if BFG_STAGE_TIMING
-    if (tid == 64) for (int i = 0; i < 8; ++i) atomicAdd(&g_stage_cycles[i], (unsigned long long)st_acc[i]);
-#endif
     // write the tile back: every pixel belongs to exactly one tile -> plain read-modify-write (unless the tile's pair list
-    // was cut into several work items)
-    for (int i = tid; i < TR * TW; i += NT) {
-        const int row = i / TW, col = i % TW;
-        const int ring = ring_lo + row;
-        if (ring > ring_hi) break;
-        int64_t start, nr64; bool shifted;
-        ring_info_small(hp, ring, start, nr64, shifted);
-        const int64_t pix = start + rows[row].k0 + col;
+    // was cut into several work items).  Each thread owns TR * TW / NT pixels.  Their map values are fetched in one burst
+    // BEFORE the final drain of the deferred-pixel queue (two dependent rounds of global loads of its own), so the two
+    // latencies overlap; the sums are stored after it.  (The epilogue was 8 % of the kernel at 1e6 halos, 39 % at 1e5.)
+    constexpr int kPerThread = (TR * TW + NT - 1) / NT;
+    int64_t wpix[kPerThread];
+    double wold[kPerThread][NACC];
+#pragma unroll
+    for (int u = 0; u < kPerThread; ++u) {
+        const int i = tid + u * NT;
+        wpix[u] = -1;
+        if (i < TR * TW) {
+            const int row = i / TW, col = i % TW;
+            const int ring = ring_lo + row;
+            if (ring <= ring_hi && rows[row].k0 + col < rows[row].k1) {
+                int64_t start, nr64; bool shifted;
+                ring_info_small(hp, ring, start, nr64, shifted);
+                wpix[u] = start + rows[row].k0 + col;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NACC; ++c) wold[u][c] = (wpix[u] >= 0 && !wk.w) ? P.out[NACC * wpix[u] + c] : 0.0;
+    }
+    if constexpr (kQCap > 0) { if (ctl[5] > 0) drain(); }
+#pragma unroll
+    for (int u = 0; u < kPerThread; ++u) {
+        if (wpix[u] < 0) continue;
+        const int i = tid + u * NT;
 #pragma unroll
         for (int c = 0; c < NACC; ++c) {
             const double v = acc[NACC * i + c];
             if (v != 0.0) {
-                if (wk.w) unsafeAtomicAdd(P.out + NACC * pix + c, v);      // the tile is shared with other workgroups
-                else P.out[NACC * pix + c] += v;
+                if (wk.w) unsafeAtomicAdd(P.out + NACC * wpix[u] + c, v);  // the tile is shared with other workgroups
+                else P.out[NACC * wpix[u] + c] = wold[u][c] + v;
             }
         }
     }
+#if BFG_STAGE_TIMING
+    __syncthreads();
+    BFG_TICK(7);                                       // epilogue: final queue drain, counters, write-back
+    if (tid == 64) for (int i = 0; i < 8; ++i) atomicAdd(&g_stage_cycles[i], (unsigned long long)st_acc[i]);
+#endif
 }
 
 }  // namespace bfg

@@ -45,9 +45,9 @@ for _ in range(reps):
     run()
 fn(ctx.handle, out, 1)
 v = np.array(list(out), dtype=np.float64) / reps
-names = ["a: pair records (wave 0) + barrier", "b: ring windows -> segments + barrier", "s: block scan of pixel counts",
-         "c1: pixel->segment table + barrier", "c2: pixel loop (own pixels)", "c3: wait at the end-of-chunk barrier", "t6", "t7"]
-print("extra ticks 6, 7:", v[6], v[7])
+names = ["a: pair records (wave 0) + barrier", "b: ring windows -> segments + barrier", "p: next chunk's record loads issued",
+         "c1: pixel->segment table + barrier", "c2: pixel loop (own pixels)", "c3: wait at the end-of-chunk barrier",
+         "prologue: LDS clear, tables, ring rows, first records", "epilogue: final drain, counters, write-back"]
 tot = v.sum()
 print(f"workload {workload} n={n} nside={nside}: {tot:.4g} cycles summed over workgroups per launch")
 for nm, x in zip(names, v):
