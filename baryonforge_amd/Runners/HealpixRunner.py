@@ -147,7 +147,8 @@ class PaintProfilesShell(DefaultRunner):
 
     def process(self):
         """returns new_map : float64[Npix] (RING), the sum over halos of the painted profiles"""
-        new_map = self.process_device().cpu().numpy()
+        d_map = self.process_device()                                      # validates the model first
+        new_map = get_context().to_host(d_map)
         return new_map.reshape(np.shape(self.LightconeShell.map))
 
 
@@ -246,20 +247,25 @@ class PaintProfilesAnisShell(DefaultRunner):
         new_map = d_sum * w
         new_map += (self.background_val * self.global_tracer_fraction) * torch.where(pos, (dV * drho_m) / safe,
                                                                                      torch.zeros_like(safe)) * d_orig
-        return new_map.cpu().numpy().reshape(orig_map.shape)
+        return get_context().to_host(new_map).reshape(orig_map.shape)
 
 
 class BaryonifyShell(DefaultRunner):
     """Baryonify a MASS map on the shell with a tabulated displacement model (HealpixRunner.py:235-373)."""
 
-    def offsets_device(self):
-        """Accumulate the unit-vector offsets of all halos (:313-355); returns float64[Npix, 3] on the device."""
+    def _checked_model_keys(self):
+        """the reference's argument checks (:304-311, BaryonCorrection.py:454-455), before anything touches the GPU"""
         keys = self._keys_checked()
         if not _is_disp_table(self.model):
             if self.model is not None and hasattr(self.model, "displacement"):
                 raise NameError("No Table created. Run setup_interpolator() method first")
             raise TypeError(f"BaryonifyShell needs a BaryonificationClass model with a displacement table; "
                             f"got {type(self.model)}")
+        return keys
+
+    def offsets_device(self):
+        """Accumulate the unit-vector offsets of all halos (:313-355); returns float64[Npix, 3] on the device."""
+        keys = self._checked_model_keys()
         ctx = get_context()
         NSIDE = self.LightconeShell.NSIDE
         bg, spline, d_cat, stride = self._device_inputs(ctx, keys)
@@ -287,28 +293,32 @@ class BaryonifyShell(DefaultRunner):
         map are all-reduced across ranks."""
         orig_map = self.LightconeShell.map
         NSIDE = self.LightconeShell.NSIDE
-        if np.allclose(orig_map, 0):
+        if orig_map.size < (1 << 16) and np.allclose(orig_map, 0):         # small maps: decided on the host, as the reference
             return orig_map
-        d_off = self.offsets_device()
+        self._checked_model_keys()
         ctx = get_context()
         npix = 12 * NSIDE * NSIDE
-        flat = np.asarray(orig_map, dtype=np.float64).ravel()
+        flat = np.ascontiguousarray(orig_map, dtype=np.float64).ravel()
+        d_orig = ctx.to_device(flat)
+        absmax, old_sum = ctx.absmax_sum(d_orig)                          # on the device: one pass instead of three host ones
+        if not (absmax > 1e-8):                                           # np.allclose(orig_map, 0) (:293); False for NaN maps
+            if np.allclose(orig_map, 0):
+                return orig_map
+        d_off = self.offsets_device()
         if distributed is not None:
             distributed.all_reduce(d_off, op=distributed.ReduceOp.SUM)
             rank, world = distributed.get_rank(), distributed.get_world_size()
             lo, hi = npix * rank // world, npix * (rank + 1) // world
-            mine = np.zeros_like(flat)
-            mine[lo:hi] = flat[lo:hi]                                     # this rank regrids its pixel range
-            d_in = ctx.to_device(mine)
+            d_in = ctx.zeros(npix)
+            d_in[lo:hi] = d_orig[lo:hi]                                   # this rank regrids its pixel range
         else:
-            d_in = ctx.to_device(flat)
+            d_in = d_orig
         d_out = ctx.zeros(npix)
         ctx.regrid_shell(NSIDE, d_off, d_in, d_out, None)                 # :357-365
         if distributed is not None:
             distributed.all_reduce(d_out, op=distributed.ReduceOp.SUM)
-        new_map = d_out.cpu().numpy()
-        new_sum = np.sum(new_map)
-        old_sum = np.sum(orig_map)
+        _, new_sum = ctx.absmax_sum(d_out)
+        new_map = ctx.to_host(d_out)
         assert np.isclose(new_sum, old_sum), \
             "ERROR in pixel regridding, sum(new_map) [%0.14e] != sum(oldmap) [%0.14e]" % (new_sum, old_sum)  # :368-370
         return new_map

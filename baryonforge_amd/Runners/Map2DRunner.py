@@ -185,7 +185,7 @@ class PaintProfilesGrid(DefaultRunnerGrid):
         d_map = self._paint_device(ctx, table, keys)
         if self.include_pixel_size:
             d_map *= float(np.power(gm.res, ndim))                         # :826
-        return d_map.cpu().numpy().reshape(np.shape(gm.map))
+        return get_context().to_host(d_map).reshape(np.shape(gm.map))
 
     def _paint_device(self, ctx, table, keys):
         """sum over halos of the table's profile in every cut-out window (:700-823), on the device"""
@@ -237,7 +237,7 @@ class BaryonifyGrid(DefaultRunnerGrid):
         d_in = ctx.to_device(orig.reshape(-1))
         d_out = ctx.zeros(npx)
         ctx.regrid_grid(ndim, gm.Npix, d_off, d_in, d_out)                 # :586-613
-        new_map = d_out.cpu().numpy().reshape(orig.shape)
+        new_map = get_context().to_host(d_out).reshape(orig.shape)
         new_sum, old_sum = np.sum(new_map), np.sum(orig)                   # :616-619
         assert np.isclose(new_sum, old_sum), \
             "ERROR in pixel regridding, sum(new_map) [%0.14e] != sum(oldmap) [%0.14e]" % (new_sum, old_sum)
@@ -299,5 +299,5 @@ class PaintProfilesAnisGrid(PaintProfilesGrid):
             torch.where(pos, (dV * drho_m) / safe, torch.zeros_like(safe)) * d_orig
         if self.include_pixel_size:
             new_map *= float(np.power(res, 2))                             # :1009-1010
-        return new_map.cpu().numpy().reshape(np.shape(gm.map))
+        return get_context().to_host(new_map).reshape(np.shape(gm.map))
 

@@ -99,7 +99,8 @@ class BaryonifySnapshot(DefaultRunnerSnapshot):
 
     def process(self):
         """returns new_cat : the particle catalog (structured array) with displaced, box-wrapped coordinates"""
-        new = self.process_device().cpu().numpy()
+        d_new = self.process_device()
+        new = get_context().to_host(d_new)
         new_cat = self.ParticleSnapshot.cat.copy()                          # :260
         new_cat["x"] = new[:, 0]
         new_cat["y"] = new[:, 1]

@@ -126,4 +126,5 @@ class SplitJoinParallel(object):
             return local.process(distributed=dist)
         d_map = local.process_device()
         dist.all_reduce(d_map, op=dist.ReduceOp.SUM)            # RCCL over xGMI
-        return d_map.cpu().numpy().reshape(np.shape(local.LightconeShell.map))
+        from ..engine import get_context
+        return get_context().to_host(d_map).reshape(np.shape(local.LightconeShell.map))

@@ -82,6 +82,12 @@ class HaloLightConeCatalog(object):
     def records(self, extra_keys=()):
         """float64 [n, 4 + len(extra_keys)] record matrix (M, z, ra, dec, extras...) for the device."""
         cols = ["M", "z", "ra", "dec"] + list(extra_keys)
+        names = self.cat.dtype.names
+        if (self.cat.flags["C_CONTIGUOUS"] and tuple(names[:len(cols)]) == tuple(cols) and
+                all(self.cat.dtype[nm] == np.float64 for nm in names) and self.cat.dtype.itemsize == 8 * len(names)):
+            # the structured array IS the record matrix (all fields float64, packed, M z ra dec first, utils/io.py:58-60):
+            # a view, no copy; columns beyond the requested ones just widen the stride
+            return self.cat.view(np.float64).reshape(self.cat.size, len(names))
         out = np.empty((self.cat.size, len(cols)), dtype=np.float64)
         for i, c in enumerate(cols):
             out[:, i] = self.cat[c]
