@@ -145,7 +145,10 @@ class Context(object):
         torch = _torch()
         if d_tensor.numel() * d_tensor.element_size() > (1 << 30):
             return d_tensor.cpu().numpy()
-        h = torch.empty(d_tensor.shape, dtype=d_tensor.dtype, pin_memory=True)
+        try:
+            h = torch.empty(d_tensor.shape, dtype=d_tensor.dtype, pin_memory=True)
+        except RuntimeError:                                   # no page-locked memory to be had (memlock limit)
+            return d_tensor.cpu().numpy()
         h.copy_(d_tensor)
         return h.numpy()
 
