@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Randomised soak of the shell path against the oracle: NSIDE, catalog size, clustering (full sky / one crowded patch /
+an octant), halo order (random / sorted by position), table shape (default / 2000-node axis / extra dimension), paint and
+baryonify.  Every case must give the oracle's pixel-update count, non-zero set and values.  usage: soak.py [seconds] [seed]"""
+import os, sys, time, warnings
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch
+import baryonforge_amd as bfg
+from baryonforge_amd import sharding, synthetic as syn
+from util import assert_maps_close, oracle_baryonify, oracle_paint
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+cosmo = dict(syn.COSMO)
+t_end = time.time() + budget
+case = 0
+while time.time() < t_end:
+    case += 1
+    nside = int(rng.choice([8, 13, 32, 64, 128, 200, 256, 512, 1024]))
+    n = int(10 ** rng.uniform(0, 4.2))
+    eps = float(rng.choice([2, 5, 10, 20]))
+    layout = rng.choice(["sky", "patch", "octant"])
+    ra, dec, M, z = syn.catalog(n, seed=int(rng.integers(1 << 30)))
+    if layout == "patch":
+        ra = (rng.uniform(0, 360) + rng.normal(0, 3, n)) % 360
+        dec = np.clip(np.degrees(np.arcsin(rng.uniform(-1, 1))) + rng.normal(0, 3, n), -89.9, 89.9)
+    elif layout == "octant":
+        ra = rng.uniform(0, 90, n); dec = np.degrees(np.arcsin(rng.uniform(0, 1, n)))
+    if nside >= 512:
+        M = np.minimum(M, 10 ** 14.6)                       # keep the oracle quick
+    if rng.uniform() < 0.5:
+        o = np.argsort(sharding.ang2pix_nest(1024, ra, dec), kind="stable"); ra, dec, M, z = ra[o], dec[o], M[o], z[o]
+    shape = [(10, 30, 100), (2, 30, 2000), (3, 12, 700)][int(rng.integers(3))]
+    extra = None
+    zax, Max, rax, T = syn.pressure_table(*shape)
+    axes, Tt = (zax, Max, rax), T
+    kw = {}
+    if shape[2] == 700:                                     # an extra table dimension
+        pax = np.array([0.6, 1.0, 1.5])
+        Tt = T[..., None] * (1.0 + 0.2 * (pax - 1.0)[None, None, None, :])
+        axes = (zax, Max, rax, pax)
+        extra = rng.uniform(0.65, 1.45, n)
+        kw = {"cdelta": extra}
+    ref, ptot = oracle_paint(cosmo, ra, dec, M, z, axes, Tt, nside, eps, extra=None if extra is None else extra[:, None])
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo, **kw)
+    model = bfg.TabulatedProfile.from_arrays(zax, Max, rax, T) if extra is None else \
+        bfg.ParamTabulatedProfile.from_arrays(zax, Max, rax, Tt, other_params={"cdelta": pax})
+    R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), eps, model, verbose=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = R.process()
+    tag = f"case {case}: nside {nside} n {n} eps {eps} {layout} table {shape}"
+    assert R.last_stats["pixel_updates"] == ptot, tag
+    assert np.array_equal(got != 0, ref != 0), tag
+    assert_maps_close(got, ref, 1e-5, what=tag)
+    if extra is None and rng.uniform() < 0.5:
+        zd, Md, rd, d = syn.displacement_table(*shape)
+        m_in = syn.mass_map(nside)
+        refb = oracle_baryonify(cosmo, ra, dec, M, z, (zd, Md, rd), d, nside, eps, 20, m_in)
+        bm = bfg.Baryonification2D.from_arrays(zd, Md, rd, d, cosmo, epsilon_max=20)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            gotb = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo), eps, bm, verbose=False).process()
+        assert_maps_close(gotb, refb, 1e-5, floor=1e-9, what=tag + " baryonify")
+        tag += " +baryonify"
+    print("ok", tag, flush=True)
+print(f"{case} cases passed")
