@@ -1480,7 +1480,8 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
             // no row windows
         } else if (win_nodes % 4 == 0 && win_nodes >= 8) {
             const int hpb = std::min(256 / (win_nodes / 4), 64);
-            hipLaunchKernelGGL(halo_row4_kernel, dim3((unsigned)((a->n_halo + hpb - 1) / hpb)), dim3(256), 0, c->stream, rp);
+            const size_t rlds = (size_t)64 * ((size_t)1 << t->dev.nouter) * 16;           // weights + offsets of 64 halos
+            hipLaunchKernelGGL(halo_row4_kernel, dim3((unsigned)((a->n_halo + hpb - 1) / hpb)), dim3(256), rlds, c->stream, rp);
         } else {
             const int hpb = 256 / win_nodes;
             hipLaunchKernelGGL(halo_row_kernel, dim3((unsigned)((a->n_halo + hpb - 1) / hpb)), dim3(256), 0, c->stream, rp);

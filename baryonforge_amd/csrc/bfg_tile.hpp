@@ -411,8 +411,12 @@ __global__ __launch_bounds__(256) void halo_row_kernel(const RowParams P)
 __global__ __launch_bounds__(256) void halo_row4_kernel(const RowParams P)
 {
     constexpr int kHpbMax = 64;
-    __shared__ double s_w[kHpbMax][kMaxCorner];
-    __shared__ int64_t s_off[kHpbMax][kMaxCorner];
+    // corner weights / row offsets of the block's halos: dynamic LDS sized for the table's 2^(ndim-1) corners (a static
+    // [64][32] pair of arrays took 33 KB and capped the kernel at 4 workgroups per CU)
+    extern __shared__ double smem_row4[];
+    const int ncorner_ = 1 << P.tab.nouter;
+    double (*s_w) = smem_row4;                                            // [kHpbMax][ncorner]
+    int64_t (*s_off) = reinterpret_cast<int64_t *>(smem_row4 + kHpbMax * ncorner_);
     __shared__ int s_winlo[kHpbMax];
     __shared__ double s_add[kHpbMax];
     const DevTable &T = P.tab;
@@ -439,7 +443,7 @@ __global__ __launch_bounds__(256) void halo_row4_kernel(const RowParams P)
                 w = w * (bit ? y : 1.0 - y);
                 off += (int64_t)(i + bit) * T.ostride[k];
             }
-            s_w[hl][c] = w; s_off[hl][c] = off;
+            s_w[hl * ncorner_ + c] = w; s_off[hl * ncorner_ + c] = off;
         }
     }
     __syncthreads();
@@ -447,8 +451,8 @@ __global__ __launch_bounds__(256) void halo_row4_kernel(const RowParams P)
     const int ir = s_winlo[hl] + e4;
     double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
     for (int c = 0; c < ncorner; ++c) {
-        const double *row = T.values + s_off[hl][c] + ir;
-        const double w = s_w[hl][c];
+        const double *row = T.values + s_off[hl * ncorner_ + c] + ir;
+        const double w = s_w[hl * ncorner_ + c];
         b0 = fma(row[0], w, b0); b1 = fma(row[1], w, b1); b2 = fma(row[2], w, b2); b3 = fma(row[3], w, b3);
     }
     const double add = s_add[hl];
