@@ -264,10 +264,12 @@ struct BinCtx {
     TileGeom geo;
     int32_t *tile_count;          // [ntiles] counts, then fill cursors
     const int32_t *tile_start;    // [ntiles+1]
-    int32_t *pairs;
+    int32_t *pairs;               // [ntiles * cap_direct] fixed slots per tile | [pair_cap] overflow lists
     unsigned long long *pair_total;
-    long long pair_cap;
+    long long pair_cap;           // capacity of the overflow region
     int mode;                     // MODE_PAINT / MODE_BARYONIFY
+    int cap_direct;               // slots per tile that the COUNT pass fills directly (see tile_bin_halo)
+    unsigned long long *ovf_mask; // [n_halo] bit i: the halo's i-th pair found its tile's slots full
 };
 
 }  // namespace bfg

@@ -97,10 +97,13 @@ struct bfg_ctx {
         TileGeom geo;
         int32_t *d_geo;             // band_ns | band_tile0 | band_nrmin | tile_band
         int32_t *d_tile_count, *d_tile_start;
-        int4 *d_work;               // [ntiles + kWorkExtra] work items of the tile kernel + [1] their number
+        int4 *d_work;               // [2 ntiles + kWorkExtra] work items of the tile kernel
+        int cap_direct;             // fixed pair slots per tile of the current call
         int32_t *d_nwork;
     } tiles[2];                     // [MODE_PAINT], [MODE_BARYONIFY]
-    int32_t *d_pairs;
+    int32_t *d_pairs;              // [ntiles * cap_direct] slots | [pair_cap] overflow lists
+    unsigned long long *d_ovf_mask; // [cap_halo]
+    int64_t pairs_alloc;           // entries allocated in d_pairs
     bfg::HaloDisp *d_hd;            // [cap_halo] baryonify tile path
     int32_t *d_left;                // [cap_halo + 1] tile variant: [0] = count, then the halos left to the scatter kernel
     // bfg_baryonify_snapshot workspace (grow-only)
@@ -326,8 +329,10 @@ __global__ __launch_bounds__(256) void halo_prep_kernel(const PrepParams P)
             }
             if (total < 4) flags |= HF_SCATTER;
         }
+        unsigned long long ovf = 0ull;
         if (!(flags & HF_SCATTER))
-            flags = tile_bin_halo(P.bin, false, j, flags, rfirst, rlast, irmin, irmax, ptheta, pphi, radius);
+            flags = tile_bin_halo(P.bin, false, j, flags, rfirst, rlast, irmin, irmax, ptheta, pphi, radius, ovf);
+        P.bin.ovf_mask[j] = ovf;
     }
     irec[I_RFIRST * cap] = rfirst; irec[I_RLAST * cap] = rlast;
     irec[I_IRMIN * cap] = irmin; irec[I_IRMAX * cap] = irmax;
@@ -1046,6 +1051,7 @@ int bfg_ctx_destroy(bfg_ctx *c)
     for (int k = 0; k < 6; ++k) if (c->grid_buf[k]) (void)hipFree(c->grid_buf[k]);
     for (int k = 0; k < 5; ++k) if (c->dep_buf[k]) (void)hipFree(c->dep_buf[k]);
     if (c->d_pairs) (void)hipFree(c->d_pairs);
+    if (c->d_ovf_mask) (void)hipFree(c->d_ovf_mask);
     (void)hipFree(c->d_mathtab); (void)hipFree(c->d_pair_total);
     for (int k = 0; k < 5; ++k) {
         for (hipEvent_t e : *c->ev_a[k]) (void)hipEventDestroy(e);
@@ -1263,8 +1269,8 @@ static int ensure_workspace(bfg_ctx *c, int64_t n)
 {
     if (n <= c->cap_halo) return BFG_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->d_rec) { (void)hipFree(c->d_rec); (void)hipFree(c->d_irec); (void)hipFree(c->d_cidx); (void)hipFree(c->d_cw); (void)hipFree(c->d_ht); (void)hipFree(c->d_hd); (void)hipFree(c->d_left); }
-    c->d_rec = nullptr; c->d_ht = nullptr; c->d_hd = nullptr; c->d_left = nullptr; c->cap_halo = 0;
+    if (c->d_rec) { (void)hipFree(c->d_rec); (void)hipFree(c->d_irec); (void)hipFree(c->d_cidx); (void)hipFree(c->d_cw); (void)hipFree(c->d_ht); (void)hipFree(c->d_hd); (void)hipFree(c->d_left); (void)hipFree(c->d_ovf_mask); }
+    c->d_rec = nullptr; c->d_ht = nullptr; c->d_hd = nullptr; c->d_left = nullptr; c->d_ovf_mask = nullptr; c->cap_halo = 0;
     int64_t cap = (n + 1023) / 1024 * 1024;
     HIP_TRY(hipMalloc((void **)&c->d_rec, (size_t)cap * F_NF * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&c->d_irec, (size_t)cap * I_NI * sizeof(int32_t)));
@@ -1273,6 +1279,7 @@ static int ensure_workspace(bfg_ctx *c, int64_t n)
     HIP_TRY(hipMalloc((void **)&c->d_ht, (size_t)cap * sizeof(HaloTile)));
     HIP_TRY(hipMalloc((void **)&c->d_hd, (size_t)cap * sizeof(HaloDisp)));
     HIP_TRY(hipMalloc((void **)&c->d_left, (size_t)(cap + 1) * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void **)&c->d_ovf_mask, (size_t)cap * sizeof(unsigned long long)));
     c->cap_halo = cap;
     return BFG_OK;
 }
@@ -1343,7 +1350,7 @@ static int ensure_tiles(bfg_ctx *c, int mode, int tr, int64_t nside, int64_t n_h
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipMalloc((void **)&ts.d_tile_count, (size_t)ntiles * sizeof(int32_t)));
         HIP_TRY(hipMalloc((void **)&ts.d_tile_start, (size_t)(ntiles + 1) * sizeof(int32_t)));
-        HIP_TRY(hipMalloc((void **)&ts.d_work, (size_t)(ntiles + kWorkExtra) * sizeof(int4)));
+        HIP_TRY(hipMalloc((void **)&ts.d_work, (size_t)(2 * ntiles + kWorkExtra) * sizeof(int4)));
         HIP_TRY(hipMalloc((void **)&ts.d_nwork, sizeof(int32_t)));
         ts.geo.tr = tr; ts.geo.nbands = nbands; ts.geo.ntiles = ntiles;
         ts.geo.band_ns = ts.d_geo;
@@ -1352,17 +1359,23 @@ static int ensure_tiles(bfg_ctx *c, int mode, int tr, int64_t nside, int64_t n_h
         ts.geo.tile_band = ts.d_geo + 3 * nbands + 1;
         ts.nside = nside;
     }
+    // pair buffer: cap_direct fixed slots per tile (filled by the count pass) followed by the overflow lists.  Slots for
+    // ~8x the mean number of halos per tile hold every pair of a catalog spread over the sky (4-5 pairs per halo).
+    int64_t cap_direct = 32;
+    while (cap_direct < 8 * n_halo / std::max(ts.geo.ntiles, 1) && cap_direct < 8192) cap_direct *= 2;
+    while (cap_direct > 32 && cap_direct * ts.geo.ntiles > ((int64_t)1 << 28)) cap_direct /= 2;
+    if (const char *tc = std::getenv("BFG_TILE_CAP")) cap_direct = std::max<int64_t>(1, std::atoll(tc));   // test hook
+    ts.cap_direct = (int)cap_direct;
     int64_t want = 8 * n_halo + 65536;
-    if (const char *pc = std::getenv("BFG_PAIR_CAP")) {      // test hook: force a tiny pair buffer (overflow fallback)
-        want = std::max<int64_t>(1, std::atoll(pc));
-        if (want != c->pair_cap) { HIP_TRY(hipStreamSynchronize(c->stream)); if (c->d_pairs) (void)hipFree(c->d_pairs); c->d_pairs = nullptr; c->pair_cap = 0; }
-    }
-    if (want > c->pair_cap) {
+    if (const char *pc = std::getenv("BFG_PAIR_CAP")) want = std::max<int64_t>(1, std::atoll(pc));   // test hook: tiny overflow region
+    c->pair_cap = want;
+    const int64_t alloc = cap_direct * ts.geo.ntiles + want;
+    if (alloc > c->pairs_alloc) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->d_pairs) (void)hipFree(c->d_pairs);
-        c->d_pairs = nullptr; c->pair_cap = 0;
-        HIP_TRY(hipMalloc((void **)&c->d_pairs, (size_t)want * sizeof(int32_t)));
-        c->pair_cap = want;
+        c->d_pairs = nullptr; c->pairs_alloc = 0;
+        HIP_TRY(hipMalloc((void **)&c->d_pairs, (size_t)alloc * sizeof(int32_t)));
+        c->pairs_alloc = alloc;
     }
     return BFG_OK;
 }
@@ -1441,6 +1454,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         pp.bin.geo = c->tiles[mode].geo; pp.bin.tile_count = c->tiles[mode].d_tile_count;
         pp.bin.tile_start = c->tiles[mode].d_tile_start;
         pp.bin.pairs = c->d_pairs; pp.bin.pair_total = c->d_pair_total; pp.bin.pair_cap = c->pair_cap;
+        pp.bin.cap_direct = c->tiles[mode].cap_direct; pp.bin.ovf_mask = c->d_ovf_mask;
         pp.bin.mode = mode;
         pp.hd = (mode == MODE_BARYONIFY) ? c->d_hd : nullptr;
         pp.eps_model = a->model_epsilon_max; pp.rdelta = a->rdelta_sampling;
@@ -1466,7 +1480,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     if (tile) {
         timing_begin(c, 3);
         const bfg_ctx::TileSet &ts = c->tiles[mode];
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, ts.geo.ntiles, ts.d_tile_count,
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, ts.geo.ntiles, ts.cap_direct, ts.d_tile_count,
                            ts.d_tile_start, ts.d_work, ts.d_nwork);
         FillParams fp;
         std::memset(&fp, 0, sizeof(fp));
@@ -1513,7 +1527,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lb));
             c->tile_attr_set = true;
         }
-        const dim3 tgrid((unsigned)(ts.geo.ntiles + kWorkExtra)), tblock(kTileThreads);   // work items; the surplus exits at once
+        const dim3 tgrid((unsigned)(2 * ts.geo.ntiles + kWorkExtra)), tblock(kTileThreads);   // work items; the surplus exits at once
         const bool wl = win_nodes <= kWinLds;
         timing_begin(c, 1);
         if (mode == MODE_PAINT) {

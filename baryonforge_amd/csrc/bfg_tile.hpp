@@ -226,13 +226,18 @@ __device__ inline int wave_merged_inc(int32_t *counter, int idx)
 }
 
 // Bin one halo into the tiles its disc's bounding box (ring band x longitude extent) overlaps.
-// fill = false: count pass (runs inside halo_prep_kernel); returns the halo's flags, with HF_SCATTER set
-// if it overlaps too many tiles or lies outside the table hull -- such halos are left to the
-// global-atomic scatter kernel.  fill = true: second pass, writes the pair lists.  If the total number of
-// pairs (known on the device after the scan) exceeds the pair buffer, the fill pass flags EVERY halo
+// fill = false: count pass (runs inside halo_prep_kernel).  The atomic that counts a pair also gives the pair its rank in
+// the tile; ranks below cap_direct are the pair's slot in the tile's fixed region of pairs[] and the halo id is stored
+// there at once -- for a catalog spread over the sky that is every pair, and the fill pass (one more returning atomic and
+// one more scattered store per pair) has nothing left to do.  Pairs that find the slots full set their bit in `mask`.
+// Returns the halo's flags, with HF_SCATTER set if it overlaps too many tiles or lies outside the table hull -- such
+// halos are left to the global-atomic scatter kernel.
+// fill = true: second pass, only for halos with a non-zero mask: appends the masked pairs to the tiles' overflow lists.
+// If the overflow lists (sized on the device by the scan) exceed the pair buffer, the fill pass flags EVERY halo
 // HF_SCATTER and the tile kernel exits: the call degrades to the scatter kernel instead of overflowing.
 __device__ inline int tile_bin_halo(const BinCtx &B, bool fill, int64_t j, int flags, int rfirst, int rlast,
-                                    int irmin, int irmax, double ptheta, double pphi, double radius)
+                                    int irmin, int irmax, double ptheta, double pphi, double radius,
+                                    unsigned long long &mask)
 {
     if (flags & HF_SKIP) return flags;
     if (fill && (flags & HF_SCATTER)) return flags;
@@ -254,15 +259,23 @@ __device__ inline int tile_bin_halo(const BinCtx &B, bool fill, int64_t j, int f
         if (npairs > kMaxPairsPerHalo) to_scatter = true;
         if (to_scatter) return flags | HF_SCATTER;
     }
+    const int64_t ovf_base = (int64_t)B.geo.ntiles * B.cap_direct;
+    int ipair = 0;                                               // the halo's pairs in enumeration order (< kMaxPairsPerHalo = 64)
     for (int b = b0; b <= b1; ++b) {
         int s_lo, n;
         band_sectors(B.geo, b, pphi, dphi_bound, s_lo, n);
         const int NS = B.geo.band_ns[b], t0 = B.geo.band_tile0[b];
-        for (int i = 0; i < n; ++i) {
+        for (int i = 0; i < n; ++i, ++ipair) {
             int s = s_lo + i; if (s >= NS) s -= NS;
             const int tile = t0 + s;
-            const int pos = wave_merged_inc(B.tile_count, tile);      // count pass: the count; fill pass: the cursor
-            if (fill) B.pairs[B.tile_start[tile] + pos] = (int32_t)j;
+            if (!fill) {
+                const int pos = wave_merged_inc(B.tile_count, tile);            // the pair's rank in its tile
+                if (pos < B.cap_direct) B.pairs[(int64_t)tile * B.cap_direct + pos] = (int32_t)j;
+                else mask |= 1ull << ipair;
+            } else if ((mask >> ipair) & 1ull) {
+                const int pos = wave_merged_inc(B.tile_count, tile);            // cursor of the tile's overflow list
+                B.pairs[ovf_base + B.tile_start[tile] + pos] = (int32_t)j;
+            }
         }
     }
     return flags;
@@ -281,30 +294,35 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const FillParams P)
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= P.n_halo) return;
     const int64_t cap = P.cap;
-    if ((long long)P.bin.tile_start[P.bin.geo.ntiles] > P.bin.pair_cap) {        // pair buffer too small: all to scatter
+    if ((long long)P.bin.tile_start[P.bin.geo.ntiles] > P.bin.pair_cap) {        // overflow lists too long: all to scatter
         const int f = P.irec[I_FLAGS * cap + j] | HF_SCATTER;
         P.irec[I_FLAGS * cap + j] = f; P.ht[j].flags = f;
         return;
     }
+    unsigned long long mask = P.bin.ovf_mask[j];
+    if (mask == 0ull) return;                                                     // every pair found a slot in the count pass
     tile_bin_halo(P.bin, true, j, P.irec[I_FLAGS * cap + j], P.irec[I_RFIRST * cap + j], P.irec[I_RLAST * cap + j],
                   P.irec[I_IRMIN * cap + j], P.irec[I_IRMAX * cap + j], P.rec[F_PTHETA * cap + j],
-                  P.rec[F_PPHI * cap + j], P.rec[F_RADIUS * cap + j]);
+                  P.rec[F_PPHI * cap + j], P.rec[F_RADIUS * cap + j], mask);
 }
 
-// exclusive scan of tile_count into tile_start[ntiles+1], then the work list of the tile kernel; single workgroup.
+// Per tile: the first cap_direct pairs sit in the tile's fixed slots (written by the count pass), the rest go to an
+// overflow list: exclusive scan of the overflow lengths into tile_start[ntiles+1] (tile_start[ntiles] = their total), then
+// the work list of the tile kernel; single workgroup.
 // A work item is (tile, first pair, last pair + 1 -- positions in pairs[], so the tile kernel needs no tile_start lookup
-// on its start-up chain --, shared): tiles with more than S pairs are cut into equal slices of at most S pairs that
-// different workgroups accumulate separately (shared = 1: the write-back uses atomics).  S = max(256, total / 4096), so a
-// full-sky catalog gives one item per tile while a catalog that crowds into part of the sky (an octant light cone, a
-// compact multi-GPU shard: 1/8 of the tiles with 8x the pairs) still yields a few thousand items of similar size instead of
-// 784 heavy ones on 512 workgroup slots.
+// on its start-up chain --, shared): a tile's slot region and its overflow list are separate items, and either is cut
+// into equal slices of at most S pairs; items of one tile are accumulated by different workgroups (shared = 1: the
+// write-back uses atomics).  S = max(256, pairs / 4096), so a full-sky catalog gives one item per tile while a catalog
+// that crowds into part of the sky (an octant light cone, a compact multi-GPU shard: 1/8 of the tiles with 8x the pairs)
+// still yields a few thousand items of similar size instead of 784 heavy ones on 512 workgroup slots.
 constexpr int kWorkExtra = 4096;
-__global__ __launch_bounds__(1024) void tile_scan_kernel(int ntiles, int32_t *count, int32_t *start, int4 *work, int32_t *n_work)
+__global__ __launch_bounds__(1024) void tile_scan_kernel(int ntiles, int cap_direct, int32_t *count, int32_t *start, int4 *work,
+                                                         int32_t *n_work)
 {
     __shared__ int32_t wsum[16];
-    __shared__ int32_t carry;
+    __shared__ int32_t carry, carry2;
     // block-wide exclusive scan of 4 values per thread (4096 tiles per trip); returns the offset of the thread's first value
-    auto scan4 = [&](const int v[4], int &running) -> int {
+    auto scan4 = [&](const int v[4]) -> int {
         const int s = v[0] + v[1] + v[2] + v[3];
         int incl = s;
         for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(incl, d, 64); if ((threadIdx.x & 63) >= d) incl += o; }
@@ -316,38 +334,52 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int ntiles, int32_t *co
         __syncthreads();
         if (threadIdx.x == 1023) carry = c + woff + incl;
         __syncthreads();
-        running = c + woff + incl;
         return c + woff + incl - s;
     };
-    if (threadIdx.x == 0) carry = 0;
+    if (threadIdx.x == 0) { carry = 0; carry2 = 0; }
     __syncthreads();
+    int mine = 0;                                       // pairs of this thread's tiles (all of them, for S)
     for (int base = 0; base < ntiles; base += 4096) {
         const int i0 = base + 4 * threadIdx.x;
-        int v[4], run;
-        for (int k = 0; k < 4; ++k) v[k] = (i0 + k < ntiles) ? count[i0 + k] : 0;
-        int o = scan4(v, run);
-        for (int k = 0; k < 4; ++k) if (i0 + k < ntiles) { start[i0 + k] = o; o += v[k]; count[i0 + k] = 0; }   // count becomes the fill cursor
-    }
-    const int total = carry;
-    __syncthreads();                                   // every thread has read the total before carry is reused
-    if (threadIdx.x == 0) { start[ntiles] = total; carry = 0; }
-    __syncthreads();
-    const int S = max(256, (total + kWorkExtra - 1) / kWorkExtra);
-    for (int base = 0; base < ntiles; base += 4096) {
-        const int i0 = base + 4 * threadIdx.x;
-        int n[4], v[4], run;
+        int v[4];
         for (int k = 0; k < 4; ++k) {
-            const int a0 = (i0 + k < ntiles) ? start[i0 + k] : total;
-            const int a1 = (i0 + k + 1 < ntiles) ? start[i0 + k + 1] : total;
-            n[k] = a1 - a0;
-            v[k] = (n[k] + S - 1) / S;
+            const int n = (i0 + k < ntiles) ? count[i0 + k] : 0;
+            mine += n;
+            v[k] = max(n - cap_direct, 0);
         }
-        int o = scan4(v, run);
+        int o = scan4(v);
+        for (int k = 0; k < 4; ++k) if (i0 + k < ntiles) { start[i0 + k] = o; o += v[k]; }
+    }
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&carry2, mine);
+    const int total_ovf = carry;
+    __syncthreads();                                   // every thread has read the total before carry is reused
+    if (threadIdx.x == 0) { start[ntiles] = total_ovf; carry = 0; }
+    __syncthreads();
+    const int total = carry2;
+    const int S = max(256, (total + kWorkExtra - 1) / kWorkExtra);
+    const int64_t ovf_base = (int64_t)ntiles * cap_direct;
+    for (int base = 0; base < ntiles; base += 4096) {
+        const int i0 = base + 4 * threadIdx.x;
+        int nd[4], no[4], v[4];
         for (int k = 0; k < 4; ++k) {
-            const int slice = (v[k] > 0) ? (n[k] + v[k] - 1) / v[k] : 0;                    // equal slices within a tile
-            const int a0 = (i0 + k < ntiles) ? start[i0 + k] : total;                       // absolute positions in pairs[]
-            for (int m = 0; m < v[k]; ++m, ++o)
-                work[o] = make_int4(i0 + k, a0 + m * slice, a0 + min(n[k], (m + 1) * slice), v[k] > 1 ? 1 : 0);
+            const int n = (i0 + k < ntiles) ? count[i0 + k] : 0;
+            nd[k] = min(n, cap_direct); no[k] = n - nd[k];
+            v[k] = (nd[k] + S - 1) / S + (no[k] + S - 1) / S;
+        }
+        int o = scan4(v);
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + k >= ntiles) continue;
+            count[i0 + k] = 0;                                                               // becomes the overflow cursor
+            const int shared = v[k] > 1 ? 1 : 0;
+            for (int part = 0; part < 2; ++part) {
+                const int n = part ? no[k] : nd[k];
+                const int nv = (n + S - 1) / S;
+                const int slice = nv ? (n + nv - 1) / nv : 0;                                // equal slices
+                const int a0 = part ? (int)(ovf_base + start[i0 + k]) : (i0 + k) * cap_direct;   // positions in pairs[]
+                for (int m = 0; m < nv; ++m, ++o)
+                    work[o] = make_int4(i0 + k, a0 + m * slice, a0 + min(n, (m + 1) * slice), shared);
+            }
         }
     }
     if (threadIdx.x == 0) *n_work = carry;

@@ -841,14 +841,43 @@ def test_tile_pair_buffer_overflow_falls_back_to_scatter(cosmo, monkeypatch):
     ref, ptot = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax), T, 256, 10)
     Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
     Shell = bfg.LightconeShell(map=np.zeros(12 * 256 * 256), cosmo=cosmo)
-    monkeypatch.setenv("BFG_PAIR_CAP", "100")
+    monkeypatch.setenv("BFG_TILE_CAP", "2")                 # two fixed slots per tile: nearly every pair overflows ...
+    monkeypatch.setenv("BFG_PAIR_CAP", "100")               # ... into lists that cannot hold them
     R = bfg.PaintProfilesShell(Cat, Shell, 10, _paint_model(zax, Max, rax, T), verbose=False, variant="tile_lds")
     got = R.process()
     assert R.last_stats["pixel_updates"] == ptot
     assert_maps_close(got, ref, RTOL, what="pair overflow fallback")
     monkeypatch.delenv("BFG_PAIR_CAP")
+    monkeypatch.delenv("BFG_TILE_CAP")
     got = R.process()
     assert_maps_close(got, ref, RTOL, what="after fallback")
+
+
+@pytest.mark.parametrize("slots", [1, 3, 17])
+def test_tile_slots_and_overflow_lists(cosmo, slots, monkeypatch):
+    """halo -> tile binning: the count pass drops a pair into one of the tile's fixed slots, pairs that find them full are
+    appended to the tile's overflow list by the fill pass; with 1 / 3 / 17 slots per tile both kinds of work item occur
+    for most tiles (and write to the same map tile with atomics) -- paint and baryonify against the oracle"""
+    import warnings
+    monkeypatch.setenv("BFG_TILE_CAP", str(slots))
+    ra, dec, M, z = syn.catalog(6000, seed=146)
+    zax, Max, rax, T = syn.pressure_table()
+    ref, ptot = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax), T, 256, 10)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * 256 * 256), cosmo=cosmo), 10,
+                               _paint_model(zax, Max, rax, T), verbose=False, variant="tile_lds")
+    got = R.process()
+    assert R.last_stats["pixel_updates"] == ptot
+    assert np.array_equal(got != 0, ref != 0)
+    assert_maps_close(got, ref, RTOL, what=f"{slots} slots per tile")
+    zd, Md, rd, d = syn.displacement_table()
+    m_in = syn.mass_map(256)
+    refb = oracle_baryonify(cosmo, ra, dec, M, z, (zd, Md, rd), d, 256, 10, 20, m_in)
+    model = bfg.Baryonification2D.from_arrays(zd, Md, rd, d, cosmo, epsilon_max=20)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gotb = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo), 10, model, verbose=False).process()
+    assert_maps_close(gotb, refb, RTOL, floor=BFLOOR, what=f"baryonify, {slots} slots per tile")
 
 
 # --------------------------------------------------------------------------- edge cases and errors
