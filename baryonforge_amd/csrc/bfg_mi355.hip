@@ -42,7 +42,7 @@ static thread_local std::string g_last_error;
         }                                                                                   \
     } while (0)
 
-enum { F_X0 = 0, F_Y0, F_Z0, F_ST, F_PTHETA, F_PPHI, F_D, F_A, F_R, F_RM, F_RADIUS, F_LNM, F_LNZ, F_NF };
+enum { F_X0 = 0, F_Y0, F_Z0, F_PTHETA, F_PPHI, F_D, F_A, F_RM, F_RADIUS, F_NF };   // only what a later kernel reads
 enum { I_RFIRST = 0, I_RLAST, I_IRMIN, I_IRMAX, I_FLAGS, I_NI };
 #define HF_OOB 1        // (z, M, extras) outside the table hull, or NaN
 #define HF_SKIP 2       // nothing to do for this halo (NaN radius etc.)
@@ -248,13 +248,12 @@ __global__ __launch_bounds__(256) void halo_prep_kernel(const PrepParams P)
 
     double *rec = P.rec + j;
     const int64_t cap = P.cap;
-    rec[F_X0 * cap] = x0; rec[F_Y0 * cap] = y0; rec[F_Z0 * cap] = z0v; rec[F_ST * cap] = st;
+    rec[F_X0 * cap] = x0; rec[F_Y0 * cap] = y0; rec[F_Z0 * cap] = z0v;
     rec[F_PTHETA * cap] = ptheta; rec[F_PPHI * cap] = pphi;
-    rec[F_D * cap] = D; rec[F_A * cap] = a; rec[F_R * cap] = R;
+    rec[F_D * cap] = D; rec[F_A * cap] = a;
     rec[F_RM * cap] = P.want_model_radius ? massdef_radius(P.md_model, M, a) / a : 0.0;  // BaryonCorrection.py:399
     rec[F_RADIUS * cap] = radius;
     const double lnM = log(M), lnz = log(1.0 / a);                           // Tabulate.py:308,312
-    rec[F_LNM * cap] = lnM; rec[F_LNZ * cap] = lnz;
 
     // disc ring range (query_disc_internal, fact = 0)
     int32_t flags = 0, rfirst = 1, rlast = 0, irmin = 1, irmax = 0;
