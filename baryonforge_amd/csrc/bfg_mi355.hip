@@ -1931,41 +1931,35 @@ int bfg_deposit_grid(bfg_ctx *c, int ndim, int64_t n_part, const double *d_pos, 
         HIP_TRY(hipGetLastError());
         return BFG_OK;
     }
-    const int64_t nblk = (ntile + 1023) / 1024;
-    const size_t want[5] = {(size_t)n_part * sizeof(int32_t), (size_t)n_part * sizeof(int32_t), (size_t)ntile * sizeof(int32_t),
-                            (size_t)(ntile + 1) * sizeof(int32_t), (size_t)(nblk + 1) * sizeof(int32_t)};
+    // slots per tile: twice the mean occupancy (a uniform 512^3 load has 4096 +- 64 per 16^3 tile); denser tiles spill
+    int64_t cap = 64;
+    while (cap < 2 * n_part / std::max<int64_t>(ntile, 1) && cap < (1 << 20)) cap *= 2;
+    while (cap > 64 && cap * ntile > ((int64_t)1 << 30)) cap /= 2;
+    if (const char *e = std::getenv("BFG_DEPOSIT_CAP")) cap = std::max<int64_t>(1, std::atoll(e));       // test hook
+    const int64_t ovf_cap = n_part;
+    const size_t want[5] = {(size_t)(ovf_cap + 2) * sizeof(int32_t), (size_t)(cap * ntile) * sizeof(int32_t),
+                            (size_t)ntile * sizeof(int32_t), 0, 0};
     rc = dep_workspace(c, want);
     if (rc) return rc;
     DepSortParams S;
-    S.d = P; S.nt = nt;
-    S.key = (int32_t *)c->dep_buf[0]; S.perm = (int32_t *)c->dep_buf[1]; S.count = (int32_t *)c->dep_buf[2];
-    int32_t *d_start = (int32_t *)c->dep_buf[3], *d_bsum = (int32_t *)c->dep_buf[4], *d_total = d_bsum + nblk;
-    S.start = d_start;
+    S.d = P; S.nt = nt; S.cap = (int)cap;
+    S.ovf_n = (unsigned long long *)c->dep_buf[0]; S.ovf = (int32_t *)c->dep_buf[0] + 2; S.ovf_cap = ovf_cap;
+    S.perm = (int32_t *)c->dep_buf[1]; S.count = (int32_t *)c->dep_buf[2];
     HIP_TRY(hipMemsetAsync(S.count, 0, (size_t)ntile * sizeof(int32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(S.ovf_n, 0, sizeof(unsigned long long), c->stream));
     const unsigned pgrid = (unsigned)std::min<int64_t>((n_part + 255) / 256, 16384);          // grid-stride
-#define BFG_DEP_LAUNCH(KERNEL, GRID)                                                                              \
+#define BFG_DEP_LAUNCH(KERNEL, GRID, THREADS)                                                                     \
     do {                                                                                                           \
-        if (ndim == 3 && mode == BFG_DEPOSIT_CIC) hipLaunchKernelGGL((KERNEL<3, BFG_DEPOSIT_CIC>), dim3(GRID), dim3(256), 0, c->stream, S); \
-        else if (ndim == 3) hipLaunchKernelGGL((KERNEL<3, BFG_DEPOSIT_NGP>), dim3(GRID), dim3(256), 0, c->stream, S);                       \
-        else if (mode == BFG_DEPOSIT_CIC) hipLaunchKernelGGL((KERNEL<2, BFG_DEPOSIT_CIC>), dim3(GRID), dim3(256), 0, c->stream, S);         \
-        else hipLaunchKernelGGL((KERNEL<2, BFG_DEPOSIT_NGP>), dim3(GRID), dim3(256), 0, c->stream, S);                                      \
+        if (ndim == 3 && mode == BFG_DEPOSIT_CIC) hipLaunchKernelGGL((KERNEL<3, BFG_DEPOSIT_CIC>), dim3(GRID), dim3(THREADS), 0, c->stream, S); \
+        else if (ndim == 3) hipLaunchKernelGGL((KERNEL<3, BFG_DEPOSIT_NGP>), dim3(GRID), dim3(THREADS), 0, c->stream, S);                       \
+        else if (mode == BFG_DEPOSIT_CIC) hipLaunchKernelGGL((KERNEL<2, BFG_DEPOSIT_CIC>), dim3(GRID), dim3(THREADS), 0, c->stream, S);         \
+        else hipLaunchKernelGGL((KERNEL<2, BFG_DEPOSIT_NGP>), dim3(GRID), dim3(THREADS), 0, c->stream, S);                                      \
     } while (0)
-    BFG_DEP_LAUNCH(dep_key_kernel, pgrid);
-    hipLaunchKernelGGL(snap_scan_block_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, ntile, S.count, d_start, d_bsum);
-    hipLaunchKernelGGL(snap_scan_sums_kernel, dim3(1), dim3(1024), 0, c->stream, (int)nblk, d_bsum, d_total);
-    hipLaunchKernelGGL(snap_scan_add_kernel, dim3((unsigned)((ntile + 255) / 256)), dim3(256), 0, c->stream, ntile, d_start,
-                       d_bsum, S.count, d_total);
-    hipLaunchKernelGGL(group_fill_kernel, dim3(pgrid), dim3(256), 0, c->stream, n_part, S.key, S.count, S.start, S.perm);
+    BFG_DEP_LAUNCH(dep_key_kernel, pgrid, 256);
+    BFG_DEP_LAUNCH(dep_tile_kernel, (unsigned)ntile, kDepThreads);
 #undef BFG_DEP_LAUNCH
-#define BFG_DEP_LAUNCH(KERNEL, GRID)                                                                              \
-    do {                                                                                                           \
-        if (ndim == 3 && mode == BFG_DEPOSIT_CIC) hipLaunchKernelGGL((KERNEL<3, BFG_DEPOSIT_CIC>), dim3(GRID), dim3(kDepThreads), 0, c->stream, S); \
-        else if (ndim == 3) hipLaunchKernelGGL((KERNEL<3, BFG_DEPOSIT_NGP>), dim3(GRID), dim3(kDepThreads), 0, c->stream, S);                       \
-        else if (mode == BFG_DEPOSIT_CIC) hipLaunchKernelGGL((KERNEL<2, BFG_DEPOSIT_CIC>), dim3(GRID), dim3(kDepThreads), 0, c->stream, S);         \
-        else hipLaunchKernelGGL((KERNEL<2, BFG_DEPOSIT_NGP>), dim3(GRID), dim3(kDepThreads), 0, c->stream, S);                                      \
-    } while (0)
-    BFG_DEP_LAUNCH(dep_tile_kernel, (unsigned)ntile);
-#undef BFG_DEP_LAUNCH
+    if (ndim == 3) hipLaunchKernelGGL(dep_overflow_kernel<3>, dim3(1024), dim3(256), 0, c->stream, S);
+    else hipLaunchKernelGGL(dep_overflow_kernel<2>, dim3(1024), dim3(256), 0, c->stream, S);
     HIP_TRY(hipGetLastError());
     return BFG_OK;
 }

@@ -571,8 +571,8 @@ __global__ __launch_bounds__(256) void deposit_kernel(const DepositParams P)
 // ---- tile-privatised deposit ------------------------------------------------------------------------------------
 // The direct kernel above issues 2^ndim scattered f64 atomics per particle (1.1e9 for 512^3 particles: 24 ms, bound
 // by the L2 atomic rate of ~4.5e10/s).  Here the particles are first grouped by the grid tile (16^3 / 64^2 cells)
-// of their lower CIC corner with a counting sort that moves 4-byte particle indices only (keys -> wave-aggregated
-// counts -> scan -> wave-aggregated slots), then one workgroup per tile accumulates its particles in LDS
+// of their lower CIC corner in one pass over the particles (the wave-aggregated counting atomic returns the particle's slot in
+// its tile's region of a 4-byte index array), then one workgroup per tile accumulates its particles in LDS
 // (ds_add_f64, ~2e12/s) and flushes the (T + 1)^ndim block once: cells no other tile can touch by a plain
 // read-add-write, the shared faces by global atomics.  Weights are computed exactly as in deposit_kernel.
 template <int NDIM> struct DepTile {
@@ -584,10 +584,12 @@ template <int NDIM> struct DepTile {
 struct DepSortParams {
     DepositParams d;
     int nt;                          // tiles per dimension = ceil(N / T)
-    int32_t *key;                    // [n_part] tile of every particle, -1 = dropped (NGP, outside the box)
-    int32_t *count;                  // [ntile] counts, then fill cursors
-    const int32_t *start;            // [ntile + 1]
-    int32_t *perm;                   // [n_part] particle indices grouped by tile
+    int cap;                         // particle slots per tile in perm[]
+    int32_t *count;                  // [ntile] particles per tile (may exceed cap)
+    int32_t *perm;                   // [ntile][cap] particle indices, slot = the particle's rank in its tile
+    unsigned long long *ovf_n;       // number of particles whose tile had no slot left ...
+    int32_t *ovf;                    // [ovf_cap] ... and their indices
+    int64_t ovf_cap;
 };
 
 // lower corner (CIC) / bin (NGP) of a particle along one axis; false = dropped
@@ -623,9 +625,56 @@ __global__ __launch_bounds__(256) void dep_key_kernel(const DepSortParams S)
                 if (!dep_cell<MODE>(P.pos[ip * NDIM + k], step, P.N, P.L, i0, w1)) { key = -1; break; }
                 key = key * S.nt + i0 / T;
             }
-            S.key[ip] = key;
         }
-        (void)wave_group_slot(S.count, key, key >= 0);
+        // the counting atomic hands the particle its rank in the tile = its slot in the tile's region of perm[]: grouped
+        // in this one pass (no scan, no fill pass, no key array).  Tiles denser than cap (2x the mean) spill into a list
+        // that dep_overflow_kernel deposits with global atomics.
+        const int slot = wave_group_slot(S.count, key, key >= 0);
+        if (key >= 0) {
+            if (slot < S.cap) S.perm[(int64_t)key * S.cap + slot] = (int32_t)ip;
+            else {
+                const int64_t o = (int64_t)atomicAdd(S.ovf_n, 1ull);
+                if (o < S.ovf_cap) S.ovf[o] = (int32_t)ip;
+            }
+        }
+    }
+}
+
+// particles that found their tile's slots full: plain deposit with global atomics (as deposit_kernel)
+template <int NDIM>
+__global__ __launch_bounds__(256) void dep_overflow_kernel(const DepSortParams S)
+{
+    const DepositParams &P = S.d;
+    const int64_t n = min((int64_t)*S.ovf_n, S.ovf_cap);
+    const double step = P.L / (double)P.N;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t ip = S.ovf[q];
+        const double m = P.mass ? P.mass[ip] : 1.0;
+        if (P.mode == BFG_DEPOSIT_NGP) {
+            int64_t c = 0;
+            bool ok = true;
+            for (int k = 0; k < NDIM; ++k) {
+                const int i = ngp_bin(P.pos[ip * NDIM + k], step, P.N, P.L);
+                if (i < 0) { ok = false; break; }
+                c = c * P.N + i;
+            }
+            if (ok) unsafeAtomicAdd(P.grid + c, m);
+        } else {
+            int i0[NDIM];
+            double w1[NDIM];
+            for (int k = 0; k < NDIM; ++k) (void)dep_cell<BFG_DEPOSIT_CIC>(P.pos[ip * NDIM + k], step, P.N, P.L, i0[k], w1[k]);
+            for (int corner = 0; corner < (1 << NDIM); ++corner) {
+                double w = m;
+                int64_t c = 0;
+                for (int k = 0; k < NDIM; ++k) {
+                    const int bit = (corner >> k) & 1;
+                    w *= bit ? w1[k] : 1.0 - w1[k];
+                    int i = i0[k] + bit; if (i >= P.N) i -= P.N;
+                    c = c * P.N + i;
+                }
+                if (w != 0.0) unsafeAtomicAdd(P.grid + c, w);
+            }
+        }
     }
 }
 
@@ -638,7 +687,7 @@ __global__ __launch_bounds__(kDepThreads) void dep_tile_kernel(const DepSortPara
     constexpr int T = DepTile<NDIM>::T, E = DepTile<NDIM>::E, NE = DepTile<NDIM>::NE;
     __shared__ double acc[NE];
     const int tile = blockIdx.x;
-    const int q0 = S.start[tile], q1 = S.start[tile + 1];
+    const int64_t q0 = (int64_t)tile * S.cap, q1 = q0 + min(S.count[tile], S.cap);
     if (q0 == q1) return;
     int tc[3] = {0, 0, 0};
     { int rem = tile; for (int k = NDIM - 1; k >= 0; --k) { tc[k] = rem % S.nt; rem /= S.nt; } }
@@ -646,7 +695,7 @@ __global__ __launch_bounds__(kDepThreads) void dep_tile_kernel(const DepSortPara
     __syncthreads();
     const double step = P.L / (double)P.N;
     constexpr int U = 2;                                       // particles per thread and trip: independent gathers
-    for (int qb = q0 + threadIdx.x; qb < q1; qb += U * kDepThreads) {
+    for (int64_t qb = q0 + threadIdx.x; qb < q1; qb += U * kDepThreads) {
         int64_t ip[U];
         double x[U][NDIM], m[U];
         for (int u = 0; u < U; ++u) ip[u] = (qb + u * kDepThreads < q1) ? S.perm[qb + u * kDepThreads] : -1;

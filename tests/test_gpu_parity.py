@@ -520,6 +520,28 @@ def test_deposit_grid_vs_oracle(cosmo, ndim, N, mode, path, monkeypatch):
 
 
 @pytest.mark.parametrize("mode", ["ngp", "cic"])
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_deposit_tile_overflow_list(cosmo, ndim, mode, monkeypatch):
+    """tiles denser than their slot count spill into the overflow list (deposited with global atomics): forced with
+    3 slots per tile, plus a clump that overflows any realistic slot count; against the oracle"""
+    monkeypatch.setenv("BFG_DEPOSIT", "tile")
+    monkeypatch.setenv("BFG_DEPOSIT_CAP", "3")
+    from baryonforge_amd.engine import get_context
+    ctx = get_context(0)
+    rng = np.random.default_rng(400 + ndim)
+    L, N, n = 60.0, 40 if ndim == 3 else 150, 120000
+    P = rng.uniform(0, L, (n, ndim))
+    P[:30000] = rng.normal(L / 2, L / 300, (30000, ndim)) % L          # a clump inside one or two cells
+    M = rng.uniform(0.5, 2.0, n)
+    got = ctx.deposit_grid(ctx.to_device(P), ctx.to_device(M), L, N, mode).cpu().numpy()
+    ref = orc.make_map(P, M, L, N, mode)
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12)
+    monkeypatch.delenv("BFG_DEPOSIT_CAP")                              # the production slot count, same clump
+    got = ctx.deposit_grid(ctx.to_device(P), ctx.to_device(M), L, N, mode).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("mode", ["ngp", "cic"])
 def test_deposit_grid_paths_agree_outside_the_box(mode, monkeypatch):
     """positions outside [0, L]: NGP drops them (histogramdd), CIC wraps them; unit masses (d_mass = NULL); the deposit
     accumulates INTO the grid.  Direct and tiled paths must agree to rounding."""
