@@ -73,7 +73,9 @@ class BaryonifySnapshot(DefaultRunnerSnapshot):
         snap, hcat = self.ParticleSnapshot, self.HaloNDCatalog.cat
         is2D = snap.is2D
         ndim = 2 if is2D else 3
-        part = np.stack([np.asarray(snap.cat[c], dtype=np.float64) for c in ("x", "y", "z")[:ndim]], axis=1)
+        recs = snap.records() if hasattr(snap, "records") else None        # the catalogue as float64[n, 4] (M, x, y, z): a view
+        part = None if recs is not None else \
+            np.stack([np.asarray(snap.cat[c], dtype=np.float64) for c in ("x", "y", "z")[:ndim]], axis=1)
         # halo columns are float32 in the reference (io.py:204): positions and masses widen exactly, but the table
         # coordinate is np.log of the float32 mass, i.e. a float32 logarithm (BaryonCorrection.py:397)
         with np.errstate(all="ignore"):
@@ -87,8 +89,17 @@ class BaryonifySnapshot(DefaultRunnerSnapshot):
         table = ctx.table(_table_axes(model, list(keys)), lambda: np.asarray(model.raw_input_d, dtype=np.float64),
                           log_values=False, cache_key=(model, "d", model.raw_input_d))
         model_bg = Background(model.cosmo) if getattr(model, "cosmo", None) is not None else bg
-        d_part, d_halo = ctx.to_device(part), ctx.to_device(halos)
-        d_out = ctx.zeros(part.shape[0], ndim)
+        d_halo = ctx.to_device(halos)
+        if recs is not None:
+            # one upload of the records as they lie in memory; the displaced coordinates are written into a device copy of
+            # them, which IS the new catalogue (no column gathering on the host, no per-column write-back)
+            d_recs = ctx.to_device(recs)
+            self._d_new_records = d_recs.clone()
+            d_part, d_out = d_recs[:, 1:1 + ndim], self._d_new_records[:, 1:1 + ndim]
+        else:
+            self._d_new_records = None
+            d_part = ctx.to_device(part)
+            d_out = ctx.zeros(part.shape[0], ndim)
         ctx.stats_reset()
         ctx.baryonify_snapshot(d_part, d_halo, ndim, snap.L, a, self.epsilon_max, ctx.massdef_struct(bg, self.mass_def),
                                ctx.massdef_struct(model_bg, getattr(model, "mass_def", None)), model.epsilon_max,
@@ -100,6 +111,10 @@ class BaryonifySnapshot(DefaultRunnerSnapshot):
     def process(self):
         """returns new_cat : the particle catalog (structured array) with displaced, box-wrapped coordinates"""
         d_new = self.process_device()
+        if self._d_new_records is not None:
+            recs = get_context().to_host(self._d_new_records)
+            self._d_new_records = None
+            return recs.view(self.ParticleSnapshot.cat.dtype).reshape(-1)   # the record matrix seen as the structured array
         new = get_context().to_host(d_new)
         new_cat = self.ParticleSnapshot.cat.copy()                          # :260
         new_cat["x"] = new[:, 0]

@@ -36,7 +36,7 @@ SYMBOLS = [
     "bfg_spline_create", "bfg_spline_destroy",
     "bfg_paint_shell", "bfg_baryonify_offsets", "bfg_regrid_shell", "bfg_reduce_absmax_sum",
     "bfg_baryonify_snapshot", "bfg_deposit_grid", "bfg_paint_grid", "bfg_baryonify_grid_offsets", "bfg_regrid_grid",
-    "bfg_build_displacement_table",
+    "bfg_build_displacement_table", "bfg_baryonify_snapshot_strided", "bfg_deposit_grid_strided",
     "bfg_stats_reset", "bfg_stats_read", "bfg_timing_enable", "bfg_timing_read",
 ]
 
@@ -130,10 +130,12 @@ def load(build_if_missing=True):
     L.bfg_spline_destroy.argtypes = [_vp, _vp]
     L.bfg_paint_shell.argtypes = [_vp, C.POINTER(ShellArgs), _vp, _vp, _vp]
     L.bfg_baryonify_snapshot.argtypes = [_vp, C.POINTER(SnapshotArgs), _vp, _vp]
+    L.bfg_baryonify_snapshot_strided.argtypes = [_vp, C.POINTER(SnapshotArgs), _vp, _vp, _i64, _i64]
     L.bfg_paint_grid.argtypes = [_vp, C.POINTER(GridArgs), _vp, _vp]
     L.bfg_baryonify_grid_offsets.argtypes = [_vp, C.POINTER(GridArgs), _vp, _vp]
     L.bfg_regrid_grid.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _vp]
     L.bfg_deposit_grid.argtypes = [_vp, C.c_int, _i64, _vp, _vp, _dbl, C.c_int, C.c_int, _vp]
+    L.bfg_deposit_grid_strided.argtypes = [_vp, C.c_int, _i64, _vp, _i64, _vp, _i64, _dbl, C.c_int, C.c_int, _vp]
     L.bfg_build_displacement_table.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(_dbl), _vp, _vp, C.c_int,
                                                C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_dbl), _vp,
                                                C.POINTER(C.c_int32)]

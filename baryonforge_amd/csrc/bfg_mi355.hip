@@ -1644,6 +1644,12 @@ static int dep_workspace(bfg_ctx *c, const size_t want[5])
 extern "C" {
 int bfg_baryonify_snapshot(bfg_ctx *c, const bfg_snapshot_args *a, const bfg_table *t, double *d_out)
 {
+    return bfg_baryonify_snapshot_strided(c, a, t, d_out, a ? a->ndim : 0, a ? a->ndim : 0);
+}
+
+int bfg_baryonify_snapshot_strided(bfg_ctx *c, const bfg_snapshot_args *a, const bfg_table *t, double *d_out,
+                                   int64_t part_stride, int64_t out_stride)
+{
     int rc = ctx_enter(c);
     if (rc) return rc;
     if (!a || !t || !d_out || (a->ndim != 2 && a->ndim != 3) || a->n_part < 0 || a->n_halo < 0 || !(a->L > 0) ||
@@ -1657,7 +1663,8 @@ int bfg_baryonify_snapshot(bfg_ctx *c, const bfg_snapshot_args *a, const bfg_tab
     P.ndim = a->ndim; P.rdelta = a->rdelta_sampling; P.n_part = a->n_part; P.n_halo = a->n_halo;
     P.L = a->L; P.a = a->a; P.eps_run = a->epsilon_max; P.eps_model = a->model_epsilon_max;
     P.md_run = a->runner_md; P.md_model = a->model_md;
-    P.part = a->d_part; P.halo = a->d_halo; P.halo_stride = a->halo_stride; P.n_extra = a->n_extra;
+    if (part_stride < a->ndim || out_stride < a->ndim) return BFG_ERR_INVALID;
+    P.part = a->d_part; P.pstride = part_stride; P.ostride = out_stride; P.halo = a->d_halo; P.halo_stride = a->halo_stride; P.n_extra = a->n_extra;
     P.tab = t->dev; P.stats = c->d_stats; P.out = d_out;
     P.logtab = reinterpret_cast<const double2 *>(c->d_mathtab);
     // coarse cell grid for the halo-overlap lists: a few candidate halos per cell
@@ -1907,6 +1914,12 @@ int bfg_regrid_grid(bfg_ctx *c, int ndim, int npix, const double *d_offsets, con
 int bfg_deposit_grid(bfg_ctx *c, int ndim, int64_t n_part, const double *d_pos, const double *d_mass, double L,
                      int n_grid, int mode, double *d_grid)
 {
+    return bfg_deposit_grid_strided(c, ndim, n_part, d_pos, ndim, d_mass, 1, L, n_grid, mode, d_grid);
+}
+
+int bfg_deposit_grid_strided(bfg_ctx *c, int ndim, int64_t n_part, const double *d_pos, int64_t pos_stride,
+                             const double *d_mass, int64_t mass_stride, double L, int n_grid, int mode, double *d_grid)
+{
     int rc = ctx_enter(c);
     if (rc) return rc;
     if ((ndim != 2 && ndim != 3) || n_part < 0 || !(L > 0) || n_grid < 1 || (mode != BFG_DEPOSIT_NGP && mode != BFG_DEPOSIT_CIC) ||
@@ -1915,6 +1928,8 @@ int bfg_deposit_grid(bfg_ctx *c, int ndim, int64_t n_part, const double *d_pos, 
     if (n_part == 0) return BFG_OK;
     DepositParams P;
     P.ndim = ndim; P.mode = mode; P.N = n_grid; P.n_part = n_part; P.L = L; P.pos = d_pos; P.mass = d_mass; P.grid = d_grid;
+    if (pos_stride < ndim || mass_stride < 1) return BFG_ERR_INVALID;
+    P.pstride = pos_stride; P.mstride = mass_stride;
     // large particle sets go through the tile-privatised path (BFG_DEPOSIT=direct / tile forces either one)
     const int T = (ndim == 3) ? DepTile<3>::T : DepTile<2>::T;
     const int nt = (n_grid + T - 1) / T;

@@ -38,7 +38,8 @@ struct SnapParams {
     int64_t n_part, n_halo;
     double L, a, eps_run, eps_model;
     bfg_massdef md_run, md_model;
-    const double *part;              // [n_part][ndim]
+    const double *part;              // particle k, coordinate c at part[k * pstride + c]
+    int64_t pstride, ostride;        // doubles per particle record of part / out (ndim when packed)
     const double *halo;              // [n_halo][stride]: M, lnM (table coordinate), x, y, z, extras...
     int halo_stride, n_extra;
     DevTable tab;
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(256) void snap_particle_kernel(const SnapParams P)
         const double inv_cell = (double)n / L;
         double p[3] = {0.0, 0.0, 0.0}, off[3] = {0.0, 0.0, 0.0};
         int64_t cid = 0;
-        for (int k = 0; k < NDIM; ++k) { p[k] = P.part[ip * NDIM + k]; cid = cid * n + snap_cell_of(p[k], inv_cell, n); }
+        for (int k = 0; k < NDIM; ++k) { p[k] = P.part[ip * P.pstride + k]; cid = cid * n + snap_cell_of(p[k], inv_cell, n); }
         // a candidate: periodic distance test (compute_distance / enforce_periodicity, :104-158; KDTree radius :225 / :240)
         auto test = [&](double hx_, double hy_, double hz_, double rq_, double *dd, double &d2) -> bool {
             const double hc[3] = {hx_, hy_, hz_};
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(256) void snap_particle_kernel(const SnapParams P)
             double v = p[k] + off[k];                          // :262-265
             v = (v > L) ? v - L : v;                           // :268-273
             v = (v < 0.0) ? v + L : v;
-            P.out[ip * NDIM + k] = v;
+            P.out[ip * P.ostride + k] = v;
         }
     }
     __shared__ unsigned long long s_red[2][4];
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(256) void snap_key_kernel(const SnapParams P)
         int key = -1;
         if (ip < P.n_part) {
             key = 0;
-            for (int k = 0; k < NDIM; ++k) key = key * n + snap_cell_of(P.part[ip * NDIM + k], inv_cell, n);
+            for (int k = 0; k < NDIM; ++k) key = key * n + snap_cell_of(P.part[ip * P.pstride + k], inv_cell, n);
             P.pkey[ip] = key;
         }
         (void)wave_group_slot(P.pcount, key, key >= 0);
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(256) void snap_cell_kernel(const SnapParams P)
             const bool valid = qb + lane < p1;
             const int64_t ip = P.perm[valid ? qb + lane : p1 - 1];
             double p[3] = {0.0, 0.0, 0.0}, off[3] = {0.0, 0.0, 0.0};
-            for (int k = 0; k < NDIM; ++k) p[k] = P.part[ip * NDIM + k];
+            for (int k = 0; k < NDIM; ++k) p[k] = P.part[ip * P.pstride + k];
             // one candidate against this lane's particle: periodic distance (compute_distance / enforce_periodicity,
             // :104-158; KDTree radius :225 / :240), then the read-out
             auto visit = [&](double hx_, double hy_, double hz_, double rq_, double xcut_, double lnshift_, int j) {
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(256) void snap_cell_kernel(const SnapParams P)
                     double v = p[k] + off[k];                  // :262-265
                     v = (v > L) ? v - L : v;                   // :268-273
                     v = (v < 0.0) ? v + L : v;
-                    P.out[ip * NDIM + k] = v;
+                    P.out[ip * P.ostride + k] = v;
                 }
             }
         }
@@ -511,8 +512,9 @@ struct DepositParams {
     int ndim, mode, N;
     int64_t n_part;
     double L;
-    const double *pos;               // [n_part][ndim]
-    const double *mass;              // [n_part] or nullptr
+    const double *pos;               // particle k, coordinate c at pos[k * pstride + c]
+    const double *mass;              // particle k at mass[k * mstride], or nullptr
+    int64_t pstride, mstride;
     double *grid;                    // [N^ndim], C order (x slowest), accumulated into
 };
 
@@ -533,12 +535,12 @@ __global__ __launch_bounds__(256) void deposit_kernel(const DepositParams P)
 {
     const int64_t ip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (ip >= P.n_part) return;
-    const double m = P.mass ? P.mass[ip] : 1.0;
+    const double m = P.mass ? P.mass[ip * P.mstride] : 1.0;
     const double step = P.L / (double)P.N;
     if (P.mode == 0) {
         int64_t c = 0;
         for (int k = 0; k < NDIM; ++k) {
-            const int i = ngp_bin(P.pos[ip * NDIM + k], step, P.N, P.L);
+            const int i = ngp_bin(P.pos[ip * P.pstride + k], step, P.N, P.L);
             if (i < 0) return;
             c = c * P.N + i;
         }
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(256) void deposit_kernel(const DepositParams P)
         int i0[NDIM];
         double w1[NDIM];
         for (int k = 0; k < NDIM; ++k) {
-            const double u = P.pos[ip * NDIM + k] / step - 0.5;     // in units of cells, relative to cell centres
+            const double u = P.pos[ip * P.pstride + k] / step - 0.5;     // in units of cells, relative to cell centres
             const double f = floor(u);
             w1[k] = u - f;
             int i = (int)f % P.N; if (i < 0) i += P.N;
@@ -622,7 +624,7 @@ __global__ __launch_bounds__(256) void dep_key_kernel(const DepSortParams S)
             key = 0;
             for (int k = 0; k < NDIM; ++k) {
                 int i0; double w1;
-                if (!dep_cell<MODE>(P.pos[ip * NDIM + k], step, P.N, P.L, i0, w1)) { key = -1; break; }
+                if (!dep_cell<MODE>(P.pos[ip * P.pstride + k], step, P.N, P.L, i0, w1)) { key = -1; break; }
                 key = key * S.nt + i0 / T;
             }
         }
@@ -649,12 +651,12 @@ __global__ __launch_bounds__(256) void dep_overflow_kernel(const DepSortParams S
     const double step = P.L / (double)P.N;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
         const int64_t ip = S.ovf[q];
-        const double m = P.mass ? P.mass[ip] : 1.0;
+        const double m = P.mass ? P.mass[ip * P.mstride] : 1.0;
         if (P.mode == BFG_DEPOSIT_NGP) {
             int64_t c = 0;
             bool ok = true;
             for (int k = 0; k < NDIM; ++k) {
-                const int i = ngp_bin(P.pos[ip * NDIM + k], step, P.N, P.L);
+                const int i = ngp_bin(P.pos[ip * P.pstride + k], step, P.N, P.L);
                 if (i < 0) { ok = false; break; }
                 c = c * P.N + i;
             }
@@ -662,7 +664,7 @@ __global__ __launch_bounds__(256) void dep_overflow_kernel(const DepSortParams S
         } else {
             int i0[NDIM];
             double w1[NDIM];
-            for (int k = 0; k < NDIM; ++k) (void)dep_cell<BFG_DEPOSIT_CIC>(P.pos[ip * NDIM + k], step, P.N, P.L, i0[k], w1[k]);
+            for (int k = 0; k < NDIM; ++k) (void)dep_cell<BFG_DEPOSIT_CIC>(P.pos[ip * P.pstride + k], step, P.N, P.L, i0[k], w1[k]);
             for (int corner = 0; corner < (1 << NDIM); ++corner) {
                 double w = m;
                 int64_t c = 0;
@@ -701,8 +703,8 @@ __global__ __launch_bounds__(kDepThreads) void dep_tile_kernel(const DepSortPara
         for (int u = 0; u < U; ++u) ip[u] = (qb + u * kDepThreads < q1) ? S.perm[qb + u * kDepThreads] : -1;
         for (int u = 0; u < U; ++u) {
             if (ip[u] < 0) continue;
-            for (int k = 0; k < NDIM; ++k) x[u][k] = P.pos[ip[u] * NDIM + k];
-            m[u] = P.mass ? P.mass[ip[u]] : 1.0;
+            for (int k = 0; k < NDIM; ++k) x[u][k] = P.pos[ip[u] * P.pstride + k];
+            m[u] = P.mass ? P.mass[ip[u] * P.mstride] : 1.0;
         }
         for (int u = 0; u < U; ++u) {
             if (ip[u] < 0) continue;

@@ -233,7 +233,9 @@ class Context(object):
 
     def baryonify_snapshot(self, d_part, d_halo, ndim, L, a, epsilon_max, runner_md, model_md, model_epsilon_max,
                            rdelta_sampling, n_extra, table, d_out):
-        """bfg_baryonify_snapshot: d_part float64[n, ndim], d_halo float64[n_halo, 5 + n_extra] (M, lnM, x, y, z, extras)"""
+        """bfg_baryonify_snapshot_strided: d_part / d_out float64[n, ndim] tensors or column views of wider record
+        tensors (inner stride 1, any row stride), d_halo float64[n_halo, 5 + n_extra] (M, lnM, x, y, z, extras)"""
+        assert d_part.stride(1) == 1 and d_out.stride(1) == 1 and d_out.shape == d_part.shape
         args = _lib.SnapshotArgs()
         args.ndim, args.rdelta_sampling = int(ndim), int(bool(rdelta_sampling))
         args.n_part, args.n_halo = int(d_part.shape[0]), int(d_halo.shape[0])
@@ -244,8 +246,9 @@ class Context(object):
         args.epsilon_max = float(epsilon_max)
         args.runner_md, args.model_md = runner_md, model_md
         args.model_epsilon_max = float(model_epsilon_max)
-        _lib.check(self.lib.bfg_baryonify_snapshot(self.handle, C.byref(args), table.handle,
-                                                   C.c_void_p(d_out.data_ptr())), "bfg_baryonify_snapshot")
+        _lib.check(self.lib.bfg_baryonify_snapshot_strided(self.handle, C.byref(args), table.handle,
+                                                           C.c_void_p(d_out.data_ptr()), int(d_part.stride(0)),
+                                                           int(d_out.stride(0))), "bfg_baryonify_snapshot_strided")
 
     def grid_args(self, ndim, npix, d_bins, d_halo, a, epsilon_max, runner_md, model_md=None, model_epsilon_max=0.0,
                   rdelta_sampling=False, n_extra=0, d_rmat=None):
@@ -276,13 +279,16 @@ class Context(object):
                    "bfg_regrid_grid")
 
     def deposit_grid(self, d_pos, d_mass, L, n_grid, mode="ngp"):
-        """mass map float64[n_grid]*ndim of particles d_pos float64[n, ndim] (d_mass float64[n] or None)"""
+        """mass map float64[n_grid]*ndim of particles d_pos float64[n, ndim] (d_mass float64[n] or None); both may be
+        column views of one record tensor (bfg_deposit_grid_strided)"""
         ndim = int(d_pos.shape[1])
+        assert d_pos.stride(1) == 1
         d_grid = self.zeros(*([int(n_grid)] * ndim))
-        _lib.check(self.lib.bfg_deposit_grid(self.handle, ndim, int(d_pos.shape[0]), C.c_void_p(d_pos.data_ptr()),
-                                             C.c_void_p(d_mass.data_ptr()) if d_mass is not None else None, float(L),
-                                             int(n_grid), {"ngp": 0, "cic": 1}[mode], C.c_void_p(d_grid.data_ptr())),
-                   "bfg_deposit_grid")
+        _lib.check(self.lib.bfg_deposit_grid_strided(
+            self.handle, ndim, int(d_pos.shape[0]), C.c_void_p(d_pos.data_ptr()), int(d_pos.stride(0)),
+            C.c_void_p(d_mass.data_ptr()) if d_mass is not None else None,
+            int(d_mass.stride(0)) if d_mass is not None else 1, float(L), int(n_grid), {"ngp": 0, "cic": 1}[mode],
+            C.c_void_p(d_grid.data_ptr())), "bfg_deposit_grid_strided")
         return d_grid
 
     def build_displacement_table(self, geometry, r_int, dens_dmo, dens_dmb, r, rdelta=None, rdelta_range=None):

@@ -229,6 +229,25 @@ class ParticleSnapshot(object):
     def cosmology(self):
         return self.cosmo
 
+    @classmethod
+    def from_catalog(cls, cat, L, redshift, cosmo, is2D=False):
+        """adopt a structured particle array (fields M, x, y, z; e.g. the output of BaryonifySnapshot.process()) without
+        copying its columns (not in the reference, whose constructor always rebuilds the array)"""
+        self = cls.__new__(cls)
+        self.L, self.cat, self.redshift, self.is2D = L, cat, redshift, bool(is2D)
+        check_cosmology_dict(cosmo)
+        self.cosmo = cosmo
+        return self
+
+    def records(self):
+        """the catalogue as a float64[n, 4] matrix (M, x, y, z) -- a view when `cat` is the packed float64 record array
+        this class builds (io.py:553-560), else None"""
+        names = self.cat.dtype.names
+        if (names == ("M", "x", "y", "z") and self.cat.flags["C_CONTIGUOUS"] and self.cat.dtype.itemsize == 32 and
+                all(self.cat.dtype[nm] == np.float64 for nm in names)):
+            return self.cat.view(np.float64).reshape(self.cat.size, 4)
+        return None
+
     def make_map(self, N_grid, mode="ngp", device=False):
         """mode 'ngp' (the reference's histogram) or 'cic' (cloud-in-cell, periodic); device=True deposits on the GPU
         (bfg_deposit_grid) -- the host path is numpy, as in the reference, and only does 'ngp'."""
@@ -237,8 +256,14 @@ class ParticleSnapshot(object):
             from ..engine import get_context
             ctx = get_context()
             cols = ("x", "y") if self.is2D else ("x", "y", "z")
-            d_pos = ctx.to_device(np.stack([self.cat[c] for c in cols], axis=1))
-            return ctx.deposit_grid(d_pos, ctx.to_device(self.cat["M"]), self.L, N_grid, mode).cpu().numpy()
+            recs = self.records()
+            if recs is not None:                          # one upload of the records; positions and masses are column views
+                d_recs = ctx.to_device(recs)
+                d_pos, d_mass = d_recs[:, 1:1 + len(cols)], d_recs[:, 0]
+            else:
+                d_pos = ctx.to_device(np.stack([self.cat[c] for c in cols], axis=1))
+                d_mass = ctx.to_device(self.cat["M"])
+            return ctx.to_host(ctx.deposit_grid(d_pos, d_mass, self.L, N_grid, mode))
         bins = np.linspace(0, self.L, N_grid + 1)
         if self.is2D:
             coords = np.vstack([self.cat["x"], self.cat["y"]]).T

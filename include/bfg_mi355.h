@@ -163,6 +163,12 @@ typedef struct {
 } bfg_snapshot_args;
 int bfg_baryonify_snapshot(bfg_ctx *ctx, const bfg_snapshot_args *args, const bfg_table *table,
                            double *d_out /* device, float64[n_part][ndim] */);
+/* The same on particle RECORDS: coordinate k of particle i is read at d_part[i * part_stride + k] and written at
+ * d_out[i * out_stride + k] (strides in doubles, >= ndim).  ParticleSnapshot.cat (utils/io.py:497-560) is a packed
+ * float64 record array (M, x, y, z): with d_part = records + 1, part_stride = 4 the catalogue is used as it lies in
+ * memory, and a copy of the records with d_out = copy + 1, out_stride = 4 becomes the new catalogue.             */
+int bfg_baryonify_snapshot_strided(bfg_ctx *ctx, const bfg_snapshot_args *args, const bfg_table *table,
+                                   double *d_out, int64_t part_stride, int64_t out_stride);
 
 /* Periodic Cartesian grid runners (Runners/Map2DRunner.py), no ellipticity.  d_halo rows as for
  * bfg_baryonify_snapshot: (M, ln M as used for the table, x, y, z [0 in 2D], extras...); d_bins = the npix pixel
@@ -205,6 +211,9 @@ int bfg_regrid_grid(bfg_ctx *ctx, int ndim, int npix, const double *d_offsets, c
 #define BFG_DEPOSIT_CIC 1
 int bfg_deposit_grid(bfg_ctx *ctx, int ndim, int64_t n_part, const double *d_pos, const double *d_mass,
                      double L, int n_grid, int mode, double *d_grid);
+/* ... on particle records: position k of particle i at d_pos[i * pos_stride + k], its mass at d_mass[i * mass_stride]. */
+int bfg_deposit_grid_strided(bfg_ctx *ctx, int ndim, int64_t n_part, const double *d_pos, int64_t pos_stride,
+                             const double *d_mass, int64_t mass_stride, double L, int n_grid, int mode, double *d_grid);
 
 /* Displacement-table builder on the device: the arithmetic of BaryonificationClass.setup_interpolator
  * (Profiles/BaryonCorrection.py:225-304) with get_masses (:669-691 Baryonification2D, :552-575 Baryonification3D)

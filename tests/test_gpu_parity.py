@@ -491,6 +491,24 @@ def test_baryonify_snapshot_vs_oracle(cosmo, is2D, path, monkeypatch):
     got = np.stack([new["x"], new["y"]] + ([] if is2D else [new["z"]]), axis=1)
     _periodic_close(got, ref, L, 1e-9)
     assert R.last_stats["pixel_updates"] > 0
+    # the packed (M, x, y, z) float64 catalogue goes to the GPU as it lies in memory (strided entry points); any other
+    # layout -- here: an extra column -- has its coordinates gathered on the host: same result
+    wide = np.zeros(npart, dtype=Part.cat.dtype.descr + [("id", np.int64)])
+    for k in Part.cat.dtype.names:
+        wide[k] = Part.cat[k]
+    wide["id"] = np.arange(npart)
+    Part2 = bfg.ParticleSnapshot.from_catalog(wide, L, zs, cosmo, is2D=is2D)
+    assert Part.records() is not None and Part2.records() is None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        new2 = bfg.BaryonifySnapshot(Cat, Part2, epsilon_max=10, model=model, verbose=False).process()
+    assert new2.dtype == wide.dtype and np.array_equal(new2["id"], wide["id"])
+    assert np.array_equal(new2["M"], new["M"])
+    got2 = np.stack([new2["x"], new2["y"]] + ([] if is2D else [new2["z"]]), axis=1)
+    _periodic_close(got2, got, L, 1e-12)             # the candidate lists are filled in atomic order: sums differ by rounding
+    m1 = bfg.ParticleSnapshot.from_catalog(new, L, zs, cosmo, is2D=is2D).make_map(32, mode="cic", device=True)
+    m2 = bfg.ParticleSnapshot.from_catalog(new2, L, zs, cosmo, is2D=is2D).make_map(32, mode="cic", device=True)
+    np.testing.assert_allclose(m1, m2, rtol=1e-12, atol=1e-12)
 
 
 @pytest.mark.parametrize("path", ["direct", "tile"])
