@@ -238,7 +238,8 @@ class BaryonifyGrid(DefaultRunnerGrid):
         d_out = ctx.zeros(npx)
         ctx.regrid_grid(ndim, gm.Npix, d_off, d_in, d_out)                 # :586-613
         new_map = get_context().to_host(d_out).reshape(orig.shape)
-        new_sum, old_sum = np.sum(new_map), np.sum(orig)                   # :616-619
+        _, new_sum = ctx.absmax_sum(d_out)                                 # :616-619, summed on the device
+        _, old_sum = ctx.absmax_sum(d_in)
         assert np.isclose(new_sum, old_sum), \
             "ERROR in pixel regridding, sum(new_map) [%0.14e] != sum(oldmap) [%0.14e]" % (new_sum, old_sum)
         return new_map
