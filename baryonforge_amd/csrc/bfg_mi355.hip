@@ -760,6 +760,10 @@ __global__ __launch_bounds__(256, 4) void regrid_tile_kernel(Hpx hp, TileGeom ge
         if (d == 0.0) return;
         bool local = lr >= 0;
         int rel = 0;
+        // healpix_cxx quirk kept literally: for phi == 2 pi exactly (a pixel at phi = 0 nudged by a y-offset of 1e-20) on an
+        // unshifted ring, tmp = phi / dphi is exactly nr, i1 = nr is not wrapped, and the weight-1 deposit lands on pixel
+        // startpix + nr -- the first pixel of the NEXT ring.  Not an LDS row of this ring: global atomic at sp + i.
+        if (local && i >= rows[lr].nr) local = false;
         if (local) {
             const RgRow &t = rows[lr];
             rel = i - t.istart;

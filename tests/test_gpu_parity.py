@@ -779,6 +779,35 @@ def test_baryonify_offsets_nside1024_vs_oracle(cosmo):
     assert np.isclose(out.sum(), Shell.map.sum(), rtol=1e-12)
 
 
+@pytest.mark.parametrize("nside", [16, 128])
+def test_regrid_phi_two_pi_quirk(nside, monkeypatch):
+    """healpix_cxx get_interpol at phi == 2 pi exactly: a pixel at phi = 0 of an unshifted ring whose displaced direction
+    has y = -1e-22 gets phi = 2 pi after healpy's wrap, tmp = phi / dphi = nr exactly, and its weight-1 deposit goes to
+    pixel startpix + nr -- the first pixel of the next ring.  Both regrid kernels must do what the oracle does (found by
+    tools/soak.py: the tile-privatised kernel used to wrap that index back into the ring)."""
+    from baryonforge_amd.engine import get_context
+    ctx = get_context(0)
+    npix = 12 * nside * nside
+    rng = np.random.default_rng(nside)
+    off = rng.normal(0, 2e-4, (npix, 3))
+    off[rng.uniform(size=npix) < 0.5] = 0.0
+    ncap, nr = 2 * nside * (nside - 1), 4 * nside
+    firsts = ncap + nr * np.arange(1, 2 * nside, 2)              # first pixels (phi = 0) of the unshifted belt rings
+    off[firsts] = 0.0
+    off[firsts[::2], 1] = -1e-22                                  # nudged to phi = 2 pi
+    off[firsts[1::2], 1] = 1e-22                                  # control: stays at phi = +0
+    m_in = rng.uniform(1, 10, npix)
+    ref = orc.regrid_shell(nside, off, m_in)
+    moved = np.abs(ref[firsts[::2]]) < 1e-9                       # the quirk moved these pixels' own mass away
+    assert moved.any()
+    for path in ("tile", "pixel"):
+        if path == "pixel":
+            monkeypatch.setenv("BFG_REGRID", "pixel")
+        out = ctx.zeros(npix)
+        ctx.regrid_shell(nside, ctx.to_device(off), ctx.to_device(m_in), out, None)
+        assert_maps_close(out.cpu().numpy(), ref, RTOL, floor=BFLOOR, what=f"regrid {path}")
+
+
 # --------------------------------------------------------------------------- full-size properties (no oracle)
 def test_paint_full_size_linearity_1e5(cosmo):
     """BASELINE config[1] at full size (1e5 halos, NSIDE 1024): painting is linear in halos

@@ -43,23 +43,30 @@ while time.time() < t_end:
         axes = (zax, Max, rax, pax)
         extra = rng.uniform(0.65, 1.45, n)
         kw = {"cdelta": extra}
-    ref, ptot = oracle_paint(cosmo, ra, dec, M, z, axes, Tt, nside, eps, extra=None if extra is None else extra[:, None])
+    ips = bool(rng.uniform() < 0.3)                         # include_pixel_size
+    if rng.uniform() < 0.3:                                 # some halos outside the table hull (paint nothing, warn)
+        M = M.copy(); M[rng.uniform(size=n) < 0.1] = 10 ** rng.uniform(16.1, 16.5)
+        z = z.copy(); z[rng.uniform(size=n) < 0.05] = 1.3
+    ref, ptot = oracle_paint(cosmo, ra, dec, M, z, axes, Tt, nside, eps, include_pixel_size=ips,
+                             extra=None if extra is None else extra[:, None])
     Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo, **kw)
     model = bfg.TabulatedProfile.from_arrays(zax, Max, rax, T) if extra is None else \
         bfg.ParamTabulatedProfile.from_arrays(zax, Max, rax, Tt, other_params={"cdelta": pax})
-    R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), eps, model, verbose=False)
+    R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), eps, model,
+                               include_pixel_size=ips, verbose=False)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         got = R.process()
-    tag = f"case {case}: nside {nside} n {n} eps {eps} {layout} table {shape}"
+    tag = f"case {case}: nside {nside} n {n} eps {eps} {layout} table {shape} ips {ips}"
     assert R.last_stats["pixel_updates"] == ptot, tag
     assert np.array_equal(got != 0, ref != 0), tag
     assert_maps_close(got, ref, 1e-5, what=tag)
     if extra is None and rng.uniform() < 0.5:
         zd, Md, rd, d = syn.displacement_table(*shape)
         m_in = syn.mass_map(nside)
-        refb = oracle_baryonify(cosmo, ra, dec, M, z, (zd, Md, rd), d, nside, eps, 20, m_in)
-        bm = bfg.Baryonification2D.from_arrays(zd, Md, rd, d, cosmo, epsilon_max=20)
+        rdelta = bool(rng.uniform() < 0.4)
+        refb = oracle_baryonify(cosmo, ra, dec, M, z, (zd, Md, rd), d, nside, eps, 20, m_in, rdelta=rdelta)
+        bm = bfg.Baryonification2D.from_arrays(zd, Md, rd, d, cosmo, epsilon_max=20, Rdelta_sampling=rdelta)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             gotb = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo), eps, bm, verbose=False).process()
