@@ -1369,7 +1369,7 @@ static int ensure_tiles(bfg_ctx *c, int mode, int tr, int64_t nside, int64_t n_h
     while (cap_direct > 32 && cap_direct * ts.geo.ntiles > ((int64_t)1 << 28)) cap_direct /= 2;
     if (const char *tc = std::getenv("BFG_TILE_CAP")) cap_direct = std::max<int64_t>(1, std::atoll(tc));   // test hook
     ts.cap_direct = (int)cap_direct;
-    int64_t want = 8 * n_halo + 65536;
+    int64_t want = std::min<int64_t>(8 * n_halo + 65536, ((int64_t)1 << 31) - 1 - cap_direct * ts.geo.ntiles);   // positions are 32-bit
     if (const char *pc = std::getenv("BFG_PAIR_CAP")) want = std::max<int64_t>(1, std::atoll(pc));   // test hook: tiny overflow region
     c->pair_cap = want;
     const int64_t alloc = cap_direct * ts.geo.ntiles + want;
@@ -1411,7 +1411,9 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
 
     int variant = a->variant;
     // the tile variant needs a uniform radial axis (direct cell computation)
-    const bool tile_ok = t->dev.r_uniform && !t->dev.hot && a->nside >= 8 && a->nside <= (1 << 24) && a->n_halo < (1ll << 31);
+    // pair counts and positions are 32-bit: at most kMaxPairsPerHalo = 64 pairs per halo -> n_halo <= 2^31 / 64 on the tile path
+    const bool tile_ok = t->dev.r_uniform && !t->dev.hot && a->nside >= 8 && a->nside <= (1 << 24) &&
+                         a->n_halo <= ((1ll << 31) / kMaxPairsPerHalo - 1);
     if (variant == BFG_VARIANT_AUTO) variant = tile_ok ? BFG_VARIANT_TILE_LDS : BFG_VARIANT_SCATTER_QUARTER;
     if (variant == BFG_VARIANT_TILE_LDS && !tile_ok) variant = BFG_VARIANT_SCATTER_QUARTER;
     const bool tile = (variant == BFG_VARIANT_TILE_LDS);
