@@ -1658,7 +1658,7 @@ int bfg_baryonify_snapshot_strided(bfg_ctx *c, const bfg_snapshot_args *a, const
 {
     int rc = ctx_enter(c);
     if (rc) return rc;
-    if (!a || !t || !d_out || (a->ndim != 2 && a->ndim != 3) || a->n_part < 0 || a->n_halo < 0 || !(a->L > 0) ||
+    if (!a || !t || (!d_out && a->n_part > 0) || (a->ndim != 2 && a->ndim != 3) || a->n_part < 0 || a->n_halo < 0 || !(a->L > 0) ||
         !(a->a > 0) || a->n_part >= (1ll << 31) || a->n_extra < 0 || a->halo_stride < 5 + a->n_extra)
         return BFG_ERR_INVALID;
     if (t->dev.ndim != 3 + a->n_extra || t->dev.log_values) return BFG_ERR_INVALID;       // linear displacement table

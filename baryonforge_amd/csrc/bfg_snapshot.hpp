@@ -291,6 +291,13 @@ __device__ inline void snap_hit(const SnapHit &H, double d2, const double *dd, i
 {
     const DevTable &T = *H.T;
     double rin, d, rinv;
+    if (d2 == 0.0) {
+        // a particle exactly on the halo centre: the reference's unit vector is 0 / 0 and its (zeroed) offset times that is
+        // NaN (SnapshotRunner.py:228-232 / :244-249) -- the particle's new position is NaN there, so it is here
+        for (int k = 0; k < ndim; ++k) off[k] += nan("");
+        ++n_oob;                                       // r = 0 lies below the table's radial axis (BaryonCorrection.py:391-394)
+        return;
+    }
     if (d2 >= 1e-290 && d2 <= 1e290) {
         double y = __builtin_amdgcn_rsq(d2);
         double g = d2 * y, h = 0.5 * y;

@@ -1116,3 +1116,49 @@ def test_tabulated_correlation3d_matches_scipy():
         assert np.isnan(X(r, 0.3)).all() and np.isnan(got).any()
     Y = bfg.utils.TabulatedCorrelation3D.from_arrays(X.raw_input_z_range, X.raw_input_r_range, X.raw_input_3D)
     np.testing.assert_array_equal(Y(r[:50], 0.9), X(r[:50], 0.9))
+
+
+def test_snapshot_and_grid_edge_cases(cosmo):
+    """empty halo catalogue / empty particle set, particles sitting exactly on a halo centre (NaN, as in the reference),
+    a halo whose mass lies outside the table (contributes nothing, warns),
+    a halo with a NaN mass; grid paint with no halos"""
+    import warnings
+    L, zs = 80.0, 0.3
+    rng = np.random.default_rng(9)
+    P = rng.uniform(0, L, (5000, 3))
+    H = rng.uniform(0, L, (6, 3)).astype(np.float32).astype(np.float64)
+    hM = np.array([3e13, 8e14, 2e14, 1e18, np.nan, 5e13])
+    P[:3] = H[:3]                                                          # particles on halo centres
+    zax, Max, rax, d = syn.displacement_table()
+    model = bfg.Baryonification2D.from_arrays(zax, Max, rax, d, cosmo, epsilon_max=20)
+    Part = bfg.ParticleSnapshot(x=P[:, 0], y=P[:, 1], z=P[:, 2], M=np.ones(len(P)), L=L, redshift=zs, cosmo=cosmo)
+    Cat = bfg.HaloNDCatalog(H[:, 0], H[:, 1], hM, zs, cosmo, z=H[:, 2])
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        new = bfg.BaryonifySnapshot(Cat, Part, epsilon_max=10, model=model, verbose=False).process()
+        c = Cat.cat
+        ref = orc.baryonify_snapshot(cosmo, L, zs, P[:, 0], P[:, 1], P[:, 2], c["M"], c["x"], c["y"], c["z"], (zax, Max, rax),
+                                     d, 10, 20)
+    got = np.stack([new["x"], new["y"], new["z"]], axis=1)
+    # 0 / 0 in the reference's unit vector: the three particles on halo centres come back NaN (SnapshotRunner.py:228-232)
+    assert np.isnan(ref[:3]).all() and np.array_equal(np.isnan(got), np.isnan(ref))
+    ok = ~np.isnan(ref).any(axis=1)
+    _periodic_close(got[ok], ref[ok], L, 1e-9)
+    assert any("outside table" in str(x.message) for x in w)               # the 1e18 Msun halo
+    # no halos: the particles come back unchanged; no particles: an empty catalogue
+    Cat0 = bfg.HaloNDCatalog(H[:0, 0], H[:0, 1], hM[:0], zs, cosmo, z=H[:0, 2])
+    new0 = bfg.BaryonifySnapshot(Cat0, Part, epsilon_max=10, model=model, verbose=False).process()
+    for k, col in zip(("x", "y", "z"), range(3)):
+        assert np.array_equal(new0[k], P[:, col])
+    Part0 = bfg.ParticleSnapshot(x=P[:0, 0], y=P[:0, 1], z=P[:0, 2], M=np.ones(0), L=L, redshift=zs, cosmo=cosmo)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert bfg.BaryonifySnapshot(Cat, Part0, epsilon_max=10, model=model, verbose=False).process().size == 0
+    # grid paint without halos: the zero map
+    N = 32
+    bins = (np.arange(N) + 0.5) * (L / N)
+    zp, Mp, rp, T = syn.pressure_table()
+    paint = bfg.TabulatedProfile.from_arrays(zp, Mp, rp, T, T)
+    out = bfg.PaintProfilesGrid(Cat0, bfg.GriddedMap(map=np.zeros((N, N, N)), redshift=zs, bins=bins, cosmo=cosmo), 5, paint,
+                                verbose=False).process()
+    assert out.shape == (N, N, N) and not out.any()
