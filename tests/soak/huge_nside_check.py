@@ -3,8 +3,8 @@
 on a few hundred halos (poles and the phi = 0 seam included): pixel-update count, non-zero set, values."""
 import os, sys, time
 import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
 import baryonforge_amd as bfg
 from baryonforge_amd import synthetic as syn

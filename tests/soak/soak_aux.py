@@ -4,8 +4,8 @@
 passes).  usage: soak_aux.py [seconds] [seed]"""
 import os, sys, time, warnings
 import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
 import baryonforge_amd as bfg
 from baryonforge_amd import synthetic as syn

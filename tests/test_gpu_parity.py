@@ -784,7 +784,7 @@ def test_regrid_phi_two_pi_quirk(nside, monkeypatch):
     """healpix_cxx get_interpol at phi == 2 pi exactly: a pixel at phi = 0 of an unshifted ring whose displaced direction
     has y = -1e-22 gets phi = 2 pi after healpy's wrap, tmp = phi / dphi = nr exactly, and its weight-1 deposit goes to
     pixel startpix + nr -- the first pixel of the next ring.  Both regrid kernels must do what the oracle does (found by
-    tools/soak.py: the tile-privatised kernel used to wrap that index back into the ring)."""
+    tests/soak/soak.py: the tile-privatised kernel used to wrap that index back into the ring)."""
     from baryonforge_amd.engine import get_context
     ctx = get_context(0)
     npix = 12 * nside * nside

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE config 4 at scale: BaryonifySnapshot 3D on n^3 particles (default 512^3) + 1e5 halos + CIC deposit.
-Times the C-ABI calls with inputs resident in HBM; checks a sample of particles against the oracle."""
+Times the C-ABI calls with inputs resident in HBM (parity: tests/test_gpu_parity.py, tests/soak/soak_aux.py)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -51,12 +51,3 @@ for _ in range(reps):
     print(f"displace {1e3*(t2-t1):8.2f} ms   deposit {1e3*(t3-t2):7.2f} ms")
 dt = (time.perf_counter() - t0) / reps
 print(f"{npart} particles, {nhalo} halos, L {L}: {1e3*dt:.2f} ms per pass = {nhalo/dt:.3e} halos/s; (halo, particle) pairs {st['pixel_updates']:.4g}; grid sum {float(grid.sum()):.6e} vs {npart}")
-# parity on a sub-volume: the oracle (KDTree) on the particles of one corner + all halos that can reach them
-if len(sys.argv) > 5:
-    sub = (P[:, 0] < 60) & (P[:, 1] < 60) & (P[:, 2] < 60)
-    idx = torch.nonzero(sub).squeeze(1)[:200000]
-    from oracle import oracle as orc
-    Pn = P.cpu().numpy()
-    ref = orc.baryonify_snapshot(cosmo, L, zs, Pn[:, 0], Pn[:, 1], Pn[:, 2], hM, H[:, 0], H[:, 1], H[:, 2], (zax, Max, rax), d, 10, 20)
-    dd = np.abs(d_out.cpu().numpy() - ref); dd = np.minimum(dd, L - dd)
-    print("max periodic deviation vs oracle", dd.max())
