@@ -760,10 +760,6 @@ __global__ __launch_bounds__(256, 4) void regrid_tile_kernel(Hpx hp, TileGeom ge
         if (d == 0.0) return;
         bool local = lr >= 0;
         int rel = 0;
-        // healpix_cxx quirk kept literally: for phi == 2 pi exactly (a pixel at phi = 0 nudged by a y-offset of 1e-20) on an
-        // unshifted ring, tmp = phi / dphi is exactly nr, i1 = nr is not wrapped, and the weight-1 deposit lands on pixel
-        // startpix + nr -- the first pixel of the NEXT ring.  Not an LDS row of this ring: global atomic at sp + i.
-        if (local && i >= rows[lr].nr) local = false;
         if (local) {
             const RgRow &t = rows[lr];
             rel = i - t.istart;
@@ -816,6 +812,10 @@ __global__ __launch_bounds__(256, 4) void regrid_tile_kernel(Hpx hp, TileGeom ge
             int ib = ia + 1;
             if (ia < 0) ia += nr1;
             if (ib >= nr1) ib -= nr1;
+            // healpix_cxx quirk kept literally: for phi == 2 pi exactly (a pixel at phi = 0 nudged by a y-offset of 1e-20) on
+            // an unshifted ring, tmp = phi / dphi is exactly nr, i1 = nr is not wrapped, and the weight-1 deposit lands on
+            // pixel startpix + nr -- the first pixel of the NEXT ring.  Not this ring's LDS row: global atomics (lr = -1).
+            if (ia >= nr1) lr1 = -1;
             i1a = ia; i1b = ib; w0 = 1 - ww; w1 = ww;
         }
         if (ir2 < nl4) {
@@ -829,6 +829,7 @@ __global__ __launch_bounds__(256, 4) void regrid_tile_kernel(Hpx hp, TileGeom ge
             int ib = ia + 1;
             if (ia < 0) ia += nr2;
             if (ib >= nr2) ib -= nr2;
+            if (ia >= nr2) lr2 = -1;                                   // same quirk on the lower ring
             i2a = ia; i2b = ib; w2 = 1 - ww; w3 = ww;
         }
         if (ir1 == 0) {                                                // above the first ring: its 4 pixels share the rest
