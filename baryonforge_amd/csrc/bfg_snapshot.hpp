@@ -62,6 +62,21 @@ struct SnapParams {
     int32_t *perm;                   // [n_part]
 };
 
+// particle coordinates from / to a record array with a runtime row stride; the packed case (stride == NDIM) keeps its
+// compile-time stride so that the three loads / stores of a particle stay one wide access
+template <int NDIM>
+__device__ inline void load_coords(const double *base, int64_t ip, int64_t stride, double *p)
+{
+    if (stride == NDIM) { for (int k = 0; k < NDIM; ++k) p[k] = base[ip * NDIM + k]; }
+    else { for (int k = 0; k < NDIM; ++k) p[k] = base[ip * stride + k]; }
+}
+template <int NDIM>
+__device__ inline void store_coords(double *base, int64_t ip, int64_t stride, const double *v)
+{
+    if (stride == NDIM) { for (int k = 0; k < NDIM; ++k) base[ip * NDIM + k] = v[k]; }
+    else { for (int k = 0; k < NDIM; ++k) base[ip * stride + k] = v[k]; }
+}
+
 __device__ inline int snap_cell_of(double x, double inv_cell, int n)
 {
     int i = (int)floor(x * inv_cell);
@@ -291,13 +306,6 @@ __device__ inline void snap_hit(const SnapHit &H, double d2, const double *dd, i
 {
     const DevTable &T = *H.T;
     double rin, d, rinv;
-    if (d2 == 0.0) {
-        // a particle exactly on the halo centre: the reference's unit vector is 0 / 0 and its (zeroed) offset times that is
-        // NaN (SnapshotRunner.py:228-232 / :244-249) -- the particle's new position is NaN there, so it is here
-        for (int k = 0; k < ndim; ++k) off[k] += nan("");
-        ++n_oob;                                       // r = 0 lies below the table's radial axis (BaryonCorrection.py:391-394)
-        return;
-    }
     if (d2 >= 1e-290 && d2 <= 1e290) {
         double y = __builtin_amdgcn_rsq(d2);
         double g = d2 * y, h = 0.5 * y;
@@ -309,6 +317,14 @@ __device__ inline void snap_hit(const SnapHit &H, double d2, const double *dd, i
         rin = 0.5 * fast_log(d2, H.logtab) - lnshift;
         if (fabs(rin - H.r_lo) < 1e-9 || fabs(rin - H.r_hi) < 1e-9) rin = log(sqrt(d2)) - lnshift;
     } else {
+        if (d2 == 0.0) {
+            // a particle exactly on the halo centre: the reference's unit vector is 0 / 0 and its (zeroed) offset times that
+            // is NaN (SnapshotRunner.py:228-232 / :244-249) -- the particle's new position is NaN there, so it is here.
+            // (Tested in this rare branch: the same test ahead of the fast path cost the kernel 7 %.)
+            for (int k = 0; k < ndim; ++k) off[k] += nan("");
+            ++n_oob;                                   // r = 0 lies below the table's radial axis (BaryonCorrection.py:391-394)
+            return;
+        }
         d = sqrt(d2); rinv = 1.0 / d;
         rin = log(d) - lnshift;
     }
@@ -349,7 +365,8 @@ __global__ __launch_bounds__(256) void snap_particle_kernel(const SnapParams P)
         const double inv_cell = (double)n / L;
         double p[3] = {0.0, 0.0, 0.0}, off[3] = {0.0, 0.0, 0.0};
         int64_t cid = 0;
-        for (int k = 0; k < NDIM; ++k) { p[k] = P.part[ip * P.pstride + k]; cid = cid * n + snap_cell_of(p[k], inv_cell, n); }
+        load_coords<NDIM>(P.part, ip, P.pstride, p);
+        for (int k = 0; k < NDIM; ++k) cid = cid * n + snap_cell_of(p[k], inv_cell, n);
         // a candidate: periodic distance test (compute_distance / enforce_periodicity, :104-158; KDTree radius :225 / :240)
         auto test = [&](double hx_, double hy_, double hz_, double rq_, double *dd, double &d2) -> bool {
             const double hc[3] = {hx_, hy_, hz_};
@@ -394,12 +411,14 @@ __global__ __launch_bounds__(256) void snap_particle_kernel(const SnapParams P)
             double dd[3] = {0, 0, 0}, d2;
             if (test(h.x, h.y, h.z, h.rq, dd, d2)) { ++hits; snap_hit(H, d2, dd, NDIM, j, h.xcut, h.lnshift, off, n_oob); }
         }
+        double pn[3] = {0.0, 0.0, 0.0};
         for (int k = 0; k < NDIM; ++k) {
             double v = p[k] + off[k];                          // :262-265
             v = (v > L) ? v - L : v;                           // :268-273
             v = (v < 0.0) ? v + L : v;
-            P.out[ip * P.ostride + k] = v;
+            pn[k] = v;
         }
+        store_coords<NDIM>(P.out, ip, P.ostride, pn);
     }
     __shared__ unsigned long long s_red[2][4];
     for (int o = 32; o > 0; o >>= 1) { hits += __shfl_down(hits, o, 64); n_oob += __shfl_down(n_oob, o, 64); }
@@ -434,7 +453,9 @@ __global__ __launch_bounds__(256) void snap_key_kernel(const SnapParams P)
         int key = -1;
         if (ip < P.n_part) {
             key = 0;
-            for (int k = 0; k < NDIM; ++k) key = key * n + snap_cell_of(P.part[ip * P.pstride + k], inv_cell, n);
+            double pk[3];
+            load_coords<NDIM>(P.part, ip, P.pstride, pk);
+            for (int k = 0; k < NDIM; ++k) key = key * n + snap_cell_of(pk[k], inv_cell, n);
             P.pkey[ip] = key;
         }
         (void)wave_group_slot(P.pcount, key, key >= 0);
@@ -462,7 +483,7 @@ __global__ __launch_bounds__(256) void snap_cell_kernel(const SnapParams P)
             const bool valid = qb + lane < p1;
             const int64_t ip = P.perm[valid ? qb + lane : p1 - 1];
             double p[3] = {0.0, 0.0, 0.0}, off[3] = {0.0, 0.0, 0.0};
-            for (int k = 0; k < NDIM; ++k) p[k] = P.part[ip * P.pstride + k];
+            load_coords<NDIM>(P.part, ip, P.pstride, p);
             // one candidate against this lane's particle: periodic distance (compute_distance / enforce_periodicity,
             // :104-158; KDTree radius :225 / :240), then the read-out
             auto visit = [&](double hx_, double hy_, double hz_, double rq_, double xcut_, double lnshift_, int j) {
@@ -488,12 +509,14 @@ __global__ __launch_bounds__(256) void snap_cell_kernel(const SnapParams P)
                 visit(h.x, h.y, h.z, h.rq, h.xcut, h.lnshift, j);
             }
             if (valid) {
+                double pn[3] = {0.0, 0.0, 0.0};
                 for (int k = 0; k < NDIM; ++k) {
                     double v = p[k] + off[k];                  // :262-265
                     v = (v > L) ? v - L : v;                   // :268-273
                     v = (v < 0.0) ? v + L : v;
-                    P.out[ip * P.ostride + k] = v;
+                    pn[k] = v;
                 }
+                store_coords<NDIM>(P.out, ip, P.ostride, pn);
             }
         }
     }
@@ -544,10 +567,12 @@ __global__ __launch_bounds__(256) void deposit_kernel(const DepositParams P)
     if (ip >= P.n_part) return;
     const double m = P.mass ? P.mass[ip * P.mstride] : 1.0;
     const double step = P.L / (double)P.N;
+    double xp[3];
+    load_coords<NDIM>(P.pos, ip, P.pstride, xp);
     if (P.mode == 0) {
         int64_t c = 0;
         for (int k = 0; k < NDIM; ++k) {
-            const int i = ngp_bin(P.pos[ip * P.pstride + k], step, P.N, P.L);
+            const int i = ngp_bin(xp[k], step, P.N, P.L);
             if (i < 0) return;
             c = c * P.N + i;
         }
@@ -556,7 +581,7 @@ __global__ __launch_bounds__(256) void deposit_kernel(const DepositParams P)
         int i0[NDIM];
         double w1[NDIM];
         for (int k = 0; k < NDIM; ++k) {
-            const double u = P.pos[ip * P.pstride + k] / step - 0.5;     // in units of cells, relative to cell centres
+            const double u = xp[k] / step - 0.5;                     // in units of cells, relative to cell centres
             const double f = floor(u);
             w1[k] = u - f;
             int i = (int)f % P.N; if (i < 0) i += P.N;
@@ -629,9 +654,11 @@ __global__ __launch_bounds__(256) void dep_key_kernel(const DepSortParams S)
         int key = -1;
         if (ip < P.n_part) {
             key = 0;
+            double xp[3];
+            load_coords<NDIM>(P.pos, ip, P.pstride, xp);
             for (int k = 0; k < NDIM; ++k) {
                 int i0; double w1;
-                if (!dep_cell<MODE>(P.pos[ip * P.pstride + k], step, P.N, P.L, i0, w1)) { key = -1; break; }
+                if (!dep_cell<MODE>(xp[k], step, P.N, P.L, i0, w1)) { key = -1; break; }
                 key = key * S.nt + i0 / T;
             }
         }
@@ -659,11 +686,13 @@ __global__ __launch_bounds__(256) void dep_overflow_kernel(const DepSortParams S
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
         const int64_t ip = S.ovf[q];
         const double m = P.mass ? P.mass[ip * P.mstride] : 1.0;
+        double xp[3];
+        load_coords<NDIM>(P.pos, ip, P.pstride, xp);
         if (P.mode == BFG_DEPOSIT_NGP) {
             int64_t c = 0;
             bool ok = true;
             for (int k = 0; k < NDIM; ++k) {
-                const int i = ngp_bin(P.pos[ip * P.pstride + k], step, P.N, P.L);
+                const int i = ngp_bin(xp[k], step, P.N, P.L);
                 if (i < 0) { ok = false; break; }
                 c = c * P.N + i;
             }
@@ -671,7 +700,7 @@ __global__ __launch_bounds__(256) void dep_overflow_kernel(const DepSortParams S
         } else {
             int i0[NDIM];
             double w1[NDIM];
-            for (int k = 0; k < NDIM; ++k) (void)dep_cell<BFG_DEPOSIT_CIC>(P.pos[ip * P.pstride + k], step, P.N, P.L, i0[k], w1[k]);
+            for (int k = 0; k < NDIM; ++k) (void)dep_cell<BFG_DEPOSIT_CIC>(xp[k], step, P.N, P.L, i0[k], w1[k]);
             for (int corner = 0; corner < (1 << NDIM); ++corner) {
                 double w = m;
                 int64_t c = 0;
@@ -710,7 +739,7 @@ __global__ __launch_bounds__(kDepThreads) void dep_tile_kernel(const DepSortPara
         for (int u = 0; u < U; ++u) ip[u] = (qb + u * kDepThreads < q1) ? S.perm[qb + u * kDepThreads] : -1;
         for (int u = 0; u < U; ++u) {
             if (ip[u] < 0) continue;
-            for (int k = 0; k < NDIM; ++k) x[u][k] = P.pos[ip[u] * P.pstride + k];
+            load_coords<NDIM>(P.pos, ip[u], P.pstride, x[u]);
             m[u] = P.mass ? P.mass[ip[u] * P.mstride] : 1.0;
         }
         for (int u = 0; u < U; ++u) {
