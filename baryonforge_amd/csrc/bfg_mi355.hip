@@ -190,7 +190,8 @@ __device__ inline double massdef_radius(const bfg_massdef &md, double M, double 
 {
     double rho;
     if (md.rho_type == 0) {
-        double E2 = md.Omega_m / (a * a * a) + md.Omega_l * pow(a, -3.0 * (1.0 + md.w0)) +
+        const double de = (md.w0 == -1.0) ? 1.0 : pow(a, -3.0 * (1.0 + md.w0));    // pow(a, -0.0) == 1: skip it for Lambda
+        double E2 = md.Omega_m / (a * a * a) + md.Omega_l * de +
                     md.Omega_r / (a * a * a * a);
         rho = md.rho_crit0_h2 * md.h * md.h * E2;
     } else {
