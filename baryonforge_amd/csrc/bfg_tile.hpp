@@ -518,7 +518,7 @@ constexpr int kSegExtra = 64;        // LDS room for second pieces of ring windo
 template <int MODE> struct TileCfg;
 template <> struct TileCfg<MODE_PAINT> {
     // rings per tile, accumulators per pixel, (pair, ring) slots / pairs per chunk, pixel -> segment table entries per round
-    static constexpr int TR = 64, NACC = 1, SLOTMAX = 512, PAIRMAX = 56, PIXMAX = 6144, QCAP = 120;
+    static constexpr int TR = 64, NACC = 1, SLOTMAX = 512, PAIRMAX = 64, PIXMAX = 6144, QCAP = 40;
     static constexpr int SEGMAX = SLOTMAX + kSegExtra;
     using Pair = PairInfo;
 };
@@ -538,6 +538,9 @@ __host__ __device__ constexpr size_t tile_lds_bytes()
            Cfg::PIXMAX * sizeof(uint16_t) + kPrOff * sizeof(int32_t) + Cfg::SEGMAX * sizeof(uint8_t) +
            Cfg::QCAP * sizeof(DeferredPixel) + 8 * sizeof(int32_t);
 }
+
+// two tile workgroups share a CU's 160 KB of LDS
+static_assert(tile_lds_bytes<MODE_PAINT>() <= 81920 && tile_lds_bytes<MODE_BARYONIFY>() <= 81920, "two workgroups per CU");
 
 // sin(h) for h^2 <= kSinSmall: odd series to h^7 (rel err < 3e-12)
 __device__ inline double sin_small(double h, double h2)
