@@ -833,6 +833,46 @@ def test_paint_full_size_linearity_1e5(cosmo):
     assert np.all(full >= 0) and np.isfinite(full).all()
 
 
+def test_workspace_regrowth_and_call_order(cosmo):
+    """One context serves shells of very different sizes in any order (the per-halo, tile-list and row-window
+    workspaces grow, are reused while larger than needed, and serve paint and baryonify alternately): every catalog
+    gives the same map whatever ran before it, and linearity ties the sizes together."""
+    ra, dec, M, z = syn.catalog(1500000, seed=77)
+    zax, Max, rax, T = syn.pressure_table()
+    model = _paint_model(zax, Max, rax, T)
+    dz, dM, dr, d = syn.displacement_table()
+    dmodel = bfg.Baryonification2D.from_arrays(dz, dM, dr, d, cosmo, epsilon_max=20)
+    nside = 512
+    Shell = bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo)
+    m_in = syn.mass_map(nside)
+
+    def paint(n0, n1):
+        Cat = bfg.HaloLightConeCatalog(ra[n0:n1], dec[n0:n1], M[n0:n1], z[n0:n1], cosmo)
+        R = bfg.PaintProfilesShell(Cat, Shell, 10, model, verbose=False)
+        return R.process(), R.last_stats["pixel_updates"]
+
+    def baryonify(n0, n1):
+        import warnings
+        Cat = bfg.HaloLightConeCatalog(ra[n0:n1], dec[n0:n1], M[n0:n1], z[n0:n1], cosmo)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo), 10, dmodel, verbose=False).process()
+
+    cuts = [(0, 1000000), (1000000, 1000007), (0, 1500000), (1000007, 1100000), (5, 5), (1100000, 1500000)]
+    first = {c: paint(*c) for c in cuts}
+    b_first = baryonify(0, 20000)
+    second = {c: paint(*c) for c in reversed(cuts)}               # shrinking, growing, empty: the other way round
+    b_second = baryonify(0, 20000)
+    for c in cuts:
+        assert first[c][1] == second[c][1]
+        assert_maps_close(second[c][0], first[c][0], 1e-10, what=f"order independence {c}")
+    assert first[(5, 5)][1] == 0 and not first[(5, 5)][0].any()
+    parts = [(0, 1000000), (1000000, 1000007), (1000007, 1100000), (1100000, 1500000)]
+    assert sum(first[c][1] for c in parts) == first[(0, 1500000)][1]
+    assert_maps_close(sum(first[c][0] for c in parts), first[(0, 1500000)][0], 1e-10, what="linearity across sizes")
+    assert_maps_close(b_second, b_first, 1e-9, floor=BFLOOR, what="baryonify between paints")
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("nside", [8, 24, 37, 100])
 def test_paint_and_baryonify_any_nside(cosmo, nside, variant):
