@@ -129,3 +129,52 @@ def test_cabi_paint_and_baryonify_without_torch_types(cosmo, variant):
     _lib.check(L.bfg_table_destroy(ctx, dtab))
     _lib.check(L.bfg_spline_destroy(ctx, spl))
     _lib.check(L.bfg_ctx_destroy(ctx))
+
+
+def test_cabi_context_lifecycle_frees_its_memory(cosmo):
+    """create -> paint + offsets + regrid (all workspaces grow) -> destroy, six times: bfg_ctx_destroy gives back what the
+    context took, results do not depend on the context's age"""
+    import torch
+    from scipy import interpolate
+    L = _lib.load()
+    nside, npix, n = 512, 12 * 512 * 512, 200000
+    ra, dec, M, z = syn.catalog(n, seed=5)
+    bg = Background(cosmo)
+    z_t = np.linspace(0, z.max() + 0.1, 1000)
+    cs = interpolate.CubicSpline(z_t, bg.angular_diameter_distance(1 / (1 + z_t)))
+    knots, coef = np.ascontiguousarray(cs.x), np.ascontiguousarray(cs.c)
+    zax, Max, rax, T = syn.pressure_table()
+    dz, dM, dr, d = syn.displacement_table()
+    m_in = syn.mass_map(nside)
+    free_after, maps = [], []
+    for it in range(6):
+        ctx = C.c_void_p()
+        _lib.check(L.bfg_ctx_create(0, C.c_void_p(-1), C.byref(ctx)), "ctx")
+        spl = C.c_void_p()
+        _lib.check(L.bfg_spline_create(ctx, knots.size, _dp(knots), _dp(coef), C.byref(spl)), "spline")
+        d_cat = Dev(L, ctx, n * 32).up(np.stack([M, z, ra, dec], 1))
+        args = _lib.ShellArgs()
+        args.nside, args.n_halo, args.d_catalog, args.cat_stride, args.n_extra = nside, n, d_cat.p.value, 4, 0
+        args.epsilon_max, args.runner_md, args.model_md = 10.0, _massdef(bg), _massdef(bg)
+        args.model_epsilon_max, args.variant = 20.0, 0
+        tab = _table(L, ctx, (zax, Max, rax), np.log(T), _lib.BFG_TABLE_LOG_VALUES)
+        dtab = _table(L, ctx, (dz, dM, dr), d, 0)
+        d_map = Dev(L, ctx, npix * 8).zero()
+        _lib.check(L.bfg_paint_shell(ctx, C.byref(args), tab, spl, d_map.p), "paint")
+        d_off, d_in, d_out, d_sums = Dev(L, ctx, npix * 24).zero(), Dev(L, ctx, npix * 8).up(m_in), \
+            Dev(L, ctx, npix * 8).zero(), Dev(L, ctx, 16)
+        _lib.check(L.bfg_baryonify_offsets(ctx, C.byref(args), dtab, spl, d_off.p), "offsets")
+        _lib.check(L.bfg_regrid_shell(ctx, nside, d_off.p, d_in.p, d_out.p, d_sums.p), "regrid")
+        _lib.check(L.bfg_ctx_synchronize(ctx))
+        maps.append((d_map.down(npix), d_out.down(npix)))
+        for b in (d_cat, d_map, d_off, d_in, d_out, d_sums):
+            b.free()
+        _lib.check(L.bfg_table_destroy(ctx, tab))
+        _lib.check(L.bfg_table_destroy(ctx, dtab))
+        _lib.check(L.bfg_spline_destroy(ctx, spl))
+        _lib.check(L.bfg_ctx_destroy(ctx))
+        free_after.append(torch.cuda.mem_get_info(0)[0])
+    assert abs(free_after[-1] - free_after[0]) <= (8 << 20), free_after       # nothing accumulates from context to context
+    for p, b in maps[1:]:
+        assert_maps_close(p, maps[0][0], 1e-10, what="paint, fresh context")
+        assert_maps_close(b, maps[0][1], 1e-9, floor=1e-9, what="baryonify, fresh context")
