@@ -833,6 +833,48 @@ def test_paint_full_size_linearity_1e5(cosmo):
     assert np.all(full >= 0) and np.isfinite(full).all()
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_non_finite_and_unphysical_catalog_rows_are_inert(cosmo, variant):
+    """rows healpy's query_disc would find no pixel for (NaN / infinite / negative radius: HealpixRunner.py:329 with a NaN,
+    zero or negative mass, z <= -1, non-finite angles) paint nothing, displace nothing and disturb no other halo"""
+    import warnings
+    nside = 256
+    ra, dec, M, z = syn.catalog(4000, seed=404)
+    good = np.ones(ra.size, bool)
+    bad = {7: ("M", np.nan), 19: ("M", -1e14), 33: ("M", 0.0), 101: ("M", np.inf), 251: ("z", -1.0),
+           252: ("z", -3.0), 999: ("ra", np.nan), 1000: ("ra", np.inf), 1500: ("dec", np.nan),
+           1501: ("dec", -np.inf), 3999: ("M", np.nan), 0: ("M", np.nan)}
+    cols = {"ra": ra, "dec": dec, "M": M, "z": z}
+    for i, (c, v) in bad.items():
+        cols[c][i] = v
+        good[i] = False
+    zax, Max, rax, T = syn.pressure_table()
+    model = _paint_model(zax, Max, rax, T)
+    dz, dM, dr, d = syn.displacement_table()
+    dmodel = bfg.Baryonification2D.from_arrays(dz, dM, dr, d, cosmo, epsilon_max=20)
+    m_in = syn.mass_map(nside)
+
+    def both(sel):
+        Cat = bfg.HaloLightConeCatalog(ra[sel], dec[sel], M[sel], z[sel], cosmo)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), 10, model,
+                                       verbose=False, variant=variant)
+            p = R.process()
+            B = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo), 10, dmodel, verbose=False,
+                                   variant=variant)
+            return p, R.last_stats["pixel_updates"], B.process()
+    p_all, n_all, b_all = both(slice(None))
+    p_good, n_good, b_good = both(good)
+    assert np.isfinite(p_all).all() and np.isfinite(b_all).all()
+    assert n_all >= n_good                      # an infinite mass is a whole-sky disc of zeros: visited, adds nothing
+    assert_maps_close(p_all, p_good, 1e-10, what="paint with inert rows")
+    assert_maps_close(b_all, b_good, 1e-9, floor=BFLOOR, what="baryonify with inert rows")
+    z[5] = np.nan                                # a NaN (or > 30) redshift fails the reference's max(z) assertion (:301, :433)
+    with pytest.raises(AssertionError, match="max"):
+        both(slice(None))
+
+
 def test_workspace_regrowth_and_call_order(cosmo):
     """One context serves shells of very different sizes in any order (the per-halo, tile-list and row-window
     workspaces grow, are reused while larger than needed, and serve paint and baryonify alternately): every catalog
