@@ -875,6 +875,46 @@ def test_non_finite_and_unphysical_catalog_rows_are_inert(cosmo, variant):
         both(slice(None))
 
 
+def test_snapshot_and_deposit_non_finite_rows_are_contained():
+    """NaN / infinite particle coordinates and NaN / infinite / negative halo rows (the reference's KDTree refuses such
+    input): nothing faults, every clean particle moves exactly as in the clean run, NGP drops what histogramdd drops"""
+    import torch
+    from baryonforge_amd.background import Background
+    from baryonforge_amd.engine import get_context
+    ctx = get_context(0)
+    rng = np.random.default_rng(11)
+    L, npart, nhalo = 200.0, 200000, 600
+    P = rng.uniform(0, L, (npart, 3))
+    H = rng.uniform(0, L, (nhalo, 3))
+    hM = 10 ** rng.uniform(13.0, 15.0, nhalo)
+    zax, Max, rax, d = syn.displacement_table()
+    table = ctx.table([zax, Max, rax], d, log_values=False)
+    md = ctx.massdef_struct(Background(dict(syn.COSMO)), None)
+
+    def run(P, H, hM):
+        with np.errstate(all="ignore"):
+            halos = np.stack([hM, np.log(hM), H[:, 0], H[:, 1], H[:, 2]], axis=1)
+        d_p, d_h = ctx.to_device(P), ctx.to_device(halos)
+        d_out = torch.empty_like(d_p)
+        ctx.baryonify_snapshot(d_p, d_h, 3, L, 0.8, 10.0, md, md, 20.0, False, 0, table, d_out)
+        grids = [ctx.deposit_grid(d_out, None, L, 64, m).cpu().numpy() for m in ("ngp", "cic")]
+        return d_out.cpu().numpy(), grids
+    clean, (ngp_clean, cic_clean) = run(P, H, hM)
+    P2, H2, M2 = P.copy(), H.copy(), hM.copy()
+    badp = np.array([3, 77, 1000, 5000, 123456, npart - 1])
+    P2[3, 0] = np.nan; P2[77, 1] = np.inf; P2[1000, 2] = -np.inf; P2[5000] = np.nan; P2[123456, 0] = 1e300; P2[npart - 1, 2] = -1e300
+    extra_h = np.array([[np.nan, 50, 50], [np.inf, 10, 10], [20, -np.inf, 20], [30, 30, 30], [40, 40, 40], [60, 60, 60], [70, 70, 70]])
+    extra_m = np.array([1e14, 1e14, 1e14, np.nan, -1e14, 0.0, np.inf])
+    H2, M2 = np.concatenate([H2, extra_h]), np.concatenate([M2, extra_m])
+    got, (ngp, cic) = run(P2, H2, M2)
+    ok = np.ones(npart, bool); ok[badp] = False
+    np.testing.assert_allclose(got[ok], clean[ok], rtol=1e-12, atol=1e-9)
+    # NGP: only in-box, finite particles are counted (np.histogramdd semantics)
+    inbox = np.all((got >= 0) & (got <= L), axis=1)
+    assert ngp.sum() == inbox.sum() and np.isfinite(ngp).all()
+    assert ngp_clean.sum() == npart and np.isclose(cic_clean.sum(), npart, rtol=1e-12)
+
+
 def test_workspace_regrowth_and_call_order(cosmo):
     """One context serves shells of very different sizes in any order (the per-halo, tile-list and row-window
     workspaces grow, are reused while larger than needed, and serve paint and baryonify alternately): every catalog
