@@ -158,7 +158,19 @@ class DefaultRunnerGrid(object):
         cols = [hcat["M"].astype(np.float64), lnM, hcat["x"].astype(np.float64), hcat["y"].astype(np.float64),
                 hcat["z"].astype(np.float64)] + [np.asarray(hcat[k], dtype=np.float64) for k in keys]
         halos = np.stack(cols, axis=1) if hcat.size else np.zeros((0, 5 + len(keys)))
-        return ctx.to_device(halos), ctx.to_device(np.asarray(self.GriddedMap.bins, dtype=np.float64))
+        bins = np.asarray(self.GriddedMap.bins, dtype=np.float64)
+        if self.GriddedMap.is2D and hcat.size:
+            # the reference's 2D branches assert dx <= res and dy <= res per halo (Map2DRunner.py:522 / :761 / :936), with
+            # dx = bins[argmin |bins - x|] - x: false only left of the grid by more than a pixel, or for a NaN position
+            res = self.GriddedMap.res
+            with np.errstate(all="ignore"):
+                ok = (bins[0] - cols[2] <= res) & (bins[0] - cols[3] <= res)
+            if not np.all(ok):
+                j = int(np.argmin(ok))
+                dx = bins[np.argmin(np.abs(bins - cols[2][j]))] - cols[2][j]
+                dy = bins[np.argmin(np.abs(bins - cols[3][j]))] - cols[3][j]
+                raise AssertionError("Halo offsets (%0.2f, %0.2f) are larger than res (%0.2f)" % (dx, dy, res))
+        return ctx.to_device(halos), ctx.to_device(bins)
 
 
 class PaintProfilesGrid(DefaultRunnerGrid):

@@ -406,3 +406,30 @@ def test_table_cache_never_hands_out_a_stale_table(monkeypatch):
     assert id(m) in key_ids and all(v[1][0] is m for v in ctx._table_cache.values())
     assert ctx.table(axes, raw, True, cache_key=(m, "3D", raw)) is not t2      # the tag is part of the key
     assert ctx.table(axes, lambda: raw, False, cache_key=None) is not None     # uncached
+
+
+def test_grid_runner_mirrors_the_halo_offset_assertion():
+    """Map2DRunner.py:522 / :761 / :936 (2D branches): a halo left of the grid by more than a pixel, or at a NaN position,
+    fails 'Halo offsets ... are larger than res'; +infinity and positions inside or right of the grid pass"""
+    import baryonforge_amd as bfg
+    from baryonforge_amd import synthetic as syn
+    from baryonforge_amd.Runners.Map2DRunner import DefaultRunnerGrid
+
+    class FakeCtx(object):
+        def to_device(self, a):
+            return a
+    cosmo = dict(syn.COSMO)
+    N, L = 64, 100.0
+    bins = (np.arange(N) + 0.5) * (L / N)
+    Map = bfg.GriddedMap(map=np.zeros((N, N)), redshift=0.2, bins=bins, cosmo=cosmo)
+
+    def inputs(x, y):
+        Cat = bfg.HaloNDCatalog(np.array(x, float), np.array(y, float), np.full(len(x), 1e14), 0.2, cosmo)
+        return DefaultRunnerGrid(Cat, Map, 6, None, verbose=False)._device_inputs(FakeCtx(), [])
+    halos, b = inputs([10.0, 99.9, 150.0, np.inf, bins[0] - 0.9 * L / N], [5.0, 5.0, 5.0, 5.0, 5.0])
+    assert halos.shape == (5, 5) and np.array_equal(b, bins)
+    for bad in (np.nan, -np.inf, bins[0] - 1.5 * L / N):
+        with pytest.raises(AssertionError, match="larger than res"):
+            inputs([10.0, bad], [5.0, 5.0])
+        with pytest.raises(AssertionError, match="larger than res"):
+            inputs([10.0, 20.0], [bad, 5.0])
