@@ -7,7 +7,7 @@ fallback.  Ellipticity (use_ellipticity=True) and PaintProfilesAnisGrid are not 
 """
 import numpy as np
 
-from ..background import Background, MassDef
+from ..background import Background, MassDef, lcdm
 from ..engine import emit_range_warnings, get_context
 from ..utils.Tabulate import ParamTabulatedProfile, _get_parameter
 from .HealpixRunner import _is_disp_table, _is_paint_table, _table_axes
@@ -204,7 +204,7 @@ class PaintProfilesGrid(DefaultRunnerGrid):
         gm = self.GriddedMap
         ndim = 2 if gm.is2D else 3
         d_halo, d_bins = self._device_inputs(ctx, keys)
-        bg = Background(self.cosmo)
+        bg = Background(lcdm(self.cosmo))
         a = 1 / (1 + self.HaloNDCatalog.redshift)                          # :707
         d_rmat = self._rmat_device(ctx)            # keep the tensor alive until the kernels have been enqueued
         args = ctx.grid_args(ndim, gm.Npix, d_bins, d_halo, a, self.epsilon_max, ctx.massdef_struct(bg, self.mass_def),
@@ -231,7 +231,7 @@ class BaryonifyGrid(DefaultRunnerGrid):
         table = ctx.table(_table_axes(model, keys), lambda: np.asarray(model.raw_input_d, dtype=np.float64),
                           log_values=False, cache_key=(model, "d", model.raw_input_d))
         d_halo, d_bins = self._device_inputs(ctx, keys)
-        bg = Background(self.cosmo)
+        bg = Background(lcdm(self.cosmo))
         model_bg = Background(model.cosmo) if getattr(model, "cosmo", None) is not None else bg
         a = 1 / (1 + self.HaloNDCatalog.redshift)                          # :470
         d_rmat = self._rmat_device(ctx)            # keep the tensor alive until the kernels have been enqueued
@@ -293,7 +293,7 @@ class PaintProfilesAnisGrid(PaintProfilesGrid):
         dL = 2 * _get_parameter(self.Mtot_model, "proj_cutoff")            # :876-878
         dV = np.power(res, 2) * dL
         rho_halos = float(d_mtot.mean().item()) / dL
-        rho_m = float(Background(self.cosmo).rho_x(1.0, "matter"))          # comoving matter density (:886)
+        rho_m = float(Background(lcdm(self.cosmo)).rho_x(1.0, "matter"))          # comoving matter density (:886)
         drho_m = float(np.clip(rho_m - rho_halos, 0, None))
         d_mtot += dV * drho_m
         if self.verbose:

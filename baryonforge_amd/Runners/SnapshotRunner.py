@@ -8,7 +8,7 @@ halo's sphere with one wavefront and accumulates the radial displacements with f
 """
 import numpy as np
 
-from ..background import Background, MassDef
+from ..background import Background, MassDef, lcdm
 from ..engine import emit_range_warnings, get_context
 from ..utils.Tabulate import ParamTabulatedProfile
 from ..Profiles.BaryonCorrection import BaryonificationClass
@@ -20,11 +20,12 @@ __all__ = ["DefaultRunnerSnapshot", "BaryonifySnapshot"]
 class DefaultRunnerSnapshot(object):
     """
     Base class (SnapshotRunner.py:11-158): holds the halo catalog, the particle snapshot, the cut-out size
-    `epsilon_max` (in halo radii), the `model` and the mass definition.  `KDTree_kwargs` is accepted for signature
-    parity and ignored: the neighbour search is a uniform cell grid on the GPU, built inside `process()`.
+    `epsilon_max` (in halo radii), the `model` and the mass definition.  Argument order as in the reference (:84-85):
+    (..., model, mass_def, verbose, KDTree_kwargs).  `KDTree_kwargs` is accepted for signature parity and ignored: the
+    neighbour search is a uniform cell grid on the GPU, built inside `process()`.
     """
 
-    def __init__(self, HaloNDCatalog, ParticleSnapshot, epsilon_max, model, KDTree_kwargs={}, mass_def=None, verbose=True):
+    def __init__(self, HaloNDCatalog, ParticleSnapshot, epsilon_max, model, mass_def=None, verbose=True, KDTree_kwargs={}):
         self.HaloNDCatalog = HaloNDCatalog
         self.ParticleSnapshot = ParticleSnapshot
         self.epsilon_max = epsilon_max
@@ -84,7 +85,7 @@ class BaryonifySnapshot(DefaultRunnerSnapshot):
                 hcat["z"].astype(np.float64)] + [np.asarray(hcat[k], dtype=np.float64) for k in keys]
         halos = np.stack(cols, axis=1) if hcat.size else np.zeros((0, 5 + len(keys)))
         a = 1 / (1 + self.HaloNDCatalog.redshift)                           # :219
-        bg = Background(self.cosmo)
+        bg = Background(lcdm(self.cosmo))        # the reference builds this cosmology without w0 (:197-200): w0 = -1
         model = self.model
         table = ctx.table(_table_axes(model, list(keys)), lambda: np.asarray(model.raw_input_d, dtype=np.float64),
                           log_values=False, cache_key=(model, "d", model.raw_input_d))

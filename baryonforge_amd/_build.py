@@ -2,6 +2,7 @@
 Build libbfg_mi355.so (the hand-written gfx950 kernels + C-ABI) in-tree with hipcc.
 hipcc cross-compiles for gfx950 without a GPU, so this also runs in the build container.
 """
+import fcntl
 import os
 import shutil
 import subprocess
@@ -32,12 +33,28 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
+    """Compile under an exclusive file lock into a temporary file and move it into place atomically: the ranks of a
+    torchrun job that all find the library stale neither interleave their linkers' writes nor load a half-written file
+    (the first rank builds, the others find it fresh once they get the lock)."""
     if not force and not needs_build():
         return SO
-    cmd = [find_hipcc()] + HIPCC_FLAGS + ["-o", SO, SRC]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=HERE)
+    with open(SO + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():
+                return SO
+            tmp = f"{SO}.{os.getpid()}.tmp"
+            cmd = [find_hipcc()] + HIPCC_FLAGS + ["-o", tmp, SRC]
+            if verbose:
+                print(" ".join(cmd))
+            try:
+                subprocess.check_call(cmd, cwd=HERE)
+                os.replace(tmp, SO)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return SO
 
 

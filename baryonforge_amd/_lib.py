@@ -30,7 +30,7 @@ WARN_Z_RANGE, WARN_M_RANGE, WARN_R_RANGE = 1, 2, 4
 # every symbol include/bfg_mi355.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "bfg_abi_version", "bfg_status_string", "bfg_last_error", "bfg_device_count",
-    "bfg_ctx_create", "bfg_ctx_destroy", "bfg_ctx_synchronize", "bfg_ctx_device_info",
+    "bfg_ctx_create", "bfg_ctx_destroy", "bfg_ctx_set_stream", "bfg_ctx_synchronize", "bfg_ctx_device_info",
     "bfg_dev_malloc", "bfg_dev_free", "bfg_memcpy_h2d", "bfg_memcpy_d2h", "bfg_dev_memset_zero",
     "bfg_table_create", "bfg_table_destroy", "bfg_table_eval",
     "bfg_spline_create", "bfg_spline_destroy",
@@ -38,7 +38,10 @@ SYMBOLS = [
     "bfg_baryonify_snapshot", "bfg_deposit_grid", "bfg_paint_grid", "bfg_baryonify_grid_offsets", "bfg_regrid_grid",
     "bfg_build_displacement_table", "bfg_baryonify_snapshot_strided", "bfg_deposit_grid_strided",
     "bfg_stats_reset", "bfg_stats_read", "bfg_timing_enable", "bfg_timing_read",
+    "bfg_comm_unique_id", "bfg_comm_init", "bfg_comm_destroy", "bfg_comm_info",
+    "bfg_allreduce_f64", "bfg_reduce_scatter_f64", "bfg_allgather_f64",
 ]
+BFG_COMM_ID_BYTES = 128
 
 
 class MassDefStruct(C.Structure):
@@ -114,6 +117,14 @@ def load(build_if_missing=True):
     L.bfg_device_count.argtypes = [C.POINTER(C.c_int)]
     L.bfg_ctx_create.argtypes = [C.c_int, _vp, C.POINTER(_vp)]
     L.bfg_ctx_destroy.argtypes = [_vp]
+    L.bfg_ctx_set_stream.argtypes = [_vp, _vp]
+    L.bfg_comm_unique_id.argtypes = [C.c_char_p, C.c_size_t]
+    L.bfg_comm_init.argtypes = [_vp, C.c_char_p, C.c_size_t, C.c_int, C.c_int]
+    L.bfg_comm_destroy.argtypes = [_vp]
+    L.bfg_comm_info.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.bfg_allreduce_f64.argtypes = [_vp, _vp, _i64]
+    L.bfg_reduce_scatter_f64.argtypes = [_vp, _vp, _i64]
+    L.bfg_allgather_f64.argtypes = [_vp, _vp, _i64]
     L.bfg_ctx_synchronize.argtypes = [_vp]
     L.bfg_ctx_device_info.argtypes = [_vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                       C.POINTER(_i64)]
@@ -159,7 +170,7 @@ def check(status, what=""):
     if status != BFG_OK:
         L = load()
         msg = L.bfg_status_string(status).decode()
-        detail = L.bfg_last_error().decode() if status == -2 else ""
+        detail = L.bfg_last_error().decode() if status in (-2, -6) else ""
         raise BFGError(f"{what}: {msg} ({status}) {detail}".strip())
 
 

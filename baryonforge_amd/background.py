@@ -58,6 +58,14 @@ def as_cosmo_dict(cosmo):
     return out
 
 
+def lcdm(cosmo):
+    """The cosmology the reference's grid and snapshot runners build: the same dict WITHOUT w0 (Map2DRunner.py:462-465,
+    :705-708, :851-854; SnapshotRunner.py:197-200 pass no w0 to ccl.Cosmology), i.e. w0 = -1 whatever the catalog says."""
+    out = dict(as_cosmo_dict(cosmo))
+    out["w0"] = -1.0
+    return out
+
+
 class Background(object):
     """E(a), chi(a), D_A(a), rho_x(a) of a flat wCDM cosmology with radiation."""
 

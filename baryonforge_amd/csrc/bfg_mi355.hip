@@ -127,7 +127,10 @@ struct bfg_ctx {
     size_t ev_used[5];
     double t_ms[5];
     int64_t t_n[5];
+    hipEvent_t ev_switch;           // orders the context's work across a change of stream (bfg_ctx_set_stream)
+    struct bfg_comm_state *comm;    // RCCL communicator of bfg_comm_init (multi-GPU), or null
 };
+static void bfg_comm_release(bfg_ctx *c);
 
 struct ShellParams {
     Hpx hpx;
@@ -966,6 +969,7 @@ const char *bfg_status_string(int s)
     case BFG_ERR_NO_DEVICE: return "no usable gfx950 device";
     case BFG_ERR_UNSUPPORTED: return "unsupported configuration";
     case BFG_ERR_NOMEM: return "out of memory";
+    case BFG_ERR_COMM: return "RCCL error";
     default: return "unknown status";
     }
 }
@@ -982,31 +986,33 @@ int bfg_device_count(int *count)
     return BFG_OK;
 }
 
-int bfg_ctx_create(int device_id, void *stream, bfg_ctx **out)
+// Every entry point makes the context's GPU current for the duration of the call and puts the caller's device back on
+// return: a process that drives several GPUs through several contexts keeps its own notion of the current device.
+struct DeviceGuard {
+    int prev = -1;
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+static int ctx_enter(bfg_ctx *c, DeviceGuard &g)
 {
-    if (!out) return BFG_ERR_INVALID;
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
-        (void)hipGetLastError();
-        g_last_error = "hipGetDeviceCount found no device";
-        return BFG_ERR_NO_DEVICE;
+    if (!c) return BFG_ERR_INVALID;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = -1; }
+    if (cur != c->device) {
+        HIP_TRY(hipSetDevice(c->device));
+        g.prev = cur;
     }
-    if (device_id < 0 || device_id >= n) return BFG_ERR_INVALID;
-    HIP_TRY(hipSetDevice(device_id));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
-    bfg_ctx *c = new bfg_ctx();
-    std::memset((void *)c, 0, sizeof(*c));
-    c->device = device_id;
-    c->n_cu = prop.multiProcessorCount;
-    c->lds_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
-    c->max_dyn_lds = prop.sharedMemPerBlock;
+    return BFG_OK;
+}
+
+static int ctx_create_body(bfg_ctx *c, void *stream)
+{
     if (stream == BFG_STREAM_OWN) { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     else { c->stream = (hipStream_t)stream; c->own_stream = false; }   // NULL = the legacy default stream
     HIP_TRY(hipMalloc((void **)&c->d_stats, sizeof(bfg_stats)));
     HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(bfg_stats), c->stream));
     HIP_TRY(hipMalloc((void **)&c->d_red, 4 * sizeof(double)));
-    for (int k = 0; k < 5; ++k) { c->ev_a[k] = new std::vector<hipEvent_t>(); c->ev_b[k] = new std::vector<hipEvent_t>(); }
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_switch, hipEventDisableTiming));
     {   // ln / exp tables of the tile kernels: {1/c, ln c} with c = 1 + (i + 0.5)/128, and 2^(j/64)
         std::vector<double> mt(2 * kLogTab + kExpTab);
         for (int i = 0; i < kLogTab; ++i) {
@@ -1019,30 +1025,51 @@ int bfg_ctx_create(int device_id, void *stream, bfg_ctx **out)
         HIP_TRY(hipMalloc((void **)&c->d_pair_total, sizeof(unsigned long long)));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
+    return BFG_OK;
+}
+
+static void ctx_free_all(bfg_ctx *c);
+
+int bfg_ctx_create(int device_id, void *stream, bfg_ctx **out)
+{
+    if (!out) return BFG_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        g_last_error = "hipGetDeviceCount found no device";
+        return BFG_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n) return BFG_ERR_INVALID;
+    DeviceGuard dg_;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = -1; }
+    HIP_TRY(hipSetDevice(device_id));
+    if (cur != device_id) dg_.prev = cur;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    bfg_ctx *c = new bfg_ctx();
+    std::memset((void *)c, 0, sizeof(*c));
+    c->device = device_id;
+    c->n_cu = prop.multiProcessorCount;
+    c->lds_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+    c->max_dyn_lds = prop.sharedMemPerBlock;
+    for (int k = 0; k < 5; ++k) { c->ev_a[k] = new std::vector<hipEvent_t>(); c->ev_b[k] = new std::vector<hipEvent_t>(); }
+    const int rc = ctx_create_body(c, stream);
+    if (rc != BFG_OK) { ctx_free_all(c); return rc; }          // nothing of a half-built context is left behind
     *out = c;
     return BFG_OK;
 }
 
-static int ctx_enter(bfg_ctx *c)
+static void ctx_free_all(bfg_ctx *c)
 {
-    if (!c) return BFG_ERR_INVALID;
-    HIP_TRY(hipSetDevice(c->device));
-    return BFG_OK;
-}
-
-int bfg_ctx_destroy(bfg_ctx *c)
-{
-    int rc = ctx_enter(c);
-    if (rc) return rc;
-    (void)hipStreamSynchronize(c->stream);
     if (c->d_rec) (void)hipFree(c->d_rec);
     if (c->d_irec) (void)hipFree(c->d_irec);
     if (c->d_cidx) (void)hipFree(c->d_cidx);
     if (c->d_cw) (void)hipFree(c->d_cw);
     if (c->d_ht) (void)hipFree(c->d_ht);
     if (c->d_hwin) (void)hipFree(c->d_hwin);
-    (void)hipFree(c->d_stats);
-    (void)hipFree(c->d_red);
+    if (c->d_stats) (void)hipFree(c->d_stats);
+    if (c->d_red) (void)hipFree(c->d_red);
     for (int m = 0; m < 2; ++m) {
         if (c->tiles[m].d_geo) (void)hipFree(c->tiles[m].d_geo);
         if (c->tiles[m].d_tile_count) (void)hipFree(c->tiles[m].d_tile_count);
@@ -1057,20 +1084,52 @@ int bfg_ctx_destroy(bfg_ctx *c)
     for (int k = 0; k < 5; ++k) if (c->dep_buf[k]) (void)hipFree(c->dep_buf[k]);
     if (c->d_pairs) (void)hipFree(c->d_pairs);
     if (c->d_ovf_mask) (void)hipFree(c->d_ovf_mask);
-    (void)hipFree(c->d_mathtab); (void)hipFree(c->d_pair_total);
+    if (c->d_mathtab) (void)hipFree(c->d_mathtab);
+    if (c->d_pair_total) (void)hipFree(c->d_pair_total);
     for (int k = 0; k < 5; ++k) {
+        if (!c->ev_a[k]) continue;
         for (hipEvent_t e : *c->ev_a[k]) (void)hipEventDestroy(e);
         for (hipEvent_t e : *c->ev_b[k]) (void)hipEventDestroy(e);
         delete c->ev_a[k]; delete c->ev_b[k];
     }
-    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    if (c->ev_switch) (void)hipEventDestroy(c->ev_switch);
+    if (c->comm) bfg_comm_release(c);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+int bfg_ctx_destroy(bfg_ctx *c)
+{
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
+    if (rc) return rc;
+    (void)hipStreamSynchronize(c->stream);
+    ctx_free_all(c);
+    return BFG_OK;
+}
+
+// Re-bind the context to another stream of its GPU (e.g. torch's current stream at call time).  The context's
+// workspaces are shared by consecutive calls, so the new stream is made to wait for everything the context has
+// enqueued on the old one (an event, no host synchronisation): calls on alternating streams stay ordered.
+int bfg_ctx_set_stream(bfg_ctx *c, void *stream)
+{
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
+    if (rc) return rc;
+    if (stream == BFG_STREAM_OWN) return BFG_ERR_INVALID;
+    hipStream_t ns = (hipStream_t)stream;
+    if (ns == c->stream) return BFG_OK;
+    HIP_TRY(hipEventRecord(c->ev_switch, c->stream));
+    HIP_TRY(hipStreamWaitEvent(ns, c->ev_switch, 0));
+    if (c->own_stream) { HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipStreamDestroy(c->stream); c->own_stream = false; }
+    c->stream = ns;
     return BFG_OK;
 }
 
 int bfg_ctx_synchronize(bfg_ctx *c)
 {
-    int rc = ctx_enter(c);
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     return BFG_OK;
@@ -1078,7 +1137,8 @@ int bfg_ctx_synchronize(bfg_ctx *c)
 
 int bfg_ctx_device_info(bfg_ctx *c, char *name, int name_len, int *n_cu, int *lds, int64_t *hbm)
 {
-    int rc = ctx_enter(c);
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, c->device));
@@ -1091,7 +1151,8 @@ int bfg_ctx_device_info(bfg_ctx *c, char *name, int name_len, int *n_cu, int *ld
 
 int bfg_dev_malloc(bfg_ctx *c, size_t bytes, void **d_ptr)
 {
-    int rc = ctx_enter(c);
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     if (!d_ptr) return BFG_ERR_INVALID;
     HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 8));
@@ -1100,7 +1161,8 @@ int bfg_dev_malloc(bfg_ctx *c, size_t bytes, void **d_ptr)
 
 int bfg_dev_free(bfg_ctx *c, void *d_ptr)
 {
-    int rc = ctx_enter(c);
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipFree(d_ptr));
@@ -1109,7 +1171,8 @@ int bfg_dev_free(bfg_ctx *c, void *d_ptr)
 
 int bfg_memcpy_h2d(bfg_ctx *c, void *d_dst, const void *src, size_t bytes)
 {
-    int rc = ctx_enter(c);
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1118,7 +1181,8 @@ int bfg_memcpy_h2d(bfg_ctx *c, void *d_dst, const void *src, size_t bytes)
 
 int bfg_memcpy_d2h(bfg_ctx *c, void *dst, const void *d_src, size_t bytes)
 {
-    int rc = ctx_enter(c);
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1127,7 +1191,8 @@ int bfg_memcpy_d2h(bfg_ctx *c, void *dst, const void *d_src, size_t bytes)
 
 int bfg_dev_memset_zero(bfg_ctx *c, void *d_ptr, size_t bytes)
 {
-    int rc = ctx_enter(c);
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(d_ptr, 0, bytes, c->stream));
     return BFG_OK;
@@ -1137,7 +1202,8 @@ int bfg_dev_memset_zero(bfg_ctx *c, void *d_ptr, size_t bytes)
 int bfg_table_create(bfg_ctx *c, int ndim, const int64_t *shape, const double *const *axes,
                      const double *values, uint32_t flags, bfg_table **out)
 {
-    int rc = ctx_enter(c);
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     if (!shape || !axes || !values || !out) return BFG_ERR_INVALID;
     if (ndim < 3) return BFG_ERR_INVALID;
@@ -1203,15 +1269,20 @@ int bfg_table_create(bfg_ctx *c, int ndim, const int64_t *shape, const double *c
     D.r_uniform = uni ? 1 : 0; D.r0 = r[0]; D.inv_dr = uni ? 1.0 / dr : 0.0;
     if (D.log_values)
         for (double v : perm) if (std::isfinite(v) && std::fabs(v) > 650.0) { D.hot = 1; break; }
-    HIP_TRY(hipMemcpyAsync(t->d_blob, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (hipMemcpyAsync(t->d_blob, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) {
+        g_last_error = std::string("bfg_table_create upload: ") + hipGetErrorString(hipGetLastError());
+        (void)hipFree(t->d_blob); delete t;
+        return BFG_ERR_HIP;
+    }
     *out = t;
     return BFG_OK;
 }
 
 int bfg_table_destroy(bfg_ctx *c, bfg_table *t)
 {
-    int rc = ctx_enter(c);
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     if (!t) return BFG_ERR_INVALID;
     (void)hipStreamSynchronize(c->stream);
@@ -1222,7 +1293,8 @@ int bfg_table_destroy(bfg_ctx *c, bfg_table *t)
 
 int bfg_table_eval(bfg_ctx *c, const bfg_table *t, int64_t npts, const double *coords, double *out)
 {
-    int rc = ctx_enter(c);
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     if (!t || !coords || !out || npts < 0) return BFG_ERR_INVALID;
     if (npts == 0) return BFG_OK;
@@ -1243,24 +1315,32 @@ int bfg_table_eval(bfg_ctx *c, const bfg_table *t, int64_t npts, const double *c
 // ---- spline ----------------------------------------------------------------------------
 int bfg_spline_create(bfg_ctx *c, int n, const double *knots, const double *coef, bfg_spline **out)
 {
-    int rc = ctx_enter(c);
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     if (n < 2 || !knots || !coef || !out) return BFG_ERR_INVALID;
     for (int i = 1; i < n; ++i) if (!(knots[i] > knots[i - 1])) return BFG_ERR_INVALID;
     bfg_spline *s = new bfg_spline();
-    s->n = n;
-    HIP_TRY(hipMalloc((void **)&s->d_knots, (size_t)n * sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&s->d_coef, (size_t)4 * (n - 1) * sizeof(double)));
-    HIP_TRY(hipMemcpyAsync(s->d_knots, knots, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(s->d_coef, coef, (size_t)4 * (n - 1) * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    s->n = n; s->d_knots = nullptr; s->d_coef = nullptr;
+    if (hipMalloc((void **)&s->d_knots, (size_t)n * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&s->d_coef, (size_t)4 * (n - 1) * sizeof(double)) != hipSuccess ||
+        hipMemcpyAsync(s->d_knots, knots, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(s->d_coef, coef, (size_t)4 * (n - 1) * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) {
+        g_last_error = std::string("bfg_spline_create: ") + hipGetErrorString(hipGetLastError());
+        if (s->d_knots) (void)hipFree(s->d_knots);
+        if (s->d_coef) (void)hipFree(s->d_coef);
+        delete s;
+        return BFG_ERR_HIP;
+    }
     *out = s;
     return BFG_OK;
 }
 
 int bfg_spline_destroy(bfg_ctx *c, bfg_spline *s)
 {
-    int rc = ctx_enter(c);
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     if (!s) return BFG_ERR_INVALID;
     (void)hipStreamSynchronize(c->stream);
@@ -1401,7 +1481,8 @@ static int check_args(const bfg_shell_args *a, const bfg_table *t, const bfg_spl
 static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, const bfg_spline *s,
                      double *d_out, int mode)
 {
-    int rc = ctx_enter(c);
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     rc = check_args(a, t, s, d_out);
     if (rc) return rc;
@@ -1591,7 +1672,8 @@ int bfg_baryonify_offsets(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *
 int bfg_regrid_shell(bfg_ctx *c, int64_t nside, const double *d_offsets, const double *d_in_map,
                      double *d_out_map, double *d_sums)
 {
-    int rc = ctx_enter(c);
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     if (nside < 1 || nside > (1 << 20) || !d_offsets || !d_in_map || !d_out_map) return BFG_ERR_INVALID;
     Hpx hp = make_hpx(nside);
@@ -1616,7 +1698,8 @@ int bfg_regrid_shell(bfg_ctx *c, int64_t nside, const double *d_offsets, const d
 
 int bfg_reduce_absmax_sum(bfg_ctx *c, int64_t n, const double *d_x, double *absmax, double *sum)
 {
-    int rc = ctx_enter(c);
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     if (n < 0 || (n > 0 && !d_x)) return BFG_ERR_INVALID;
     double h[2] = {0.0, 0.0};
@@ -1658,7 +1741,8 @@ int bfg_baryonify_snapshot(bfg_ctx *c, const bfg_snapshot_args *a, const bfg_tab
 int bfg_baryonify_snapshot_strided(bfg_ctx *c, const bfg_snapshot_args *a, const bfg_table *t, double *d_out,
                                    int64_t part_stride, int64_t out_stride)
 {
-    int rc = ctx_enter(c);
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     if (!a || !t || (!d_out && a->n_part > 0) || (a->ndim != 2 && a->ndim != 3) || a->n_part < 0 || a->n_halo < 0 || !(a->L > 0) ||
         !(a->a > 0) || a->n_part >= (1ll << 31) || a->n_extra < 0 || a->halo_stride < 5 + a->n_extra)
@@ -1766,7 +1850,8 @@ int bfg_baryonify_snapshot_strided(bfg_ctx *c, const bfg_snapshot_args *a, const
 
 static int run_grid(bfg_ctx *c, const bfg_grid_args *a, const bfg_table *t, double *d_out, int mode)
 {
-    int rc = ctx_enter(c);
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     if (!a || !t || !d_out || (a->ndim != 2 && a->ndim != 3) || a->n_halo < 0 || a->npix < 4 || !(a->a > 0) ||
         a->n_extra < 0 || a->halo_stride < 5 + a->n_extra || !a->d_bins)
@@ -1908,7 +1993,8 @@ int bfg_baryonify_grid_offsets(bfg_ctx *c, const bfg_grid_args *a, const bfg_tab
 
 int bfg_regrid_grid(bfg_ctx *c, int ndim, int npix, const double *d_offsets, const double *d_in_map, double *d_out_map)
 {
-    int rc = ctx_enter(c);
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     if ((ndim != 2 && ndim != 3) || npix < 1 || !d_offsets || !d_in_map || !d_out_map) return BFG_ERR_INVALID;
     const int64_t ntot = (ndim == 2) ? (int64_t)npix * npix : (int64_t)npix * npix * npix;
@@ -1928,7 +2014,8 @@ int bfg_deposit_grid(bfg_ctx *c, int ndim, int64_t n_part, const double *d_pos, 
 int bfg_deposit_grid_strided(bfg_ctx *c, int ndim, int64_t n_part, const double *d_pos, int64_t pos_stride,
                              const double *d_mass, int64_t mass_stride, double L, int n_grid, int mode, double *d_grid)
 {
-    int rc = ctx_enter(c);
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     if ((ndim != 2 && ndim != 3) || n_part < 0 || !(L > 0) || n_grid < 1 || (mode != BFG_DEPOSIT_NGP && mode != BFG_DEPOSIT_CIC) ||
         !d_grid || (n_part > 0 && !d_pos))
@@ -1991,7 +2078,8 @@ int bfg_build_displacement_table(bfg_ctx *c, int geometry, int n_rows, int n_int
                                  const double *d_dens_dmo, const double *d_dens_dmb, int nr, const double *r,
                                  const double *rdelta, const double *rdelta_range, double *d_out, int32_t *status)
 {
-    int rc = ctx_enter(c);
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     if ((geometry != 2 && geometry != 3) || n_rows < 0 || n_int < 3 || nr < 2 || !r_int || !r || !d_out || !status ||
         (n_rows > 0 && (!d_dens_dmo || !d_dens_dmb)) || ((rdelta != nullptr) != (rdelta_range != nullptr)))
@@ -2037,7 +2125,8 @@ int bfg_build_displacement_table(bfg_ctx *c, int geometry, int n_rows, int n_int
 
 int bfg_stats_reset(bfg_ctx *c)
 {
-    int rc = ctx_enter(c);
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(bfg_stats), c->stream));
     return BFG_OK;
@@ -2045,7 +2134,8 @@ int bfg_stats_reset(bfg_ctx *c)
 
 int bfg_stats_read(bfg_ctx *c, bfg_stats *out)
 {
-    int rc = ctx_enter(c);
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     if (!out) return BFG_ERR_INVALID;
     HIP_TRY(hipMemcpyAsync(out, c->d_stats, sizeof(bfg_stats), hipMemcpyDeviceToHost, c->stream));
@@ -2059,7 +2149,8 @@ int bfg_stats_read(bfg_ctx *c, bfg_stats *out)
 
 int bfg_timing_enable(bfg_ctx *c, int enable)
 {
-    int rc = ctx_enter(c);
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->timing = enable != 0;
@@ -2069,7 +2160,8 @@ int bfg_timing_enable(bfg_ctx *c, int enable)
 
 int bfg_timing_read(bfg_ctx *c, int which, double *ms_total, int64_t *launches)
 {
-    int rc = ctx_enter(c);
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     if (which < 0 || which > 4) return BFG_ERR_INVALID;
     timing_fold(c, which);
@@ -2080,11 +2172,14 @@ int bfg_timing_read(bfg_ctx *c, int which, double *ms_total, int64_t *launches)
 
 }  // extern "C"
 
+#include "bfg_comm.hpp"
+
 #if BFG_STAGE_TIMING
 // profiling build only (not declared in include/bfg_mi355.h)
 extern "C" int bfg_debug_stage_cycles(bfg_ctx *c, unsigned long long *out8, int reset)
 {
-    int rc = ctx_enter(c);
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     (void)hipStreamSynchronize(c->stream);
     if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(bfg::g_stage_cycles), 8 * sizeof(unsigned long long));

@@ -27,11 +27,12 @@ def _torch():
 
 
 def _fingerprint(arr):
-    """cheap content stamp of an array: shape, a strided sample of <= 4096 elements and the two ends"""
-    a = np.asarray(arr)
-    flat = a.reshape(-1)
-    step = max(1, flat.size // 4096)
-    return (a.shape, a.dtype.str, flat[::step].tobytes(), flat[-1:].tobytes())
+    """content stamp of an array: shape, dtype and a hash of ALL its bytes (an in-place edit of any element between two
+    process() calls must miss the device-table cache: the reference re-reads its table on every call).  ~0.3 ms per MB,
+    small next to the upload it saves."""
+    import hashlib
+    a = np.ascontiguousarray(arr)
+    return (a.shape, a.dtype.str, hashlib.blake2b(a.view(np.uint8).reshape(-1), digest_size=16).digest())
 
 
 def require_gpu():
@@ -60,6 +61,7 @@ class Table(object):
         ax_ptrs = (C.POINTER(C.c_double) * self.ndim)(*[_lib.dptr(a) for a in axes])
         handle = C.c_void_p()
         flags = _lib.BFG_TABLE_LOG_VALUES if log_values else 0
+        ctx._on_current_stream()
         _lib.check(ctx.lib.bfg_table_create(ctx.handle, self.ndim, shape, ax_ptrs, _lib.dptr(values), flags,
                                             C.byref(handle)), "bfg_table_create")
         self.handle = handle
@@ -69,6 +71,7 @@ class Table(object):
         """stand-alone read-out at coords [npts, ndim] = (ln(1+z), ln M, ln r, extras...)"""
         coords = np.ascontiguousarray(coords, dtype=np.float64).reshape(-1, self.ndim)
         out = np.empty(coords.shape[0])
+        self.ctx._on_current_stream()
         _lib.check(self.ctx.lib.bfg_table_eval(self.ctx.handle, self.handle, coords.shape[0], _lib.dptr(coords),
                                                _lib.dptr(out)), "bfg_table_eval")
         return out
@@ -90,6 +93,7 @@ class Spline(object):
         assert coef.shape == (4, knots.size - 1)
         self.ctx = ctx
         handle = C.c_void_p()
+        ctx._on_current_stream()
         _lib.check(ctx.lib.bfg_spline_create(ctx.handle, knots.size, _lib.dptr(knots), _lib.dptr(coef),
                                              C.byref(handle)), "bfg_spline_create")
         self.handle = handle
@@ -103,7 +107,10 @@ class Spline(object):
 
 
 class Context(object):
-    """One bfg_ctx bound to a GPU and to torch's current stream on it."""
+    """One bfg_ctx per GPU.  Every call that enqueues work first binds the context to torch's CURRENT stream on that
+    GPU (`_on_current_stream`), so the kernels are ordered with the torch ops around them (zero-fills, copies,
+    collectives) also inside `with torch.cuda.stream(s)` blocks or after the caller changed the current stream; the
+    library orders its own work across such a change with an event (bfg_ctx_set_stream)."""
 
     def __init__(self, device_index):
         torch = require_gpu()
@@ -111,13 +118,65 @@ class Context(object):
         self.device_index = int(device_index)
         self.device = torch.device("cuda", self.device_index)
         with torch.cuda.device(self.device):
-            self.stream = torch.cuda.current_stream(self.device)
+            self._stream_ptr = int(torch.cuda.current_stream(self.device).cuda_stream)
             handle = C.c_void_p()
-            _lib.check(self.lib.bfg_ctx_create(self.device_index, C.c_void_p(self.stream.cuda_stream),
+            _lib.check(self.lib.bfg_ctx_create(self.device_index, C.c_void_p(self._stream_ptr),
                                                C.byref(handle)), "bfg_ctx_create")
         self.handle = handle
         self._table_cache = {}
         self._spline_cache = {}
+        self.comm_world = 1
+        self.comm_rank = 0
+
+    def _on_current_stream(self):
+        ptr = int(_torch().cuda.current_stream(self.device).cuda_stream)
+        if ptr != self._stream_ptr:
+            _lib.check(self.lib.bfg_ctx_set_stream(self.handle, C.c_void_p(ptr)), "bfg_ctx_set_stream")
+            self._stream_ptr = ptr
+
+    # ---- multi-GPU: RCCL communicator of this context (bfg_comm_*) ----------------------
+    def comm_init(self, dist=None, group=None):
+        """Build the context's RCCL communicator over the ranks of a torch.distributed process group (any backend: the
+        128-byte id travels through the group's object broadcast).  Needs one GPU per rank."""
+        if dist is None:
+            import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        ident = [None]
+        if rank == 0:
+            buf = C.create_string_buffer(_lib.BFG_COMM_ID_BYTES)
+            _lib.check(self.lib.bfg_comm_unique_id(buf, _lib.BFG_COMM_ID_BYTES), "bfg_comm_unique_id")
+            ident[0] = buf.raw
+        dist.broadcast_object_list(ident, src=0, group=group)
+        self.comm_init_id(ident[0], rank, world)
+
+    def comm_init_id(self, ident, rank, world):
+        self._on_current_stream()
+        _lib.check(self.lib.bfg_comm_init(self.handle, ident, len(ident), int(rank), int(world)), "bfg_comm_init")
+        self.comm_world, self.comm_rank = int(world), int(rank)
+
+    def comm_destroy(self):
+        _lib.check(self.lib.bfg_comm_destroy(self.handle), "bfg_comm_destroy")
+        self.comm_world, self.comm_rank = 1, 0
+
+    def allreduce(self, d_tensor):
+        """in-place sum over the ranks of the context's communicator, asynchronous on the current stream"""
+        assert d_tensor.is_contiguous() and d_tensor.dtype == _torch().float64
+        self._on_current_stream()
+        _lib.check(self.lib.bfg_allreduce_f64(self.handle, C.c_void_p(d_tensor.data_ptr()), d_tensor.numel()),
+                   "bfg_allreduce_f64")
+
+    def reduce_scatter(self, d_tensor):
+        """in place: rank r ends up owning the summed elements [r n / world, (r + 1) n / world)"""
+        assert d_tensor.is_contiguous() and d_tensor.dtype == _torch().float64
+        self._on_current_stream()
+        _lib.check(self.lib.bfg_reduce_scatter_f64(self.handle, C.c_void_p(d_tensor.data_ptr()), d_tensor.numel()),
+                   "bfg_reduce_scatter_f64")
+
+    def allgather(self, d_tensor):
+        assert d_tensor.is_contiguous() and d_tensor.dtype == _torch().float64
+        self._on_current_stream()
+        _lib.check(self.lib.bfg_allgather_f64(self.handle, C.c_void_p(d_tensor.data_ptr()), d_tensor.numel()),
+                   "bfg_allgather_f64")
 
     # ---- device info -------------------------------------------------------------
     def device_info(self):
@@ -127,6 +186,7 @@ class Context(object):
         return {"name": name.value.decode(), "n_cu": ncu.value, "lds_per_cu": lds.value, "hbm_bytes": hbm.value}
 
     def synchronize(self):
+        self._on_current_stream()
         _lib.check(self.lib.bfg_ctx_synchronize(self.handle), "bfg_ctx_synchronize")
 
     # ---- uploads ---------------------------------------------------------------------
@@ -218,14 +278,17 @@ class Context(object):
         return a
 
     def paint_shell(self, args, table, spline, d_map):
+        self._on_current_stream()
         _lib.check(self.lib.bfg_paint_shell(self.handle, C.byref(args), table.handle, spline.handle,
                                             C.c_void_p(d_map.data_ptr())), "bfg_paint_shell")
 
     def baryonify_offsets(self, args, table, spline, d_offsets):
+        self._on_current_stream()
         _lib.check(self.lib.bfg_baryonify_offsets(self.handle, C.byref(args), table.handle, spline.handle,
                                                   C.c_void_p(d_offsets.data_ptr())), "bfg_baryonify_offsets")
 
     def regrid_shell(self, nside, d_offsets, d_in_map, d_out_map, d_sums=None):
+        self._on_current_stream()
         _lib.check(self.lib.bfg_regrid_shell(self.handle, int(nside), C.c_void_p(d_offsets.data_ptr()),
                                              C.c_void_p(d_in_map.data_ptr()), C.c_void_p(d_out_map.data_ptr()),
                                              C.c_void_p(d_sums.data_ptr()) if d_sums is not None else None),
@@ -235,6 +298,7 @@ class Context(object):
                            rdelta_sampling, n_extra, table, d_out):
         """bfg_baryonify_snapshot_strided: d_part / d_out float64[n, ndim] tensors or column views of wider record
         tensors (inner stride 1, any row stride), d_halo float64[n_halo, 5 + n_extra] (M, lnM, x, y, z, extras)"""
+        self._on_current_stream()
         assert d_part.stride(1) == 1 and d_out.stride(1) == 1 and d_out.shape == d_part.shape
         args = _lib.SnapshotArgs()
         args.ndim, args.rdelta_sampling = int(ndim), int(bool(rdelta_sampling))
@@ -266,14 +330,17 @@ class Context(object):
         return g
 
     def paint_grid(self, args, table, d_map):
+        self._on_current_stream()
         _lib.check(self.lib.bfg_paint_grid(self.handle, C.byref(args), table.handle, C.c_void_p(d_map.data_ptr())),
                    "bfg_paint_grid")
 
     def baryonify_grid_offsets(self, args, table, d_offsets):
+        self._on_current_stream()
         _lib.check(self.lib.bfg_baryonify_grid_offsets(self.handle, C.byref(args), table.handle,
                                                        C.c_void_p(d_offsets.data_ptr())), "bfg_baryonify_grid_offsets")
 
     def regrid_grid(self, ndim, npix, d_offsets, d_in_map, d_out_map):
+        self._on_current_stream()
         _lib.check(self.lib.bfg_regrid_grid(self.handle, int(ndim), int(npix), C.c_void_p(d_offsets.data_ptr()),
                                             C.c_void_p(d_in_map.data_ptr()), C.c_void_p(d_out_map.data_ptr())),
                    "bfg_regrid_grid")
@@ -281,6 +348,7 @@ class Context(object):
     def deposit_grid(self, d_pos, d_mass, L, n_grid, mode="ngp"):
         """mass map float64[n_grid]*ndim of particles d_pos float64[n, ndim] (d_mass float64[n] or None); both may be
         column views of one record tensor (bfg_deposit_grid_strided)"""
+        self._on_current_stream()
         ndim = int(d_pos.shape[1])
         assert d_pos.stride(1) == 1
         d_grid = self.zeros(*([int(n_grid)] * ndim))
@@ -293,6 +361,7 @@ class Context(object):
 
     def build_displacement_table(self, geometry, r_int, dens_dmo, dens_dmb, r, rdelta=None, rdelta_range=None):
         """bfg_build_displacement_table: dens_* float64[n_rows, n_int] (host), returns (d[n_rows, nr], status[n_rows])"""
+        self._on_current_stream()
         r_int = np.ascontiguousarray(r_int, dtype=np.float64)
         r = np.ascontiguousarray(r, dtype=np.float64)
         d_dmo, d_dmb = self.to_device(dens_dmo), self.to_device(dens_dmb)
@@ -313,15 +382,18 @@ class Context(object):
         return d_out.cpu().numpy(), status
 
     def absmax_sum(self, d_x):
+        self._on_current_stream()
         amax, s = C.c_double(), C.c_double()
         _lib.check(self.lib.bfg_reduce_absmax_sum(self.handle, d_x.numel(), C.c_void_p(d_x.data_ptr()),
                                                   C.byref(amax), C.byref(s)), "bfg_reduce_absmax_sum")
         return amax.value, s.value
 
     def stats_reset(self):
+        self._on_current_stream()
         _lib.check(self.lib.bfg_stats_reset(self.handle))
 
     def stats(self):
+        self._on_current_stream()
         st = _lib.Stats()
         _lib.check(self.lib.bfg_stats_read(self.handle, C.byref(st)))
         return {"pixel_updates": int(st.pixel_updates), "halos_out_of_table": int(st.halos_out_of_table),

@@ -39,7 +39,8 @@ typedef enum {
     BFG_ERR_HIP = -2,          /* a HIP runtime call failed; see bfg_last_error()      */
     BFG_ERR_NO_DEVICE = -3,    /* no usable gfx950 device                              */
     BFG_ERR_UNSUPPORTED = -4,  /* e.g. more table dimensions than BFG_MAX_DIM          */
-    BFG_ERR_NOMEM = -5
+    BFG_ERR_NOMEM = -5,
+    BFG_ERR_COMM = -6          /* RCCL missing or a collective failed; see bfg_last_error() */
 } bfg_status;
 
 #define BFG_MAX_DIM 6          /* (ln(1+z), ln M, ln r) + up to 3 extra p_keys axes    */
@@ -52,7 +53,7 @@ typedef struct bfg_spline bfg_spline;  /* the D_A(z) cubic spline resident in HB
 /* ---- library / context ------------------------------------------------------- */
 int bfg_abi_version(void);
 const char *bfg_status_string(int status);
-const char *bfg_last_error(void);                 /* thread-local detail of the last BFG_ERR_HIP */
+const char *bfg_last_error(void);                 /* thread-local detail of the last BFG_ERR_HIP / BFG_ERR_COMM */
 int bfg_device_count(int *count);
 
 /* stream: the hipStream_t to enqueue on -- e.g. torch's current stream; NULL is the legacy
@@ -61,6 +62,11 @@ int bfg_device_count(int *count);
 #define BFG_STREAM_OWN ((void *)(intptr_t)-1)
 int bfg_ctx_create(int device_id, void *stream, bfg_ctx **out);
 int bfg_ctx_destroy(bfg_ctx *ctx);
+/* Re-bind the context to another stream of its GPU (a caller whose "current stream" changes between calls, e.g. inside
+ * `with torch.cuda.stream(s)`, passes the stream it is on before every call).  The new stream is made to wait (an event,
+ * no host synchronisation) for what the context enqueued on the old one: the context's workspaces are shared by
+ * consecutive calls.  A stream the context created itself (BFG_STREAM_OWN) is drained and destroyed. */
+int bfg_ctx_set_stream(bfg_ctx *ctx, void *stream);
 int bfg_ctx_synchronize(bfg_ctx *ctx);
 /* device name, CU count, LDS per CU etc. (for bench/DESIGN bookkeeping) */
 int bfg_ctx_device_info(bfg_ctx *ctx, char *name, int name_len, int *n_cu, int *lds_per_cu_bytes,
@@ -271,6 +277,31 @@ int bfg_baryonify_offsets(bfg_ctx *ctx, const bfg_shell_args *args, const bfg_ta
  * for the mass-conservation assert of :368-370.                                       */
 int bfg_regrid_shell(bfg_ctx *ctx, int64_t nside, const double *d_offsets, const double *d_in_map,
                      double *d_out_map, double *d_sums);
+
+/* ---- multi-GPU: the one exchange step ---------------------------------------------------
+ * One process per GPU, one context per process.  Replaces the parent-side join of the reference's joblib wrapper,
+ * map_out = np.sum(outputs, axis=0) (utils/Parallelize.py:312-318), by an RCCL collective over xGMI on the context's
+ * stream: the per-rank maps of PaintProfilesShell (float64[Npix]) are all-reduced; BaryonifyShell -- which the
+ * reference's splitter refuses (Parallelize.py:206-209) -- shards too because the offset field is linear in halos
+ * (Runners/HealpixRunner.py:355): reduce-scatter the offsets float64[Npix][3], every rank regrids the pixel range it
+ * owns, all-reduce the output map.
+ * bfg_comm_unique_id   one rank creates the 128-byte id (an ncclUniqueId) and hands it to the others by whatever
+ *                      channel the job has (a file, MPI, torch.distributed's store);
+ * bfg_comm_init        collective over all ranks: builds the communicator of this context (rank in [0, world));
+ * bfg_allreduce_f64    d_buf[count] <- sum over ranks, in place, asynchronous on the context's stream; a context
+ *                      without a communicator is a world of one (no-op);
+ * bfg_reduce_scatter_f64 / bfg_allgather_f64   the two halves, in place: rank r owns elements
+ *                      [r count / world, (r + 1) count / world); count must be a multiple of world.
+ * RCCL is loaded at the first of these calls (dlopen "librccl.so.1"; override with BFG_RCCL_SO): the library has no
+ * link-time dependency on it.                                                                                   */
+#define BFG_COMM_ID_BYTES 128
+int bfg_comm_unique_id(char *id_out, size_t id_bytes);
+int bfg_comm_init(bfg_ctx *ctx, const char *id, size_t id_bytes, int rank, int world);
+int bfg_comm_destroy(bfg_ctx *ctx);
+int bfg_comm_info(bfg_ctx *ctx, int *rank, int *world);
+int bfg_allreduce_f64(bfg_ctx *ctx, double *d_buf, int64_t count);
+int bfg_reduce_scatter_f64(bfg_ctx *ctx, double *d_buf, int64_t count);
+int bfg_allgather_f64(bfg_ctx *ctx, double *d_buf, int64_t count);
 
 /* max |x| over a device array (np.allclose(orig_map, 0) early return, :293-294) and sum. */
 int bfg_reduce_absmax_sum(bfg_ctx *ctx, int64_t n, const double *d_x, double *absmax, double *sum);

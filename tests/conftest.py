@@ -14,6 +14,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """a plain `pytest` on a box without a GPU skips the gpu-marked tests instead of failing them (the product has no
+    CPU path to fall back to).  device_count() does not initialise the GPU runtime."""
+    import torch
+    if torch.cuda.device_count() > 0:
+        return
+    skip = pytest.mark.skip(reason="no GPU visible: the HIP path has no CPU fallback")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np

@@ -178,3 +178,72 @@ def test_cabi_context_lifecycle_frees_its_memory(cosmo):
     for p, b in maps[1:]:
         assert_maps_close(p, maps[0][0], 1e-10, what="paint, fresh context")
         assert_maps_close(b, maps[0][1], 1e-9, floor=1e-9, what="baryonify, fresh context")
+
+
+def test_cabi_comm_world_of_one_and_collectives():
+    """the multi-GPU entry points on a one-GPU box: RCCL is dlopen'ed, a communicator of world size 1 is built from a
+    unique id, the three collectives run on the context's stream and leave the buffer as the sum over one rank; a
+    context without a communicator treats them as no-ops; bad arguments are refused."""
+    L = _lib.load()
+    ctx = C.c_void_p()
+    _lib.check(L.bfg_ctx_create(0, C.c_void_p(-1), C.byref(ctx)), "ctx")
+    x = np.random.default_rng(3).normal(size=4096)
+    d = Dev(L, ctx, x.nbytes).up(x)
+    rank, world = C.c_int(-1), C.c_int(-1)
+    _lib.check(L.bfg_comm_info(ctx, C.byref(rank), C.byref(world)))
+    assert (rank.value, world.value) == (0, 1)
+    _lib.check(L.bfg_allreduce_f64(ctx, d.p, x.size), "allreduce without communicator")
+    ident = C.create_string_buffer(_lib.BFG_COMM_ID_BYTES)
+    assert L.bfg_comm_unique_id(ident, 16) == -1                                   # buffer too small
+    _lib.check(L.bfg_comm_unique_id(ident, _lib.BFG_COMM_ID_BYTES), "unique id")
+    assert L.bfg_comm_init(ctx, ident.raw, _lib.BFG_COMM_ID_BYTES, 1, 1) == -1       # rank outside [0, world)
+    _lib.check(L.bfg_comm_init(ctx, ident.raw, _lib.BFG_COMM_ID_BYTES, 0, 1), "comm init")
+    _lib.check(L.bfg_comm_info(ctx, C.byref(rank), C.byref(world)))
+    assert (rank.value, world.value) == (0, 1)
+    _lib.check(L.bfg_allreduce_f64(ctx, d.p, x.size), "allreduce")
+    _lib.check(L.bfg_reduce_scatter_f64(ctx, d.p, x.size), "reduce-scatter")
+    _lib.check(L.bfg_allgather_f64(ctx, d.p, x.size), "all-gather")
+    assert L.bfg_allreduce_f64(ctx, None, 8) == -1
+    _lib.check(L.bfg_ctx_synchronize(ctx))
+    assert np.array_equal(d.down(x.shape), x)
+    _lib.check(L.bfg_comm_destroy(ctx))
+    d.free()
+    _lib.check(L.bfg_ctx_destroy(ctx))
+
+
+def test_cabi_set_stream_orders_work_across_streams(cosmo):
+    """bfg_ctx_set_stream: a context created on its own stream is moved to a second stream; the paint enqueued there
+    sees the zero-fill enqueued on the first one (event ordering, no host synchronisation in between)"""
+    import torch
+    from scipy import interpolate
+    L = _lib.load()
+    ctx = C.c_void_p()
+    _lib.check(L.bfg_ctx_create(0, C.c_void_p(-1), C.byref(ctx)), "ctx")
+    nside, npix, n = 256, 12 * 256 * 256, 5000
+    ra, dec, M, z = syn.catalog(n, seed=8)
+    bg = Background(cosmo)
+    z_t = np.linspace(0, z.max() + 0.1, 1000)
+    cs = interpolate.CubicSpline(z_t, bg.angular_diameter_distance(1 / (1 + z_t)))
+    knots, coef = np.ascontiguousarray(cs.x), np.ascontiguousarray(cs.c)
+    spl = C.c_void_p()
+    _lib.check(L.bfg_spline_create(ctx, knots.size, _dp(knots), _dp(coef), C.byref(spl)), "spline")
+    zax, Max, rax, T = syn.pressure_table()
+    tab = _table(L, ctx, (zax, Max, rax), np.log(T), _lib.BFG_TABLE_LOG_VALUES)
+    d_cat = Dev(L, ctx, n * 32).up(np.stack([M, z, ra, dec], 1))
+    args = _lib.ShellArgs()
+    args.nside, args.n_halo, args.d_catalog, args.cat_stride, args.n_extra = nside, n, d_cat.p.value, 4, 0
+    args.epsilon_max, args.runner_md, args.model_md, args.variant = 10.0, _massdef(bg), _massdef(bg), 0
+    d_map = Dev(L, ctx, npix * 8).up(np.full(npix, 5.0))
+    d_map.zero()                                                    # async, on the context's first stream
+    s2 = torch.cuda.Stream()
+    assert L.bfg_ctx_set_stream(ctx, C.c_void_p(-1)) == -1          # BFG_STREAM_OWN is not a stream to move to
+    _lib.check(L.bfg_ctx_set_stream(ctx, C.c_void_p(s2.cuda_stream)), "set_stream")
+    _lib.check(L.bfg_paint_shell(ctx, C.byref(args), tab, spl, d_map.p), "paint")
+    _lib.check(L.bfg_ctx_synchronize(ctx))
+    a, R, D = orc.halo_scalars(cosmo, M, z)
+    ref, _ = orc.paint_shell(nside, ra, dec, M, a, D, R, (zax, Max, rax), np.log(T), 10.0)
+    assert_maps_close(d_map.down(npix), ref, 1e-5, what="paint after a stream switch")
+    d_cat.free(); d_map.free()
+    _lib.check(L.bfg_table_destroy(ctx, tab))
+    _lib.check(L.bfg_spline_destroy(ctx, spl))
+    _lib.check(L.bfg_ctx_destroy(ctx))

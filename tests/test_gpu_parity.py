@@ -511,6 +511,66 @@ def test_baryonify_snapshot_vs_oracle(cosmo, is2D, path, monkeypatch):
     np.testing.assert_allclose(m1, m2, rtol=1e-12, atol=1e-12)
 
 
+def test_snapshot_positional_mass_def_sets_the_query_radius(cosmo):
+    """the reference's argument order (SnapshotRunner.py:84-85): a positional mass_def is the mass definition of R_j and
+    R_q (:222-225) -- against the oracle run with the same Delta, and different from the 200c result"""
+    import warnings
+    rng = np.random.default_rng(77)
+    L, npart, nhalo, zs = 200.0, 100000, 300, 0.3
+    P, H = rng.uniform(0, L, (npart, 3)), rng.uniform(0, L, (nhalo, 3))
+    hM = 10 ** rng.uniform(13.5, 15.2, nhalo)
+    zax, Max, rax, d = syn.displacement_table()
+    Cat = bfg.HaloNDCatalog(H[:, 0], H[:, 1], hM, zs, cosmo, z=H[:, 2])
+    Part = bfg.ParticleSnapshot(x=P[:, 0], y=P[:, 1], z=P[:, 2], M=np.ones(npart), L=L, redshift=zs, cosmo=cosmo)
+    model = bfg.Baryonification2D.from_arrays(zax, Max, rax, d, cosmo, epsilon_max=20)
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for tag, args in (("500c", (bfg.MassDef(500, "critical"), False)), ("200c", ())):
+            new = bfg.BaryonifySnapshot(Cat, Part, 3, model, *args).process() if args else \
+                bfg.BaryonifySnapshot(Cat, Part, 3, model, verbose=False).process()
+            out[tag] = np.stack([new["x"], new["y"], new["z"]], axis=1)
+        ref = orc.baryonify_snapshot(cosmo, L, zs, P[:, 0], P[:, 1], P[:, 2], hM, H[:, 0], H[:, 1], H[:, 2],
+                                     (zax, Max, rax), d, 3, 20, Delta=500, rho_type="critical")
+    _periodic_close(out["500c"], ref, L, 1e-9)
+    moved500 = np.any(out["500c"] != P, axis=1).sum()
+    moved200 = np.any(out["200c"] != P, axis=1).sum()
+    assert 0 < moved500 < moved200            # R_500c < R_200c: fewer particles inside eps * R
+
+
+def test_kernels_follow_torchs_current_stream(cosmo):
+    """engine.Context binds the library to torch's CURRENT stream at every call (bfg_ctx_set_stream): a paint issued
+    inside `with torch.cuda.stream(s)` is ordered after the zero-fill and before the copy that torch enqueues on s, and a
+    later call on the default stream is ordered after it (the workspaces are shared)."""
+    import torch
+    from baryonforge_amd.engine import get_context
+    nside, n = 256, 20000
+    ra, dec, M, z = syn.catalog(n, seed=9)
+    zax, Max, rax, T = syn.pressure_table()
+    ref, ptot = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax), T, nside, 10)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    Shell = bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo)
+    R = bfg.PaintProfilesShell(Cat, Shell, 10, _paint_model(zax, Max, rax, T), verbose=False)
+    base = R.process()                                            # default stream; also warms every workspace
+    ctx = get_context()
+    side = torch.cuda.Stream()
+    big = torch.empty(1 << 27, dtype=torch.float64, device="cuda")
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            big.fill_(1.0)                                        # ~1 GB of stores ahead of the paint on this stream
+            d_map = ctx.zeros(12 * nside * nside)
+            d_map.fill_(123.0)
+            d_map.zero_()                                         # the paint must come after this ...
+            R.process_device(d_map)
+            got = d_map.clone()                                   # ... and before this
+        again = R.process()                                       # default stream, right behind: shares the workspaces
+        side.synchronize()
+        assert ctx._stream_ptr == torch.cuda.current_stream().cuda_stream
+        assert_maps_close(got.cpu().numpy(), ref, RTOL, what="paint on a side stream")
+        assert np.array_equal(again != 0, base != 0)
+        assert_maps_close(again, ref, RTOL, what="paint on the default stream after a side-stream call")
+
+
 @pytest.mark.parametrize("path", ["direct", "tile"])
 @pytest.mark.parametrize("ndim,N", [(2, 200), (3, 48), (3, 50), (2, 40), (3, 9)])
 @pytest.mark.parametrize("mode", ["ngp", "cic"])
