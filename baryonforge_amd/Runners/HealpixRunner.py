@@ -19,7 +19,7 @@ evaluated per halo are outside the scope of this build.
 import numpy as np
 
 from ..background import Background, MassDef
-from ..engine import emit_range_warnings, get_context
+from ..engine import emit_fallback_warning, emit_range_warnings, get_context
 from ..utils.Tabulate import ParamTabulatedProfile, _get_parameter
 from ..Profiles.BaryonCorrection import BaryonificationClass
 
@@ -106,6 +106,7 @@ class DefaultRunner(object):
         cat = self.HaloLightConeCatalog.cat
         z_m = np.max(cat["z"]) if cat.size else 0.0
         assert z_m <= 30, f"We assume max(z) = 30, but your catalog has max(z) = {z_m}"   # :301 / :433
+        z_m = max(z_m, getattr(self, "_spline_z_max", z_m))              # a shard of a split catalog: the whole catalog's max(z)
         bg = Background(self.cosmo)
         spline = ctx.da_spline(bg, z_m)                                  # :297-299 / :429-431
         recs = self.HaloLightConeCatalog.records(keys) if hasattr(self.HaloLightConeCatalog, "records") else \
@@ -143,6 +144,7 @@ class PaintProfilesShell(DefaultRunner):
         ctx.stats_reset()
         ctx.paint_shell(args, table, spline, d_map)
         self.last_stats = ctx.stats()
+        emit_fallback_warning(self.last_stats)
         return d_map
 
     def process(self):
@@ -283,42 +285,82 @@ class BaryonifyShell(DefaultRunner):
         ctx.baryonify_offsets(args, table, spline, d_off)                 # :315-355
         self.last_stats = ctx.stats()
         emit_range_warnings(self.last_stats, "table")                     # BaryonCorrection.py:382-394
+        emit_fallback_warning(self.last_stats)
         return d_off
 
     def process(self, distributed=None):
         """returns new_map : float64[Npix]; the input array itself if the map is all zeros (:293-294).
 
-        distributed: a torch.distributed module with an initialised group (set by SplitJoinParallel):
-        this runner then holds one sky-patch shard of the halos; the offset field and the regridded
-        map are all-reduced across ranks."""
-        orig_map = self.LightconeShell.map
-        NSIDE = self.LightconeShell.NSIDE
-        if orig_map.size < (1 << 16) and np.allclose(orig_map, 0):         # small maps: decided on the host, as the reference
+        distributed: a utils.Parallelize.Exchange (set by SplitJoinParallel; a torch.distributed module with an initialised
+        group is wrapped into one): this runner then holds one sky-patch shard of the halos.  The offset field is linear
+        in halos (:355), so it is summed across the ranks -- by a reduce-scatter, because every rank regrids only the
+        sources of the pixel range it owns (:357-365 on that range) --, and the regridded maps, whose deposits can cross
+        the range borders, are all-reduced."""
+        return _baryonify_process(self, _DeviceOps(self), distributed)
+
+
+class _DeviceOps(object):
+    """the GPU side of BaryonifyShell.process: HBM tensors and C-ABI calls"""
+
+    def __init__(self, runner):
+        self.runner = runner
+
+    def upload(self, flat):
+        return get_context().to_device(flat)
+
+    def zeros(self, *shape):
+        return get_context().zeros(*shape)
+
+    def absmax_sum(self, t):
+        return get_context().absmax_sum(t)
+
+    def offsets(self):
+        return self.runner.offsets_device()
+
+    def regrid(self, nside, d_off, d_in, d_out):
+        get_context().regrid_shell(nside, d_off, d_in, d_out, None)
+
+    def to_host(self, t):
+        return get_context().to_host(t)
+
+
+def _baryonify_process(runner, ops, exchange):
+    """BaryonifyShell.process (HealpixRunner.py:252-373) over an `ops` object (the GPU, or the test seam of
+    utils.Parallelize) and an optional Exchange between ranks"""
+    orig_map = runner.LightconeShell.map
+    NSIDE = runner.LightconeShell.NSIDE
+    if orig_map.size < (1 << 16) and np.allclose(orig_map, 0):         # small maps: decided on the host, as the reference
+        return orig_map
+    runner._checked_model_keys()
+    npix = 12 * NSIDE * NSIDE
+    flat = np.ascontiguousarray(orig_map, dtype=np.float64).ravel()
+    d_orig = ops.upload(flat)
+    absmax, old_sum = ops.absmax_sum(d_orig)                          # on the device: one pass instead of three host ones
+    if not (absmax > 1e-8):                                           # np.allclose(orig_map, 0) (:293); False for NaN maps
+        if np.allclose(orig_map, 0):
             return orig_map
-        self._checked_model_keys()
-        ctx = get_context()
-        npix = 12 * NSIDE * NSIDE
-        flat = np.ascontiguousarray(orig_map, dtype=np.float64).ravel()
-        d_orig = ctx.to_device(flat)
-        absmax, old_sum = ctx.absmax_sum(d_orig)                          # on the device: one pass instead of three host ones
-        if not (absmax > 1e-8):                                           # np.allclose(orig_map, 0) (:293); False for NaN maps
-            if np.allclose(orig_map, 0):
-                return orig_map
-        d_off = self.offsets_device()
-        if distributed is not None:
-            distributed.all_reduce(d_off, op=distributed.ReduceOp.SUM)
-            rank, world = distributed.get_rank(), distributed.get_world_size()
+    if exchange is not None and not hasattr(exchange, "reduce_scatter"):
+        from ..utils.Parallelize import Exchange
+        exchange = Exchange(exchange)
+    d_off = ops.offsets()                                             # :313-355, this rank's halos
+    if exchange is not None and exchange.world > 1:
+        rank, world = exchange.rank, exchange.world
+        if npix % world == 0:
+            exchange.reduce_scatter(d_off)                            # summed offsets of the pixels this rank owns
+            lo, hi = (x // 3 for x in exchange.own_range(3 * npix))
+        else:                                                         # a world size that does not divide 12 NSIDE^2
+            exchange.allreduce(d_off)
             lo, hi = npix * rank // world, npix * (rank + 1) // world
-            d_in = ctx.zeros(npix)
-            d_in[lo:hi] = d_orig[lo:hi]                                   # this rank regrids its pixel range
-        else:
-            d_in = d_orig
-        d_out = ctx.zeros(npix)
-        ctx.regrid_shell(NSIDE, d_off, d_in, d_out, None)                 # :357-365
-        if distributed is not None:
-            distributed.all_reduce(d_out, op=distributed.ReduceOp.SUM)
-        _, new_sum = ctx.absmax_sum(d_out)
-        new_map = ctx.to_host(d_out)
-        assert np.isclose(new_sum, old_sum), \
-            "ERROR in pixel regridding, sum(new_map) [%0.14e] != sum(oldmap) [%0.14e]" % (new_sum, old_sum)  # :368-370
-        return new_map
+        d_in = ops.zeros(npix)
+        d_in[lo:hi] = d_orig[lo:hi]                                   # sources outside the range have no mass here
+    else:
+        d_in = d_orig
+    d_out = ops.zeros(npix)
+    ops.regrid(NSIDE, d_off, d_in, d_out)                             # :357-365
+    if exchange is not None and exchange.world > 1:
+        exchange.allreduce(d_out)
+    _, new_sum = ops.absmax_sum(d_out)
+    new_map = ops.to_host(d_out)
+    assert np.isclose(new_sum, old_sum), \
+        "ERROR in pixel regridding, sum(new_map) [%0.14e] != sum(oldmap) [%0.14e]" % (new_sum, old_sum)  # :368-370
+    return new_map

@@ -39,7 +39,7 @@ SYMBOLS = [
     "bfg_build_displacement_table", "bfg_baryonify_snapshot_strided", "bfg_deposit_grid_strided",
     "bfg_stats_reset", "bfg_stats_read", "bfg_timing_enable", "bfg_timing_read",
     "bfg_comm_unique_id", "bfg_comm_init", "bfg_comm_destroy", "bfg_comm_info",
-    "bfg_allreduce_f64", "bfg_reduce_scatter_f64", "bfg_allgather_f64",
+    "bfg_allreduce_f64", "bfg_allreduce_f64_begin", "bfg_comm_wait", "bfg_reduce_scatter_f64", "bfg_allgather_f64",
 ]
 BFG_COMM_ID_BYTES = 128
 
@@ -74,7 +74,7 @@ class GridArgs(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("pixel_updates", C.c_uint64), ("halos_out_of_table", C.c_uint64),
                 ("pixels_out_of_table", C.c_uint64), ("halos_fallback4", C.c_uint64),
-                ("warn_mask", C.c_uint32), ("reserved", C.c_uint32)]
+                ("warn_mask", C.c_uint32), ("halos_scatter_fallback", C.c_uint32)]
 
 
 class BFGError(RuntimeError):
@@ -123,6 +123,8 @@ def load(build_if_missing=True):
     L.bfg_comm_destroy.argtypes = [_vp]
     L.bfg_comm_info.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.bfg_allreduce_f64.argtypes = [_vp, _vp, _i64]
+    L.bfg_allreduce_f64_begin.argtypes = [_vp, _vp, _i64]
+    L.bfg_comm_wait.argtypes = [_vp]
     L.bfg_reduce_scatter_f64.argtypes = [_vp, _vp, _i64]
     L.bfg_allgather_f64.argtypes = [_vp, _vp, _i64]
     L.bfg_ctx_synchronize.argtypes = [_vp]

@@ -12,6 +12,10 @@
 struct bfg_comm_state {
     ncclComm_t comm;
     int rank, world;
+    hipStream_t side;        // the communication stream of bfg_allreduce_f64_begin (created on first use)
+    hipEvent_t ev_ready;     // context stream -> communication stream: the buffer has been produced
+    hipEvent_t ev_done;      // communication stream -> context stream: the collectives begun so far have finished
+    bool pending;
 };
 
 namespace bfg_rccl {
@@ -72,6 +76,9 @@ static const Api *api()
 static void bfg_comm_release(bfg_ctx *c)
 {
     if (!c->comm) return;
+    if (c->comm->side) { (void)hipStreamSynchronize(c->comm->side); (void)hipStreamDestroy(c->comm->side); }
+    if (c->comm->ev_ready) (void)hipEventDestroy(c->comm->ev_ready);
+    if (c->comm->ev_done) (void)hipEventDestroy(c->comm->ev_done);
     if (const bfg_rccl::Api *A = bfg_rccl::api()) (void)A->CommDestroy(c->comm->comm);
     delete c->comm;
     c->comm = nullptr;
@@ -104,7 +111,7 @@ int bfg_comm_init(bfg_ctx *c, const char *id, size_t id_bytes, int rank, int wor
     std::memcpy(uid.internal, id, NCCL_UNIQUE_ID_BYTES);
     ncclComm_t comm;
     RCCL_TRY(A, A->CommInitRank(&comm, world, uid, rank));
-    c->comm = new bfg_comm_state{comm, rank, world};
+    c->comm = new bfg_comm_state{comm, rank, world, nullptr, nullptr, nullptr, false};
     return BFG_OK;
 }
 
@@ -139,6 +146,44 @@ int bfg_allreduce_f64(bfg_ctx *c, double *d_buf, int64_t count)
     const bfg_rccl::Api *A = bfg_rccl::api();
     if (!A) return BFG_ERR_COMM;
     RCCL_TRY(A, A->AllReduce(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum, c->comm->comm, c->stream));
+    return BFG_OK;
+}
+
+// The same sum on the context's COMMUNICATION stream, so that it overlaps whatever the caller enqueues next on the
+// context's stream (the painting of the next shell into another buffer): the collective is ordered after everything
+// enqueued on the context's stream so far; bfg_comm_wait makes the context's stream wait for all collectives begun so
+// far (before the buffer is read, zeroed or reused).
+int bfg_allreduce_f64_begin(bfg_ctx *c, double *d_buf, int64_t count)
+{
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
+    if (rc) return rc;
+    if (count < 0 || (count > 0 && !d_buf)) return BFG_ERR_INVALID;
+    if (!c->comm || c->comm->world == 1 || count == 0) return BFG_OK;
+    const bfg_rccl::Api *A = bfg_rccl::api();
+    if (!A) return BFG_ERR_COMM;
+    bfg_comm_state *m = c->comm;
+    if (!m->side) {
+        HIP_TRY(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_ready, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_done, hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(m->ev_ready, c->stream));
+    HIP_TRY(hipStreamWaitEvent(m->side, m->ev_ready, 0));
+    RCCL_TRY(A, A->AllReduce(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum, m->comm, m->side));
+    HIP_TRY(hipEventRecord(m->ev_done, m->side));
+    m->pending = true;
+    return BFG_OK;
+}
+
+int bfg_comm_wait(bfg_ctx *c)
+{
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
+    if (rc) return rc;
+    if (!c->comm || !c->comm->pending) return BFG_OK;
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->comm->ev_done, 0));
+    c->comm->pending = false;
     return BFG_OK;
 }
 

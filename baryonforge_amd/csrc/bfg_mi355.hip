@@ -47,6 +47,7 @@ enum { I_RFIRST = 0, I_RLAST, I_IRMIN, I_IRMAX, I_FLAGS, I_NI };
 #define HF_OOB 1        // (z, M, extras) outside the table hull, or NaN
 #define HF_SKIP 2       // nothing to do for this halo (NaN radius etc.)
 #define HF_SCATTER 4    // tile variant: this halo is left to the global-atomic scatter kernel
+#define HF_SLOW 8       // ... although it has work to do (too many tiles, exp() range, pair buffer full): ~12x slower, counted
 
 struct DevTable {
     int ndim;                       // 3 + n_extra
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256) void halo_prep_kernel(const PrepParams P)
     // paint: the tile path folds ln(pixarea D^2) into the halo's row window; keep exp() range handling exact
     const double pixfac = (P.pixfac_area != 0.0) ? P.pixfac_area * (D * D) : 1.0;
     const double lnpf = (P.pixfac_area != 0.0) ? log(pixfac) : 0.0;
-    if (P.ht && P.bin.mode == MODE_PAINT && !(fabs(lnpf) < 50.0)) flags |= HF_SCATTER;
+    if (P.ht && P.bin.mode == MODE_PAINT && !(fabs(lnpf) < 50.0)) flags |= HF_SCATTER | HF_SLOW;
     if (P.ht) {
         if (P.bin.mode == MODE_BARYONIFY && !(flags & HF_SKIP) && rlast >= rfirst && rlast - rfirst < 8) {
             // small disc: count its pixels exactly; fewer than 4 -> 4-neighbour fallback (HealpixRunner.py:333-334),
@@ -341,6 +342,7 @@ __global__ __launch_bounds__(256) void halo_prep_kernel(const PrepParams P)
     irec[I_IRMIN * cap] = irmin; irec[I_IRMAX * cap] = irmax;
     irec[I_FLAGS * cap] = flags;
     if (P.left && (flags & HF_SCATTER) && !(flags & HF_SKIP)) P.left[1 + atomicAdd(&P.left[0], 1)] = (int32_t)j;
+    if ((flags & HF_SLOW) && !(flags & (HF_SKIP | HF_OOB))) atomicAdd(&P.stats->halos_scatter_fallback, 1u);
     if (P.ht) {
         HaloTile h;
         h.st = st; h.ct = z0v; h.pphi = pphi;
@@ -1572,7 +1574,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
                            ts.d_tile_start, ts.d_work, ts.d_nwork);
         FillParams fp;
         std::memset(&fp, 0, sizeof(fp));
-        fp.n_halo = a->n_halo; fp.cap = c->cap_halo; fp.rec = c->d_rec; fp.irec = c->d_irec; fp.ht = c->d_ht; fp.bin = pp.bin;
+        fp.stats = c->d_stats; fp.n_halo = a->n_halo; fp.cap = c->cap_halo; fp.rec = c->d_rec; fp.irec = c->d_irec; fp.ht = c->d_ht; fp.bin = pp.bin;
         hipLaunchKernelGGL(tile_fill_kernel, dim3((unsigned)((a->n_halo + 255) / 256)), dim3(256), 0, c->stream, fp);
         RowParams rp;
         std::memset(&rp, 0, sizeof(rp));

@@ -256,7 +256,7 @@ __device__ inline int tile_bin_halo(const BinCtx &B, bool fill, int64_t j, int f
     if (!fill) {
         int npairs = 0;
         for (int b = b0; b <= b1; ++b) { int s_lo, n; band_sectors(B.geo, b, pphi, dphi_bound, s_lo, n); npairs += n; }
-        if (npairs > kMaxPairsPerHalo) to_scatter = true;
+        if (npairs > kMaxPairsPerHalo) { to_scatter = true; flags |= HF_SLOW; }   // a disc over more than 64 tiles
         if (to_scatter) return flags | HF_SCATTER;
     }
     const int64_t ovf_base = (int64_t)B.geo.ntiles * B.cap_direct;
@@ -282,6 +282,7 @@ __device__ inline int tile_bin_halo(const BinCtx &B, bool fill, int64_t j, int f
 }
 
 struct FillParams {
+    bfg_stats *stats;
     int64_t n_halo, cap;
     const double *rec;
     int32_t *irec;
@@ -295,8 +296,9 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const FillParams P)
     if (j >= P.n_halo) return;
     const int64_t cap = P.cap;
     if ((long long)P.bin.tile_start[P.bin.geo.ntiles] > P.bin.pair_cap) {        // overflow lists too long: all to scatter
-        const int f = P.irec[I_FLAGS * cap + j] | HF_SCATTER;
+        const int f0 = P.irec[I_FLAGS * cap + j], f = f0 | HF_SCATTER;
         P.irec[I_FLAGS * cap + j] = f; P.ht[j].flags = f;
+        if (!(f0 & (HF_SCATTER | HF_SKIP))) atomicAdd(&P.stats->halos_scatter_fallback, 1u);
         return;
     }
     unsigned long long mask = P.bin.ovf_mask[j];

@@ -165,6 +165,18 @@ class Context(object):
         _lib.check(self.lib.bfg_allreduce_f64(self.handle, C.c_void_p(d_tensor.data_ptr()), d_tensor.numel()),
                    "bfg_allreduce_f64")
 
+    def allreduce_begin(self, d_tensor):
+        """the same sum on the context's communication stream (overlaps the work enqueued next); see comm_wait"""
+        assert d_tensor.is_contiguous() and d_tensor.dtype == _torch().float64
+        self._on_current_stream()
+        _lib.check(self.lib.bfg_allreduce_f64_begin(self.handle, C.c_void_p(d_tensor.data_ptr()), d_tensor.numel()),
+                   "bfg_allreduce_f64_begin")
+
+    def comm_wait(self):
+        """the current stream waits for every collective begun with allreduce_begin"""
+        self._on_current_stream()
+        _lib.check(self.lib.bfg_comm_wait(self.handle), "bfg_comm_wait")
+
     def reduce_scatter(self, d_tensor):
         """in place: rank r ends up owning the summed elements [r n / world, (r + 1) n / world)"""
         assert d_tensor.is_contiguous() and d_tensor.dtype == _torch().float64
@@ -398,7 +410,7 @@ class Context(object):
         _lib.check(self.lib.bfg_stats_read(self.handle, C.byref(st)))
         return {"pixel_updates": int(st.pixel_updates), "halos_out_of_table": int(st.halos_out_of_table),
                 "pixels_out_of_table": int(st.pixels_out_of_table), "halos_fallback4": int(st.halos_fallback4),
-                "warn_mask": int(st.warn_mask)}
+                "warn_mask": int(st.warn_mask), "fallback_halos": int(st.halos_scatter_fallback)}
 
     def timing_enable(self, on=True):
         _lib.check(self.lib.bfg_timing_enable(self.handle, int(bool(on))))
@@ -423,6 +435,16 @@ def get_context(device=None):
         if ctx is None:
             ctx = _contexts[index] = Context(index)
     return ctx
+
+
+def emit_fallback_warning(stats):
+    """the tile path's silent degradation made visible: halos that took the global-atomic scatter kernel although they had
+    work to do (bfg_stats.halos_scatter_fallback)"""
+    n = stats.get("fallback_halos", 0)
+    if n > 0:
+        warnings.warn(f"{n} halos were painted by the slower global-atomic scatter kernel (disc over more than 64 sky "
+                      f"tiles, pixel factor outside the fast exp range, or tile pair buffer exhausted); the result is "
+                      f"unaffected, the run time is not", UserWarning)
 
 
 def emit_range_warnings(stats, what="table"):

@@ -5,19 +5,26 @@ halos/s + achieved HBM GB/s, NSIDE = 1024 shell, 1e6 halos, at 1/2/4/8 GPUs).
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+         --master-port P bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--collective torch|bfg]
 
 One "step" = one full pass of the hot path over one synthetic catalog that is already
 resident in HBM as float64 (M, z, ra, dec) records: zero the map, halo preparation kernel,
 shell paint kernel, and -- for N > 1 -- the RCCL all-reduce of the per-rank maps.
-Weak scaling: every rank paints its own sky-patch shard (sharding.shard_by_sky_patch) of `--halos` halos PER GPU
-(N x halos in total); value = all halos painted by all ranks / max-over-ranks time.
+--scaling weak (default): every rank paints its own sky-patch shard (sharding.shard_by_sky_patch) of a catalog of
+`--halos` halos PER GPU (N x halos in total); --scaling strong: `--halos` halos IN TOTAL, cut into N shards (how
+BASELINE.json's metric reads: one 1e6-halo catalog at 1/2/4/8 GPUs).  Either way value = all halos painted by all ranks
+/ max-over-ranks time, and the N = 1 run is the same workload.
+--collective torch (default): torch.distributed's all_reduce (backend nccl = RCCL), asynchronous on RCCL's stream;
+--collective bfg: the library's own RCCL communicator (bfg_allreduce_f64_begin / bfg_comm_wait of include/bfg_mi355.h).
+Both overlap the all-reduce of shell k with the painting of shell k + 1 (two map buffers).
 
-Rank 0 prints ONE JSON line (see the contract in the task statement) with two extra objects:
+Rank 0 prints ONE JSON line (see the contract in the task statement) with these extra objects:
   "roofline":     algorithmic bytes of the dominant kernel / its mean duration (HIP events on the
                   kernel's own stream, live in this process) against the 8 TB/s HBM peak
   "cpu_baseline": the CPU oracle (a C port of the reference loop; kind "port") timed on this
                   box's host cores on a bounded sample of the same workload (N = 1 only)
+  "ranks":        N > 1: per-rank shard size, compute-only ms, collective-only ms and how much of the collective
+                  the overlap hid (measured in two extra untimed legs after the timed region)
 """
 import argparse
 import json
@@ -31,6 +38,11 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+# the only throughput the reference publishes for this path: tqdm rate of PaintProfilesShell on the
+# author's laptop, 18 512 halos, NSIDE 1024, epsilon_max 10, 2 x 30 x 2000 table (examples/05_Paint_tSZ_shell.ipynb:271)
+REFERENCE_PUBLISHED = {"value": 3365.69, "unit": "halos/s", "what": "PaintProfilesShell tqdm rate, 18512 halos, NSIDE 1024, "
+                       "eps 10, table 2x30x2000, author's laptop, 1 process",
+                       "source": "examples/05_Paint_tSZ_shell.ipynb:271"}
 
 
 def parse():
@@ -38,7 +50,9 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--halos", type=int, default=1_000_000, help="halos per GPU")
+    p.add_argument("--halos", type=int, default=1_000_000, help="halos per GPU (weak scaling) / in total (strong scaling)")
+    p.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    p.add_argument("--collective", choices=["torch", "bfg"], default="torch")
     p.add_argument("--nside", type=int, default=1024)
     p.add_argument("--eps", type=float, default=10.0)
     p.add_argument("--workload", choices=["paint", "baryonify"], default="paint")
@@ -46,22 +60,64 @@ def parse():
     p.add_argument("--table", choices=["default", "stress"], default="default")
     p.add_argument("--steep", action="store_true", help="dn/dlnM ~ M^-0.9 catalog instead of uniform log M")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of each baseline leg")
+    p.add_argument("--no-e2e", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the single-thread baseline leg")
     return p.parse_args()
+
+
+def usable_cores():
+    """cores this process may actually run on: affinity mask and cgroup cpu quota (a one-GPU box is a share of its host)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+        except Exception:
+            pass
+    return n
+
+
+def usable_memory():
+    avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+        try:
+            txt = open(path).read().strip()
+            if txt != "max":
+                avail = min(avail, int(txt)) if avail else int(txt)
+        except Exception:
+            pass
+    return avail or (8 << 30)
 
 
 def cpu_baseline(args, cosmo, ra, dec, M, z, axes, T):
     """The oracle (oracle/bfg_oracle.c: a plain-C port of HealpixRunner.py:449-481) on a bounded sample of the
-    same catalog, (1) single thread = Runner.process(), (2) split-join over the host cores =
-    SplitJoinParallel (Parallelize.py:218-320: private full-size map per worker, summed by the parent)."""
+    same catalog, (1) single thread = Runner.process(), (2) split-join over ALL usable host cores =
+    SplitJoinParallel (Parallelize.py:218-320: private full-size map per worker, summed by the parent), and the same with
+    32 workers (the join of one 101 MB map per worker is serial in the parent, as np.sum(outputs, axis=0) is, so more
+    workers is not always faster); the best of them is the stated baseline."""
     from oracle import oracle as orc
-    cores = os.cpu_count() or 1
+    host_cores = os.cpu_count() or 1
+    cores = usable_cores()
     a, R, D = orc.halo_scalars(cosmo, M, z)
     lnT = np.log(T)
+    npix = 12 * args.nside * args.nside
 
-    def run(n, njobs):
+    def run(n, njobs, perm=None):
+        sel = (lambda x: x[:n]) if perm is None else (lambda x: x[:n][perm])
         t0 = time.perf_counter()
-        _, ptot = orc.paint_shell(args.nside, ra[:n], dec[:n], M[:n], a[:n], D[:n], R[:n], axes, lnT, args.eps,
+        _, ptot = orc.paint_shell(args.nside, sel(ra), sel(dec), sel(M), sel(a), sel(D), sel(R), axes, lnT, args.eps,
                                   njobs=njobs)
         return time.perf_counter() - t0, ptot
     n0 = min(5000, M.size)
@@ -69,27 +125,48 @@ def cpu_baseline(args, cosmo, ra, dec, M, z, axes, T):
     n1 = int(min(M.size, max(n0, n0 * args.cpu_seconds / max(t, 1e-3))))
     t1, p1 = run(n1, None)
     single = n1 / t1
-    njobs = min(cores, 32)     # each worker owns a full-size float64 map (101 MB at NSIDE 1024)
     out = {"value": single, "unit": "halos/s", "cores": 1, "kind": "port",
            "sample": f"first {n1} halos of the same catalog, NSIDE {args.nside}, eps {args.eps:g}, "
                      f"oracle/bfg_oracle.c single thread, {t1:.1f} s, {p1 / t1:.3g} pixel-updates/s",
-           "host_cores": cores, "single_thread_halos_per_s": single}
-    if njobs > 1:
-        rng = np.random.default_rng(42)                           # Parallelize.py:255 shuffle
-        n2 = int(min(M.size, n1 * min(njobs, 8)))
-        perm = rng.choice(n2, size=n2, replace=False)
-        t0 = time.perf_counter()
-        orc.paint_shell(args.nside, ra[:n2][perm], dec[:n2][perm], M[:n2][perm], a[:n2][perm], D[:n2][perm],
-                        R[:n2][perm], axes, lnT, args.eps, njobs=njobs)
-        t2 = time.perf_counter() - t0
-        out["splitjoin_halos_per_s"] = n2 / t2
-        out["splitjoin_workers"] = njobs
-        out["splitjoin_sample"] = f"{n2} halos, {njobs} workers, {t2:.1f} s incl. per-worker map zeroing and the join"
-        if n2 / t2 > single:
+           "host_cores": host_cores, "usable_cores": cores, "single_thread_halos_per_s": single,
+           "reference_published": REFERENCE_PUBLISHED, "splitjoin": []}
+    # every worker owns a full-size float64 map (101 MB at NSIDE 1024): keep them under 40 % of the memory we may use
+    fit = max(1, int(0.4 * usable_memory() / (npix * 8.0)))
+    tried = []
+    for njobs in (min(cores, fit), min(32, cores, fit)):
+        if njobs <= 1 or njobs in tried:
+            continue
+        tried.append(njobs)
+        n2 = M.size                                                   # the whole catalog: the same job the GPU step does
+        perm = np.random.default_rng(42).choice(n2, size=n2, replace=False)     # Parallelize.py:255 shuffle
+        t2, _ = run(n2, njobs, perm)
+        out["splitjoin"].append({"workers": njobs, "halos": n2, "seconds": t2, "halos_per_s": n2 / t2})
+        if n2 / t2 > out["value"]:
             out.update(value=n2 / t2, cores=njobs,
-                       sample=f"first {n2} halos (seed-42 shuffled) of the same catalog, NSIDE {args.nside}, "
-                              f"eps {args.eps:g}, split-join over {njobs} worker threads, {t2:.1f} s")
+                       sample=f"all {n2} halos (seed-42 shuffled) of the same catalog, NSIDE {args.nside}, "
+                              f"eps {args.eps:g}, split-join over {njobs} worker threads of {cores} usable cores, "
+                              f"{t2:.1f} s incl. per-worker map zeroing and the serial join")
     return out
+
+
+def e2e_python_api(args, cosmo, ra, dec, M, z, zax, Max, rax, T):
+    """PCIe-inclusive time of the reference-shaped call: host catalog in, PaintProfilesShell.process(), host map out.
+    Never `value` (the contract times device-resident inputs); reported so that the line says what a user of the Python
+    API sees.  Best of 3 after one warm call (the device table and the D_A spline are cached per model / cosmology)."""
+    import baryonforge_amd as bfg
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    Shell = bfg.LightconeShell(map=np.zeros(12 * args.nside * args.nside), cosmo=cosmo)
+    R = bfg.PaintProfilesShell(Cat, Shell, args.eps, bfg.TabulatedProfile.from_arrays(zax, Max, rax, T), verbose=False,
+                               variant=args.variant)
+    R.process()
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        m = R.process()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        del m
+    return best * 1e3
 
 
 def _mark(msg):
@@ -121,18 +198,20 @@ def main():
             dist.init_process_group(backend)
 
     _mark("process group up")
-    import baryonforge_amd as bfg
     from baryonforge_amd import sharding, synthetic as syn
     from baryonforge_amd.background import Background
     from baryonforge_amd.engine import get_context
 
     cosmo = dict(syn.COSMO)
     nside, npix = args.nside, 12 * args.nside * args.nside
-    n_total = args.halos * world
+    n_total = args.halos * world if args.scaling == "weak" else args.halos
     ra, dec, M, z = syn.catalog(n_total, seed=42, steep=args.steep)
     shape = (10, 30, 100) if args.table == "default" else (2, 30, 2000)
     ctx = get_context(local_rank)
     bg = Background(cosmo)
+    use_bfg = dist is not None and args.collective == "bfg" and backend == "nccl"
+    if use_bfg:
+        ctx.comm_init(dist)                      # the library's own RCCL communicator (id broadcast through the group)
 
     # this rank's sky-patch shard (the whole catalog at N = 1), resident in HBM before timing starts
     if world > 1:
@@ -144,6 +223,18 @@ def main():
     d_cat = ctx.to_device(recs)
     spline = ctx.da_spline(bg, float(np.max(z)))
     md = ctx.massdef_struct(bg, None)
+
+    def allreduce_async(t):
+        """start the sum of t over the ranks so that it overlaps what is enqueued next; returns a waiter"""
+        if use_bfg:
+            ctx.allreduce_begin(t)
+            return ctx.comm_wait
+        if backend != "nccl":                                     # gloo rehearsal: staged through the host, synchronous
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+            return lambda: None
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True).wait
 
     if args.workload == "paint":
         zax, Max, rax, T = syn.pressure_table(*shape)
@@ -158,46 +249,81 @@ def main():
         pending = [None] * nbuf
         counter = [0]
 
-        def step():
+        def compute(b):
+            d_maps[b].zero_()
+            ctx.paint_shell(sargs, table, spline, d_maps[b])
+
+        def step(collective=True, do_compute=True):
             b = counter[0] % nbuf
             counter[0] += 1
             if pending[b] is not None:
-                pending[b].wait()            # the current stream waits for that buffer's all-reduce
+                pending[b]()                 # the current stream waits for that buffer's all-reduce
                 pending[b] = None
-            d_maps[b].zero_()
-            ctx.paint_shell(sargs, table, spline, d_maps[b])
-            if dist is not None:
-                pending[b] = dist.all_reduce(d_maps[b], op=dist.ReduceOp.SUM, async_op=True)
+            if do_compute:
+                compute(b)
+            if dist is not None and collective:
+                pending[b] = allreduce_async(d_maps[b])
 
         def finish():
             for b in range(nbuf):
                 if pending[b] is not None:
-                    pending[b].wait()
+                    pending[b]()
                     pending[b] = None
+        exchange_bytes = 8.0 * npix
     else:
         zax, Max, rax, T = syn.displacement_table(*shape)
         table = ctx.table([zax, Max, rax], T, log_values=False)
         d_off = ctx.zeros(npix, 3)
-        d_in = ctx.to_device(syn.mass_map(nside))
+        d_in_full = ctx.to_device(syn.mass_map(nside))
         d_map = ctx.zeros(npix)
         sargs = ctx.shell_args(nside, d_cat, idx.size, 4, 0, args.eps, md, model_md=md, model_epsilon_max=20.0,
                                variant=args.variant)
+        ex = None
+        d_in = d_in_full
+        if dist is not None:
+            from baryonforge_amd.utils.Parallelize import Exchange
+            ex = Exchange(dist, "bfg" if use_bfg else "torch", ctx)
+            if npix % world == 0:                                   # this rank regrids the sources of its pixel range
+                lo, hi = (x // 3 for x in ex.own_range(3 * npix))
+            else:
+                lo, hi = npix * rank // world, npix * (rank + 1) // world
+            d_in = ctx.zeros(npix)
+            d_in[lo:hi] = d_in_full[lo:hi]
 
-        def step():
-            d_off.zero_()
-            d_map.zero_()
-            ctx.baryonify_offsets(sargs, table, spline, d_off)
-            if dist is not None:
-                dist.all_reduce(d_off, op=dist.ReduceOp.SUM)
-            ctx.regrid_shell(nside, d_off, d_in, d_map, None)
+        def step(collective=True, do_compute=True):
+            # BaryonifyShell.process(distributed=...): offsets of this rank's halos -> reduce-scatter (every rank needs the
+            # summed offsets of its own pixel range only) -> regrid of that range -> all-reduce of the output maps
+            if do_compute:
+                d_off.zero_()
+                d_map.zero_()
+                ctx.baryonify_offsets(sargs, table, spline, d_off)
+            if ex is not None and collective:
+                if npix % world == 0:
+                    ex.reduce_scatter(d_off)
+                else:
+                    ex.allreduce(d_off)
+            if do_compute:
+                ctx.regrid_shell(nside, d_off, d_in, d_map, None)
+            if ex is not None and collective:
+                ex.allreduce(d_map)
 
         def finish():
             pass
+        exchange_bytes = 8.0 * npix * 4
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def timed(n, **kw):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step(**kw)
+        finish()                         # every outstanding collective has completed inside the timed region
+        barrier()
+        return time.perf_counter() - t0
 
     _mark("inputs resident")
     for _ in range(args.warmup):
@@ -208,17 +334,14 @@ def main():
     _mark("warmup done")
     ctx.stats_reset()
     ctx.timing_enable(True)          # hipEvents around each kernel, on the kernels' own stream
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    finish()                         # every outstanding collective has completed inside the timed region
-    barrier()
-    dt = time.perf_counter() - t0
+    dt = timed(args.steps)
     _mark("timed region done")
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if backend == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        else:
+            h = t.cpu(); dist.all_reduce(h, op=dist.ReduceOp.MAX); t.copy_(h)
         dt = float(t.item())
     stats = ctx.stats()
     k_ms, k_n = ctx.timing_read(1)
@@ -228,10 +351,18 @@ def main():
     l_ms, l_n = ctx.timing_read(4)
     ctx.timing_enable(False)
     ptot_step = stats["pixel_updates"] / max(args.steps, 1)
+
+    # ---- N > 1: two extra legs OUTSIDE the timed region: this rank's compute alone, the collective alone -------------
+    ranks = None
     if dist is not None:
-        pt = torch.tensor([ptot_step], dtype=torch.float64, device="cuda")
-        dist.all_reduce(pt, op=dist.ReduceOp.SUM)
-        ptot_all = float(pt.item())
+        t_comp = timed(args.steps, collective=False) / args.steps * 1e3
+        t_coll = timed(args.steps, do_compute=False) / args.steps * 1e3
+        mine = {"rank": rank, "shard_halos": int(idx.size), "pixel_updates_per_step": ptot_step,
+                "compute_ms": t_comp, "allreduce_ms": t_coll, "kernel_ms": k_ms / max(k_n, 1),
+                "prep_kernel_ms": p_ms / max(p_n, 1), "tile_binning_ms": (b_ms / b_n) if b_n else None}
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+        ptot_all = float(sum(r["pixel_updates_per_step"] for r in ranks))
     else:
         ptot_all = ptot_step
 
@@ -250,17 +381,24 @@ def main():
     kernel_bytes = 32.0 * idx.size + per_px * ptot_step
     kernel_s = (k_ms / max(k_n, 1)) * 1e-3
     achieved = kernel_bytes / kernel_s if kernel_s > 0 else 0.0
-    traffic = None
+    # HBM traffic of the dominant kernel per launch: rocprofv3 PMC passes cannot run inside this process, so the value
+    # is the stored measurement of tools/pmc_run.sh for this workload key (profiles/pmc_traffic.json names the build it
+    # was taken on); null for workloads that were not measured
+    traffic, traffic_source = None, None
     tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get(f"{args.workload}_{args.variant}_n{args.halos}_nside{nside}")
+            tj = json.load(open(tfile))
+            traffic = tj.get(f"{args.workload}_{args.variant}_n{idx.size}_nside{nside}")
+            if traffic is not None:
+                traffic_source = f"stored: {tj.get('_source', 'profiles/pmc_traffic.json')}"
         except Exception:
             traffic = None
     tile = args.variant in ("auto", "tile_lds")
+    step_bytes = kernel_bytes + 16.0 * npix * (1 if args.workload == "paint" else 8)
     roofline = {"bound": "hbm", "kernel": "shell_tile_kernel" if tile else "shell_scatter_kernel",
                 "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel_ms": k_ms / max(k_n, 1), "kernel_launches": k_n,
                 "algorithmic_bytes_per_launch": kernel_bytes,
                 "bytes_per_halo": kernel_bytes / max(idx.size, 1),
@@ -270,22 +408,48 @@ def main():
                 "tile_binning_ms": (b_ms / b_n) if b_n else None,
                 "leftover_scatter_kernel_ms": (l_ms / l_n) if l_n else None,
                 "regrid_kernel_ms": (r_ms / r_n) if r_n else None,
-                "step_algorithmic_GBps": (kernel_bytes + 16.0 * npix * (1 if args.workload == "paint" else 8)) /
-                                         (dt / args.steps) / 1e9}
+                "fallback_halos_per_step": stats["fallback_halos"] / max(args.steps, 1),
+                "step_algorithmic_GBps": step_bytes / (dt / args.steps) / 1e9 if world == 1 else None,
+                "step_frac": step_bytes / (dt / args.steps) / HBM_PEAK if world == 1 else None}
+    sharding_txt = "none"
+    if world > 1:
+        sharding_txt = ("sky patch (contiguous NEST ranges of nside-8 patches, balanced by pixel work) + "
+                        + ("RCCL all-reduce of the map, overlapped with the next shell (two map buffers)"
+                           if args.workload == "paint" else
+                           "RCCL reduce-scatter of the offsets, regrid of the rank's pixel range, all-reduce of the map")
+                        + f"; collective = {'libbfg_mi355 communicator (bfg_allreduce_f64*)' if use_bfg else 'torch.distributed ' + backend}")
+    halo_txt = (f"{args.halos} halos per GPU ({n_total} total)" if args.scaling == "weak" or world == 1
+                else f"{n_total} halos in total over {world} GPUs")
     out = {
         "metric": "halos_per_s", "value": value, "unit": "halos/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{'PaintProfilesShell' if args.workload == 'paint' else 'BaryonifyShell'}: "
-                               f"{args.halos} halos per GPU ({n_total} total), NSIDE={nside}, epsilon_max={args.eps:g}, "
+                               f"{halo_txt}, NSIDE={nside}, epsilon_max={args.eps:g}, "
                                f"{'TabulatedProfile(Pressure)' if args.workload == 'paint' else 'Baryonification2D'} "
                                f"table {shape[0]}x{shape[1]}x{shape[2]}, catalog "
                                f"{'dn/dlnM~M^-0.9' if args.steep else 'log10M~U(12,15.5)'}, z~U(0.4,0.5), seed 42",
-                   "variant": args.variant, "halos_per_gpu": args.halos, "nside": nside,
-                   "sharding": "sky patch (contiguous NEST ranges of nside-8 patches, balanced by pixel work) + RCCL all-reduce of the map, overlapped with the next shell (two map buffers)" if world > 1 else "none",
-                   "pixel_updates_total_per_step": ptot_all},
+                   "variant": args.variant, "halos_per_gpu": n_total // world, "halos_total": n_total, "nside": nside,
+                   "sharding": sharding_txt, "world_size": world,
+                   "pixel_updates_total_per_step": ptot_all,
+                   "timed_region": "inputs resident in HBM, map left in HBM (contract); see e2e_ms_python_api for the "
+                                   "PCIe-inclusive Python-API call"},
         "roofline": roofline,
     }
+    if ranks is not None:
+        for r in ranks:
+            r["overlap_ms"] = max(0.0, r["compute_ms"] + r["allreduce_ms"] - ms_per_step)   # collective time hidden behind compute
+        out["ranks"] = ranks
+        out["exchange"] = {"bytes_per_rank_per_step": exchange_bytes, "backend": backend,
+                           "collective": "bfg" if use_bfg else "torch",
+                           "busbw_GBps": 2.0 * (world - 1) / world * exchange_bytes /
+                           max(max(r["allreduce_ms"] for r in ranks) * 1e-3, 1e-9) / 1e9}
+    if world == 1 and not args.no_e2e and args.workload == "paint":
+        try:
+            out["e2e_ms_python_api"] = e2e_python_api(args, cosmo, ra, dec, M, z, zax, Max, rax, T)
+        except Exception as exc:                       # never lose the line to the side measurement
+            out["e2e_ms_python_api"] = None
+            out["e2e_error"] = repr(exc)
     if world == 1 and not args.no_cpu_baseline and args.workload == "paint":
         out["cpu_baseline"] = cpu_baseline(args, cosmo, ra, dec, M, z, (zax, Max, rax), T)
         out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -250,7 +250,9 @@ typedef struct {
     uint64_t pixels_out_of_table;/* pixel queries whose radius lies outside the r axis     */
     uint64_t halos_fallback4; /* baryonify: halos that used the <4-pixel fallback          */
     uint32_t warn_mask;       /* BFG_WARN_* bits (BaryonCorrection.py:382-394)             */
-    uint32_t reserved;
+    uint32_t halos_scatter_fallback; /* tile variant: halos WITH work that were handed to the ~12x slower global-atomic
+                               * scatter kernel (disc over > 64 sky tiles, ln(pixarea D^2) outside the fast exp range, or
+                               * the whole call after a pair-buffer overflow); results are the same, the time is not    */
 } bfg_stats;
 #define BFG_WARN_Z_RANGE 1u
 #define BFG_WARN_M_RANGE 2u
@@ -290,6 +292,10 @@ int bfg_regrid_shell(bfg_ctx *ctx, int64_t nside, const double *d_offsets, const
  * bfg_comm_init        collective over all ranks: builds the communicator of this context (rank in [0, world));
  * bfg_allreduce_f64    d_buf[count] <- sum over ranks, in place, asynchronous on the context's stream; a context
  *                      without a communicator is a world of one (no-op);
+ * bfg_allreduce_f64_begin / bfg_comm_wait   the same sum on the context's own communication stream, ordered after what
+ *                      the context's stream holds so far, so that it overlaps the work enqueued next (the next shell,
+ *                      painted into another buffer); bfg_comm_wait makes the context's stream wait for every
+ *                      collective begun so far -- call it before the buffer is read, zeroed or reused;
  * bfg_reduce_scatter_f64 / bfg_allgather_f64   the two halves, in place: rank r owns elements
  *                      [r count / world, (r + 1) count / world); count must be a multiple of world.
  * RCCL is loaded at the first of these calls (dlopen "librccl.so.1"; override with BFG_RCCL_SO): the library has no
@@ -300,6 +306,8 @@ int bfg_comm_init(bfg_ctx *ctx, const char *id, size_t id_bytes, int rank, int w
 int bfg_comm_destroy(bfg_ctx *ctx);
 int bfg_comm_info(bfg_ctx *ctx, int *rank, int *world);
 int bfg_allreduce_f64(bfg_ctx *ctx, double *d_buf, int64_t count);
+int bfg_allreduce_f64_begin(bfg_ctx *ctx, double *d_buf, int64_t count);
+int bfg_comm_wait(bfg_ctx *ctx);
 int bfg_reduce_scatter_f64(bfg_ctx *ctx, double *d_buf, int64_t count);
 int bfg_allgather_f64(bfg_ctx *ctx, double *d_buf, int64_t count);
 

@@ -1,0 +1,85 @@
+"""
+One rank of tests/test_gpu_distributed.py: a FRESH python process (started with subprocess, never a re-exec of a process
+that has touched the GPU) that joins a torch.distributed group and runs the reference-shaped multi-GPU API --
+SplitJoinParallel(PaintProfilesShell) and SplitJoinParallel(BaryonifyShell) -- through the real HIP kernels (no test
+seam).  On a one-GPU box every rank uses cuda:0 and the group is gloo; with one GPU per rank the group is nccl (= RCCL)
+and the library's own communicator (collective="bfg") is exercised too.  Results go to <out>/..._<rank>.npy.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+NSIDE, N_PAINT, N_BARY, EPS = 256, 4000, 3000, 10.0
+
+
+def inputs():
+    from baryonforge_amd import synthetic as syn
+    ra, dec, M, z = syn.catalog(N_PAINT, seed=2024)
+    zax, Max, rax, T = syn.pressure_table()
+    dz, dM, dr, dtab = syn.displacement_table()
+    m_in = syn.mass_map(NSIDE)
+    m_in[::9] = 0.0
+    return dict(cosmo=dict(syn.COSMO), ra=ra, dec=dec, M=M, z=z, paint=(zax, Max, rax, T), disp=(dz, dM, dr, dtab), m_in=m_in)
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--rank", type=int, required=True)
+    p.add_argument("--world", type=int, required=True)
+    p.add_argument("--port", type=int, required=True)
+    p.add_argument("--out", required=True)
+    p.add_argument("--backend", default="gloo")
+    a = p.parse_args()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(a.port), RANK=str(a.rank), WORLD_SIZE=str(a.world))
+    import torch
+    import torch.distributed as dist
+    one_device = a.backend != "nccl"
+    dev = 0 if one_device else a.rank
+    torch.cuda.set_device(dev)
+    if a.backend == "nccl":
+        dist.init_process_group("nccl", rank=a.rank, world_size=a.world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group(a.backend, rank=a.rank, world_size=a.world)
+    import baryonforge_amd as bfg
+    I = inputs()
+    cosmo = I["cosmo"]
+    zax, Max, rax, T = I["paint"]
+    Cat = bfg.HaloLightConeCatalog(I["ra"], I["dec"], I["M"], I["z"], cosmo)
+    npix = 12 * NSIDE * NSIDE
+    info = {"rank": a.rank, "world": a.world, "backend": a.backend, "device": dev}
+    collectives = ["torch"] + (["bfg"] if a.backend == "nccl" else [])
+    for coll in collectives:
+        R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(npix), cosmo=cosmo), EPS,
+                                   bfg.TabulatedProfile.from_arrays(zax, Max, rax, T), verbose=False)
+        SJ = bfg.SplitJoinParallel(R, collective=coll)
+        assert SJ.world == a.world and SJ.rank == a.rank and SJ.local_ops is None
+        out = SJ.process()
+        np.save(os.path.join(a.out, f"paint_{coll}_{a.rank}.npy"), out)
+        np.save(os.path.join(a.out, f"idx_{coll}_{a.rank}.npy"), SJ.shard_indices)
+        info[f"paint_{coll}_pixel_updates"] = int(SJ.Runner_list[0].last_stats["pixel_updates"])
+
+        dz, dM, dr, dtab = I["disp"]
+        sub = bfg.HaloLightConeCatalog(I["ra"][:N_BARY], I["dec"][:N_BARY], I["M"][:N_BARY], I["z"][:N_BARY], cosmo)
+        BR = bfg.BaryonifyShell(sub, bfg.LightconeShell(map=I["m_in"].copy(), cosmo=cosmo), EPS,
+                                bfg.Baryonification2D.from_arrays(dz, dM, dr, dtab, cosmo, epsilon_max=20), verbose=False)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            bout = bfg.SplitJoinParallel(BR, collective=coll).process()
+        np.save(os.path.join(a.out, f"bary_{coll}_{a.rank}.npy"), bout)
+    from baryonforge_amd import _lib
+    info["so"] = _lib.so_path()
+    info["maps"] = [m.split()[-1] for m in open("/proc/self/maps") if "libbfg_mi355" in m][:1]
+    json.dump(info, open(os.path.join(a.out, f"info_{a.rank}.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,8 +1,10 @@
 """
-World-size-2 tests of the multi-GPU path on CPU (gloo): sky-patch sharding of the catalog across ranks +
-all-reduce of the per-rank maps, exactly the code path SplitJoinParallel takes under RCCL, with the
-per-rank paint kernel replaced through the documented test seam (`local_process`) by the CPU oracle.
-Checks: every halo painted exactly once, reduced map == serial oracle map on every rank.
+World-size-2 (and 3) tests of the multi-GPU path on CPU (gloo): sky-patch sharding of the catalog across ranks +
+the exchange steps (paint: all-reduce of the per-rank maps; baryonify: reduce-scatter of the offset field, regrid of the
+rank's own pixel range, all-reduce of the output maps), exactly the code path SplitJoinParallel takes under RCCL, with the
+per-rank kernels replaced through the documented test seam (`local_ops`) by the CPU oracle.
+Checks: every halo handled exactly once, reduced map == serial oracle map on every rank, mass conserved.
+(tests/test_gpu_distributed.py runs the same with the real HIP kernels in the ranks.)
 """
 import os
 import socket
@@ -55,6 +57,31 @@ def _worker(rank, world, port, out_dir):
     out = SJ.process()
     np.save(os.path.join(out_dir, f"map_{rank}.npy"), out)
     np.save(os.path.join(out_dir, f"idx_{rank}.npy"), SJ.shard_indices)
+
+    # ---- BaryonifyShell, which the reference's splitter refuses (Parallelize.py:206-209): offsets are linear in halos
+    dz, dM, dr, dtab = syn.displacement_table(5, 8, 50)
+    bmodel = bfg.Baryonification2D.from_arrays(dz, dM, dr, dtab, cosmo, epsilon_max=20)
+    m_in = syn.mass_map(nside)
+    m_in[::5] = 0.0
+    BR = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo), 10, bmodel, verbose=False)
+    calls = {"offsets": 0, "regrid_sources": None}
+
+    def oracle_offsets(runner):
+        c = runner.HaloLightConeCatalog.cat
+        calls["offsets"] += 1
+        a, R, D = orc.halo_scalars(cosmo, c["M"], c["z"])
+        return orc.baryonify_offsets(nside, c["ra"], c["dec"], c["M"], a, D, R, R / a, (dz, dM, dr), dtab, 10, 20.0, False,
+                                     None)[0]
+
+    def oracle_regrid(ns, off, in_map):
+        calls["regrid_sources"] = np.flatnonzero(in_map)
+        return orc.regrid_shell(ns, off, in_map)
+    BSJ = bfg.SplitJoinParallel(BR, local_ops=bfg.HostOps(offsets=oracle_offsets, regrid=oracle_regrid))
+    bout = BSJ.process()
+    np.save(os.path.join(out_dir, f"bmap_{rank}.npy"), bout)
+    np.save(os.path.join(out_dir, f"bidx_{rank}.npy"), BSJ.shard_indices)
+    np.save(os.path.join(out_dir, f"bsrc_{rank}.npy"), calls["regrid_sources"])
+    assert calls["offsets"] == 1
     # SimpleParallel: runners dealt round-robin, every rank gets every output
     class Fake(object):
         def __init__(self, k):
@@ -67,9 +94,10 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_splitjoin_two_ranks_gloo(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_splitjoin_ranks_gloo(tmp_path, world):
     import torch.multiprocessing as mp
-    world, port = 2, _free_port()
+    port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     from baryonforge_amd import synthetic as syn
@@ -84,6 +112,22 @@ def test_splitjoin_two_ranks_gloo(tmp_path):
     for m in maps:                                                            # all-reduce: same map everywhere
         np.testing.assert_allclose(m, ref, rtol=1e-9, atol=0)
     assert np.array_equal(maps[0], maps[1])
+    # distributed BaryonifyShell == the serial oracle run, on every rank; mass conserved; every source pixel regridded once
+    from util import oracle_baryonify
+    dz, dM, dr, dtab = syn.displacement_table(5, 8, 50)
+    m_in = syn.mass_map(64)
+    m_in[::5] = 0.0
+    bref = oracle_baryonify(dict(syn.COSMO), ra, dec, M, z, (dz, dM, dr), dtab, 64, 10, 20.0, m_in)
+    bmaps = [np.load(tmp_path / f"bmap_{r}.npy") for r in range(world)]
+    bidx = [np.load(tmp_path / f"bidx_{r}.npy") for r in range(world)]
+    bsrc = [np.load(tmp_path / f"bsrc_{r}.npy") for r in range(world)]
+    assert np.array_equal(np.sort(np.concatenate(bidx)), np.arange(600))
+    assert np.array_equal(np.sort(np.concatenate(bsrc)), np.flatnonzero(m_in))   # pixel ranges partition the sources
+    assert all(s.size > 0 for s in bsrc)
+    assert not np.allclose(bref, m_in)
+    for m in bmaps:
+        np.testing.assert_allclose(m, bref, rtol=1e-9, atol=1e-9 * np.abs(bref).max())
+        assert np.isclose(m.sum(), m_in.sum(), rtol=1e-12)
 
 
 def test_splitjoin_single_process_is_passthrough():

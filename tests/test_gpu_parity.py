@@ -1095,13 +1095,33 @@ def test_tile_pair_buffer_overflow_falls_back_to_scatter(cosmo, monkeypatch):
     monkeypatch.setenv("BFG_TILE_CAP", "2")                 # two fixed slots per tile: nearly every pair overflows ...
     monkeypatch.setenv("BFG_PAIR_CAP", "100")               # ... into lists that cannot hold them
     R = bfg.PaintProfilesShell(Cat, Shell, 10, _paint_model(zax, Max, rax, T), verbose=False, variant="tile_lds")
-    got = R.process()
+    with pytest.warns(UserWarning, match="scatter kernel"):  # the degradation is reported, not silent
+        got = R.process()
     assert R.last_stats["pixel_updates"] == ptot
+    assert R.last_stats["fallback_halos"] == 3000             # bfg_stats.halos_scatter_fallback: every halo
     assert_maps_close(got, ref, RTOL, what="pair overflow fallback")
     monkeypatch.delenv("BFG_PAIR_CAP")
     monkeypatch.delenv("BFG_TILE_CAP")
-    got = R.process()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                        # ... and the normal path neither counts nor warns
+        got = R.process()
+    assert R.last_stats["fallback_halos"] == 0
     assert_maps_close(got, ref, RTOL, what="after fallback")
+    # a disc that overlaps more than 64 sky tiles is left to the scatter kernel on its own: counted as one
+    big = bfg.HaloLightConeCatalog(np.append(ra[:50], 10.0), np.append(dec[:50], 5.0), np.append(M[:50], 5e15),
+                                   np.append(z[:50], 0.012), cosmo)
+    zb = np.append(z[:50], 0.012)
+    refb, ptb = oracle_paint(cosmo, np.append(ra[:50], 10.0), np.append(dec[:50], 5.0), np.append(M[:50], 5e15), zb,
+                             (zax, Max, rax), T, 256, 10)
+    Rb = bfg.PaintProfilesShell(big, Shell, 10, _paint_model(zax, Max, rax, T), verbose=False, variant="tile_lds")
+    with warnings.catch_warnings(record=True) as wrec:
+        warnings.simplefilter("always")
+        gotb = Rb.process()
+    assert Rb.last_stats["pixel_updates"] == ptb
+    assert_maps_close(gotb, refb, RTOL, what="one huge disc")
+    if Rb.last_stats["fallback_halos"]:
+        assert Rb.last_stats["fallback_halos"] == 1 and any("scatter kernel" in str(w.message) for w in wrec)
 
 
 @pytest.mark.parametrize("slots", [1, 3, 17])
