@@ -14,6 +14,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_report_header(config):
+    """what produced the golden fixtures: real healpy / pyccl or their stand-ins (tests/golden/make_golden.py --real-deps)"""
+    import json
+    import numpy as np
+    lines = []
+    for f in sorted(os.listdir(GOLDEN)):
+        if f.endswith(".npz"):
+            try:
+                p = json.loads(str(np.load(os.path.join(GOLDEN, f))["_provenance"]))
+                lines.append(f"golden {f}: deps={p.get('deps')} healpy={p.get('healpy')} | pyccl={p.get('pyccl')} | "
+                             f"numba={p.get('numba')} | numpy {p.get('numpy')} scipy {p.get('scipy')}")
+            except Exception:
+                lines.append(f"golden {f}: no provenance record")
+    return lines
+
+
 def pytest_collection_modifyitems(config, items):
     """a plain `pytest` on a box without a GPU skips the gpu-marked tests instead of failing them (the product has no
     CPU path to fall back to).  device_count() does not initialise the GPU runtime."""

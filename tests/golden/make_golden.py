@@ -27,9 +27,20 @@ What is executed verbatim from the reference:
   Runners/HealpixRunner.py  PaintProfilesShell.process, BaryonifyShell.process,
                             regrid_pixels_hpix
 
-Usage:  python tests/golden/make_golden.py      (writes tests/golden/*.npz)
+Usage:  python tests/golden/make_golden.py [section] [--real-deps] [--out DIR]     (writes tests/golden/*.npz)
+
+--real-deps: the closing path for the two rows the stand-ins cannot pin (HEALPix geometry = a8, CCL
+background = a9).  Wherever the real `healpy`, `pyccl` or `numba` is importable in the interpreter that runs this script,
+it is used INSTEAD of its stand-in (each package on its own; with all three present the reference is imported as the
+ordinary package it is), and the fixtures then pin the oracle and the GPU path against the real healpix_cxx / libccl.
+Every .npz records what produced it in a `_provenance` entry (a JSON string: per package "real <version>" or "stub
+(<what stands in>)", plus numpy / scipy versions and the reference commit if known); tests/conftest.py prints it in the
+pytest header.  Neither package exists in the build container of this repository (no network), so the committed
+fixtures say "stub" for healpy and pyccl: parity against the live libraries stays unpinned until someone who has them
+runs this one command.
 """
 import importlib.util
+import json
 import os
 import sys
 import types
@@ -47,22 +58,57 @@ from scipy import interpolate  # noqa: E402
 
 COSMO = {"Omega_m": 0.30, "Omega_b": 0.04, "h": 0.7, "sigma8": 0.8, "n_s": 0.96, "w0": -1.0}
 
+REAL_DEPS = False          # --real-deps
+OUT = HERE                 # --out
+PROVENANCE = {}            # package -> "real <version>" | "stub (...)"
+
+
+def _try_real(name):
+    """import the real package if --real-deps asks for it and it exists; None otherwise"""
+    if not REAL_DEPS:
+        return None
+    try:
+        mod = importlib.import_module(name)
+    except Exception:
+        return None
+    if getattr(mod, "__file__", None) is None:        # one of our own stand-ins left in sys.modules
+        return None
+    PROVENANCE[name] = f"real {getattr(mod, '__version__', '?')}"
+    return mod
+
+
+def save(name, **arrays):
+    prov = dict(PROVENANCE)
+    prov.update(numpy=np.__version__, scipy=__import__("scipy").__version__, generator="tests/golden/make_golden.py",
+                deps="real" if all(str(PROVENANCE.get(k, "")).startswith("real") for k in ("healpy", "pyccl")) else "stub")
+    arrays["_provenance"] = np.array(json.dumps(prov, sort_keys=True))
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name), **arrays)
+
 
 # ------------------------------------------------------------------ stubs
 def install_stubs():
     # numba
-    numba = types.ModuleType("numba")
-    numba.njit = lambda f: f
-    sys.modules["numba"] = numba
+    if _try_real("numba") is None:
+        numba = types.ModuleType("numba")
+        numba.njit = lambda f: f
+        sys.modules["numba"] = numba
+        PROVENANCE["numba"] = "stub (identity decorator)"
 
     # healpy <- oracle HEALPix
-    hp = types.ModuleType("healpy")
-    for name in ("ang2vec", "pix2vec", "query_disc", "get_interp_weights", "vec2ang",
-                 "nside2pixarea", "npix2nside", "nside2npix", "nside2resol"):
-        setattr(hp, name, getattr(orc, name))
-    sys.modules["healpy"] = hp
+    if _try_real("healpy") is None:
+        hp = types.ModuleType("healpy")
+        for name in ("ang2vec", "pix2vec", "query_disc", "get_interp_weights", "vec2ang",
+                     "nside2pixarea", "npix2nside", "nside2npix", "nside2resol"):
+            setattr(hp, name, getattr(orc, name))
+        sys.modules["healpy"] = hp
+        PROVENANCE["healpy"] = "stub (oracle/oracle.py HEALPix RING restatement)"
 
     # pyccl
+    real_ccl = _try_real("pyccl")
+    if real_ccl is not None:
+        return real_ccl
+    PROVENANCE["pyccl"] = "stub (oracle/oracle.py flat-wCDM background)"
     ccl = types.ModuleType("pyccl")
     halos = types.ModuleType("pyccl.halos")
     massdef = types.ModuleType("pyccl.halos.massdef")
@@ -119,13 +165,16 @@ def install_stubs():
     sys.modules.update({"pyccl": ccl, "pyccl.halos": halos, "pyccl.halos.massdef": massdef,
                         "pyccl.halos.profiles": profiles})
 
+    return ccl
+
+
+def install_package_shells():
     # package shells so relative imports resolve without running the star-import __init__ files
     for pkg, sub in (("BaryonForge", ""), ("BaryonForge.utils", "utils"),
                      ("BaryonForge.Profiles", "Profiles"), ("BaryonForge.Runners", "Runners")):
         m = types.ModuleType(pkg)
         m.__path__ = [os.path.join(REF, sub)]
         sys.modules[pkg] = m
-    return ccl
 
 
 def load(modname, relpath):
@@ -138,6 +187,7 @@ def load(modname, relpath):
 
 def load_reference():
     ccl = install_stubs()
+    install_package_shells()
     load("BaryonForge.utils.misc", "utils/misc.py")
     tab = load("BaryonForge.utils.Tabulate", "utils/Tabulate.py")
     sys.modules["BaryonForge.utils"].ParamTabulatedProfile = tab.ParamTabulatedProfile
@@ -218,6 +268,7 @@ def rgi(axes, values, **kw):
 def main(only=None):
     """only: None = regenerate every fixture; 'anis' = just anis_shell.npz (added later; the others stay untouched)"""
     ccl, tab, bc, io, run = load_reference()
+    print("provenance:", json.dumps(PROVENANCE, sort_keys=True))
     warnings.simplefilter("ignore")
     np.seterr(all="ignore")
     cosmo_obj = ccl.Cosmology(Omega_c=COSMO["Omega_m"] - COSMO["Omega_b"], Omega_b=COSMO["Omega_b"],
@@ -296,7 +347,7 @@ def main(only=None):
         out.update({f"rb_{tag}_zax": zd, f"rb_{tag}_Max": Md, f"rb_{tag}_rax": rd, f"rb_{tag}_d": d,
                     f"rb_{tag}_eps": np.array(disp.epsilon_max), f"rb_{tag}_disp": vals,
                     f"rb_{tag}_Rcom": Rm})
-    np.savez_compressed(os.path.join(HERE, "readout.npz"), **out)
+    save("readout.npz", **out)
     print("readout.npz", {k: np.shape(v) for k, v in out.items() if "proj" in k or "disp" in k})
 
     # ---------------------------------------------------------------- 2. PaintProfilesShell.process
@@ -329,7 +380,7 @@ def main(only=None):
     out.update(p_nside=np.array(32), p_ra=ra, p_dec=dec, p_M=M, p_z=z, p_cdelta=cd, p_eps=np.array(10),
                p_zax=zax4, p_Max=Max4, p_rax=rax4, p_pax=pax, p_T2D=T4, p_map=res)
     print("paint p", "sum", res.sum(), "nonzero", np.count_nonzero(res))
-    np.savez_compressed(os.path.join(HERE, "paint_shell.npz"), **out)
+    save("paint_shell.npz", **out)
 
     # ---------------------------------------------------------------- 3. BaryonifyShell.process
     out = {}
@@ -354,7 +405,7 @@ def main(only=None):
                     f"{tag}_rax": rd, f"{tag}_d": d, f"{tag}_map_in": m_in, f"{tag}_map_out": res})
         print("baryonify", tag, "sum in/out", m_in.sum(), res.sum(), "changed px",
               np.count_nonzero(~np.isclose(res, m_in)))
-    np.savez_compressed(os.path.join(HERE, "baryonify_shell.npz"), **out)
+    save("baryonify_shell.npz", **out)
 
     # ---------------------------------------------------------------- 4. regrid_pixels_hpix
     rng = np.random.default_rng(3)
@@ -363,8 +414,7 @@ def main(only=None):
     cpix = rng.integers(0, npix, (N, 4))
     cw = rng.dirichlet(np.ones(4), N)
     hm = run.regrid_pixels_hpix(np.zeros(npix), vals, cpix, cw)
-    np.savez_compressed(os.path.join(HERE, "regrid.npz"), vals=vals, child_pix=cpix,
-                        child_weights=cw, hmap=hm)
+    save("regrid.npz", vals=vals, child_pix=cpix, child_weights=cw, hmap=hm)
 
     # ---------------------------------------------------------------- 5. Baryonification2D table builder (a6)
     class Sigma(ccl.halos.profiles.HaloProfile):
@@ -399,15 +449,15 @@ def main(only=None):
     out.update(tb_z_tab=zs, tb_d_interp=B2.raw_input_d,
                tb_Sigma_DMO_z=np.array([DMO._projected(None, S_r, M_t, 1 / (1 + zz)) / (1 + zz) for zz in zs]),
                tb_Sigma_DMB_z=np.array([DMB._projected(None, S_r, M_t, 1 / (1 + zz)) / (1 + zz) for zz in zs]))
-    np.savez_compressed(os.path.join(HERE, "table_builder.npz"), **out)
+    save("table_builder.npz", **out)
     print("table_builder d range", np.nanmin(B2.raw_input_d), np.nanmax(B2.raw_input_d))
 
     anis_section(ccl, io, run, make_tabulated, mdef)
     snapshot_section(io, make_disp, mdef)
     grid_section(io, make_tabulated, make_disp, mdef)
-    for f in sorted(os.listdir(HERE)):
+    for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
-            print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
+            print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 
 
 def anis_section(ccl, io, run, make_tabulated, mdef):
@@ -441,7 +491,7 @@ def anis_section(ccl, io, run, make_tabulated, mdef):
                     f"{tag}_background_val": np.array(bval), f"{tag}_global_tracer_fraction": np.array(gfrac),
                     f"{tag}_map_out": res})
         print("anis", tag, "sum", res.sum(), "nonzero", np.count_nonzero(res))
-    np.savez_compressed(os.path.join(HERE, "anis_shell.npz"), **out)
+    save("anis_shell.npz", **out)
 
 
 def snapshot_section(io, make_disp, mdef):
@@ -475,7 +525,7 @@ def snapshot_section(io, make_disp, mdef):
                     f"{tag}_Max": Md, f"{tag}_rax": rd, f"{tag}_d": d, f"{tag}_P_new": new})
         moved = np.abs(new - old); moved = np.minimum(moved, L - moved)
         print("snapshot", tag, "moved particles", np.count_nonzero(moved.max(axis=1) > 0), "max shift", moved.max())
-    np.savez_compressed(os.path.join(HERE, "snapshot.npz"), **out)
+    save("snapshot.npz", **out)
 
 
 def grid_section(io, make_tabulated, make_disp, mdef):
@@ -524,6 +574,39 @@ def grid_section(io, make_tabulated, make_disp, mdef):
                     f"{tag}_eps_model": np.array(emod), f"{tag}_rdelta": np.array(rdelta), f"{tag}_zax": zd, f"{tag}_Max": Md,
                     f"{tag}_rax": rd, f"{tag}_d": d, f"{tag}_map_in": m_in, f"{tag}_map_out": resmap})
         print("grid baryonify", tag, "sum in/out", m_in.sum(), resmap.sum(), "changed", np.count_nonzero(~np.isclose(resmap, m_in)))
+    # catalogue rows the loop cannot use (resolves the open question of round 1): an infinite mass, a position at
+    # +infinity, a zero mass.  BaryonifyGrid ADDS the row's NaN displacements to every pixel of its cut-out (:553-555 /
+    # :599-602; the cut-out of M = inf is the half box, :492-498) and the regrid then zeroes non-finite offsets
+    # (:613 / :623): the accumulated displacement of all OTHER halos on those pixels is lost with them.
+    for tag, is2D, Npix, L, nhalo, seed, eps in (("x2", True, 64, 80.0, 30, 85, 5), ("x3", False, 16, 40.0, 12, 86, 3)):
+        rng = np.random.default_rng(seed)
+        res = L / Npix
+        bins = (np.arange(Npix) + 0.5) * res
+        nd = 2 if is2D else 3
+        H = rng.uniform(0, L, (nhalo, 3))
+        hM = 10 ** rng.uniform(13.5, 15.3, nhalo)
+        H[5], hM[5] = [0.3 * L, 0.6 * L, 0.5 * L], np.inf          # infinite mass
+        H[9, 0] = np.inf                                           # position at +infinity (passes the 2D assert, :522)
+        hM[12 if nhalo > 12 else 3] = 0.0                          # zero mass
+        zd, Md, rd, d = disp_table()
+        d = d * 8.0
+        disp = make_disp(zd, Md, rd, d, eps=20)
+        m_in = rng.uniform(0, 10, (Npix,) * nd)
+        m_in[rng.uniform(size=m_in.shape) < 0.1] = 0.0
+        Cat = io.HaloNDCatalog(H[:, 0], H[:, 1], hM, 0.3, COSMO, z=None if is2D else H[:, 2])
+        Map = io.GriddedMap(map=m_in, redshift=0.3, bins=bins, cosmo=COSMO)
+        resmap = m2d.BaryonifyGrid(Cat, Map, epsilon_max=eps, model=disp, mass_def=mdef, verbose=False).process()
+        good = np.isfinite(hM) & (hM > 0) & np.all(np.isfinite(H[:, :nd]), axis=1)
+        CatG = io.HaloNDCatalog(H[good, 0], H[good, 1], hM[good], 0.3, COSMO, z=None if is2D else H[good, 2])
+        clean = m2d.BaryonifyGrid(CatG, io.GriddedMap(map=m_in, redshift=0.3, bins=bins, cosmo=COSMO), epsilon_max=eps,
+                                  model=disp, mass_def=mdef, verbose=False).process()
+        out.update({f"{tag}_is2D": np.array(is2D), f"{tag}_Npix": np.array(Npix), f"{tag}_bins": bins, f"{tag}_H": H[:, :nd],
+                    f"{tag}_hM": hM, f"{tag}_redshift": np.array(0.3), f"{tag}_eps": np.array(eps),
+                    f"{tag}_eps_model": np.array(20), f"{tag}_rdelta": np.array(False), f"{tag}_zax": zd, f"{tag}_Max": Md,
+                    f"{tag}_rax": rd, f"{tag}_d": d, f"{tag}_map_in": m_in, f"{tag}_map_out": resmap,
+                    f"{tag}_map_out_without_bad_rows": clean})
+        print("grid baryonify, unusable rows", tag, "sum in/out", m_in.sum(), resmap.sum(), "pixels that differ from the run "
+              "without those rows", np.count_nonzero(~np.isclose(resmap, clean)), "of", resmap.size)
     # ellipticity (2D only, :518-524 / :753-757) and PaintProfilesAnisGrid (:833-1015)
     rng = np.random.default_rng(90)
     Npix, L, nhalo = 80, 70.0, 30
@@ -560,8 +643,16 @@ def grid_section(io, make_tabulated, make_disp, mdef):
                e_map_in=m_in, e_zd=zd, e_Md=Md, e_rd=rd, e_d=dd * 8.0, e_background_val=np.array(0.7),
                e_global_tracer_fraction=np.array(0.35), e_paint_ell=e_paint, e_bary_ell=e_bary, e_anis=anis, e_anis_ell=anis_e)
     print("grid ellipticity / anis sums", e_paint.sum(), e_bary.sum(), anis.sum(), anis_e.sum())
-    np.savez_compressed(os.path.join(HERE, "grid.npz"), **out)
+    save("grid.npz", **out)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else None)
+    argv = sys.argv[1:]
+    if "--real-deps" in argv:
+        REAL_DEPS = True
+        argv.remove("--real-deps")
+    if "--out" in argv:
+        i = argv.index("--out")
+        OUT = os.path.abspath(argv[i + 1])
+        del argv[i:i + 2]
+    main(argv[0] if argv else None)

@@ -182,7 +182,7 @@ def test_oracle_paint_grid_matches_reference(golden, cosmo, tag):
     np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-300)
 
 
-@pytest.mark.parametrize("tag", ["b2", "b3"])
+@pytest.mark.parametrize("tag", ["b2", "b3", "x2", "x3"])
 def test_oracle_baryonify_grid_matches_reference(golden, cosmo, tag):
     """oracle restatement of BaryonifyGrid.process (incl. regrid_pixels_2D/3D) vs the reference's own run"""
     g = golden("grid.npz")
