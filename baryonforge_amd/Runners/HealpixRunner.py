@@ -136,11 +136,12 @@ class PaintProfilesShell(DefaultRunner):
                 return np.log(np.asarray(self.model.raw_input_2D, dtype=np.float64))
         table = ctx.table(_table_axes(self.model, keys), log_table, log_values=True,
                           cache_key=(self.model, "2D", self.model.raw_input_2D))
-        if d_map is None:
+        fresh = d_map is None
+        if fresh:
             d_map = ctx.zeros(12 * NSIDE * NSIDE)                         # :424
         args = ctx.shell_args(NSIDE, d_cat, d_cat.shape[0], stride, len(keys), self.epsilon_max,
                               ctx.massdef_struct(bg, self.mass_def), include_pixel_size=self.include_pixel_size,
-                              variant=self.variant)
+                              variant=self.variant, out_is_zero=fresh)
         ctx.stats_reset()
         ctx.paint_shell(args, table, spline, d_map)
         self.last_stats = ctx.stats()
@@ -279,7 +280,8 @@ class BaryonifyShell(DefaultRunner):
         args = ctx.shell_args(NSIDE, d_cat, d_cat.shape[0], stride, len(keys), self.epsilon_max,
                               ctx.massdef_struct(bg, self.mass_def), model_md=model_md,
                               model_epsilon_max=model.epsilon_max,
-                              rdelta_sampling=getattr(model, "Rdelta_sampling", False), variant=self.variant)
+                              rdelta_sampling=getattr(model, "Rdelta_sampling", False), variant=self.variant,
+                              out_is_zero=True)
         d_off = ctx.zeros(12 * NSIDE * NSIDE, 3)                          # :313
         ctx.stats_reset()
         ctx.baryonify_offsets(args, table, spline, d_off)                 # :315-355

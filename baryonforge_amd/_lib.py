@@ -26,6 +26,7 @@ VARIANTS = {"auto": VARIANT_AUTO, "scatter_wave": VARIANT_SCATTER_WAVE,
             "scatter_quarter": VARIANT_SCATTER_QUARTER, "tile_lds": VARIANT_TILE_LDS}
 
 WARN_Z_RANGE, WARN_M_RANGE, WARN_R_RANGE = 1, 2, 4
+SHELL_OUT_IS_ZERO = 1
 
 # every symbol include/bfg_mi355.h declares (tests check the .so exports all of them)
 SYMBOLS = [
@@ -54,7 +55,7 @@ class ShellArgs(C.Structure):
                 ("n_extra", C.c_int32), ("epsilon_max", _dbl), ("runner_md", MassDefStruct),
                 ("model_md", MassDefStruct), ("model_epsilon_max", _dbl),
                 ("rdelta_sampling", C.c_int32), ("include_pixel_size", C.c_int32),
-                ("variant", C.c_int32), ("reserved", C.c_int32)]
+                ("variant", C.c_int32), ("flags", C.c_int32)]
 
 
 class SnapshotArgs(C.Structure):

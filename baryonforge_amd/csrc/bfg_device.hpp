@@ -249,7 +249,8 @@ constexpr int kLogTab = 128;
 constexpr int kExpTab = 64;
 
 struct TileGeom {
-    int tr;                      // rings per band (64 for paint tiles, 32 for the 3-component offset tiles)
+    int tr;                      // rings per band
+    int tw;                      // max pixels of one ring inside one sector
     int nbands;
     int ntiles;
     const int32_t *band_ns;      // [nbands]   sectors per band

@@ -40,6 +40,9 @@ struct GridParams {
 // np.argmin(np.abs(bins - h)): nearest pixel centre, the lowest index on ties
 __device__ inline int grid_nearest_bin(const double *bins, int n, double res, double h)
 {
+    // a coordinate at +-infinity (or NaN) is equally far from every pixel centre: np.argmin returns index 0
+    // (pinned by tests/golden/grid.npz x2 / x3: the reference cuts such a halo's window around pixel 0)
+    if (!(fabs(h) < __builtin_huge_val())) return 0;
     int i = (int)floor((h - bins[0]) / res + 0.5);
     i = min(max(i, 0), n - 1);
     int best = i;

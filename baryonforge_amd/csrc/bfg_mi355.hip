@@ -76,7 +76,7 @@ struct bfg_spline {
     double *d_coef;   // [4][n-1]
 };
 
-namespace bfg { struct HaloTile; struct HaloDisp; }
+namespace bfg { struct HaloTile; struct HaloDisp; struct DeferredOut; }
 struct bfg_ctx {
     int device;
     hipStream_t stream;
@@ -99,9 +99,11 @@ struct bfg_ctx {
         int32_t *d_geo;             // band_ns | band_tile0 | band_nrmin | tile_band
         int32_t *d_tile_count, *d_tile_start;
         int4 *d_work;               // [2 ntiles + kWorkExtra] work items of the tile kernel
+        bfg::DeferredOut *d_defer;  // [2 ntiles + kWorkExtra][kDeferCap] pixels left to tile_deferred_kernel (paint)
+        int32_t *d_defer_count;     // [2 ntiles + kWorkExtra]
         int cap_direct;             // fixed pair slots per tile of the current call
         int32_t *d_nwork;
-    } tiles[2];                     // [MODE_PAINT], [MODE_BARYONIFY]
+    } tiles[3];                     // [MODE_PAINT], [MODE_BARYONIFY], [2] = the regrid kernel's tiles
     int32_t *d_pairs;              // [ntiles * cap_direct] slots | [pair_cap] overflow lists
     unsigned long long *d_ovf_mask; // [cap_halo]
     int64_t pairs_alloc;           // entries allocated in d_pairs
@@ -151,7 +153,8 @@ struct ShellParams {
     double *out;             // map [npix] or offsets [npix][3]
     bfg_stats *stats;
     int only_flagged;        // process only halos the tile binning flagged HF_SCATTER
-    const int32_t *left;     // only_flagged: left[0] = count, left[1..] = the flagged halos (else nullptr)
+    const int32_t *left;     // only_flagged: left[1..] = the flagged halos (else nullptr)
+    const int32_t *left_n;   // ... and their number
     const int32_t *pair_total_ptr;   // tile_start[ntiles] and the pair buffer capacity (overflow -> every halo is flagged)
     long long pair_cap;
 };
@@ -180,7 +183,8 @@ struct PrepParams {
     double pixfac_area;
     bfg::BinCtx bin;         // tile variant: count pass of the halo -> tile binning
     bfg::HaloDisp *hd;       // baryonify tile path
-    int32_t *left;           // tile variant: left[0] = count, left[1..] = halos flagged for the scatter kernel
+    int32_t *left;           // tile variant: left[1..] = halos flagged for the scatter kernel
+    int32_t *left_n;         // ... their number: the int32 after the tile counters, cleared by the same memset
     double eps_model;
     int rdelta;
 };
@@ -189,6 +193,7 @@ struct PrepParams {
 #define MODE_BARYONIFY 1
 constexpr int kMaxCorner = 1 << (BFG_MAX_DIM - 1);
 #include "bfg_tile.hpp"
+#include "bfg_wtile.hpp"
 
 __device__ inline double massdef_radius(const bfg_massdef &md, double M, double a)
 {
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(256) void halo_prep_kernel(const PrepParams P)
     irec[I_RFIRST * cap] = rfirst; irec[I_RLAST * cap] = rlast;
     irec[I_IRMIN * cap] = irmin; irec[I_IRMAX * cap] = irmax;
     irec[I_FLAGS * cap] = flags;
-    if (P.left && (flags & HF_SCATTER) && !(flags & HF_SKIP)) P.left[1 + atomicAdd(&P.left[0], 1)] = (int32_t)j;
+    if (P.left && (flags & HF_SCATTER) && !(flags & HF_SKIP)) P.left[1 + atomicAdd(P.left_n, 1)] = (int32_t)j;
     if ((flags & HF_SLOW) && !(flags & (HF_SKIP | HF_OOB))) atomicAdd(&P.stats->halos_scatter_fallback, 1u);
     if (P.ht) {
         HaloTile h;
@@ -618,7 +623,7 @@ __global__ __launch_bounds__(256) void shell_scatter_kernel(const ShellParams P)
         return;
     }
     const bool all = (long long)P.pair_total_ptr[0] > P.pair_cap;
-    const int64_t n = all ? P.n_halo : (int64_t)P.left[0];
+    const int64_t n = all ? P.n_halo : (int64_t)*P.left_n;
     for (int64_t it = first; it < n; it += stride) {
         scatter_halo<G, MODE>(P, all ? it : (int64_t)P.left[1 + it], smem_raw);
         __builtin_amdgcn_wave_barrier();
@@ -1072,12 +1077,14 @@ static void ctx_free_all(bfg_ctx *c)
     if (c->d_hwin) (void)hipFree(c->d_hwin);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_red) (void)hipFree(c->d_red);
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < 3; ++m) {
         if (c->tiles[m].d_geo) (void)hipFree(c->tiles[m].d_geo);
         if (c->tiles[m].d_tile_count) (void)hipFree(c->tiles[m].d_tile_count);
         if (c->tiles[m].d_tile_start) (void)hipFree(c->tiles[m].d_tile_start);
         if (c->tiles[m].d_work) (void)hipFree(c->tiles[m].d_work);
         if (c->tiles[m].d_nwork) (void)hipFree(c->tiles[m].d_nwork);
+        if (c->tiles[m].d_defer) (void)hipFree(c->tiles[m].d_defer);
+        if (c->tiles[m].d_defer_count) (void)hipFree(c->tiles[m].d_defer_count);
     }
     if (c->d_hd) (void)hipFree(c->d_hd);
     if (c->d_left) (void)hipFree(c->d_left);
@@ -1403,13 +1410,16 @@ static void timing_end(bfg_ctx *c, int which)
 }
 
 // tile geometry of one (nside, rings-per-tile) (cached per mode) and the binning buffers
-static int ensure_tiles(bfg_ctx *c, int mode, int tr, int64_t nside, int64_t n_halo)
+constexpr int kRegridSet = 2, kRegridTR = 64;     // regrid_tile_kernel: 64-ring x kTileWidth tiles of source pixels
+static int ensure_tiles(bfg_ctx *c, int mode, int tr, int tw, int64_t nside, int64_t n_halo)
 {
     bfg_ctx::TileSet &ts = c->tiles[mode];
-    if (ts.nside != nside || ts.geo.tr != tr) {
+    if (ts.nside != nside || ts.geo.tr != tr || ts.geo.tw != tw) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (ts.d_geo) { (void)hipFree(ts.d_geo); (void)hipFree(ts.d_tile_count); (void)hipFree(ts.d_tile_start); (void)hipFree(ts.d_work); (void)hipFree(ts.d_nwork); }
+        if (ts.d_defer) { (void)hipFree(ts.d_defer); (void)hipFree(ts.d_defer_count); }
         ts.d_geo = nullptr; ts.d_tile_count = nullptr; ts.d_tile_start = nullptr; ts.d_work = nullptr; ts.d_nwork = nullptr; ts.nside = 0;
+        ts.d_defer = nullptr; ts.d_defer_count = nullptr;
         const int64_t nrings = 4 * nside - 1;
         const int nbands = (int)((nrings + tr - 1) / tr);
         std::vector<int32_t> ns(nbands), t0(nbands + 1), nrmin(nbands);
@@ -1421,7 +1431,7 @@ static int ensure_tiles(bfg_ctx *c, int mode, int tr, int64_t nside, int64_t n_h
                 int64_t nr = (r < nside) ? 4 * r : (r <= 3 * nside ? 4 * nside : 4 * (4 * nside - r));
                 mx = std::max(mx, nr); mn = std::min(mn, nr);
             }
-            ns[b] = (int32_t)((mx + kTileWidth - 1) / kTileWidth);
+            ns[b] = (int32_t)((mx + tw - 1) / tw);
             nrmin[b] = (int32_t)mn;
             t0[b] = ntiles;
             ntiles += ns[b];
@@ -1435,11 +1445,19 @@ static int ensure_tiles(bfg_ctx *c, int mode, int tr, int64_t nside, int64_t n_h
         HIP_TRY(hipMalloc((void **)&ts.d_geo, blob.size() * sizeof(int32_t)));
         HIP_TRY(hipMemcpyAsync(ts.d_geo, blob.data(), blob.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipMalloc((void **)&ts.d_tile_count, (size_t)ntiles * sizeof(int32_t)));
+        HIP_TRY(hipMalloc((void **)&ts.d_tile_count, (size_t)(ntiles + 1) * sizeof(int32_t)));   // + the left-over list's length
         HIP_TRY(hipMalloc((void **)&ts.d_tile_start, (size_t)(ntiles + 1) * sizeof(int32_t)));
-        HIP_TRY(hipMalloc((void **)&ts.d_work, (size_t)(2 * ntiles + kWorkExtra) * sizeof(int4)));
-        HIP_TRY(hipMalloc((void **)&ts.d_nwork, sizeof(int32_t)));
-        ts.geo.tr = tr; ts.geo.nbands = nbands; ts.geo.ntiles = ntiles;
+        HIP_TRY(hipMalloc((void **)&ts.d_work, (size_t)(2 * ntiles + kWorkExtra) * 2 * sizeof(int4)));
+        HIP_TRY(hipMalloc((void **)&ts.d_nwork, 2 * sizeof(int32_t)));     // [0] items in the work list, [1] the tile kernel's item counter
+        if (mode == MODE_PAINT) {
+            // a failed allocation (the list is ~1 KB per work item) only means the tile workgroups drain their own queues
+            const size_t items = (size_t)(2 * ntiles + kWorkExtra);
+            if (hipMalloc((void **)&ts.d_defer, items * kDeferCap * sizeof(bfg::DeferredOut)) != hipSuccess) { (void)hipGetLastError(); ts.d_defer = nullptr; }
+            else if (hipMalloc((void **)&ts.d_defer_count, items * sizeof(int32_t)) != hipSuccess) {
+                (void)hipGetLastError(); (void)hipFree(ts.d_defer); ts.d_defer = nullptr; ts.d_defer_count = nullptr;
+            }
+        }
+        ts.geo.tr = tr; ts.geo.tw = tw; ts.geo.nbands = nbands; ts.geo.ntiles = ntiles;
         ts.geo.band_ns = ts.d_geo;
         ts.geo.band_tile0 = ts.d_geo + nbands;
         ts.geo.band_nrmin = ts.d_geo + 2 * nbands + 1;
@@ -1513,8 +1531,8 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         win_table = win_nodes > kWinLds && (2 << t->dev.nouter) <= kWinLds;         // weights + offsets fit the pair's LDS slot
         if (const char *e = std::getenv("BFG_WINDOWS")) if (!std::strcmp(e, "hbm")) win_table = false;   // A/B: windows in HBM
         if (win_table) win_nodes = (int)t->dev.nr;                   // the "window" is the whole axis
-        rc = ensure_tiles(c, mode, mode == MODE_PAINT ? TileCfg<MODE_PAINT>::TR : TileCfg<MODE_BARYONIFY>::TR, a->nside,
-                          a->n_halo);
+        rc = ensure_tiles(c, mode, mode == MODE_PAINT ? TileCfg<MODE_PAINT>::TR : TileCfg<MODE_BARYONIFY>::TR,
+                          mode == MODE_PAINT ? TileCfg<MODE_PAINT>::TW : TileCfg<MODE_BARYONIFY>::TW, a->nside, a->n_halo);
         if (rc) return rc;
         const int64_t want = win_table ? 0 : a->n_halo * (int64_t)win_nodes;
         if (want > c->hwin_cap) {
@@ -1548,9 +1566,9 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         pp.bin.mode = mode;
         pp.hd = (mode == MODE_BARYONIFY) ? c->d_hd : nullptr;
         pp.eps_model = a->model_epsilon_max; pp.rdelta = a->rdelta_sampling;
-        HIP_TRY(hipMemsetAsync(c->tiles[mode].d_tile_count, 0, (size_t)c->tiles[mode].geo.ntiles * sizeof(int32_t), c->stream));
-        HIP_TRY(hipMemsetAsync(c->d_left, 0, sizeof(int32_t), c->stream));
-        pp.left = c->d_left;
+        // one memset: the tile counters and, right behind them, the length of the left-over list
+        HIP_TRY(hipMemsetAsync(c->tiles[mode].d_tile_count, 0, (size_t)(c->tiles[mode].geo.ntiles + 1) * sizeof(int32_t), c->stream));
+        pp.left = c->d_left; pp.left_n = c->tiles[mode].d_tile_count + c->tiles[mode].geo.ntiles;
     }
     timing_begin(c, 0);
     hipLaunchKernelGGL(halo_prep_kernel, dim3((unsigned)((a->n_halo + 255) / 256)), dim3(256), 0, c->stream, pp);
@@ -1570,8 +1588,18 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     if (tile) {
         timing_begin(c, 3);
         const bfg_ctx::TileSet &ts = c->tiles[mode];
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, ts.geo.ntiles, ts.cap_direct, ts.d_tile_count,
-                           ts.d_tile_start, ts.d_work, ts.d_nwork);
+        // grid of the tile kernel: persistent (a few workgroups per CU looping over the work list) unless BFG_TILE_PERSIST=0
+        const bool win_lds_path = win_nodes <= kWinLds;
+        // BFG_TILE_LIGHT=1: the 256-thread instantiation with three workgroups per CU (TileCfg<., 1>); measured no faster than
+        // the 512-thread one at any density (profiles/r02_tile_variants.txt), kept as an A/B switch
+        bool light = false;
+        if (const char *e = std::getenv("BFG_TILE_LIGHT")) light = win_lds_path && std::atoi(e) != 0;
+        const int items_max = 2 * ts.geo.ntiles + kWorkExtra;
+        int persist = c->n_cu * (light ? 3 : 2);
+        if (const char *e = std::getenv("BFG_TILE_PERSIST")) persist = std::atoi(e) > 1 ? std::atoi(e) : (std::atoi(e) ? persist : 0);
+        const int tile_grid = persist > 0 ? std::min(persist, items_max) : items_max;
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, ts.geo, ts.cap_direct, ts.d_tile_count,
+                           ts.d_tile_start, ts.d_work, ts.d_nwork, ts.d_nwork + 1, 3 * tile_grid);
         FillParams fp;
         std::memset(&fp, 0, sizeof(fp));
         fp.stats = c->d_stats; fp.n_halo = a->n_halo; fp.cap = c->cap_halo; fp.rec = c->d_rec; fp.irec = c->d_irec; fp.ht = c->d_ht; fp.bin = pp.bin;
@@ -1605,6 +1633,10 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         tp.logtab = reinterpret_cast<const double2 *>(c->d_mathtab);
         tp.exptab = c->d_mathtab + 2 * kLogTab;
         { const char *dbg = std::getenv("BFG_DEBUG"); tp.debug = dbg ? std::atoi(dbg) : 0; }
+        tp.out_zero = (a->flags & BFG_SHELL_OUT_IS_ZERO) ? 1 : 0;
+        if (const char *e = std::getenv("BFG_OUT_ZERO")) tp.out_zero = std::atoi(e);              // A/B switch
+        tp.defer = (mode == MODE_PAINT) ? ts.d_defer : nullptr; tp.defer_count = ts.d_defer_count;
+        if (const char *e = std::getenv("BFG_FINAL_DRAIN")) if (e[0] == 'i') tp.defer = nullptr;  // "inline": drain in the tile kernel
         if (!c->tile_attr_set) {
             const int lp = (int)tile_lds_bytes<MODE_PAINT>(), lb = (int)tile_lds_bytes<MODE_BARYONIFY>();
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_tile_kernel<MODE_PAINT, true>),
@@ -1615,12 +1647,34 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lb));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_tile_kernel<MODE_BARYONIFY, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_wave_kernel<MODE_PAINT>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)wave_lds_bytes<MODE_PAINT>()));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_wave_kernel<MODE_BARYONIFY>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)wave_lds_bytes<MODE_BARYONIFY>()));
             c->tile_attr_set = true;
         }
-        const dim3 tgrid((unsigned)(2 * ts.geo.ntiles + kWorkExtra)), tblock(kTileThreads);   // work items; the surplus exits at once
+        const dim3 tgrid((unsigned)tile_grid), tblock(kTileThreads);
+        tp.work_counter = persist > 0 ? ts.d_nwork + 1 : nullptr;
         const bool wl = win_nodes <= kWinLds;
+        // wave-private chunks (bfg_wtile.hpp) for the 32-node LDS-staged windows; BFG_TILE_KERNEL=block|wave overrides
+        bool use_wave = false;
+        if (const char *tk = std::getenv("BFG_TILE_KERNEL")) use_wave = (tk[0] == 'w');
+        use_wave = use_wave && wl && win_nodes == kWinLds && !win_table;
         timing_begin(c, 1);
-        if (mode == MODE_PAINT) {
+        if (use_wave) {
+            const dim3 wblock(kWaveThreads), wgrid((unsigned)items_max);      // one workgroup per work item
+            if (mode == MODE_PAINT)
+                hipLaunchKernelGGL((shell_wave_kernel<MODE_PAINT>), wgrid, wblock, wave_lds_bytes<MODE_PAINT>(), c->stream, tp);
+            else
+                hipLaunchKernelGGL((shell_wave_kernel<MODE_BARYONIFY>), wgrid, wblock, wave_lds_bytes<MODE_BARYONIFY>(), c->stream, tp);
+        } else if (light && wl) {
+            constexpr int ntp = TileCfg<MODE_PAINT, 1>::NT, ntb = TileCfg<MODE_BARYONIFY, 1>::NT;
+            constexpr size_t ldp = tile_lds_bytes<MODE_PAINT, 1>(), ldb = tile_lds_bytes<MODE_BARYONIFY, 1>();
+            if (mode == MODE_PAINT)
+                hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, true, 1>), tgrid, dim3(ntp), ldp, c->stream, tp);
+            else
+                hipLaunchKernelGGL((shell_tile_kernel<MODE_BARYONIFY, true, 1>), tgrid, dim3(ntb), ldb, c->stream, tp);
+        } else if (mode == MODE_PAINT) {
             const size_t tlds = tile_lds_bytes<MODE_PAINT>();
             if (wl) hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, true>), tgrid, tblock, tlds, c->stream, tp);
             else hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, false>), tgrid, tblock, tlds, c->stream, tp);
@@ -1629,10 +1683,14 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
             if (wl) hipLaunchKernelGGL((shell_tile_kernel<MODE_BARYONIFY, true>), tgrid, tblock, tlds, c->stream, tp);
             else hipLaunchKernelGGL((shell_tile_kernel<MODE_BARYONIFY, false>), tgrid, tblock, tlds, c->stream, tp);
         }
+        if (mode == MODE_PAINT && tp.defer && !use_wave) {
+            const int n_items = 2 * ts.geo.ntiles + kWorkExtra;
+            hipLaunchKernelGGL(tile_deferred_kernel, dim3((unsigned)std::min((n_items + 3) / 4, 2 * c->n_cu)), dim3(256), 0, c->stream, tp, n_items);
+        }
         HIP_TRY(hipGetLastError());
         timing_end(c, 1);
         sp.only_flagged = 1;     // leftovers: halos the binning left to the global-atomic kernel
-        sp.left = c->d_left;
+        sp.left = c->d_left; sp.left_n = ts.d_tile_count + ts.geo.ntiles;
         sp.pair_total_ptr = ts.d_tile_start + ts.geo.ntiles; sp.pair_cap = c->pair_cap;
     }
     const int G = (variant == BFG_VARIANT_SCATTER_WAVE) ? 64 : 16;
@@ -1682,14 +1740,14 @@ int bfg_regrid_shell(bfg_ctx *c, int64_t nside, const double *d_offsets, const d
     const char *rg_env = std::getenv("BFG_REGRID");                 // "pixel" forces the one-thread-per-pixel kernel
     const bool use_tiles = nside >= 8 && !(rg_env && rg_env[0] == 'p');
     if (use_tiles) {
-        rc = ensure_tiles(c, MODE_PAINT, TileCfg<MODE_PAINT>::TR, nside, 0);
+        rc = ensure_tiles(c, kRegridSet, kRegridTR, kTileWidth, nside, 0);
         if (rc) return rc;
     }
     if (d_sums) HIP_TRY(hipMemsetAsync(d_sums, 0, 2 * sizeof(double), c->stream));
     timing_begin(c, 2);
     if (use_tiles)
-        hipLaunchKernelGGL(regrid_tile_kernel, dim3((unsigned)c->tiles[MODE_PAINT].geo.ntiles), dim3(256), 0, c->stream, hp,
-                           c->tiles[MODE_PAINT].geo, d_offsets, d_in_map, d_out_map, d_sums);
+        hipLaunchKernelGGL(regrid_tile_kernel, dim3((unsigned)c->tiles[kRegridSet].geo.ntiles), dim3(256), 0, c->stream, hp,
+                           c->tiles[kRegridSet].geo, d_offsets, d_in_map, d_out_map, d_sums);
     else
         hipLaunchKernelGGL(regrid_kernel, dim3((unsigned)((hp.npix + 255) / 256)), dim3(256), 0, c->stream, hp,
                            d_offsets, d_in_map, d_out_map, d_sums);

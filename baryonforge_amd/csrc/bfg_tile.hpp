@@ -153,6 +153,17 @@ struct __align__(16) DeferredPixel { // a pixel whose table cell lies outside th
     double t;                        // cell coordinate on the radial axis
 };
 
+// A deferred pixel that is still queued when its work item ends: handed to tile_deferred_kernel (a follow-up launch)
+// instead of being drained by the tile workgroup itself -- the drain is two dependent rounds of global loads on the
+// critical path of every tile (6 % of the kernel at 1e6 halos, 33 % at 1e5: profiles/r01_v25_stage_cycles.txt).
+constexpr int kDeferCap = 40;        // >= the largest QCAP
+struct __align__(16) DeferredOut {
+    int64_t pix;                     // RING pixel index
+    double t;                        // cell coordinate on the radial axis
+    int32_t halo, pad[3];
+};
+static_assert(sizeof(DeferredOut) == 32, "DeferredOut must be 32 bytes");
+
 struct __align__(16) RingRow {       // one ring of the tile's band (computed once per workgroup)
     double z, sth, phistep, phioff;
     int32_t nr, k0, k1, rowoff;      // rowoff = row * TW - k0
@@ -168,7 +179,7 @@ struct TileParams {
     DevTable tab;
     TileGeom geo;
     const int32_t *tile_start;       // [ntiles+1]
-    const int4 *work;                // [n_work] (tile, first pair, last pair + 1 [positions in pairs], shared) -- see tile_scan_kernel
+    const int4 *work;                // [n_work][2] (tile, first pair, last pair + 1 [positions in pairs], shared), (band, sector, NS, -) -- see tile_scan_kernel
     const int32_t *n_work;
     const int32_t *pairs;            // halo ids grouped by tile
     const double *hwin;              // [n_halo][win_nodes] blended row values B_i, i = win_lo + e
@@ -181,6 +192,10 @@ struct TileParams {
     const double *exptab;            // [64]  2^(j/64)
     long long pair_cap;              // capacity of pairs[]; a larger total means the binning fell back to scatter
     int debug;                       // ablation switches for profiling (BFG_DEBUG env; 0 in production)
+    int out_zero;                    // BFG_SHELL_OUT_IS_ZERO: the caller cleared `out`; tiles are stored, not read-modify-written
+    DeferredOut *defer;              // [grid][kDeferCap] deferred pixels a work item leaves to tile_deferred_kernel (paint)
+    int32_t *defer_count;            // [grid]
+    int32_t *work_counter;           // persistent grid: the next work item to hand out (starts at 3 gridDim.x); null: one item per workgroup
 };
 
 // sectors of band b whose phi range can intersect the disc: [s_lo, s_lo + n) modulo NS
@@ -311,16 +326,17 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const FillParams P)
 // Per tile: the first cap_direct pairs sit in the tile's fixed slots (written by the count pass), the rest go to an
 // overflow list: exclusive scan of the overflow lengths into tile_start[ntiles+1] (tile_start[ntiles] = their total), then
 // the work list of the tile kernel; single workgroup.
-// A work item is (tile, first pair, last pair + 1 -- positions in pairs[], so the tile kernel needs no tile_start lookup
-// on its start-up chain --, shared): a tile's slot region and its overflow list are separate items, and either is cut
+// A work item is two int4: (tile, first pair, last pair + 1 -- positions in pairs[], so the tile kernel needs no tile_start
+// lookup on its start-up chain --, shared) and (band, sector, sectors in the band, -): a tile's slot region and its overflow list are separate items, and either is cut
 // into equal slices of at most S pairs; items of one tile are accumulated by different workgroups (shared = 1: the
 // write-back uses atomics).  S = max(256, pairs / 4096), so a full-sky catalog gives one item per tile while a catalog
 // that crowds into part of the sky (an octant light cone, a compact multi-GPU shard: 1/8 of the tiles with 8x the pairs)
 // still yields a few thousand items of similar size instead of 784 heavy ones on 512 workgroup slots.
 constexpr int kWorkExtra = 4096;
-__global__ __launch_bounds__(1024) void tile_scan_kernel(int ntiles, int cap_direct, int32_t *count, int32_t *start, int4 *work,
-                                                         int32_t *n_work)
+__global__ __launch_bounds__(1024) void tile_scan_kernel(const TileGeom geo, int cap_direct, int32_t *count, int32_t *start, int4 *work,
+                                                         int32_t *n_work, int32_t *work_counter, int first_dynamic)
 {
+    const int ntiles = geo.ntiles;
     __shared__ int32_t wsum[16];
     __shared__ int32_t carry, carry2;
     // block-wide exclusive scan of 4 values per thread (4096 tiles per trip); returns the offset of the thread's first value
@@ -363,7 +379,9 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int ntiles, int cap_dir
     const int64_t ovf_base = (int64_t)ntiles * cap_direct;
     for (int base = 0; base < ntiles; base += 4096) {
         const int i0 = base + 4 * threadIdx.x;
-        int nd[4], no[4], v[4];
+        int nd[4], no[4], v[4], gb[4], gs[4], gn[4];
+        for (int k = 0; k < 4; ++k) gb[k] = (i0 + k < ntiles) ? geo.tile_band[i0 + k] : 0;     // all loads of a trip in flight together
+        for (int k = 0; k < 4; ++k) { gs[k] = i0 + k - geo.band_tile0[gb[k]]; gn[k] = geo.band_ns[gb[k]]; }
         for (int k = 0; k < 4; ++k) {
             const int n = (i0 + k < ntiles) ? count[i0 + k] : 0;
             nd[k] = min(n, cap_direct); no[k] = n - nd[k];
@@ -379,12 +397,14 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int ntiles, int cap_dir
                 const int nv = (n + S - 1) / S;
                 const int slice = nv ? (n + nv - 1) / nv : 0;                                // equal slices
                 const int a0 = part ? (int)(ovf_base + start[i0 + k]) : (i0 + k) * cap_direct;   // positions in pairs[]
-                for (int m = 0; m < nv; ++m, ++o)
-                    work[o] = make_int4(i0 + k, a0 + m * slice, a0 + min(n, (m + 1) * slice), shared);
+                for (int m = 0; m < nv; ++m, ++o) {
+                    work[2 * o] = make_int4(i0 + k, a0 + m * slice, a0 + min(n, (m + 1) * slice), shared);
+                    work[2 * o + 1] = make_int4(gb[k], gs[k], gn[k], 0);     // what the tile kernel needs about the tile, in one load
+                }
             }
         }
     }
-    if (threadIdx.x == 0) *n_work = carry;
+    if (threadIdx.x == 0) { *n_work = carry; *work_counter = first_dynamic; }   // the first items of a workgroup are static
 }
 
 // Per-halo blended radial row: hwin[j][e] = B_i, i = win_lo_j + e, where
@@ -504,6 +524,22 @@ __global__ __launch_bounds__(256) void halo_row4_kernel(const RowParams P)
 #ifndef BFG_STAGE_TIMING
 #define BFG_STAGE_TIMING 0
 #endif
+// shape of the paint tiles: rings per band x pixels per ring row (the product sets the LDS accumulator: 2048 pixels)
+// 32 x 64 instead of round 1's 64 x 32: the same number of (halo, tile) pairs, but a disc's ring is cut by fewer sector
+// borders, i.e. fewer and longer (pair, ring) segments for stage b: tile kernel -7 % at 1e6 halos (profiles/r02_tile_variants.txt)
+#ifndef BFG_PAINT_TR
+#define BFG_PAINT_TR 32
+#endif
+#ifndef BFG_PAINT_TW
+#define BFG_PAINT_TW 64
+#endif
+// offsets tiles (3 accumulators per pixel, 1024 pixels): 16 x 64 instead of 32 x 32, tile kernel -5 %
+#ifndef BFG_BARY_TR
+#define BFG_BARY_TR 16
+#endif
+#ifndef BFG_BARY_TW
+#define BFG_BARY_TW 64
+#endif
 #if BFG_STAGE_TIMING
 __device__ unsigned long long g_stage_cycles[8];      // profiling build only: barrier-to-barrier cycles per stage
 #define BFG_TICK(slot) do { if (tid == 64) { const long long now_ = clock64(); st_acc[slot] += now_ - st_t; st_t = now_; } } while (0)
@@ -511,38 +547,56 @@ __device__ unsigned long long g_stage_cycles[8];      // profiling build only: b
 #define BFG_TICK(slot) do { } while (0)
 #endif
 constexpr int kTileThreads = BFG_TILE_THREADS;
-constexpr int kTileWaves = kTileThreads / 64;
 constexpr int kWinLds = 32;          // row windows up to this many nodes are staged in LDS
 constexpr int kPrOff = 64;           // slot offsets of the chunk's pairs (one per lane of a wavefront), padded with INT_MAX
 constexpr int kSegExtra = 64;        // LDS room for second pieces of ring windows that wrap around inside a sector
 
-// per-mode shape of a tile workgroup: rings per tile, accumulators per pixel, LDS capacities of a chunk
-template <int MODE> struct TileCfg;
-template <> struct TileCfg<MODE_PAINT> {
+// per-mode shape of a tile workgroup: threads, rings per tile, accumulators per pixel, LDS capacities of a chunk.
+// LIGHT = 1: the instantiation for sparse catalogs (a few dozen pairs per tile, BASELINE configs 1-2).  There a tile is one
+// or two chunks and the workgroup's time is its chain of latencies (pair list -> halo records -> row windows -> write-back),
+// not its arithmetic: 256 threads and half-size chunks need ~52 KB of LDS, so THREE workgroups share a CU instead of two and
+// half again as many tiles are in flight.
+template <int MODE, int LIGHT = 0> struct TileCfg;
+template <> struct TileCfg<MODE_PAINT, 0> {
     // rings per tile, accumulators per pixel, (pair, ring) slots / pairs per chunk, pixel -> segment table entries per round
-    static constexpr int TR = 64, NACC = 1, SLOTMAX = 512, PAIRMAX = 64, PIXMAX = 6144, QCAP = 40;
+    static constexpr int NT = kTileThreads, WPS = BFG_TILE_WAVES_PER_SIMD, LDS_MAX = 81920;
+    static constexpr int TR = BFG_PAINT_TR, TW = BFG_PAINT_TW, NACC = 1, SLOTMAX = 512, PAIRMAX = 64, PIXMAX = 6144, QCAP = 40;
     static constexpr int SEGMAX = SLOTMAX + kSegExtra;
     using Pair = PairInfo;
 };
-template <> struct TileCfg<MODE_BARYONIFY> {
-    static constexpr int TR = 32, NACC = 3, SLOTMAX = 448, PAIRMAX = 48, PIXMAX = 4096, QCAP = 0;
+template <> struct TileCfg<MODE_BARYONIFY, 0> {
+    static constexpr int NT = kTileThreads, WPS = BFG_TILE_WAVES_PER_SIMD, LDS_MAX = 81920;
+    static constexpr int TR = BFG_BARY_TR, TW = BFG_BARY_TW, NACC = 3, SLOTMAX = 448, PAIRMAX = 48, PIXMAX = 4096, QCAP = 0;
     static constexpr int SEGMAX = SLOTMAX + kSegExtra;
     using Pair = PairInfoDisp;
 };
+template <> struct TileCfg<MODE_PAINT, 1> {
+    static constexpr int NT = 256, WPS = 3, LDS_MAX = 54608;
+    static constexpr int TR = BFG_PAINT_TR, TW = BFG_PAINT_TW, NACC = 1, SLOTMAX = 256, PAIRMAX = 32, PIXMAX = 3072, QCAP = 16;
+    static constexpr int SEGMAX = SLOTMAX + kSegExtra / 2;
+    using Pair = PairInfo;
+};
+template <> struct TileCfg<MODE_BARYONIFY, 1> {
+    static constexpr int NT = 256, WPS = 3, LDS_MAX = 54608;
+    static constexpr int TR = BFG_BARY_TR, TW = BFG_BARY_TW, NACC = 3, SLOTMAX = 192, PAIRMAX = 24, PIXMAX = 2048, QCAP = 0;
+    static constexpr int SEGMAX = SLOTMAX + kSegExtra / 2;
+    using Pair = PairInfoDisp;
+};
 
-template <int MODE>
+template <int MODE, int LIGHT = 0>
 __host__ __device__ constexpr size_t tile_lds_bytes()
 {
-    using Cfg = TileCfg<MODE>;
-    return (size_t)Cfg::TR * kTileWidth * Cfg::NACC * sizeof(double) + kLogTab * sizeof(double2) +
+    using Cfg = TileCfg<MODE, LIGHT>;
+    return (size_t)Cfg::TR * Cfg::TW * Cfg::NACC * sizeof(double) + kLogTab * sizeof(double2) +
            kExpTab * sizeof(double) + Cfg::TR * sizeof(RingRow) + Cfg::SEGMAX * sizeof(Seg) +
            Cfg::PAIRMAX * sizeof(typename Cfg::Pair) + (size_t)Cfg::PAIRMAX * kWinLds * sizeof(double) +
            Cfg::PIXMAX * sizeof(uint16_t) + kPrOff * sizeof(int32_t) + Cfg::SEGMAX * sizeof(uint8_t) +
            Cfg::QCAP * sizeof(DeferredPixel) + 8 * sizeof(int32_t);
 }
 
-// two tile workgroups share a CU's 160 KB of LDS
+// two (LIGHT: three) tile workgroups share a CU's 160 KB of LDS
 static_assert(tile_lds_bytes<MODE_PAINT>() <= 81920 && tile_lds_bytes<MODE_BARYONIFY>() <= 81920, "two workgroups per CU");
+static_assert(tile_lds_bytes<MODE_PAINT, 1>() <= 54608 && tile_lds_bytes<MODE_BARYONIFY, 1>() <= 54608, "three workgroups per CU");
 
 // sin(h) for h^2 <= kSinSmall: odd series to h^7 (rel err < 3e-12)
 __device__ inline double sin_small(double h, double h2)
@@ -634,12 +688,22 @@ __device__ inline int wave_scan_incl(int v)
     return v;
 }
 
-template <int MODE, bool WIN_LDS>
-__global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_tile_kernel(const TileParams P)
+// Workgroup barrier that orders LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier.  __syncthreads() also waits for
+// vmcnt(0), i.e. for every global load, store and LDS-DMA the wavefront has in flight: prefetches meant to stay in flight
+// across the barrier, and -- in a persistent workgroup -- the previous tile's write-back stores (~5 us per tile).
+__device__ __forceinline__ void lds_barrier()
 {
-    using Cfg = TileCfg<MODE>;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int MODE, bool WIN_LDS, int LIGHT = 0>
+__global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::WPS)) void shell_tile_kernel(const TileParams P)
+{
+    using Cfg = TileCfg<MODE, LIGHT>;
     using Pair = typename Cfg::Pair;
-    constexpr int TR = Cfg::TR, TW = kTileWidth, NT = kTileThreads, NACC = Cfg::NACC;
+    constexpr int TR = Cfg::TR, TW = Cfg::TW, NT = Cfg::NT, NACC = Cfg::NACC;
+    static_assert(TR <= 64 && TW <= 128, "segment records pack the ring row in 6 bits; segment lengths in 8");
+    constexpr int kTileWaves = NT / 64;
     constexpr int kSegMax = Cfg::SEGMAX, kPairMax = Cfg::PAIRMAX, kSlotMax = Cfg::SLOTMAX, kPixMax = Cfg::PIXMAX;
     static_assert(kSegMax * sizeof(Seg) <= 65536, "ptab holds 16-bit byte offsets of segment records");
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -657,7 +721,7 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
     constexpr int kQCap = Cfg::QCAP;
     constexpr int rq_off = scnt_off + kSegMax * (int)sizeof(uint8_t);         // DeferredPixel [kQCap]
     constexpr int ctl_off = rq_off + kQCap * (int)sizeof(DeferredPixel);      // n_take, nslots, extra segments, pixel total, -, queue fill
-    static_assert(kSegMax % 16 == 0 && kPairMax <= kPrOff && kSlotMax <= kTileThreads && kPairMax <= 64, "chunk shape");
+    static_assert(kSegMax % 16 == 0 && kPairMax <= kPrOff && kSlotMax <= NT && kPairMax <= 64, "chunk shape");
     double *acc = reinterpret_cast<double *>(smem_raw + acc_off);
     double2 *logtab = reinterpret_cast<double2 *>(smem_raw + logtab_off);
     double *exptab = reinterpret_cast<double *>(smem_raw + exptab_off);
@@ -671,29 +735,78 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
     [[maybe_unused]] DeferredPixel *rq = reinterpret_cast<DeferredPixel *>(smem_raw + rq_off);
     int32_t *ctl = reinterpret_cast<int32_t *>(smem_raw + ctl_off);
     static_assert(sizeof(RingRow) % 16 == 0 && sizeof(Pair) % 16 == 0, "16-byte aligned LDS records");
-    static_assert(ctl_off + 8 * sizeof(int32_t) == tile_lds_bytes<MODE>(), "layout and tile_lds_bytes() must agree");
+    static_assert(ctl_off + 8 * sizeof(int32_t) == tile_lds_bytes<MODE, LIGHT>(), "layout and tile_lds_bytes() must agree");
 
-    if ((int)blockIdx.x >= *P.n_work || (long long)P.tile_start[P.geo.ntiles] > P.pair_cap) return;
-    const int4 wk = P.work[blockIdx.x];
-    const int tile = wk.x;
-    const int n_pairs = wk.z - wk.y;
+    // Persistent workgroups: the grid is a few workgroups per CU and every workgroup takes work items from a counter until
+    // the list is empty.  (One workgroup per item -- 16 640 launches at NSIDE 1024, 10 368 of them with nothing to do --
+    // cost more in dispatch than the items of a sparse catalog cost to process: at 1e4 halos the kernel took 0.10 ms
+    // whether two or three workgroups shared a CU.)  The ln / exp tables are loaded once per workgroup.
+    const int n_work_total = *P.n_work;
+    if ((long long)P.tile_start[P.geo.ntiles] > P.pair_cap) return;
     const Hpx &hp = P.hpx;
     const DevTable &T = P.tab;
-    const int band = P.geo.tile_band[tile];
-    const int sector = tile - P.geo.band_tile0[band];
-    const int NS = P.geo.band_ns[band];
-    const int ring_lo = 1 + band * TR;
-    const int ring_hi = min((int)(4 * hp.nside - 1), ring_lo + TR - 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #if BFG_STAGE_TIMING
     long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = clock64();
 #endif
-
-    for (int i = tid; i < TR * TW * NACC; i += NT) acc[i] = 0.0;
-    if (tid == 0) ctl[5] = 0;
     if (tid < kLogTab) logtab[tid] = P.logtab[tid];
     if (tid < kExpTab) exptab[tid] = P.exptab[tid];
-    if (tid < TR) {
+    // segment records carry absolute LDS byte addresses: the dynamic LDS block of this kernel (it has no static
+    // __shared__) starts at address 0; refuse to run otherwise
+    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_raw != 0u) {
+        if (threadIdx.x == 0) atomicOr(&P.stats->warn_mask, 0x80000000u);
+        return;
+    }
+    constexpr unsigned lds_base = 0u;
+    const double inv_dr = T.inv_dr;
+    const double t_c = (-T.r0) * inv_dr, t_m = 0.5 * inv_dr;     // cell coordinate t = ln(x) * t_m + t_c
+    // the pixel loop works with t1 = t + 1 from the exponent-biased logarithm: t1 = fast_log_biased(x) * t_m + t_c1
+    const double t_c1 = t_c + 1.0 - kLogBias * t_m;
+    const int NRm1 = T.nr - 1;
+    const int W = P.win_nodes;
+    constexpr bool win_in_lds = WIN_LDS;     // row windows of <= kWinLds nodes live in LDS, longer ones stay in HBM/L2
+    unsigned long long px_total = 0;
+    unsigned int oob_total = 0;
+
+    // Work items are handed out by a counter (they differ in size: a static round-robin was 5 % slower) and pipelined three
+    // deep, so that no item starts with the chain of dependent global loads counter -> work record -> pair list -> halo
+    // records: while item k is processed, the index of item k + 3 is requested, the work record of item k + 2 and the first
+    // pair-list windows of item k + 1 are loaded, and -- after the pixel stage of item k's last chunk -- wave 0 requests the
+    // halo records of item k + 1's first candidates.  An item then starts with everything but its row windows at hand.
+    // (Stripped of all its work the kernel took 0.083 ms for the 6 272 items of an NSIDE-1024 map.)  The first three items of
+    // a workgroup are blockIdx, blockIdx + gridDim, blockIdx + 2 gridDim; the counter starts at 3 gridDim.
+    int pjA = -1, pjB = -1, pjA1 = -1, pjB1 = -1;
+    int nx_j = -1, nx_first = 0, nx_last = -1, nx_wl = 0;
+    [[maybe_unused]] double nx_lnpf = 0.0;
+    bool primed = false;                              // wave 0 holds the first chunk's candidates of the item about to start
+    constexpr int kNoItem = 0x7fffffff;
+    int item = blockIdx.x;
+    int item1 = P.work_counter ? (int)(blockIdx.x + gridDim.x) : kNoItem;
+    int item2 = P.work_counter ? (int)(blockIdx.x + 2 * gridDim.x) : kNoItem;
+    const int4 wzero = make_int4(0, 0, 0, 0);
+    int4 wk = wzero, wg = wzero, wk1 = wzero, wg1 = wzero;
+    if (item < n_work_total) { wk = P.work[2 * item]; wg = P.work[2 * item + 1]; }
+    if (item1 < n_work_total) { wk1 = P.work[2 * item1]; wg1 = P.work[2 * item1 + 1]; }
+    while (item < n_work_total) {
+    int item3 = kNoItem;
+    if (tid == 0 && P.work_counter) item3 = atomicAdd(P.work_counter, 1);
+    const bool have_next = item1 < n_work_total;
+    int4 wk2 = wzero, wg2 = wzero;
+    if (item2 < n_work_total) { wk2 = P.work[2 * item2]; wg2 = P.work[2 * item2 + 1]; }
+    if (wave == 0 && have_next) {                     // first pair-list windows of the next item
+        const int32_t *plist1 = P.pairs + wk1.y;
+        const int n1 = wk1.z - wk1.y;
+        pjA1 = (lane < n1) ? plist1[lane] : -1;
+        pjB1 = (64 + lane < n1) ? plist1[64 + lane] : -1;
+    }
+    const int n_pairs = wk.z - wk.y;
+    const int band = wg.x, sector = wg.y, NS = wg.z;
+    const int ring_lo = 1 + band * TR;
+    const int ring_hi = min((int)(4 * hp.nside - 1), ring_lo + TR - 1);
+
+    if (!(P.debug & 512)) for (int i = tid; i < TR * TW * NACC; i += NT) acc[i] = 0.0;
+    if (tid == 0) ctl[5] = 0;
+    if (tid < TR && !(P.debug & 256)) {
         const int ring = ring_lo + tid;
         RingRow rr;
         rr.z = 0; rr.sth = 0; rr.phistep = 0; rr.phioff = 0; rr.nr = 1; rr.k0 = 0; rr.k1 = 0; rr.rowoff = 0;
@@ -708,31 +821,16 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
         rows[tid] = rr;
     }
 
-    const double inv_dr = T.inv_dr;
-    const double t_c = (-T.r0) * inv_dr, t_m = 0.5 * inv_dr;     // cell coordinate t = ln(x) * t_m + t_c
-    // the pixel loop works with t1 = t + 1 from the exponent-biased logarithm: t1 = fast_log_biased(x) * t_m + t_c1
-    const double t_c1 = t_c + 1.0 - kLogBias * t_m;
-    // segment records carry absolute LDS byte addresses: the dynamic LDS block of this kernel (it has no static
-    // __shared__) starts at address 0; refuse to run otherwise
-    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_raw != 0u) {
-        if (threadIdx.x == 0) atomicOr(&P.stats->warn_mask, 0x80000000u);
-        return;
-    }
-    constexpr unsigned lds_base = 0u;
-    const int NRm1 = T.nr - 1;
-    const int W = P.win_nodes;
-    constexpr bool win_in_lds = WIN_LDS;     // row windows of <= kWinLds nodes live in LDS, longer ones stay in HBM/L2
     unsigned long long my_pixels = 0;
     const int32_t *plist = P.pairs + wk.y;
+    const int tile = wk.x;
+    (void)tile;
 
     // Wave 0 runs the pair pipeline two chunks deep, so that no stage waits for a dependent pair -> halo record load:
     //   pjA / pjB  the pair list entries [base, base + 128) of the current chunk's first pair (issued one chunk ago);
     //   nx_*       halo-record fields of the NEXT chunk's candidate pairs.
     // Both sets of loads are issued at the start of stage c (not before the stage-b barrier, whose vmcnt(0) -- needed
     // for the LDS-DMA -- would expose their latency) and are consumed in the next chunk's stage a.
-    int pjA = -1, pjB = -1;
-    int nx_j = -1, nx_first = 0, nx_last = -1, nx_wl = 0;
-    [[maybe_unused]] double nx_lnpf = 0.0;
     auto load_list_windows = [&](int wb) {
         pjA = (wb + lane < n_pairs) ? plist[wb + lane] : -1;
         pjB = (wb + 64 + lane < n_pairs) ? plist[wb + 64 + lane] : -1;
@@ -745,12 +843,12 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
             if constexpr (MODE == MODE_PAINT) nx_lnpf = h.spare[0];
         }
     };
-    if (wave == 0) {
+    if (wave == 0 && !primed) {
         load_list_windows(0);
         nx_j = (lane < kPairMax) ? pjA : -1;
         load_records();
     }
-    __syncthreads();
+    lds_barrier();
 
     unsigned int n_oob32 = 0;
 
@@ -792,9 +890,9 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
                     __hip_atomic_fetch_add(lds_ptr<double>(lds_base + e.abyte), fast_exp(L, exptab), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            __syncthreads();
+            lds_barrier();
             if (tid == 0) ctl[5] = 0;
-            __syncthreads();
+            lds_barrier();
         }
     };
 
@@ -948,7 +1046,7 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
             const int fa = __shfl(pjA, idx & 63), fb = __shfl(pjB, idx & 63);
             nx_j = (lane < kPairMax) ? ((idx < 64) ? fa : fb) : -1;
         }
-        __syncthreads();
+        lds_barrier();
         const int n_take = ctl[0], nslots = ctl[1];
         BFG_TICK(0);
 
@@ -993,7 +1091,7 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
             }
         }
         if constexpr (MODE == MODE_BARYONIFY) {
-            static_assert(MODE != MODE_BARYONIFY || kSlotMax <= kTileThreads - 64, "the last wavefront has no slots");
+            static_assert(MODE != MODE_BARYONIFY || kSlotMax <= NT - 64, "the last wavefront has no slots");
             if (wave == kTileWaves - 1 && lane < n_take) {              // per-pair constants of the pixel stage
                 Pair &pi = pinfo[lane];
                 const int j = pi.halo;
@@ -1129,14 +1227,17 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
         const int nseg = min(nslots + ctl[2], kSegMax);
         const int ptotal = (P.debug & 2) ? 0 : ctl[3];
         my_pixels += (tid == 0) ? (unsigned long long)ctl[3] : 0ull;
-        if (wave == 0) { load_records(); load_list_windows(base + n_take); }   // in flight during the pixel stage
+        // in flight during the pixel stage: the records of the next chunk's candidates and the list windows after them -- or,
+        // in the item's last chunk, the first list windows of the NEXT item (its records follow after the pixel stage)
+        const bool last_chunk = base + n_take >= n_pairs;
+        if (wave == 0 && !last_chunk) { load_records(); load_list_windows(base + n_take); }
         BFG_TICK(2);
 
         // ---- stage c: one thread per pixel of the flattened list (rounds of kPixMax pixels; the first round's
         //      pixel -> segment table was filled by stage b) -------------------------------------------------
         for (int pbase = 0; pbase < ptotal; pbase += kPixMax) {
             if (pbase > 0) {                                          // rare: refill the table for the next round
-                __syncthreads();
+                lds_barrier();
                 for (int sidx = tid; sidx < nseg; sidx += NT) {
                     const int cnt = scnt[sidx];
                     if (cnt > 0) {
@@ -1145,7 +1246,7 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
                         for (int q = a0; q < a1; ++q) ptab[q - pbase] = (uint16_t)(sidx * (int)sizeof(Seg));
                     }
                 }
-                __syncthreads();
+                lds_barrier();
             }
             BFG_TICK(3);
             const int pend = min(ptotal, pbase + kPixMax);
@@ -1155,24 +1256,27 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
                 do_pixel(q, sg);
             }
         }
+        if (wave == 0 && last_chunk && have_next) {     // the next item's first candidates: their records arrive during the write-back
+            pjA = pjA1; pjB = pjB1;
+            nx_j = (lane < kPairMax) ? pjA : -1;
+            load_records();
+        }
         BFG_TICK(4);
-        __syncthreads();
+        lds_barrier();
         BFG_TICK(5);
         base += n_take;
         if constexpr (kQCap > 0) { if (ctl[5] >= qcap / 2) drain(); }     // uniform: ctl[5] is stable between the barriers
     }
-    if (my_pixels) atomicAdd((unsigned long long *)&P.stats->pixel_updates, my_pixels);
-    if (n_oob32) {
-        atomicAdd((unsigned long long *)&P.stats->pixels_out_of_table, (unsigned long long)n_oob32);
-        atomicOr(&P.stats->warn_mask, BFG_WARN_R_RANGE);
-    }
     // write the tile back: every pixel belongs to exactly one tile -> plain read-modify-write (unless the tile's pair list
-    // was cut into several work items).  Each thread owns TR * TW / NT pixels.  Their map values are fetched in one burst
-    // BEFORE the final drain of the deferred-pixel queue (two dependent rounds of global loads of its own), so the two
-    // latencies overlap; the sums are stored after it.  (The epilogue was 8 % of the kernel at 1e6 halos, 39 % at 1e5.)
+    // was cut into several work items), or plain stores when the caller vouches for a cleared map (out_zero).  Each thread
+    // owns TR * TW / NT pixels; their map values are fetched in one burst.  Deferred pixels still in the queue are not
+    // drained here (two dependent rounds of global loads, 33 % of the kernel at 1e5 halos): they go to this work item's
+    // slice of a global list and tile_deferred_kernel adds them after this kernel.
     constexpr int kPerThread = (TR * TW + NT - 1) / NT;
     int64_t wpix[kPerThread];
     double wold[kPerThread][NACC];
+    const bool rmw = !wk.w && !P.out_zero;
+    if (!(P.debug & 128)) {                            // profiling: bit 128 skips the write-back (wrong results)
 #pragma unroll
     for (int u = 0; u < kPerThread; ++u) {
         const int i = tid + u * NT;
@@ -1187,9 +1291,24 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
             }
         }
 #pragma unroll
-        for (int c = 0; c < NACC; ++c) wold[u][c] = (wpix[u] >= 0 && !wk.w) ? P.out[NACC * wpix[u] + c] : 0.0;
+        for (int c = 0; c < NACC; ++c) wold[u][c] = (wpix[u] >= 0 && rmw) ? P.out[NACC * wpix[u] + c] : 0.0;
     }
-    if constexpr (kQCap > 0) { if (ctl[5] > 0) drain(); }
+    if constexpr (kQCap > 0) {
+        const int n = min(ctl[5], qcap);
+        if (P.defer) {
+            if (tid < n) {
+                const DeferredPixel e = rq[tid];
+                const int i = (e.abyte - acc_off) >> 3;                    // accumulator index = row * TW + column
+                const int row = i / TW, col = i % TW;
+                int64_t start, nr64; bool shifted;
+                ring_info_small(hp, ring_lo + row, start, nr64, shifted);
+                DeferredOut o;
+                o.pix = start + rows[row].k0 + col; o.t = e.t; o.halo = e.halo; o.pad[0] = o.pad[1] = o.pad[2] = 0;
+                P.defer[(size_t)item * kDeferCap + tid] = o;
+            }
+            if (tid == 0) P.defer_count[item] = n;
+        } else if (n > 0) drain();
+    }
 #pragma unroll
     for (int u = 0; u < kPerThread; ++u) {
         if (wpix[u] < 0) continue;
@@ -1203,11 +1322,65 @@ __global__ __launch_bounds__(kTileThreads, BFG_TILE_WAVES_PER_SIMD) void shell_t
             }
         }
     }
+    }
+    px_total += my_pixels;
+    oob_total += n_oob32;
 #if BFG_STAGE_TIMING
     __syncthreads();
-    BFG_TICK(7);                                       // epilogue: final queue drain, counters, write-back
+    BFG_TICK(7);                                       // epilogue: final queue drain, write-back
+#endif
+    // on to the next work item: every thread is done with the accumulator, the ring rows and the queue
+    if (tid == 0) ctl[6] = item3;
+    lds_barrier();
+    primed = have_next;
+    item = item1; item1 = item2; item2 = ctl[6];
+    wk = wk1; wg = wg1; wk1 = wk2; wg1 = wg2;
+    }   // work items
+    // counters last, once per workgroup: nothing waits for these atomics
+    if (px_total) atomicAdd((unsigned long long *)&P.stats->pixel_updates, px_total);
+    if (oob_total) {
+        atomicAdd((unsigned long long *)&P.stats->pixels_out_of_table, (unsigned long long)oob_total);
+        atomicOr(&P.stats->warn_mask, BFG_WARN_R_RANGE);
+    }
+#if BFG_STAGE_TIMING
     if (tid == 64) for (int i = 0; i < 8; ++i) atomicAdd(&g_stage_cycles[i], (unsigned long long)st_acc[i]);
 #endif
+}
+
+// The deferred pixels the paint tile workgroups left behind (DeferredOut): blend the halo's corner rows directly from the
+// table (same corner order and arithmetic as halo_row_kernel / the in-kernel drain) and add exp(.) to the map.  Several
+// halos can leave the same pixel: atomics.  One 64-lane workgroup per 4 work items.
+__global__ __launch_bounds__(256) void tile_deferred_kernel(const TileParams P, int n_items)
+{
+    if ((long long)P.tile_start[P.geo.ntiles] > P.pair_cap) return;
+    const int n_work = min(n_items, *P.n_work);
+    const int lane = threadIdx.x & 63;
+    // a small grid (launching a workgroup per item costs more than the items: ~6 ns of dispatch each); one wavefront per
+    // item, striding over the work list
+    for (int item = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); item < n_work; item += (int)gridDim.x * 4) {
+    const int n = P.defer_count[item];
+    if (lane >= n) continue;
+    const DeferredOut e = P.defer[(size_t)item * kDeferCap + lane];
+    const DevTable &T = P.tab;
+    const int64_t j = e.halo;
+    const int i = min(max((int)e.t, 0), T.nr - 2);
+    const double f = e.t - (double)i;
+    double c0v = 0.0, c1v = 0.0;
+    const int ncorner = 1 << T.nouter;
+    for (int c = 0; c < ncorner; ++c) {
+        double w = 1.0; int64_t off = 0;
+        for (int k = 0; k < T.nouter; ++k) {
+            const int bit = (c >> (T.nouter - 1 - k)) & 1;
+            const double y = P.cw[k * P.cap + j];
+            w = w * (bit ? y : 1.0 - y);
+            off += (int64_t)(P.cidx[k * P.cap + j] + bit) * T.ostride[k];
+        }
+        c0v = fma(T.values[off + i], w, c0v);
+        c1v = fma(T.values[off + i + 1], w, c1v);
+    }
+    const double L = fma(f, c1v - c0v, c0v) + P.ht[j].spare[0];
+    if (fabs(L) < 709.0) unsafeAtomicAdd(P.out + e.pix, fast_exp(L, P.exptab));
+    }
 }
 
 }  // namespace bfg

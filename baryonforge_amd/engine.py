@@ -275,7 +275,8 @@ class Context(object):
         return s
 
     def shell_args(self, nside, d_catalog, n_halo, cat_stride, n_extra, epsilon_max, runner_md, model_md=None,
-                   model_epsilon_max=0.0, rdelta_sampling=False, include_pixel_size=False, variant="auto"):
+                   model_epsilon_max=0.0, rdelta_sampling=False, include_pixel_size=False, variant="auto",
+                   out_is_zero=False):
         a = _lib.ShellArgs()
         a.nside, a.n_halo = int(nside), int(n_halo)
         a.d_catalog = d_catalog.data_ptr() if n_halo else None
@@ -287,6 +288,7 @@ class Context(object):
         a.rdelta_sampling = int(bool(rdelta_sampling))
         a.include_pixel_size = int(bool(include_pixel_size))
         a.variant = _lib.VARIANTS[variant]
+        a.flags = _lib.SHELL_OUT_IS_ZERO if out_is_zero else 0      # the caller cleared the output: tiles are stored, not added
         return a
 
     def paint_shell(self, args, table, spline, d_map):

@@ -240,7 +240,7 @@ def main():
         zax, Max, rax, T = syn.pressure_table(*shape)
         with np.errstate(all="ignore"):
             table = ctx.table([zax, Max, rax], np.log(T), log_values=True)
-        sargs = ctx.shell_args(nside, d_cat, idx.size, 4, 0, args.eps, md, variant=args.variant)
+        sargs = ctx.shell_args(nside, d_cat, idx.size, 4, 0, args.eps, md, variant=args.variant, out_is_zero=True)   # step() clears the map first
         # N > 1: consecutive shells go to alternating map buffers, so the all-reduce of shell k (async, on RCCL's own
         # stream) overlaps the painting of shell k+1; every collective is waited for before its buffer is reused and
         # before the timed region ends (finish()).

@@ -138,8 +138,14 @@ typedef struct {
     int32_t rdelta_sampling;   /* BaryonificationClass.Rdelta_sampling                    */
     int32_t include_pixel_size;/* PaintProfilesShell only                                 */
     int32_t variant;           /* BFG_VARIANT_*                                           */
-    int32_t reserved;
+    int32_t flags;             /* BFG_SHELL_* bits                                        */
 } bfg_shell_args;
+
+/* The caller vouches that the output (d_map / d_offsets) is all zeros on entry -- the reference's runners always start
+ * from np.zeros (Runners/HealpixRunner.py:313, :424).  The tile kernels then store their tiles instead of
+ * read-modify-writing them (one global round trip less at the end of every tile).  Without the flag the calls
+ * accumulate INTO whatever the buffer holds.                                                                    */
+#define BFG_SHELL_OUT_IS_ZERO 1
 
 #define BFG_VARIANT_AUTO 0
 #define BFG_VARIANT_SCATTER_WAVE 1     /* one 64-lane wavefront per halo, global f64 atomics   */
