@@ -138,10 +138,10 @@ class PaintProfilesShell(DefaultRunner):
                           cache_key=(self.model, "2D", self.model.raw_input_2D))
         fresh = d_map is None
         if fresh:
-            d_map = ctx.zeros(12 * NSIDE * NSIDE)                         # :424
+            d_map = ctx.empty(12 * NSIDE * NSIDE)                         # :424 -- the zeros come from the kernels (OUT_OVERWRITE)
         args = ctx.shell_args(NSIDE, d_cat, d_cat.shape[0], stride, len(keys), self.epsilon_max,
                               ctx.massdef_struct(bg, self.mass_def), include_pixel_size=self.include_pixel_size,
-                              variant=self.variant, out_is_zero=fresh)
+                              variant=self.variant, out_overwrite=fresh)
         ctx.stats_reset()
         ctx.paint_shell(args, table, spline, d_map)
         self.last_stats = ctx.stats()
@@ -281,8 +281,8 @@ class BaryonifyShell(DefaultRunner):
                               ctx.massdef_struct(bg, self.mass_def), model_md=model_md,
                               model_epsilon_max=model.epsilon_max,
                               rdelta_sampling=getattr(model, "Rdelta_sampling", False), variant=self.variant,
-                              out_is_zero=True)
-        d_off = ctx.zeros(12 * NSIDE * NSIDE, 3)                          # :313
+                              out_overwrite=True)
+        d_off = ctx.empty(12 * NSIDE * NSIDE, 3)                          # :313 -- the zeros come from the kernels
         ctx.stats_reset()
         ctx.baryonify_offsets(args, table, spline, d_off)                 # :315-355
         self.last_stats = ctx.stats()

@@ -26,7 +26,7 @@ VARIANTS = {"auto": VARIANT_AUTO, "scatter_wave": VARIANT_SCATTER_WAVE,
             "scatter_quarter": VARIANT_SCATTER_QUARTER, "tile_lds": VARIANT_TILE_LDS}
 
 WARN_Z_RANGE, WARN_M_RANGE, WARN_R_RANGE = 1, 2, 4
-SHELL_OUT_IS_ZERO = 1
+SHELL_OUT_IS_ZERO, SHELL_OUT_OVERWRITE = 1, 2
 
 # every symbol include/bfg_mi355.h declares (tests check the .so exports all of them)
 SYMBOLS = [

@@ -103,6 +103,7 @@ struct bfg_ctx {
         int32_t *d_defer_count;     // [2 ntiles + kWorkExtra]
         int cap_direct;             // fixed pair slots per tile of the current call
         int32_t *d_nwork;
+        int32_t *d_shared;          // [ntiles] 1: the tile's pair list was cut into several work items (atomics on the map)
     } tiles[3];                     // [MODE_PAINT], [MODE_BARYONIFY], [2] = the regrid kernel's tiles
     int32_t *d_pairs;              // [ntiles * cap_direct] slots | [pair_cap] overflow lists
     unsigned long long *d_ovf_mask; // [cap_halo]
@@ -1085,6 +1086,7 @@ static void ctx_free_all(bfg_ctx *c)
         if (c->tiles[m].d_nwork) (void)hipFree(c->tiles[m].d_nwork);
         if (c->tiles[m].d_defer) (void)hipFree(c->tiles[m].d_defer);
         if (c->tiles[m].d_defer_count) (void)hipFree(c->tiles[m].d_defer_count);
+        if (c->tiles[m].d_shared) (void)hipFree(c->tiles[m].d_shared);
     }
     if (c->d_hd) (void)hipFree(c->d_hd);
     if (c->d_left) (void)hipFree(c->d_left);
@@ -1418,6 +1420,8 @@ static int ensure_tiles(bfg_ctx *c, int mode, int tr, int tw, int64_t nside, int
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (ts.d_geo) { (void)hipFree(ts.d_geo); (void)hipFree(ts.d_tile_count); (void)hipFree(ts.d_tile_start); (void)hipFree(ts.d_work); (void)hipFree(ts.d_nwork); }
         if (ts.d_defer) { (void)hipFree(ts.d_defer); (void)hipFree(ts.d_defer_count); }
+        if (ts.d_shared) (void)hipFree(ts.d_shared);
+        ts.d_shared = nullptr;
         ts.d_geo = nullptr; ts.d_tile_count = nullptr; ts.d_tile_start = nullptr; ts.d_work = nullptr; ts.d_nwork = nullptr; ts.nside = 0;
         ts.d_defer = nullptr; ts.d_defer_count = nullptr;
         const int64_t nrings = 4 * nside - 1;
@@ -1449,6 +1453,7 @@ static int ensure_tiles(bfg_ctx *c, int mode, int tr, int tw, int64_t nside, int
         HIP_TRY(hipMalloc((void **)&ts.d_tile_start, (size_t)(ntiles + 1) * sizeof(int32_t)));
         HIP_TRY(hipMalloc((void **)&ts.d_work, (size_t)(2 * ntiles + kWorkExtra) * 2 * sizeof(int4)));
         HIP_TRY(hipMalloc((void **)&ts.d_nwork, 2 * sizeof(int32_t)));     // [0] items in the work list, [1] the tile kernel's item counter
+        HIP_TRY(hipMalloc((void **)&ts.d_shared, (size_t)ntiles * sizeof(int32_t)));
         if (mode == MODE_PAINT) {
             // a failed allocation (the list is ~1 KB per work item) only means the tile workgroups drain their own queues
             const size_t items = (size_t)(2 * ntiles + kWorkExtra);
@@ -1508,7 +1513,15 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     if (rc) return rc;
     if (mode == MODE_PAINT && !t->dev.log_values) return BFG_ERR_INVALID;
     if (mode == MODE_BARYONIFY && t->dev.log_values) return BFG_ERR_INVALID;
-    if (a->n_halo == 0) return BFG_OK;
+    // BFG_SHELL_OUT_OVERWRITE: the output is uninitialised.  The tile kernels write every pixel themselves; every other route
+    // (no halos, scatter variants, the wave-chunk kernel) clears it here first.
+    const size_t out_bytes = (size_t)12 * a->nside * a->nside * sizeof(double) * (mode == MODE_PAINT ? 1 : 3);
+    bool overwrite = (a->flags & BFG_SHELL_OUT_OVERWRITE) != 0;
+    bool out_zero = (a->flags & BFG_SHELL_OUT_IS_ZERO) != 0;
+    if (a->n_halo == 0) {
+        if (overwrite) HIP_TRY(hipMemsetAsync(d_out, 0, out_bytes, c->stream));
+        return BFG_OK;
+    }
     rc = ensure_workspace(c, a->n_halo);
     if (rc) return rc;
 
@@ -1520,6 +1533,18 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     if (variant == BFG_VARIANT_AUTO) variant = tile_ok ? BFG_VARIANT_TILE_LDS : BFG_VARIANT_SCATTER_QUARTER;
     if (variant == BFG_VARIANT_TILE_LDS && !tile_ok) variant = BFG_VARIANT_SCATTER_QUARTER;
     const bool tile = (variant == BFG_VARIANT_TILE_LDS);
+    bool use_wave = false;         // wave-private chunks (bfg_wtile.hpp): BFG_TILE_KERNEL=wave, an A/B variant
+    if (const char *tk = std::getenv("BFG_TILE_KERNEL")) use_wave = (tk[0] == 'w');
+    if (const char *e = std::getenv("BFG_OUT_ZERO")) out_zero = std::atoi(e) != 0;                // A/B switches
+    if (const char *e = std::getenv("BFG_OUT_OVERWRITE")) overwrite = overwrite && std::atoi(e) != 0;
+    if (overwrite && (!tile || use_wave)) {
+        HIP_TRY(hipMemsetAsync(d_out, 0, out_bytes, c->stream));
+        overwrite = false; out_zero = true;
+    }
+    if ((a->flags & BFG_SHELL_OUT_OVERWRITE) && !overwrite && tile && !use_wave) {       // switched off by the environment
+        HIP_TRY(hipMemsetAsync(d_out, 0, out_bytes, c->stream));
+        out_zero = true;
+    }
     // row window of the tile path: ~3.5 e-folds of radius below the disc edge (r_max/33 .. r_max)
     int win_nodes = 0;
     bool win_table = false;      // finely sampled radial axis: no row windows, the pixel stage reads the table (bfg_tile.hpp)
@@ -1599,9 +1624,11 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         if (const char *e = std::getenv("BFG_TILE_PERSIST")) persist = std::atoi(e) > 1 ? std::atoi(e) : (std::atoi(e) ? persist : 0);
         const int tile_grid = persist > 0 ? std::min(persist, items_max) : items_max;
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, ts.geo, ts.cap_direct, ts.d_tile_count,
-                           ts.d_tile_start, ts.d_work, ts.d_nwork, ts.d_nwork + 1, 3 * tile_grid);
+                           ts.d_tile_start, ts.d_work, ts.d_nwork, ts.d_nwork + 1, 3 * tile_grid, overwrite ? 1 : 0, ts.d_shared);
         FillParams fp;
         std::memset(&fp, 0, sizeof(fp));
+        fp.overwrite = overwrite ? 1 : 0; fp.nacc = (mode == MODE_PAINT) ? 1 : 3; fp.shared_flag = ts.d_shared; fp.out = d_out;
+        fp.hpx = pp.hpx;
         fp.stats = c->d_stats; fp.n_halo = a->n_halo; fp.cap = c->cap_halo; fp.rec = c->d_rec; fp.irec = c->d_irec; fp.ht = c->d_ht; fp.bin = pp.bin;
         hipLaunchKernelGGL(tile_fill_kernel, dim3((unsigned)((a->n_halo + 255) / 256)), dim3(256), 0, c->stream, fp);
         RowParams rp;
@@ -1633,8 +1660,8 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         tp.logtab = reinterpret_cast<const double2 *>(c->d_mathtab);
         tp.exptab = c->d_mathtab + 2 * kLogTab;
         { const char *dbg = std::getenv("BFG_DEBUG"); tp.debug = dbg ? std::atoi(dbg) : 0; }
-        tp.out_zero = (a->flags & BFG_SHELL_OUT_IS_ZERO) ? 1 : 0;
-        if (const char *e = std::getenv("BFG_OUT_ZERO")) tp.out_zero = std::atoi(e);              // A/B switch
+        tp.out_zero = out_zero ? 1 : 0;
+        tp.overwrite = overwrite ? 1 : 0;
         tp.defer = (mode == MODE_PAINT) ? ts.d_defer : nullptr; tp.defer_count = ts.d_defer_count;
         if (const char *e = std::getenv("BFG_FINAL_DRAIN")) if (e[0] == 'i') tp.defer = nullptr;  // "inline": drain in the tile kernel
         if (!c->tile_attr_set) {
@@ -1656,9 +1683,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         const dim3 tgrid((unsigned)tile_grid), tblock(kTileThreads);
         tp.work_counter = persist > 0 ? ts.d_nwork + 1 : nullptr;
         const bool wl = win_nodes <= kWinLds;
-        // wave-private chunks (bfg_wtile.hpp) for the 32-node LDS-staged windows; BFG_TILE_KERNEL=block|wave overrides
-        bool use_wave = false;
-        if (const char *tk = std::getenv("BFG_TILE_KERNEL")) use_wave = (tk[0] == 'w');
+        // wave-private chunks (bfg_wtile.hpp) need the 32-node LDS-staged windows
         use_wave = use_wave && wl && win_nodes == kWinLds && !win_table;
         timing_begin(c, 1);
         if (use_wave) {

@@ -193,6 +193,7 @@ struct TileParams {
     long long pair_cap;              // capacity of pairs[]; a larger total means the binning fell back to scatter
     int debug;                       // ablation switches for profiling (BFG_DEBUG env; 0 in production)
     int out_zero;                    // BFG_SHELL_OUT_IS_ZERO: the caller cleared `out`; tiles are stored, not read-modify-written
+    int overwrite;                   // BFG_SHELL_OUT_OVERWRITE: `out` is uninitialised; every tile (also one without halos) is stored in full
     DeferredOut *defer;              // [grid][kDeferCap] deferred pixels a work item leaves to tile_deferred_kernel (paint)
     int32_t *defer_count;            // [grid]
     int32_t *work_counter;           // persistent grid: the next work item to hand out (starts at 3 gridDim.x); null: one item per workgroup
@@ -298,6 +299,10 @@ __device__ inline int tile_bin_halo(const BinCtx &B, bool fill, int64_t j, int f
 
 struct FillParams {
     bfg_stats *stats;
+    int overwrite, nacc;             // overwrite: clear the tiles the tile kernel will add to with atomics (shared_flag)
+    const int32_t *shared_flag;
+    double *out;
+    Hpx hpx;
     int64_t n_halo, cap;
     const double *rec;
     int32_t *irec;
@@ -307,6 +312,23 @@ struct FillParams {
 
 __global__ __launch_bounds__(256) void tile_fill_kernel(const FillParams P)
 {
+    if (P.overwrite) {
+        const TileGeom &G = P.bin.geo;
+        for (int t = blockIdx.x; t < G.ntiles; t += gridDim.x) {
+            if (!P.shared_flag[t]) continue;                     // workgroup-uniform
+            const int band = G.tile_band[t], sector = t - G.band_tile0[band], NS = G.band_ns[band];
+            const int ring_lo = 1 + band * G.tr;
+            for (int i = threadIdx.x; i < G.tr * G.tw; i += blockDim.x) {
+                const int row = i / G.tw, col = i % G.tw;
+                const int64_t ring = ring_lo + row;
+                if (ring > 4 * P.hpx.nside - 1) continue;
+                int64_t start, nr; bool shifted;
+                ring_info_small(P.hpx, ring, start, nr, shifted);
+                const int k0 = (int)(((int64_t)sector * nr) / NS), k1 = (int)(((int64_t)(sector + 1) * nr) / NS);
+                if (k0 + col < k1) for (int c = 0; c < P.nacc; ++c) P.out[P.nacc * (start + k0 + col) + c] = 0.0;
+            }
+        }
+    }
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= P.n_halo) return;
     const int64_t cap = P.cap;
@@ -334,8 +356,11 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const FillParams P)
 // still yields a few thousand items of similar size instead of 784 heavy ones on 512 workgroup slots.
 constexpr int kWorkExtra = 4096;
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const TileGeom geo, int cap_direct, int32_t *count, int32_t *start, int4 *work,
-                                                         int32_t *n_work, int32_t *work_counter, int first_dynamic)
+                                                         int32_t *n_work, int32_t *work_counter, int first_dynamic,
+                                                         int overwrite, int32_t *shared_flag)
 {
+    // overwrite: the tile kernel initialises the map itself, so tiles without a single pair get an (empty) work item too,
+    // and tiles cut into several items -- which add to the map with atomics -- are listed for tile_fill_kernel to clear first
     const int ntiles = geo.ntiles;
     __shared__ int32_t wsum[16];
     __shared__ int32_t carry, carry2;
@@ -386,12 +411,19 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const TileGeom geo, int
             const int n = (i0 + k < ntiles) ? count[i0 + k] : 0;
             nd[k] = min(n, cap_direct); no[k] = n - nd[k];
             v[k] = (nd[k] + S - 1) / S + (no[k] + S - 1) / S;
+            if (overwrite && v[k] == 0 && i0 + k < ntiles) v[k] = 1;
         }
         int o = scan4(v);
         for (int k = 0; k < 4; ++k) {
             if (i0 + k >= ntiles) continue;
             count[i0 + k] = 0;                                                               // becomes the overflow cursor
             const int shared = v[k] > 1 ? 1 : 0;
+            if (shared_flag) shared_flag[i0 + k] = shared;
+            if (nd[k] + no[k] == 0 && overwrite) {                                           // a tile no halo touches: zeros
+                work[2 * o] = make_int4(i0 + k, 0, 0, 0);
+                work[2 * o + 1] = make_int4(gb[k], gs[k], gn[k], 0);
+                ++o;
+            }
             for (int part = 0; part < 2; ++part) {
                 const int n = part ? no[k] : nd[k];
                 const int nv = (n + S - 1) / S;
@@ -742,7 +774,9 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     // cost more in dispatch than the items of a sparse catalog cost to process: at 1e4 halos the kernel took 0.10 ms
     // whether two or three workgroups shared a CU.)  The ln / exp tables are loaded once per workgroup.
     const int n_work_total = *P.n_work;
-    if ((long long)P.tile_start[P.geo.ntiles] > P.pair_cap) return;
+    // the binning gave up (pair buffer too small): every halo goes to the scatter kernel; an uninitialised map still has to be cleared
+    const bool degraded = (long long)P.tile_start[P.geo.ntiles] > P.pair_cap;
+    if (degraded && !P.overwrite) return;
     const Hpx &hp = P.hpx;
     const DevTable &T = P.tab;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -799,7 +833,8 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         pjA1 = (lane < n1) ? plist1[lane] : -1;
         pjB1 = (64 + lane < n1) ? plist1[64 + lane] : -1;
     }
-    const int n_pairs = wk.z - wk.y;
+    const int n_pairs = degraded ? 0 : wk.z - wk.y;
+    bool handed = false;
     const int band = wg.x, sector = wg.y, NS = wg.z;
     const int ring_lo = 1 + band * TR;
     const int ring_hi = min((int)(4 * hp.nside - 1), ring_lo + TR - 1);
@@ -1261,6 +1296,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
             nx_j = (lane < kPairMax) ? pjA : -1;
             load_records();
         }
+        handed = handed || (last_chunk && have_next);
         BFG_TICK(4);
         lds_barrier();
         BFG_TICK(5);
@@ -1275,7 +1311,8 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     constexpr int kPerThread = (TR * TW + NT - 1) / NT;
     int64_t wpix[kPerThread];
     double wold[kPerThread][NACC];
-    const bool rmw = !wk.w && !P.out_zero;
+    const bool shared = wk.w && !degraded;
+    const bool rmw = !shared && !P.out_zero && !P.overwrite;
     if (!(P.debug & 128)) {                            // profiling: bit 128 skips the write-back (wrong results)
 #pragma unroll
     for (int u = 0; u < kPerThread; ++u) {
@@ -1316,10 +1353,9 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
 #pragma unroll
         for (int c = 0; c < NACC; ++c) {
             const double v = acc[NACC * i + c];
-            if (v != 0.0) {
-                if (wk.w) unsafeAtomicAdd(P.out + NACC * wpix[u] + c, v);  // the tile is shared with other workgroups
-                else P.out[NACC * wpix[u] + c] = wold[u][c] + v;
-            }
+            if (shared) { if (v != 0.0) unsafeAtomicAdd(P.out + NACC * wpix[u] + c, v); }   // the tile is shared with other workgroups
+            else if (P.overwrite) P.out[NACC * wpix[u] + c] = v;             // every pixel, zeros included: the map was not cleared
+            else if (v != 0.0) P.out[NACC * wpix[u] + c] = wold[u][c] + v;
         }
     }
     }
@@ -1332,7 +1368,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     // on to the next work item: every thread is done with the accumulator, the ring rows and the queue
     if (tid == 0) ctl[6] = item3;
     lds_barrier();
-    primed = have_next;
+    primed = handed;                                  // (an item without pairs has no last chunk to hand over in)
     item = item1; item1 = item2; item2 = ctl[6];
     wk = wk1; wg = wg1; wk1 = wk2; wg1 = wg2;
     }   // work items

@@ -210,6 +210,15 @@ class Context(object):
         torch = _torch()
         return torch.zeros(*shape, dtype=torch.float64, device=self.device)
 
+    def empty(self, *shape):
+        """uninitialised HBM for outputs a call defines completely (BFG_SHELL_OUT_OVERWRITE); BFG_POISON=1 (the GPU tests)
+        fills it with NaN so that a pixel the kernels fail to write cannot go unnoticed"""
+        import os
+        torch = _torch()
+        if os.environ.get("BFG_POISON"):
+            return torch.full(shape, float("nan"), dtype=torch.float64, device=self.device)
+        return torch.empty(*shape, dtype=torch.float64, device=self.device)
+
     def to_host(self, d_tensor):
         """device tensor -> numpy array.  Up to 1 GiB the copy lands in page-locked memory from torch's caching host
         allocator and the array is a view of it: 1.8 ms instead of 11 ms for a 101 MB map once a block is being
@@ -276,7 +285,7 @@ class Context(object):
 
     def shell_args(self, nside, d_catalog, n_halo, cat_stride, n_extra, epsilon_max, runner_md, model_md=None,
                    model_epsilon_max=0.0, rdelta_sampling=False, include_pixel_size=False, variant="auto",
-                   out_is_zero=False):
+                   out_is_zero=False, out_overwrite=False):
         a = _lib.ShellArgs()
         a.nside, a.n_halo = int(nside), int(n_halo)
         a.d_catalog = d_catalog.data_ptr() if n_halo else None
@@ -288,7 +297,9 @@ class Context(object):
         a.rdelta_sampling = int(bool(rdelta_sampling))
         a.include_pixel_size = int(bool(include_pixel_size))
         a.variant = _lib.VARIANTS[variant]
-        a.flags = _lib.SHELL_OUT_IS_ZERO if out_is_zero else 0      # the caller cleared the output: tiles are stored, not added
+        # out_is_zero: the caller cleared the output (tiles are stored, not added); out_overwrite: the output is uninitialised
+        # memory and the call defines all of it (no clearing pass at all on the tile path)
+        a.flags = (_lib.SHELL_OUT_IS_ZERO if out_is_zero else 0) | (_lib.SHELL_OUT_OVERWRITE if out_overwrite else 0)
         return a
 
     def paint_shell(self, args, table, spline, d_map):

@@ -8,8 +8,9 @@ halos/s + achieved HBM GB/s, NSIDE = 1024 shell, 1e6 halos, at 1/2/4/8 GPUs).
          --master-port P bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--collective torch|bfg]
 
 One "step" = one full pass of the hot path over one synthetic catalog that is already
-resident in HBM as float64 (M, z, ra, dec) records: zero the map, halo preparation kernel,
-shell paint kernel, and -- for N > 1 -- the RCCL all-reduce of the per-rank maps.
+resident in HBM as float64 (M, z, ra, dec) records: halo preparation + binning kernels, row windows,
+shell paint kernel (which also defines the pixels no halo touches: the map buffer is not cleared beforehand),
+and -- for N > 1 -- the RCCL all-reduce of the per-rank maps.
 --scaling weak (default): every rank paints its own sky-patch shard (sharding.shard_by_sky_patch) of a catalog of
 `--halos` halos PER GPU (N x halos in total); --scaling strong: `--halos` halos IN TOTAL, cut into N shards (how
 BASELINE.json's metric reads: one 1e6-halo catalog at 1/2/4/8 GPUs).  Either way value = all halos painted by all ranks
@@ -240,7 +241,8 @@ def main():
         zax, Max, rax, T = syn.pressure_table(*shape)
         with np.errstate(all="ignore"):
             table = ctx.table([zax, Max, rax], np.log(T), log_values=True)
-        sargs = ctx.shell_args(nside, d_cat, idx.size, 4, 0, args.eps, md, variant=args.variant, out_is_zero=True)   # step() clears the map first
+        # BFG_SHELL_OUT_OVERWRITE: the map buffer is not cleared beforehand, the call defines every pixel of it
+        sargs = ctx.shell_args(nside, d_cat, idx.size, 4, 0, args.eps, md, variant=args.variant, out_overwrite=True)
         # N > 1: consecutive shells go to alternating map buffers, so the all-reduce of shell k (async, on RCCL's own
         # stream) overlaps the painting of shell k+1; every collective is waited for before its buffer is reused and
         # before the timed region ends (finish()).
@@ -250,8 +252,7 @@ def main():
         counter = [0]
 
         def compute(b):
-            d_maps[b].zero_()
-            ctx.paint_shell(sargs, table, spline, d_maps[b])
+            ctx.paint_shell(sargs, table, spline, d_maps[b])        # overwrites the buffer (zeros where no halo paints)
 
         def step(collective=True, do_compute=True):
             b = counter[0] % nbuf
@@ -277,7 +278,7 @@ def main():
         d_in_full = ctx.to_device(syn.mass_map(nside))
         d_map = ctx.zeros(npix)
         sargs = ctx.shell_args(nside, d_cat, idx.size, 4, 0, args.eps, md, model_md=md, model_epsilon_max=20.0,
-                               variant=args.variant)
+                               variant=args.variant, out_overwrite=True)
         ex = None
         d_in = d_in_full
         if dist is not None:
@@ -294,9 +295,8 @@ def main():
             # BaryonifyShell.process(distributed=...): offsets of this rank's halos -> reduce-scatter (every rank needs the
             # summed offsets of its own pixel range only) -> regrid of that range -> all-reduce of the output maps
             if do_compute:
-                d_off.zero_()
-                d_map.zero_()
-                ctx.baryonify_offsets(sargs, table, spline, d_off)
+                d_map.zero_()                                       # the regrid deposits INTO the output map
+                ctx.baryonify_offsets(sargs, table, spline, d_off)  # overwrites the offset field
             if ex is not None and collective:
                 if npix % world == 0:
                     ex.reduce_scatter(d_off)

@@ -146,6 +146,10 @@ typedef struct {
  * read-modify-writing them (one global round trip less at the end of every tile).  Without the flag the calls
  * accumulate INTO whatever the buffer holds.                                                                    */
 #define BFG_SHELL_OUT_IS_ZERO 1
+/* The output buffer is UNINITIALISED memory and the call defines every element of it: pixels no halo touches become 0.
+ * On the tile path the kernels write each sky tile exactly once, so no separate clearing pass over the 101 MB map (302 MB
+ * of offsets) is needed; on every other path the library clears the buffer itself first.                        */
+#define BFG_SHELL_OUT_OVERWRITE 2
 
 #define BFG_VARIANT_AUTO 0
 #define BFG_VARIANT_SCATTER_WAVE 1     /* one 64-lane wavefront per halo, global f64 atomics   */

@@ -36,6 +36,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--modes", default="BFG_TILE_KERNEL=block,wave")
     ap.add_argument("--out-zero", action="store_true", help="set BFG_SHELL_OUT_IS_ZERO (the step clears the output first)")
+    ap.add_argument("--overwrite", action="store_true", help="BFG_SHELL_OUT_OVERWRITE: no clearing pass, the call defines the output")
     ap.add_argument("--workloads", default="paint1e6,paint1e5,bary1e5,steep")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--steps", type=int, default=10)
@@ -64,10 +65,11 @@ def main():
             with np.errstate(all="ignore"):
                 table = ctx.table([zax, Max, rax], np.log(T), log_values=True)
             d_out = ctx.zeros(npix)
-            sargs = ctx.shell_args(nside, d_cat, n, 4, 0, w["eps"], md, out_is_zero=a.out_zero)
+            sargs = ctx.shell_args(nside, d_cat, n, 4, 0, w["eps"], md, out_is_zero=a.out_zero, out_overwrite=a.overwrite)
 
             def step():
-                d_out.zero_()
+                if not a.overwrite:
+                    d_out.zero_()
                 ctx.paint_shell(sargs, table, spline, d_out)
         else:
             zax, Max, rax, T = syn.displacement_table(*shape)
@@ -76,10 +78,11 @@ def main():
             d_in = ctx.to_device(syn.mass_map(nside))
             d_map = ctx.zeros(npix)
             sargs = ctx.shell_args(nside, d_cat, n, 4, 0, w["eps"], md, model_md=md, model_epsilon_max=20.0,
-                                   out_is_zero=a.out_zero)
+                                   out_is_zero=a.out_zero, out_overwrite=a.overwrite)
 
             def step():
-                d_out.zero_()
+                if not a.overwrite:
+                    d_out.zero_()
                 d_map.zero_()
                 ctx.baryonify_offsets(sargs, table, spline, d_out)
                 ctx.regrid_shell(nside, d_out, d_in, d_map, None)
