@@ -1449,7 +1449,7 @@ static int ensure_tiles(bfg_ctx *c, int mode, int tr, int tw, int64_t nside, int
         HIP_TRY(hipMalloc((void **)&ts.d_geo, blob.size() * sizeof(int32_t)));
         HIP_TRY(hipMemcpyAsync(ts.d_geo, blob.data(), blob.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipMalloc((void **)&ts.d_tile_count, (size_t)(ntiles + 1) * sizeof(int32_t)));   // + the left-over list's length
+        HIP_TRY(hipMalloc((void **)&ts.d_tile_count, (size_t)(ntiles + 2) * sizeof(int32_t)));   // + the left-over list's length, + needs_scan
         HIP_TRY(hipMalloc((void **)&ts.d_tile_start, (size_t)(ntiles + 1) * sizeof(int32_t)));
         HIP_TRY(hipMalloc((void **)&ts.d_work, (size_t)(2 * ntiles + kWorkExtra) * 2 * sizeof(int4)));
         HIP_TRY(hipMalloc((void **)&ts.d_nwork, 2 * sizeof(int32_t)));     // [0] items in the work list, [1] the tile kernel's item counter
@@ -1592,7 +1592,10 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         pp.hd = (mode == MODE_BARYONIFY) ? c->d_hd : nullptr;
         pp.eps_model = a->model_epsilon_max; pp.rdelta = a->rdelta_sampling;
         // one memset: the tile counters and, right behind them, the length of the left-over list
-        HIP_TRY(hipMemsetAsync(c->tiles[mode].d_tile_count, 0, (size_t)(c->tiles[mode].geo.ntiles + 1) * sizeof(int32_t), c->stream));
+        HIP_TRY(hipMemsetAsync(c->tiles[mode].d_tile_count, 0, (size_t)(c->tiles[mode].geo.ntiles + 2) * sizeof(int32_t), c->stream));
+        pp.bin.needs_scan = c->tiles[mode].d_tile_count + c->tiles[mode].geo.ntiles + 1;
+        pp.bin.direct_limit = std::min(c->tiles[mode].cap_direct, 256);
+        if (std::getenv("BFG_TILE_SCAN")) pp.bin.direct_limit = 0;                   // A/B: always the scan kernel
         pp.left = c->d_left; pp.left_n = c->tiles[mode].d_tile_count + c->tiles[mode].geo.ntiles;
     }
     timing_begin(c, 0);
@@ -1623,8 +1626,9 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         int persist = c->n_cu * (light ? 3 : 2);
         if (const char *e = std::getenv("BFG_TILE_PERSIST")) persist = std::atoi(e) > 1 ? std::atoi(e) : (std::atoi(e) ? persist : 0);
         const int tile_grid = persist > 0 ? std::min(persist, items_max) : items_max;
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, ts.geo, ts.cap_direct, ts.d_tile_count,
-                           ts.d_tile_start, ts.d_work, ts.d_nwork, ts.d_nwork + 1, 3 * tile_grid, overwrite ? 1 : 0, ts.d_shared);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3((unsigned)(1 + (ts.geo.ntiles + 1023) / 1024)), dim3(1024), 0, c->stream, ts.geo,
+                           ts.cap_direct, ts.d_tile_count, ts.d_tile_start, ts.d_work, ts.d_nwork, ts.d_nwork + 1, 3 * tile_grid,
+                           overwrite ? 1 : 0, ts.d_shared, ts.d_tile_count + ts.geo.ntiles + 1);
         FillParams fp;
         std::memset(&fp, 0, sizeof(fp));
         fp.overwrite = overwrite ? 1 : 0; fp.nacc = (mode == MODE_PAINT) ? 1 : 3; fp.shared_flag = ts.d_shared; fp.out = d_out;

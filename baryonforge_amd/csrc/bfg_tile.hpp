@@ -276,6 +276,7 @@ __device__ inline int tile_bin_halo(const BinCtx &B, bool fill, int64_t j, int f
         if (to_scatter) return flags | HF_SCATTER;
     }
     const int64_t ovf_base = (int64_t)B.geo.ntiles * B.cap_direct;
+    bool crowded = false;                                        // some tile of this halo holds more pairs than one plain work item takes
     int ipair = 0;                                               // the halo's pairs in enumeration order (< kMaxPairsPerHalo = 64)
     for (int b = b0; b <= b1; ++b) {
         int s_lo, n;
@@ -288,12 +289,14 @@ __device__ inline int tile_bin_halo(const BinCtx &B, bool fill, int64_t j, int f
                 const int pos = wave_merged_inc(B.tile_count, tile);            // the pair's rank in its tile
                 if (pos < B.cap_direct) B.pairs[(int64_t)tile * B.cap_direct + pos] = (int32_t)j;
                 else mask |= 1ull << ipair;
+                crowded = crowded || pos >= B.direct_limit;
             } else if ((mask >> ipair) & 1ull) {
                 const int pos = wave_merged_inc(B.tile_count, tile);            // cursor of the tile's overflow list
                 B.pairs[ovf_base + B.tile_start[tile] + pos] = (int32_t)j;
             }
         }
     }
+    if (crowded) *B.needs_scan = 1;                              // same value from every writer
     return flags;
 }
 
@@ -313,19 +316,31 @@ struct FillParams {
 __global__ __launch_bounds__(256) void tile_fill_kernel(const FillParams P)
 {
     if (P.overwrite) {
+        // clear the tiles the tile kernel will add to with atomics.  256 flags per workgroup and trip, one per thread (a
+        // workgroup walking the flags one by one took 78 us at 1e4 halos, where the grid is 40 workgroups); shared tiles are rare
         const TileGeom &G = P.bin.geo;
-        for (int t = blockIdx.x; t < G.ntiles; t += gridDim.x) {
-            if (!P.shared_flag[t]) continue;                     // workgroup-uniform
-            const int band = G.tile_band[t], sector = t - G.band_tile0[band], NS = G.band_ns[band];
-            const int ring_lo = 1 + band * G.tr;
-            for (int i = threadIdx.x; i < G.tr * G.tw; i += blockDim.x) {
-                const int row = i / G.tw, col = i % G.tw;
-                const int64_t ring = ring_lo + row;
-                if (ring > 4 * P.hpx.nside - 1) continue;
-                int64_t start, nr; bool shifted;
-                ring_info_small(P.hpx, ring, start, nr, shifted);
-                const int k0 = (int)(((int64_t)sector * nr) / NS), k1 = (int)(((int64_t)(sector + 1) * nr) / NS);
-                if (k0 + col < k1) for (int c = 0; c < P.nacc; ++c) P.out[P.nacc * (start + k0 + col) + c] = 0.0;
+        __shared__ int s_any;
+        for (int base = blockIdx.x * 256; base < G.ntiles; base += gridDim.x * 256) {
+            const int tt = base + (int)threadIdx.x;
+            const int f = (tt < G.ntiles) ? P.shared_flag[tt] : 0;
+            if (threadIdx.x == 0) s_any = 0;
+            __syncthreads();
+            if (f) s_any = 1;
+            __syncthreads();
+            if (!s_any) continue;                                // workgroup-uniform
+            for (int t = base; t < min(base + 256, G.ntiles); ++t) {
+                if (!P.shared_flag[t]) continue;
+                const int band = G.tile_band[t], sector = t - G.band_tile0[band], NS = G.band_ns[band];
+                const int ring_lo = 1 + band * G.tr;
+                for (int i = threadIdx.x; i < G.tr * G.tw; i += blockDim.x) {
+                    const int row = i / G.tw, col = i % G.tw;
+                    const int64_t ring = ring_lo + row;
+                    if (ring > 4 * P.hpx.nside - 1) continue;
+                    int64_t start, nr; bool shifted;
+                    ring_info_small(P.hpx, ring, start, nr, shifted);
+                    const int k0 = (int)(((int64_t)sector * nr) / NS), k1 = (int)(((int64_t)(sector + 1) * nr) / NS);
+                    if (k0 + col < k1) for (int c = 0; c < P.nacc; ++c) P.out[P.nacc * (start + k0 + col) + c] = 0.0;
+                }
             }
         }
     }
@@ -357,11 +372,28 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const FillParams P)
 constexpr int kWorkExtra = 4096;
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const TileGeom geo, int cap_direct, int32_t *count, int32_t *start, int4 *work,
                                                          int32_t *n_work, int32_t *work_counter, int first_dynamic,
-                                                         int overwrite, int32_t *shared_flag)
+                                                         int overwrite, int32_t *shared_flag, const int32_t *needs_scan)
 {
     // overwrite: the tile kernel initialises the map itself, so tiles without a single pair get an (empty) work item too,
     // and tiles cut into several items -- which add to the map with atomics -- are listed for tile_fill_kernel to clear first
     const int ntiles = geo.ntiles;
+    // Fast path (no tile holds more than min(cap_direct, 256) pairs -- the count pass found out: needs_scan): one work item
+    // per tile, item = tile, nothing to scan; blocks 1 .. write them in parallel and block 0 has nothing to do.  The
+    // single-workgroup scan below (~20 us) is left to dense or crowded catalogs, where it is 1-2 % of the call.
+    if (!*needs_scan) {
+        if (blockIdx.x == 0) return;
+        const int t = ((int)blockIdx.x - 1) * 1024 + (int)threadIdx.x;
+        if (t == 0) { *n_work = ntiles; *work_counter = first_dynamic; start[ntiles] = 0; }
+        if (t >= ntiles) return;
+        const int n = count[t];
+        count[t] = 0; start[t] = 0;
+        if (shared_flag) shared_flag[t] = 0;
+        const int band = geo.tile_band[t];
+        work[2 * t] = make_int4(t, t * cap_direct, t * cap_direct + n, 0);
+        work[2 * t + 1] = make_int4(band, t - geo.band_tile0[band], geo.band_ns[band], 0);
+        return;
+    }
+    if (blockIdx.x != 0) return;
     __shared__ int32_t wsum[16];
     __shared__ int32_t carry, carry2;
     // block-wide exclusive scan of 4 values per thread (4096 tiles per trip); returns the offset of the thread's first value
@@ -839,6 +871,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     const int ring_lo = 1 + band * TR;
     const int ring_hi = min((int)(4 * hp.nside - 1), ring_lo + TR - 1);
 
+    if (n_pairs != 0) {
     if (!(P.debug & 512)) for (int i = tid; i < TR * TW * NACC; i += NT) acc[i] = 0.0;
     if (tid == 0) ctl[5] = 0;
     if (tid < TR && !(P.debug & 256)) {
@@ -1365,6 +1398,25 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     __syncthreads();
     BFG_TICK(7);                                       // epilogue: final queue drain, write-back
 #endif
+    } else {
+        // an item without pairs (a tile no halo touches; every item when the binning gave up): nothing to paint.  An
+        // uninitialised map still gets its zeros (tiles shared between items were cleared by tile_fill_kernel).
+        if (P.overwrite && !(wk.w && !degraded)) {
+            for (int i = tid; i < TR * TW; i += NT) {
+                const int row = i / TW, col = i % TW;
+                const int ring = ring_lo + row;
+                if (ring > ring_hi) continue;
+                int64_t start, nr64; bool shifted;
+                ring_info_small(hp, ring, start, nr64, shifted);
+                const int k0 = (int)(((int64_t)sector * nr64) / NS), k1 = (int)(((int64_t)(sector + 1) * nr64) / NS);
+                if (k0 + col < k1) {
+#pragma unroll
+                    for (int c = 0; c < NACC; ++c) P.out[NACC * (start + k0 + col) + c] = 0.0;
+                }
+            }
+        }
+        if constexpr (kQCap > 0) { if (P.defer && tid == 0) P.defer_count[item] = 0; }
+    }
     // on to the next work item: every thread is done with the accumulator, the ring rows and the queue
     if (tid == 0) ctl[6] = item3;
     lds_barrier();
