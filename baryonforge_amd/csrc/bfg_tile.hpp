@@ -316,24 +316,29 @@ struct FillParams {
 __global__ __launch_bounds__(256) void tile_fill_kernel(const FillParams P)
 {
     if (P.overwrite) {
-        // clear the tiles the tile kernel will add to with atomics.  256 flags per workgroup and trip, one per thread (a
-        // workgroup walking the flags one by one took 78 us at 1e4 halos, where the grid is 40 workgroups); shared tiles are rare
+        // Clear the tiles the tile kernel will add to with atomics (those cut into several work items: crowded catalogs,
+        // compact multi-GPU shards).  Tile t belongs to workgroup t mod gridDim, so the clearing is spread over the whole
+        // grid; a workgroup reads the flags of up to 256 of its tiles in one go, one per thread (a small grid walking its
+        // flags one by one took 78 us at 1e4 halos; 25 workgroups clearing 256 tiles each took 1 ms on a half-sky shard).
         const TileGeom &G = P.bin.geo;
-        __shared__ int s_any;
-        for (int base = blockIdx.x * 256; base < G.ntiles; base += gridDim.x * 256) {
-            const int tt = base + (int)threadIdx.x;
+        __shared__ unsigned long long s_mask[4];
+        for (int base = 0; base < G.ntiles; base += 256 * (int)gridDim.x) {
+            const int tt = base + (int)threadIdx.x * (int)gridDim.x + (int)blockIdx.x;
             const int f = (tt < G.ntiles) ? P.shared_flag[tt] : 0;
-            if (threadIdx.x == 0) s_any = 0;
+            const unsigned long long m = __ballot(f != 0);
             __syncthreads();
-            if (f) s_any = 1;
+            if ((threadIdx.x & 63) == 0) s_mask[threadIdx.x >> 6] = m;
             __syncthreads();
-            if (!s_any) continue;                                // workgroup-uniform
-            for (int t = base; t < min(base + 256, G.ntiles); ++t) {
-                if (!P.shared_flag[t]) continue;
+            for (int w = 0; w < 4; ++w) {
+              unsigned long long todo = s_mask[w];               // workgroup-uniform; zero for a catalog spread over the sky
+              while (todo) {
+                const int i = 64 * w + __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int t = base + i * (int)gridDim.x + (int)blockIdx.x;
                 const int band = G.tile_band[t], sector = t - G.band_tile0[band], NS = G.band_ns[band];
                 const int ring_lo = 1 + band * G.tr;
-                for (int i = threadIdx.x; i < G.tr * G.tw; i += blockDim.x) {
-                    const int row = i / G.tw, col = i % G.tw;
+                for (int e = threadIdx.x; e < G.tr * G.tw; e += blockDim.x) {
+                    const int row = e / G.tw, col = e % G.tw;
                     const int64_t ring = ring_lo + row;
                     if (ring > 4 * P.hpx.nside - 1) continue;
                     int64_t start, nr; bool shifted;
@@ -341,6 +346,7 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const FillParams P)
                     const int k0 = (int)(((int64_t)sector * nr) / NS), k1 = (int)(((int64_t)(sector + 1) * nr) / NS);
                     if (k0 + col < k1) for (int c = 0; c < P.nacc; ++c) P.out[P.nacc * (start + k0 + col) + c] = 0.0;
                 }
+              }
             }
         }
     }
@@ -598,6 +604,9 @@ __global__ __launch_bounds__(256) void halo_row4_kernel(const RowParams P)
 #define BFG_PAINT_TW 64
 #endif
 // offsets tiles (3 accumulators per pixel, 1024 pixels): 16 x 64 instead of 32 x 32, tile kernel -5 %
+#ifndef BFG_PAINT_PIXMAX
+#define BFG_PAINT_PIXMAX 6912      // pixel -> segment table entries per round of stage c: what the LDS left by the 32-ring rows holds
+#endif
 #ifndef BFG_BARY_TR
 #define BFG_BARY_TR 16
 #endif
@@ -624,7 +633,7 @@ template <int MODE, int LIGHT = 0> struct TileCfg;
 template <> struct TileCfg<MODE_PAINT, 0> {
     // rings per tile, accumulators per pixel, (pair, ring) slots / pairs per chunk, pixel -> segment table entries per round
     static constexpr int NT = kTileThreads, WPS = BFG_TILE_WAVES_PER_SIMD, LDS_MAX = 81920;
-    static constexpr int TR = BFG_PAINT_TR, TW = BFG_PAINT_TW, NACC = 1, SLOTMAX = 512, PAIRMAX = 64, PIXMAX = 6144, QCAP = 40;
+    static constexpr int TR = BFG_PAINT_TR, TW = BFG_PAINT_TW, NACC = 1, SLOTMAX = 512, PAIRMAX = 64, PIXMAX = BFG_PAINT_PIXMAX, QCAP = 40;
     static constexpr int SEGMAX = SLOTMAX + kSegExtra;
     using Pair = PairInfo;
 };

@@ -26,13 +26,13 @@ if workload == "paint":
     zax, Max, rax, T = syn.pressure_table(10, 30, 100)
     table = ctx.table([zax, Max, rax], np.log(T), log_values=True)
     d_map = ctx.zeros(npix)
-    sargs = ctx.shell_args(nside, d_cat, n, 4, 0, 10.0, md)
+    sargs = ctx.shell_args(nside, d_cat, n, 4, 0, 10.0, md, out_overwrite=True)
     run = lambda: ctx.paint_shell(sargs, table, spline, d_map)
 else:
     zax, Max, rax, T = syn.displacement_table(10, 30, 100)
     table = ctx.table([zax, Max, rax], T, log_values=False)
     d_off = ctx.zeros(npix, 3)
-    sargs = ctx.shell_args(nside, d_cat, n, 4, 0, 10.0, md, model_md=md, model_epsilon_max=20.0)
+    sargs = ctx.shell_args(nside, d_cat, n, 4, 0, 10.0, md, model_md=md, model_epsilon_max=20.0, out_overwrite=True)
     run = lambda: ctx.baryonify_offsets(sargs, table, spline, d_off)
 L = _lib.load()
 fn = L.bfg_debug_stage_cycles
