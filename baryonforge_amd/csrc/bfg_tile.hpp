@@ -881,9 +881,9 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     const int ring_hi = min((int)(4 * hp.nside - 1), ring_lo + TR - 1);
 
     if (n_pairs != 0) {
-    if (!(P.debug & 512)) for (int i = tid; i < TR * TW * NACC; i += NT) acc[i] = 0.0;
+    for (int i = tid; i < TR * TW * NACC; i += NT) acc[i] = 0.0;
     if (tid == 0) ctl[5] = 0;
-    if (tid < TR && !(P.debug & 256)) {
+    if (tid < TR) {
         const int ring = ring_lo + tid;
         RingRow rr;
         rr.z = 0; rr.sth = 0; rr.phistep = 0; rr.phioff = 0; rr.nr = 1; rr.k0 = 0; rr.k1 = 0; rr.rowoff = 0;

@@ -1046,6 +1046,43 @@ def test_paint_and_baryonify_any_nside(cosmo, nside, variant):
     assert_maps_close(gotb, refb, RTOL, floor=BFLOOR, what=f"baryonify nside {nside}")
 
 
+@pytest.mark.parametrize("switch", ["BFG_TILE_KERNEL=wave", "BFG_TILE_LIGHT=1", "BFG_TILE_PERSIST=0", "BFG_TILE_PERSIST=7",
+                                    "BFG_FINAL_DRAIN=inline", "BFG_TILE_SCAN=1", "BFG_OUT_OVERWRITE=0"])
+def test_tile_kernel_switches_agree(cosmo, switch, monkeypatch):
+    """every A/B switch of the tile path paints the default build's map: the wave-private-chunk kernel, the
+    256-thread instantiation, one workgroup per item / a tiny persistent grid, the in-kernel final drain, the scan-built work
+    list, a cleared instead of an overwritten output -- paint and baryonify, against the default path and the oracle"""
+    import warnings
+    nside, n, eps = 512, 20000, 10.0
+    ra, dec, M, z = syn.catalog(n, seed=91)
+    zax, Max, rax, T = syn.pressure_table()
+    ref, ptot = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax), T, nside, eps)
+    zd, Md, rd, d = syn.displacement_table()
+    m_in = syn.mass_map(nside)
+    refb = oracle_baryonify(cosmo, ra, dec, M, z, (zd, Md, rd), d, nside, eps, 20, m_in)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    bm = bfg.Baryonification2D.from_arrays(zd, Md, rd, d, cosmo, epsilon_max=20)
+
+    def run():
+        R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), eps,
+                                   _paint_model(zax, Max, rax, T), verbose=False)
+        got = R.process()
+        assert R.last_stats["pixel_updates"] == ptot
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            gotb = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo), eps, bm, verbose=False).process()
+        return got, gotb
+    base, baseb = run()
+    k, v = switch.split("=")
+    monkeypatch.setenv(k, v)
+    got, gotb = run()
+    assert np.array_equal(got != 0, ref != 0)
+    assert_maps_close(got, ref, RTOL, what=f"paint with {switch}")
+    assert_maps_close(got, base, 1e-12, what=f"paint with {switch} vs default")
+    assert_maps_close(gotb, refb, RTOL, floor=BFLOOR, what=f"baryonify with {switch}")
+    assert_maps_close(gotb, baseb, 1e-8, floor=BFLOOR, what=f"baryonify with {switch} vs default")
+
+
 def test_tile_deferred_pixel_queue_overflow(cosmo, monkeypatch):
     """pixels below a halo's staged row window are queued in LDS and drained in batches; with a full queue they are
     painted inline (forced here with debug bit 32: a 4-entry queue)"""
