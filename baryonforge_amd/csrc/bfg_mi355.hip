@@ -77,6 +77,7 @@ struct bfg_spline {
 };
 
 namespace bfg { struct HaloTile; struct HaloDisp; struct DeferredOut; }
+constexpr int kTimingSlots = 6;     // bfg_timing_read: prep, dominant shell kernel, regrid, binning, left-overs, deferred pixels
 struct bfg_ctx {
     int device;
     hipStream_t stream;
@@ -127,10 +128,10 @@ struct bfg_ctx {
     bool tile_attr_set;             // MaxDynamicSharedMemorySize raised for the tile kernels on this device
     // timing: a growing pool of event pairs per kernel class, resolved lazily in bfg_timing_read
     bool timing;
-    std::vector<hipEvent_t> *ev_a[5], *ev_b[5];
-    size_t ev_used[5];
-    double t_ms[5];
-    int64_t t_n[5];
+    std::vector<hipEvent_t> *ev_a[kTimingSlots], *ev_b[kTimingSlots];
+    size_t ev_used[kTimingSlots];
+    double t_ms[kTimingSlots];
+    int64_t t_n[kTimingSlots];
     hipEvent_t ev_switch;           // orders the context's work across a change of stream (bfg_ctx_set_stream)
     struct bfg_comm_state *comm;    // RCCL communicator of bfg_comm_init (multi-GPU), or null
 };
@@ -1061,7 +1062,7 @@ int bfg_ctx_create(int device_id, void *stream, bfg_ctx **out)
     c->n_cu = prop.multiProcessorCount;
     c->lds_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
     c->max_dyn_lds = prop.sharedMemPerBlock;
-    for (int k = 0; k < 5; ++k) { c->ev_a[k] = new std::vector<hipEvent_t>(); c->ev_b[k] = new std::vector<hipEvent_t>(); }
+    for (int k = 0; k < kTimingSlots; ++k) { c->ev_a[k] = new std::vector<hipEvent_t>(); c->ev_b[k] = new std::vector<hipEvent_t>(); }
     const int rc = ctx_create_body(c, stream);
     if (rc != BFG_OK) { ctx_free_all(c); return rc; }          // nothing of a half-built context is left behind
     *out = c;
@@ -1097,7 +1098,7 @@ static void ctx_free_all(bfg_ctx *c)
     if (c->d_ovf_mask) (void)hipFree(c->d_ovf_mask);
     if (c->d_mathtab) (void)hipFree(c->d_mathtab);
     if (c->d_pair_total) (void)hipFree(c->d_pair_total);
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < kTimingSlots; ++k) {
         if (!c->ev_a[k]) continue;
         for (hipEvent_t e : *c->ev_a[k]) (void)hipEventDestroy(e);
         for (hipEvent_t e : *c->ev_b[k]) (void)hipEventDestroy(e);
@@ -1712,12 +1713,15 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
             if (wl) hipLaunchKernelGGL((shell_tile_kernel<MODE_BARYONIFY, true>), tgrid, tblock, tlds, c->stream, tp);
             else hipLaunchKernelGGL((shell_tile_kernel<MODE_BARYONIFY, false>), tgrid, tblock, tlds, c->stream, tp);
         }
-        if (mode == MODE_PAINT && tp.defer && !use_wave) {
-            const int n_items = 2 * ts.geo.ntiles + kWorkExtra;
-            hipLaunchKernelGGL(tile_deferred_kernel, dim3((unsigned)std::min((n_items + 3) / 4, 2 * c->n_cu)), dim3(256), 0, c->stream, tp, n_items);
-        }
         HIP_TRY(hipGetLastError());
         timing_end(c, 1);
+        if (mode == MODE_PAINT && tp.defer && !use_wave) {
+            timing_begin(c, 5);
+            const int n_items = 2 * ts.geo.ntiles + kWorkExtra;
+            hipLaunchKernelGGL(tile_deferred_kernel, dim3((unsigned)std::min((n_items + 3) / 4, 8 * c->n_cu)), dim3(256), 0, c->stream, tp, n_items);
+            HIP_TRY(hipGetLastError());
+            timing_end(c, 5);
+        }
         sp.only_flagged = 1;     // leftovers: halos the binning left to the global-atomic kernel
         sp.left = c->d_left; sp.left_n = ts.d_tile_count + ts.geo.ntiles;
         sp.pair_total_ptr = ts.d_tile_start + ts.geo.ntiles; sp.pair_cap = c->pair_cap;
@@ -2243,7 +2247,7 @@ int bfg_timing_enable(bfg_ctx *c, int enable)
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->timing = enable != 0;
-    for (int k = 0; k < 5; ++k) { c->t_ms[k] = 0; c->t_n[k] = 0; c->ev_used[k] = 0; }
+    for (int k = 0; k < kTimingSlots; ++k) { c->t_ms[k] = 0; c->t_n[k] = 0; c->ev_used[k] = 0; }
     return BFG_OK;
 }
 
@@ -2252,7 +2256,7 @@ int bfg_timing_read(bfg_ctx *c, int which, double *ms_total, int64_t *launches)
     DeviceGuard dg_;
     int rc = ctx_enter(c, dg_);
     if (rc) return rc;
-    if (which < 0 || which > 4) return BFG_ERR_INVALID;
+    if (which < 0 || which >= kTimingSlots) return BFG_ERR_INVALID;
     timing_fold(c, which);
     if (ms_total) *ms_total = c->t_ms[which];
     if (launches) *launches = c->t_n[which];

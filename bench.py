@@ -349,6 +349,7 @@ def main():
     r_ms, r_n = ctx.timing_read(2)
     b_ms, b_n = ctx.timing_read(3)
     l_ms, l_n = ctx.timing_read(4)
+    f_ms, f_n = ctx.timing_read(5)
     ctx.timing_enable(False)
     ptot_step = stats["pixel_updates"] / max(args.steps, 1)
 
@@ -407,6 +408,7 @@ def main():
                 "prep_kernel_ms": p_ms / max(p_n, 1),
                 "tile_binning_ms": (b_ms / b_n) if b_n else None,
                 "leftover_scatter_kernel_ms": (l_ms / l_n) if l_n else None,
+                "deferred_pixels_kernel_ms": (f_ms / f_n) if f_n else None,
                 "regrid_kernel_ms": (r_ms / r_n) if r_n else None,
                 "fallback_halos_per_step": stats["fallback_halos"] / max(args.steps, 1),
                 "step_algorithmic_GBps": step_bytes / (dt / args.steps) / 1e9 if world == 1 else None,

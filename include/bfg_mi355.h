@@ -330,8 +330,9 @@ int bfg_stats_read(bfg_ctx *ctx, bfg_stats *out);   /* synchronises the stream *
 /* Optional per-kernel timing with hipEvents on the context's stream (bench.py's
  * roofline leg).  which: 0 = halo preparation kernel, 1 = the dominant shell kernel
  * (tile kernel, or the scatter kernel of the scatter variants), 2 = regrid kernel,
- * 3 = tile binning (count + scan + fill), 4 = left-over scatter kernel of the tile
- * variant.  Returns the accumulated milliseconds and launch count since the last enable. */
+ * 3 = tile binning (work list + overflow fill + row windows), 4 = left-over scatter kernel of the tile
+ * variant, 5 = the follow-up kernel that adds the tile kernel's deferred pixels (paint).
+ * Returns the accumulated milliseconds and launch count since the last enable. */
 int bfg_timing_enable(bfg_ctx *ctx, int enable);
 int bfg_timing_read(bfg_ctx *ctx, int which, double *ms_total, int64_t *launches);
 

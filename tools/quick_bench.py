@@ -103,7 +103,7 @@ def main():
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t0) / a.steps * 1e3
                 st = ctx.stats()
-                k = ctx.timing_read(1); p = ctx.timing_read(0); b = ctx.timing_read(3); l = ctx.timing_read(4); r = ctx.timing_read(2)
+                k = ctx.timing_read(1); p = ctx.timing_read(0); b = ctx.timing_read(3); l = ctx.timing_read(4); r = ctx.timing_read(2); f = ctx.timing_read(5)
                 ctx.timing_enable(False)
                 ms = lambda x: x[0] / max(x[1], 1)
                 ptot = st["pixel_updates"] // a.steps
@@ -120,7 +120,7 @@ def main():
                         extra = (f" | vs {vals[0]}: max rel {rel:.2e} nonzero-set equal {np.array_equal(out != 0, nz)} "
                                  f"P_tot equal {ptot == ref[1]}")
                 print(f"{name:9s} {v:40s} step {dt:7.3f} ms  kernel {ms(k):7.3f}  prep {ms(p):6.3f}  bin {ms(b):6.3f}  "
-                      f"left {ms(l):6.3f}  regrid {ms(r):6.3f}  frac {frac:5.3f}  fallback {st['fallback_halos'] // a.steps}{extra}",
+                      f"left {ms(l):6.3f}  defer {ms(f):6.3f}  regrid {ms(r):6.3f}  frac {frac:5.3f}  fallback {st['fallback_halos'] // a.steps}{extra}",
                       flush=True)
         del d_cat, d_out
 

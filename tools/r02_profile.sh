@@ -33,6 +33,13 @@ cd $R
 for n in 1000000 100000; do BFG_SO=/tmp/bfg_st.so python3 tools/stage_timing.py $n 1024 paint; done > $O/${tag}_stage_cycles.txt 2>&1
 BFG_SO=/tmp/bfg_st.so python3 tools/stage_timing.py 100000 1024 bary >> $O/${tag}_stage_cycles.txt 2>&1
 grep -v "^/opt" $O/${tag}_stage_cycles.txt
+python3 tools/pmc_to_json.py $O/${tag}_pmc_FETCH_SIZE.txt $O/${tag}_pmc_WRITE_SIZE.txt ${tag} $O/${tag}_pmc_traffic.json > /dev/null
 bash tools/workloads.sh > $O/${tag}_other_workloads.txt 2>&1; cat $O/${tag}_other_workloads.txt
 python3 tools/shard_scale.py > $O/${tag}_shard_scale.txt 2>&1; grep -v "^/opt" $O/${tag}_shard_scale.txt
 python3 tools/e2e_probe.py > $O/${tag}_e2e_probe.txt 2>&1; grep -v "^/opt" $O/${tag}_e2e_probe.txt
+# 2-rank rehearsals of the multi-GPU bench on this one GPU (gloo, both ranks on cuda:0)
+export BFG_BENCH_BACKEND=gloo BFG_BENCH_ONE_DEVICE=1
+for sc in weak strong; do
+  timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 10 --warmup 2 --scaling $sc > $O/${tag}_rehearsal_n2_${sc}.json 2> $O/${tag}_rehearsal_n2_${sc}.err && tail -c 300 $O/${tag}_rehearsal_n2_${sc}.json && echo
+done
+timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 2 --steps 5 --warmup 2 --workload baryonify --halos 100000 > $O/${tag}_rehearsal_n2_bary.json 2> $O/${tag}_rehearsal_n2_bary.err && tail -c 300 $O/${tag}_rehearsal_n2_bary.json && echo
