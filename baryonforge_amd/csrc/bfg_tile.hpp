@@ -1462,20 +1462,32 @@ __global__ __launch_bounds__(256) void tile_deferred_kernel(const TileParams P, 
     const int64_t j = e.halo;
     const int i = min(max((int)e.t, 0), T.nr - 2);
     const double f = e.t - (double)i;
+    // the halo's outer cell first (one round of independent loads), then all corner values (another): written as nested
+    // loops over corners and axes the compiler serialised 2^(ndim-1) x 2 dependent rounds per entry
+    int ci[BFG_MAX_DIM - 1];
+    double cy[BFG_MAX_DIM - 1];
+#pragma unroll
+    for (int k = 0; k < BFG_MAX_DIM - 1; ++k) {
+        ci[k] = (k < T.nouter) ? P.cidx[k * P.cap + j] : 0;
+        cy[k] = (k < T.nouter) ? P.cw[k * P.cap + j] : 0.0;
+    }
+    const double lnpf = P.ht[j].spare[0];
     double c0v = 0.0, c1v = 0.0;
     const int ncorner = 1 << T.nouter;
-    for (int c = 0; c < ncorner; ++c) {
+    for (int c = 0; c < ncorner; ++c) {                            // corner order and products of halo_row_kernel
         double w = 1.0; int64_t off = 0;
-        for (int k = 0; k < T.nouter; ++k) {
-            const int bit = (c >> (T.nouter - 1 - k)) & 1;
-            const double y = P.cw[k * P.cap + j];
-            w = w * (bit ? y : 1.0 - y);
-            off += (int64_t)(P.cidx[k * P.cap + j] + bit) * T.ostride[k];
+#pragma unroll
+        for (int k = 0; k < BFG_MAX_DIM - 1; ++k) {
+            if (k < T.nouter) {
+                const int bit = (c >> (T.nouter - 1 - k)) & 1;
+                w = w * (bit ? cy[k] : 1.0 - cy[k]);
+                off += (int64_t)(ci[k] + bit) * T.ostride[k];
+            }
         }
         c0v = fma(T.values[off + i], w, c0v);
         c1v = fma(T.values[off + i + 1], w, c1v);
     }
-    const double L = fma(f, c1v - c0v, c0v) + P.ht[j].spare[0];
+    const double L = fma(f, c1v - c0v, c0v) + lnpf;
     if (fabs(L) < 709.0) unsafeAtomicAdd(P.out + e.pix, fast_exp(L, P.exptab));
     }
 }
