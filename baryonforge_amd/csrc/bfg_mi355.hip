@@ -2269,14 +2269,14 @@ int bfg_timing_read(bfg_ctx *c, int which, double *ms_total, int64_t *launches)
 
 #if BFG_STAGE_TIMING
 // profiling build only (not declared in include/bfg_mi355.h)
-extern "C" int bfg_debug_stage_cycles(bfg_ctx *c, unsigned long long *out8, int reset)
+extern "C" int bfg_debug_stage_cycles(bfg_ctx *c, unsigned long long *out16, int reset)
 {
     DeviceGuard dg_;
     int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     (void)hipStreamSynchronize(c->stream);
-    if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(bfg::g_stage_cycles), 8 * sizeof(unsigned long long));
-    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(bfg::g_stage_cycles), z, sizeof(z)); }
+    if (out16) (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(bfg::g_stage_cycles), 16 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(bfg::g_stage_cycles), z, sizeof(z)); }
     return 0;
 }
 #endif

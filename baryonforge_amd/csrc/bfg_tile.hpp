@@ -614,10 +614,15 @@ __global__ __launch_bounds__(256) void halo_row4_kernel(const RowParams P)
 #define BFG_BARY_TW 64
 #endif
 #if BFG_STAGE_TIMING
-__device__ unsigned long long g_stage_cycles[8];      // profiling build only: barrier-to-barrier cycles per stage
+__device__ unsigned long long g_stage_cycles[16];     // profiling build only: barrier-to-barrier cycles per stage ([8..]: inside stage b)
 #define BFG_TICK(slot) do { if (tid == 64) { const long long now_ = clock64(); st_acc[slot] += now_ - st_t; st_t = now_; } } while (0)
 #else
 #define BFG_TICK(slot) do { } while (0)
+#endif
+#if BFG_STAGE_TIMING > 1
+#define BFG_SUBTICK(slot) do { if (tid == 64) { const long long now_ = clock64(); st_acc[8 + slot] += now_ - st_sub; st_sub = now_; } } while (0)
+#else
+#define BFG_SUBTICK(slot) do { } while (0)
 #endif
 constexpr int kTileThreads = BFG_TILE_THREADS;
 constexpr int kWinLds = 32;          // row windows up to this many nodes are staged in LDS
@@ -814,7 +819,11 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     // the list is empty.  (One workgroup per item -- 16 640 launches at NSIDE 1024, 10 368 of them with nothing to do --
     // cost more in dispatch than the items of a sparse catalog cost to process: at 1e4 halos the kernel took 0.10 ms
     // whether two or three workgroups shared a CU.)  The ln / exp tables are loaded once per workgroup.
-    const int n_work_total = *P.n_work;
+    // the work-list state is the same in every lane: readfirstlane tells the compiler, which then keeps it (and what is derived
+    // from it: pair counts, ring range, sector) in scalar registers instead of ~30 vector registers: -4 % at 1e5 halos
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    auto uni4 = [&](int4 v) { return make_int4(uni(v.x), uni(v.y), uni(v.z), uni(v.w)); };
+    const int n_work_total = uni(*P.n_work);
     // the binning gave up (pair buffer too small): every halo goes to the scatter kernel; an uninitialised map still has to be cleared
     const bool degraded = (long long)P.tile_start[P.geo.ntiles] > P.pair_cap;
     if (degraded && !P.overwrite) return;
@@ -822,7 +831,8 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     const DevTable &T = P.tab;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #if BFG_STAGE_TIMING
-    long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = clock64();
+    long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = clock64();
+    [[maybe_unused]] long long st_sub = st_t;
 #endif
     if (tid < kLogTab) logtab[tid] = P.logtab[tid];
     if (tid < kExpTab) exptab[tid] = P.exptab[tid];
@@ -860,14 +870,14 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     int item2 = P.work_counter ? (int)(blockIdx.x + 2 * gridDim.x) : kNoItem;
     const int4 wzero = make_int4(0, 0, 0, 0);
     int4 wk = wzero, wg = wzero, wk1 = wzero, wg1 = wzero;
-    if (item < n_work_total) { wk = P.work[2 * item]; wg = P.work[2 * item + 1]; }
-    if (item1 < n_work_total) { wk1 = P.work[2 * item1]; wg1 = P.work[2 * item1 + 1]; }
+    if (item < n_work_total) { wk = uni4(P.work[2 * item]); wg = uni4(P.work[2 * item + 1]); }
+    if (item1 < n_work_total) { wk1 = uni4(P.work[2 * item1]); wg1 = uni4(P.work[2 * item1 + 1]); }
     while (item < n_work_total) {
     int item3 = kNoItem;
     if (tid == 0 && P.work_counter) item3 = atomicAdd(P.work_counter, 1);
     const bool have_next = item1 < n_work_total;
     int4 wk2 = wzero, wg2 = wzero;
-    if (item2 < n_work_total) { wk2 = P.work[2 * item2]; wg2 = P.work[2 * item2 + 1]; }
+    if (item2 < n_work_total) { wk2 = uni4(P.work[2 * item2]); wg2 = uni4(P.work[2 * item2 + 1]); }
     if (wave == 0 && have_next) {                     // first pair-list windows of the next item
         const int32_t *plist1 = P.pairs + wk1.y;
         const int n1 = wk1.z - wk1.y;
@@ -1126,6 +1136,9 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         lds_barrier();
         const int n_take = ctl[0], nslots = ctl[1];
         BFG_TICK(0);
+#if BFG_STAGE_TIMING > 1
+        if (tid == 64) st_sub = clock64();
+#endif
 
         // ---- stage b: one thread per (pair, ring) slot; row windows -> LDS -----------------------------
         // With full-width windows the copy is an LDS-DMA (global_load_lds_dwordx4: no VGPRs, asynchronous;
@@ -1196,6 +1209,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                     p += (slot >= o) ? 1 : 0;
                 }
             }
+            BFG_SUBTICK(0);                                          // window DMA issued, pair of the slot found
             int cnt1 = 0, cnt2 = 0, aa1 = 0, aa2 = 0, ab1 = 0, ab2 = 0;
             Seg sg;
             sg.excl = 0; sg.abyte = 0; sg.wbyte = 0; sg.pk = 0; sg.hstep = 0; sg.c0 = 0; sg.Aq = 0; sg.Bq = 0;
@@ -1211,6 +1225,10 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                 // fetched in one burst (a branch on irmin / irmax first serialises three L2 round trips); rings that
                 // lie entirely inside the disc (ring outside [irmin, irmax]) override the result.
                 const int irmin = h.irmin, irmax = h.irmax;
+#if BFG_STAGE_TIMING > 1
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                BFG_SUBTICK(1);                                      // halo record arrived
+#endif
                 int lo = 0, cnt = 0;
                 {
                     const double x = (h.cosr - rr.z * h.z0) * h.xa;
@@ -1257,6 +1275,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                     }
                 }
             }
+            BFG_SUBTICK(2);                                          // ring window, clipping, segment constants
             // a second piece needs its own segment record; should the chunk run out of them (only possible where a
             // sector spans a whole ring, at the poles) the piece is painted right here, through the direct read-out
             int idx2 = 0;
@@ -1270,10 +1289,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
             if (lane == 0 && wtot > 0) wbase = atomicAdd(&ctl[3], wtot);
             wbase = __builtin_amdgcn_readfirstlane(wbase);
             const int e1 = wbase + incl - tot;
-#if BFG_STAGE_TIMING > 1
-            if (live) atomicAdd(&g_stage_cycles[6], 1ull);
-            if (cnt1 > 0) atomicAdd(&g_stage_cycles[7], 1ull);
-#endif
+            BFG_SUBTICK(3);                                          // pixel-list offsets (scan + LDS atomics)
             if (live) {
                 scnt[slot] = (uint8_t)cnt1;
                 if (cnt1 > 0) {
@@ -1299,7 +1315,9 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                 }
             }
         }
+        BFG_SUBTICK(4);                                              // segment records + pixel -> segment table written
         __syncthreads();
+        BFG_SUBTICK(5);                                              // wait for the other wavefronts and the window DMA
         BFG_TICK(1);
         const int nseg = min(nslots + ctl[2], kSegMax);
         const int ptotal = (P.debug & 2) ? 0 : ctl[3];
@@ -1430,7 +1448,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     if (tid == 0) ctl[6] = item3;
     lds_barrier();
     primed = handed;                                  // (an item without pairs has no last chunk to hand over in)
-    item = item1; item1 = item2; item2 = ctl[6];
+    item = item1; item1 = item2; item2 = uni(ctl[6]);
     wk = wk1; wg = wg1; wk1 = wk2; wg1 = wg2;
     }   // work items
     // counters last, once per workgroup: nothing waits for these atomics
@@ -1440,7 +1458,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         atomicOr(&P.stats->warn_mask, BFG_WARN_R_RANGE);
     }
 #if BFG_STAGE_TIMING
-    if (tid == 64) for (int i = 0; i < 8; ++i) atomicAdd(&g_stage_cycles[i], (unsigned long long)st_acc[i]);
+    if (tid == 64) for (int i = 0; i < 16; ++i) atomicAdd(&g_stage_cycles[i], (unsigned long long)st_acc[i]);
 #endif
 }
 

@@ -112,6 +112,7 @@ def main():
                 extra = ""
                 if rep == 0:
                     out = d_out.cpu().numpy()
+                    extra = f" | sum {out.sum():.12e} nonzero {np.count_nonzero(out)} P_tot {ptot}"
                     if ref is None:
                         ref = (out, ptot)
                     else:

@@ -37,7 +37,7 @@ else:
 L = _lib.load()
 fn = L.bfg_debug_stage_cycles
 fn.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
-out = (ctypes.c_ulonglong * 8)()
+out = (ctypes.c_ulonglong * 16)()
 run(); run()
 fn(ctx.handle, out, 1)
 reps = 3
@@ -48,8 +48,16 @@ v = np.array(list(out), dtype=np.float64) / reps
 names = ["a: pair records (wave 0) + barrier", "b: ring windows -> segments + barrier", "p: next chunk's record loads issued",
          "c1: pixel->segment table + barrier", "c2: pixel loop (own pixels)", "c3: wait at the end-of-chunk barrier",
          "prologue: LDS clear, tables, ring rows, first records", "epilogue: final drain, counters, write-back"]
+sub = v[8:]
+v = v[:8]
 tot = v.sum()
 print(f"workload {workload} n={n} nside={nside}: {tot:.4g} cycles summed over workgroups per launch")
 for nm, x in zip(names, v):
     if x:
         print(f"  {nm:45s} {x:12.4g}  {100 * x / tot:5.1f} %")
+if sub.sum():
+    subn = ["b0: window DMA issued, pair of the slot found", "b1: halo record arrived", "b2: ring window, clipping, segment constants",
+            "b3: pixel-list offsets (scan + LDS atomics)", "b4: segment records + pixel->segment table", "b5: barrier (other waves, window DMA)"]
+    print("  inside stage b (wave 1 of every workgroup; a -DBFG_STAGE_TIMING=2 build):")
+    for nm, x in zip(subn, sub):
+        print(f"    {nm:50s} {x:12.4g}  {100 * x / sub.sum():5.1f} %")
