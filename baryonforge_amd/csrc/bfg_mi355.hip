@@ -189,6 +189,8 @@ struct PrepParams {
     int32_t *left_n;         // ... their number: the int32 after the tile counters, cleared by the same memset
     double eps_model;
     int rdelta;
+    double *hwin;            // tile variant, row windows of 4 k nodes: the kernel also builds the halos' blended rows (null: a
+                             // separate halo_row*_kernel does)
 };
 
 #define MODE_PAINT 0
@@ -226,21 +228,35 @@ __device__ inline double spline_eval(int n, const double *__restrict__ x, const 
 
 constexpr int kPrepKnots = 1024;     // D_A spline knots staged in LDS (the reference uses 1000, HealpixRunner.py:297)
 constexpr int kPrepAxis = 64;        // nodes of a non-radial table axis staged in LDS
+constexpr int kPrepRadial = 512;     // nodes of the radial axis staged in LDS (the window search is one more bisection)
 
-__global__ __launch_bounds__(256) void halo_prep_kernel(const PrepParams P)
+#ifndef BFG_PREP_WAVES
+#define BFG_PREP_WAVES 1
+#endif
+__global__ __launch_bounds__(256, BFG_PREP_WAVES) void halo_prep_kernel(const PrepParams P)
 {
     // the bisections below (spline knots: 10 steps; table axes: 4-5 steps each) are chains of dependent loads: from L2 they
     // cost ~10 us per wavefront, from LDS well under 1 us.  Same comparisons on the same values, so the same cells.
     __shared__ double s_knots[kPrepKnots];
     __shared__ double s_axis[BFG_MAX_DIM - 1][kPrepAxis];
+    __shared__ double s_raxis[kPrepRadial];
+    // per halo of the block, for the row phase at the end: outer cell (index, weight per axis), window start, flags, ln(pixfac)
+    __shared__ int32_t s_ci[BFG_MAX_DIM - 1][256];
+    __shared__ double s_cy[BFG_MAX_DIM - 1][256];
+    __shared__ int32_t s_wl[256], s_fl[256];
+    __shared__ double s_ln[256];
+    extern __shared__ double smem_prep[];               // row phase: corner weights / row offsets of the halos of one pass
     const bool knots_lds = P.spl_n <= kPrepKnots;
+    const bool raxis_lds = P.ht && P.tab.nr <= kPrepRadial;
+    if (raxis_lds) for (int i = threadIdx.x; i < P.tab.nr; i += blockDim.x) s_raxis[i] = P.tab.raxis[i];
     if (knots_lds) for (int i = threadIdx.x; i < P.spl_n; i += blockDim.x) s_knots[i] = P.spl_knots[i];
     for (int k = 0; k < P.tab.nouter; ++k)
         if (P.tab.oshape[k] <= kPrepAxis)
             for (int i = threadIdx.x; i < P.tab.oshape[k]; i += blockDim.x) s_axis[k][i] = P.tab.oaxis[k][i];
     __syncthreads();
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= P.n_halo) return;
+    s_fl[threadIdx.x] = HF_SKIP; s_wl[threadIdx.x] = 0; s_ln[threadIdx.x] = 0.0;
+    if (j < P.n_halo) {
     const double *c = P.cat + j * (int64_t)P.cat_stride;
     const double M = c[0], zred = c[1], ra = c[2], dec = c[3];
     const double a = 1.0 / (1.0 + zred);                                   // HealpixRunner.py:319/:453
@@ -301,8 +317,10 @@ __global__ __launch_bounds__(256) void halo_prep_kernel(const PrepParams P)
             if (k == 1) warn |= BFG_WARN_M_RANGE;
         }
         int i = find_interval(g, n, x);
+        const double y = (x - g[i]) / (g[i + 1] - g[i]);
         P.cidx[k * cap + j] = i;
-        P.cw[k * cap + j] = (x - g[i]) / (g[i + 1] - g[i]);
+        P.cw[k * cap + j] = y;
+        s_ci[k][threadIdx.x] = i; s_cy[k][threadIdx.x] = y;
     }
     if (oob) {
         flags |= HF_OOB;
@@ -363,7 +381,7 @@ __global__ __launch_bounds__(256) void halo_prep_kernel(const PrepParams P)
         const double sr = sin(0.5 * fmin(radius, kPi));
         const double axis_shift = (P.hd && P.rdelta) ? log(Rm_com) : 0.0;
         const double rho_max = 0.5 * log(4.0 * h.S * sr * sr) - axis_shift;
-        int win_lo = find_interval(P.tab.raxis, P.tab.nr, rho_max) + 1 - (P.win_nodes - 1);
+        int win_lo = find_interval(raxis_lds ? s_raxis : P.tab.raxis, P.tab.nr, rho_max) + 1 - (P.win_nodes - 1);
         if (win_lo > P.tab.nr - P.win_nodes) win_lo = P.tab.nr - P.win_nodes;
         if (win_lo < 0) win_lo = 0;
         if (P.hd) {
@@ -377,6 +395,51 @@ __global__ __launch_bounds__(256) void halo_prep_kernel(const PrepParams P)
         h.win_lo = win_lo; h.flags = flags; h.pad0 = 0; h.pad1 = 0;
         h.spare[0] = lnpf; h.spare[1] = h.spare[2] = h.spare[3] = 0.0;
         P.ht[j] = h;
+        s_wl[threadIdx.x] = win_lo; s_fl[threadIdx.x] = flags; s_ln[threadIdx.x] = lnpf;
+    }
+    }   // j < n_halo
+    // ---- row phase (what halo_row4_kernel does, same arithmetic): hwin[j][e] = sum over the corners of the halo's outer cell of
+    // w_c T[c][win_lo + e] (+ ln(pixfac) for ln tables), four nodes per thread.  Done here the rows cost neither a second
+    // read of the 128-byte halo records and the cell arrays nor a launch, and their 256 B per halo of stores overlap the
+    // atomics of the binning in other workgroups (separate: 0.168 + 0.125 ms at 1e6 halos).
+    if (!P.hwin) return;
+    __syncthreads();
+    {
+        const DevTable &T = P.tab;
+        const int W = P.win_nodes, tph = W >> 2, hpb = min(256 / tph, 64);
+        const int hl = threadIdx.x / tph, q = threadIdx.x - hl * tph;
+        const int ncorner = 1 << T.nouter;
+        double *s_w = smem_prep;                                               // [64][ncorner]
+        int64_t *s_off = reinterpret_cast<int64_t *>(smem_prep + 64 * ncorner);
+        const int64_t j0 = (int64_t)blockIdx.x * blockDim.x;
+        for (int h0 = 0; h0 < 256 && j0 + h0 < P.n_halo; h0 += hpb) {
+            const int hh = h0 + hl;
+            const bool in = hl < hpb && hh < 256 && j0 + hh < P.n_halo;
+            if (in) {
+                for (int cc = q; cc < ncorner; cc += tph) {                    // corner order and products of halo_row_kernel
+                    double w = 1.0;
+                    int64_t off = 0;
+                    for (int k = 0; k < T.nouter; ++k) {
+                        const int bit = (cc >> (T.nouter - 1 - k)) & 1;
+                        const double y = s_cy[k][hh];
+                        w = w * (bit ? y : 1.0 - y);
+                        off += (int64_t)(s_ci[k][hh] + bit) * T.ostride[k];
+                    }
+                    s_w[hl * ncorner + cc] = w; s_off[hl * ncorner + cc] = off;
+                }
+            }
+            __syncthreads();
+            if (in && !(s_fl[hh] & (HF_SKIP | HF_OOB))) {
+                const int e4 = q << 2;
+                double b0, b1, b2, b3;
+                blend_row4(T, s_w + hl * ncorner, s_off + hl * ncorner, ncorner, s_wl[hh] + e4, b0, b1, b2, b3);
+                const double add = T.log_values ? s_ln[hh] : 0.0;
+                double4 out;
+                out.x = b0 + add; out.y = b1 + add; out.z = b2 + add; out.w = b3 + add;
+                *reinterpret_cast<double4 *>(P.hwin + (j0 + hh) * W + e4) = out;
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -1599,8 +1662,13 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         if (std::getenv("BFG_TILE_SCAN")) pp.bin.direct_limit = 0;                   // A/B: always the scan kernel
         pp.left = c->d_left; pp.left_n = c->tiles[mode].d_tile_count + c->tiles[mode].geo.ntiles;
     }
+    // row windows of 4 k nodes are built by the prep kernel itself (BFG_ROWS=separate: by halo_row4_kernel, the A/B)
+    bool fuse_rows = tile && !win_table && win_nodes % 4 == 0 && win_nodes >= 8;
+    if (const char *e = std::getenv("BFG_ROWS")) if (!std::strcmp(e, "separate")) fuse_rows = false;
+    pp.hwin = fuse_rows ? c->d_hwin : nullptr;
+    const size_t prep_lds = fuse_rows ? (size_t)64 * ((size_t)1 << t->dev.nouter) * 16 : 0;
     timing_begin(c, 0);
-    hipLaunchKernelGGL(halo_prep_kernel, dim3((unsigned)((a->n_halo + 255) / 256)), dim3(256), 0, c->stream, pp);
+    hipLaunchKernelGGL(halo_prep_kernel, dim3((unsigned)((a->n_halo + 255) / 256)), dim3(256), prep_lds, c->stream, pp);
     HIP_TRY(hipGetLastError());
     timing_end(c, 0);
 
@@ -1640,8 +1708,8 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         std::memset(&rp, 0, sizeof(rp));
         rp.n_halo = a->n_halo; rp.cap = c->cap_halo; rp.ht = c->d_ht; rp.cidx = c->d_cidx; rp.cw = c->d_cw;
         rp.tab = t->dev; rp.win_nodes = win_nodes; rp.hwin = c->d_hwin;
-        if (win_table) {
-            // no row windows
+        if (win_table || fuse_rows) {
+            // no row windows / built by halo_prep_kernel
         } else if (win_nodes % 4 == 0 && win_nodes >= 8) {
             const int hpb = std::min(256 / (win_nodes / 4), 64);
             const size_t rlds = (size_t)64 * ((size_t)1 << t->dev.nouter) * 16;           // weights + offsets of 64 halos

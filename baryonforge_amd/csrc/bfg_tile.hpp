@@ -530,6 +530,33 @@ __global__ __launch_bounds__(256) void halo_row_kernel(const RowParams P)
     P.hwin[j * W + e] = b0 + s_add[hl];          // paint: ln(T) + ln(pixarea D^2), see shell_tile_kernel
 }
 
+// Four consecutive nodes ir .. ir + 3 of a halo's blended row: b_k = sum_c w[c] * T[off[c] + ir + k], corners in index order.
+// Corners go in groups of four with all their loads in flight together (a plain loop over a run-time corner count waits
+// for each corner's two loads before it asks for the next: four dependent L2 round trips for the usual 3-D table).
+__device__ __forceinline__ void blend_row4(const DevTable &T, const double *w, const int64_t *off, int ncorner, int ir,
+                                           double &b0, double &b1, double &b2, double &b3)
+{
+    b0 = 0.0; b1 = 0.0; b2 = 0.0; b3 = 0.0;
+    int c = 0;
+    for (; c + 4 <= ncorner; c += 4) {
+        const double *r0 = T.values + off[c] + ir, *r1 = T.values + off[c + 1] + ir;
+        const double *r2 = T.values + off[c + 2] + ir, *r3 = T.values + off[c + 3] + ir;
+        double v[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[0][k] = r0[k]; v[1][k] = r1[k]; v[2][k] = r2[k]; v[3][k] = r3[k]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                      // same order of additions as the plain loop
+            const double wi = w[c + i];
+            b0 = fma(v[i][0], wi, b0); b1 = fma(v[i][1], wi, b1); b2 = fma(v[i][2], wi, b2); b3 = fma(v[i][3], wi, b3);
+        }
+    }
+    for (; c < ncorner; ++c) {
+        const double *row = T.values + off[c] + ir;
+        const double wi = w[c];
+        b0 = fma(row[0], wi, b0); b1 = fma(row[1], wi, b1); b2 = fma(row[2], wi, b2); b3 = fma(row[3], wi, b3);
+    }
+}
+
 // Same for windows whose length is a multiple of 4: one thread per (halo, 4 consecutive nodes), i.e. 4 x 2^(ndim-1)
 // independent table loads in flight per thread (the one-node form is latency-bound).
 __global__ __launch_bounds__(256) void halo_row4_kernel(const RowParams P)
@@ -573,12 +600,8 @@ __global__ __launch_bounds__(256) void halo_row4_kernel(const RowParams P)
     __syncthreads();
     if (!live || skip) return;
     const int ir = s_winlo[hl] + e4;
-    double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
-    for (int c = 0; c < ncorner; ++c) {
-        const double *row = T.values + s_off[hl * ncorner_ + c] + ir;
-        const double w = s_w[hl * ncorner_ + c];
-        b0 = fma(row[0], w, b0); b1 = fma(row[1], w, b1); b2 = fma(row[2], w, b2); b3 = fma(row[3], w, b3);
-    }
+    double b0, b1, b2, b3;
+    blend_row4(T, s_w + hl * ncorner_, s_off + hl * ncorner_, ncorner, ir, b0, b1, b2, b3);
     const double add = s_add[hl];
     double4 out;
     out.x = b0 + add; out.y = b1 + add; out.z = b2 + add; out.w = b3 + add;
