@@ -247,6 +247,7 @@ constexpr int kTileWidth = 32;      // TW: max pixels of one ring inside one sec
 constexpr int kMaxPairsPerHalo = 64;
 constexpr int kLogTab = 128;
 constexpr int kExpTab = 64;
+constexpr int kAtanTab = 72;       // atan(k / 64), k = 0 .. 64 (padded to a multiple of 8)
 
 struct TileGeom {
     int tr;                      // rings per band

@@ -121,7 +121,7 @@ struct bfg_ctx {
     size_t dep_cap[5];
     int64_t pair_cap;
     unsigned long long *d_pair_total;
-    double *d_mathtab;              // logtab (256 doubles) | exptab (64 doubles)
+    double *d_mathtab;              // logtab (256 doubles) | exptab (64 doubles) | atantab (72 doubles)
     bfg::HaloTile *d_ht;            // [cap_halo]
     double *d_hwin;                 // [hwin_cap] pre-blended row windows
     int64_t hwin_cap;
@@ -1085,13 +1085,14 @@ static int ctx_create_body(bfg_ctx *c, void *stream)
     HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(bfg_stats), c->stream));
     HIP_TRY(hipMalloc((void **)&c->d_red, 4 * sizeof(double)));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_switch, hipEventDisableTiming));
-    {   // ln / exp tables of the tile kernels: {1/c, ln c} with c = 1 + (i + 0.5)/128, and 2^(j/64)
-        std::vector<double> mt(2 * kLogTab + kExpTab);
+    {   // ln / exp / atan tables of the tile kernels: {1/c, ln c} with c = 1 + (i + 0.5)/128, 2^(j/64), atan(k/64)
+        std::vector<double> mt(2 * kLogTab + kExpTab + kAtanTab, 0.0);
         for (int i = 0; i < kLogTab; ++i) {
             double cc = 1.0 + ((double)i + 0.5) / (double)kLogTab;
             mt[2 * i] = 1.0 / cc; mt[2 * i + 1] = std::log(cc);
         }
         for (int j = 0; j < kExpTab; ++j) mt[2 * kLogTab + j] = std::exp2((double)j / (double)kExpTab);
+        for (int k = 0; k <= 64; ++k) mt[2 * kLogTab + kExpTab + k] = std::atan((double)k / 64.0);
         HIP_TRY(hipMalloc((void **)&c->d_mathtab, mt.size() * sizeof(double)));
         HIP_TRY(hipMemcpyAsync(c->d_mathtab, mt.data(), mt.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMalloc((void **)&c->d_pair_total, sizeof(unsigned long long)));
@@ -1658,7 +1659,10 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         // one memset: the tile counters and, right behind them, the length of the left-over list
         HIP_TRY(hipMemsetAsync(c->tiles[mode].d_tile_count, 0, (size_t)(c->tiles[mode].geo.ntiles + 2) * sizeof(int32_t), c->stream));
         pp.bin.needs_scan = c->tiles[mode].d_tile_count + c->tiles[mode].geo.ntiles + 1;
-        pp.bin.direct_limit = std::min(c->tiles[mode].cap_direct, 256);
+        // tiles of up to 512 pairs are one work item each and need no scan (256: the 1e6-halo headline, ~115 pairs per tile with
+        // a tail beyond 256, paid the 0.02 ms single-workgroup scan -- 0.043 ms on the offsets tiles -- for items no better balanced)
+        pp.bin.direct_limit = std::min(c->tiles[mode].cap_direct, 512);
+        if (const char *e = std::getenv("BFG_DIRECT_LIMIT")) pp.bin.direct_limit = std::min(c->tiles[mode].cap_direct, std::atoi(e));
         if (std::getenv("BFG_TILE_SCAN")) pp.bin.direct_limit = 0;                   // A/B: always the scan kernel
         pp.left = c->d_left; pp.left_n = c->tiles[mode].d_tile_count + c->tiles[mode].geo.ntiles;
     }
@@ -1732,6 +1736,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         tp.out = d_out; tp.stats = c->d_stats;
         tp.logtab = reinterpret_cast<const double2 *>(c->d_mathtab);
         tp.exptab = c->d_mathtab + 2 * kLogTab;
+        tp.atantab = c->d_mathtab + 2 * kLogTab + kExpTab;
         { const char *dbg = std::getenv("BFG_DEBUG"); tp.debug = dbg ? std::atoi(dbg) : 0; }
         tp.out_zero = out_zero ? 1 : 0;
         tp.overwrite = overwrite ? 1 : 0;

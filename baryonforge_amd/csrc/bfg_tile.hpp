@@ -164,10 +164,12 @@ struct __align__(16) DeferredOut {
 };
 static_assert(sizeof(DeferredOut) == 32, "DeferredOut must be 32 bytes");
 
-struct __align__(16) RingRow {       // one ring of the tile's band (computed once per workgroup)
+struct __align__(16) RingRow {       // one ring of the tile's band (computed once per work item)
     double z, sth, phistep, phioff;
     int32_t nr, k0, k1, rowoff;      // rowoff = row * TW - k0
+    int64_t start, pad;              // RING index of the ring's first pixel (the write-back needs no ring arithmetic of its own)
 };
+static_assert(sizeof(RingRow) == 64, "RingRow must be 64 bytes");
 
 struct TileParams {
     Hpx hpx;
@@ -190,6 +192,7 @@ struct TileParams {
     bfg_stats *stats;
     const double2 *logtab;           // [128] {1/c, ln c}
     const double *exptab;            // [64]  2^(j/64)
+    const double *atantab;           // [72]  atan(k/64), k = 0 .. 64
     long long pair_cap;              // capacity of pairs[]; a larger total means the binning fell back to scatter
     int debug;                       // ablation switches for profiling (BFG_DEBUG env; 0 in production)
     int out_zero;                    // BFG_SHELL_OUT_IS_ZERO: the caller cleared `out`; tiles are stored, not read-modify-written
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const TileGeom geo, int
     // overwrite: the tile kernel initialises the map itself, so tiles without a single pair get an (empty) work item too,
     // and tiles cut into several items -- which add to the map with atomics -- are listed for tile_fill_kernel to clear first
     const int ntiles = geo.ntiles;
-    // Fast path (no tile holds more than min(cap_direct, 256) pairs -- the count pass found out: needs_scan): one work item
+    // Fast path (no tile holds more than min(cap_direct, 512) pairs -- the count pass found out: needs_scan): one work item
     // per tile, item = tile, nothing to scan; blocks 1 .. write them in parallel and block 0 has nothing to do.  The
     // single-workgroup scan below (~20 us) is left to dense or crowded catalogs, where it is 1-2 % of the call.
     if (!*needs_scan) {
@@ -650,7 +653,9 @@ __device__ unsigned long long g_stage_cycles[16];     // profiling build only: b
 constexpr int kTileThreads = BFG_TILE_THREADS;
 constexpr int kWinLds = 32;          // row windows up to this many nodes are staged in LDS
 constexpr int kPrOff = 64;           // slot offsets of the chunk's pairs (one per lane of a wavefront), padded with INT_MAX
-constexpr int kSegExtra = 64;        // LDS room for second pieces of ring windows that wrap around inside a sector
+// LDS room for second pieces of ring windows that wrap around inside a sector (only where a sector spans most of a ring,
+// next to the poles; a chunk that runs out paints the piece through the direct read-out)
+constexpr int kSegExtra = 32;
 
 // per-mode shape of a tile workgroup: threads, rings per tile, accumulators per pixel, LDS capacities of a chunk.
 // LIGHT = 1: the instantiation for sparse catalogs (a few dozen pairs per tile, BASELINE configs 1-2).  There a tile is one
@@ -689,7 +694,7 @@ __host__ __device__ constexpr size_t tile_lds_bytes()
 {
     using Cfg = TileCfg<MODE, LIGHT>;
     return (size_t)Cfg::TR * Cfg::TW * Cfg::NACC * sizeof(double) + kLogTab * sizeof(double2) +
-           kExpTab * sizeof(double) + Cfg::TR * sizeof(RingRow) + Cfg::SEGMAX * sizeof(Seg) +
+           (kExpTab + kAtanTab) * sizeof(double) + Cfg::TR * sizeof(RingRow) + Cfg::SEGMAX * sizeof(Seg) +
            Cfg::PAIRMAX * sizeof(typename Cfg::Pair) + (size_t)Cfg::PAIRMAX * kWinLds * sizeof(double) +
            Cfg::PIXMAX * sizeof(uint16_t) + kPrOff * sizeof(int32_t) + Cfg::SEGMAX * sizeof(uint8_t) +
            Cfg::QCAP * sizeof(DeferredPixel) + 8 * sizeof(int32_t);
@@ -762,6 +767,31 @@ __device__ inline double atan2_upper(double y, double x)
     return (x < 0.0) ? 3.14159265358979323846 - a : a;
 }
 
+// The same with the reduction constant from a table: c = k / 64 nearest to min / max (picked through a single-precision
+// quotient: any neighbour of the nearest will do), atan(c) from `tab` (LDS), |u| <= 1/128 + 2^-20 so the odd series stops at
+// u^7 (next term < 2e-18 relative).  One division as before; ~25 instructions fewer than the compare-and-select ladder.
+__device__ inline double atan2_upper_tab(double y, double x, const double *tab)
+{
+    const double ax = fabs(x);
+    const double mx = fmax(ax, y), mn = fmin(ax, y);
+    const float qf = (float)mn * __builtin_amdgcn_rcpf((float)mx);     // mx >= sin(theta_ring) / sqrt 2: never denormal as a float
+    int k = (int)fmaf(qf, 64.0f, 0.5f);
+    k = min(max(k, 0), 64);
+    const double c = (double)k * 0.015625;
+    const double num = fma(-c, mx, mn), den = fma(c, mn, mx);
+    double r = __builtin_amdgcn_rcp(den);
+    r = fma(fma(-den, r, 1.0), r, r);
+    r = fma(fma(-den, r, 1.0), r, r);
+    double u = num * r;
+    u = fma(fma(-den, u, num), r, u);
+    const double u2 = u * u;
+    double p = fma(u2, -1.0 / 7.0, 1.0 / 5.0);
+    p = fma(u2, p, -1.0 / 3.0);
+    double a = tab[k] + fma(u * u2, p, u);
+    a = (ax < y) ? 1.57079632679489661923 - a : a;
+    return (x < 0.0) ? 3.14159265358979323846 - a : a;
+}
+
 __device__ inline int med3_i32(int x, int lo, int hi)      // clamp(x, lo, hi) in one instruction (lo <= hi)
 {
     int r;
@@ -812,7 +842,8 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     constexpr int acc_off = 0;                                                // double [TR*TW*NACC]
     constexpr int logtab_off = acc_off + TR * TW * NACC * (int)sizeof(double);    // double2 [128]
     constexpr int exptab_off = logtab_off + kLogTab * (int)sizeof(double2);   // double [64]
-    constexpr int rows_off = exptab_off + kExpTab * (int)sizeof(double);      // RingRow [TR]
+    constexpr int atantab_off = exptab_off + kExpTab * (int)sizeof(double);   // double [72]
+    constexpr int rows_off = atantab_off + kAtanTab * (int)sizeof(double);    // RingRow [TR]
     constexpr int segs_off = rows_off + TR * (int)sizeof(RingRow);            // Seg [kSegMax]
     constexpr int pinfo_off = segs_off + kSegMax * (int)sizeof(Seg);          // Pair [kPairMax]
     constexpr int pwin_off = pinfo_off + kPairMax * (int)sizeof(Pair);        // double [kPairMax][kWinLds] row values B_i
@@ -826,6 +857,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     double *acc = reinterpret_cast<double *>(smem_raw + acc_off);
     double2 *logtab = reinterpret_cast<double2 *>(smem_raw + logtab_off);
     double *exptab = reinterpret_cast<double *>(smem_raw + exptab_off);
+    double *atantab = reinterpret_cast<double *>(smem_raw + atantab_off);
     RingRow *rows = reinterpret_cast<RingRow *>(smem_raw + rows_off);
     Seg *segs = reinterpret_cast<Seg *>(smem_raw + segs_off);
     Pair *pinfo = reinterpret_cast<Pair *>(smem_raw + pinfo_off);
@@ -859,6 +891,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
 #endif
     if (tid < kLogTab) logtab[tid] = P.logtab[tid];
     if (tid < kExpTab) exptab[tid] = P.exptab[tid];
+    if (tid >= 128 && tid < 128 + kAtanTab) atantab[tid - 128] = P.atantab[tid - 128];
     // segment records carry absolute LDS byte addresses: the dynamic LDS block of this kernel (it has no static
     // __shared__) starts at address 0; refuse to run otherwise
     if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_raw != 0u) {
@@ -919,11 +952,11 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     if (tid < TR) {
         const int ring = ring_lo + tid;
         RingRow rr;
-        rr.z = 0; rr.sth = 0; rr.phistep = 0; rr.phioff = 0; rr.nr = 1; rr.k0 = 0; rr.k1 = 0; rr.rowoff = 0;
+        rr.z = 0; rr.sth = 0; rr.phistep = 0; rr.phioff = 0; rr.nr = 1; rr.k0 = 0; rr.k1 = 0; rr.rowoff = 0; rr.start = 0; rr.pad = 0;
         if (ring <= ring_hi) {
             const RingGeom g = ring_geom(hp, ring);
             rr.z = g.z;                // identical formula to ring2z, which query_disc uses
-            rr.sth = g.sth; rr.phistep = g.phistep; rr.phioff = g.phioff; rr.nr = g.nr;
+            rr.sth = g.sth; rr.phistep = g.phistep; rr.phioff = g.phioff; rr.nr = g.nr; rr.start = g.start;
             rr.k0 = (int)(((int64_t)sector * g.nr) / NS);
             rr.k1 = (int)(((int64_t)(sector + 1) * g.nr) / NS);
             rr.rowoff = tid * TW - rr.k0;
@@ -1256,7 +1289,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                 {
                     const double x = (h.cosr - rr.z * h.z0) * h.xa;
                     const double ysq = 1.0 - rr.z * rr.z - x * x;
-                    const double dphi = (ysq > 0.0) ? atan2_upper(sqrt_unit(ysq), x) : 0.0;
+                    const double dphi = (ysq > 0.0) ? atan2_upper_tab(sqrt_unit(ysq), x, atantab) : 0.0;
                     if (dphi > 0.0) {
                         const double shift = (rr.phioff != 0.0) ? 0.5 : 0.0;
                         // |nr (pphi -+ dphi) / 2 pi| < 2 nr <= 8 nside: 32-bit is enough (the tile variant needs nside <= 2^24)
@@ -1404,11 +1437,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         if (i < TR * TW) {
             const int row = i / TW, col = i % TW;
             const int ring = ring_lo + row;
-            if (ring <= ring_hi && rows[row].k0 + col < rows[row].k1) {
-                int64_t start, nr64; bool shifted;
-                ring_info_small(hp, ring, start, nr64, shifted);
-                wpix[u] = start + rows[row].k0 + col;
-            }
+            if (ring <= ring_hi && rows[row].k0 + col < rows[row].k1) wpix[u] = rows[row].start + rows[row].k0 + col;
         }
 #pragma unroll
         for (int c = 0; c < NACC; ++c) wold[u][c] = (wpix[u] >= 0 && rmw) ? P.out[NACC * wpix[u] + c] : 0.0;
@@ -1420,10 +1449,8 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                 const DeferredPixel e = rq[tid];
                 const int i = (e.abyte - acc_off) >> 3;                    // accumulator index = row * TW + column
                 const int row = i / TW, col = i % TW;
-                int64_t start, nr64; bool shifted;
-                ring_info_small(hp, ring_lo + row, start, nr64, shifted);
                 DeferredOut o;
-                o.pix = start + rows[row].k0 + col; o.t = e.t; o.halo = e.halo; o.pad[0] = o.pad[1] = o.pad[2] = 0;
+                o.pix = rows[row].start + rows[row].k0 + col; o.t = e.t; o.halo = e.halo; o.pad[0] = o.pad[1] = o.pad[2] = 0;
                 P.defer[(size_t)item * kDeferCap + tid] = o;
             }
             if (tid == 0) P.defer_count[item] = n;

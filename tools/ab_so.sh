@@ -6,6 +6,6 @@ cd "${GRAFT_REPO_ROOT:-.}"
 for round in 1 2; do
   for so in "$@"; do
     echo "== $so (round $round)"
-    BFG_SO=$PWD/$so python3 tools/quick_bench.py --modes=- --overwrite --workloads $wl --reps 1 --steps 20 2>&1 | grep -v "^/opt\|warn"
+    BFG_SO=$PWD/$so python3 tools/quick_bench.py --modes="${MODES:--}" --overwrite --workloads $wl --reps 1 --steps 20 2>&1 | grep -v "^/opt\|warn"
   done
 done
