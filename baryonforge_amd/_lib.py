@@ -38,7 +38,7 @@ SYMBOLS = [
     "bfg_paint_shell", "bfg_baryonify_offsets", "bfg_regrid_shell", "bfg_reduce_absmax_sum",
     "bfg_baryonify_snapshot", "bfg_deposit_grid", "bfg_paint_grid", "bfg_baryonify_grid_offsets", "bfg_regrid_grid",
     "bfg_build_displacement_table", "bfg_baryonify_snapshot_strided", "bfg_deposit_grid_strided",
-    "bfg_stats_reset", "bfg_stats_read", "bfg_timing_enable", "bfg_timing_read",
+    "bfg_stats_reset", "bfg_stats_read", "bfg_timing_enable", "bfg_timing_select", "bfg_timing_read",
     "bfg_comm_unique_id", "bfg_comm_init", "bfg_comm_destroy", "bfg_comm_info",
     "bfg_allreduce_f64", "bfg_allreduce_f64_begin", "bfg_comm_wait", "bfg_reduce_scatter_f64", "bfg_allgather_f64",
 ]
@@ -159,6 +159,7 @@ def load(build_if_missing=True):
     L.bfg_stats_reset.argtypes = [_vp]
     L.bfg_stats_read.argtypes = [_vp, C.POINTER(Stats)]
     L.bfg_timing_enable.argtypes = [_vp, C.c_int]
+    L.bfg_timing_select.argtypes = [_vp, C.c_uint]
     L.bfg_timing_read.argtypes = [_vp, C.c_int, C.POINTER(_dbl), C.POINTER(_i64)]
     for name in SYMBOLS:
         if name not in ("bfg_status_string", "bfg_last_error"):

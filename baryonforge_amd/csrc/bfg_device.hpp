@@ -273,7 +273,7 @@ struct BinCtx {
     int cap_direct;               // slots per tile that the COUNT pass fills directly (see tile_bin_halo)
     unsigned long long *ovf_mask; // [n_halo] bit i: the halo's i-th pair found its tile's slots full
     int32_t *needs_scan;          // set when a tile gets more pairs than direct_limit: the work list then needs the scan kernel
-    int direct_limit;             // min(cap_direct, 256): up to here a tile is one plain work item
+    int direct_limit;             // min(cap_direct, 512): up to here a tile is one plain work item
 };
 
 }  // namespace bfg

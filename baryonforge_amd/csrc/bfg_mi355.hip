@@ -98,7 +98,10 @@ struct bfg_ctx {
         int64_t nside;
         TileGeom geo;
         int32_t *d_geo;             // band_ns | band_tile0 | band_nrmin | tile_band
-        int32_t *d_tile_count, *d_tile_start;
+        int32_t *d_tile_count, *d_tile_start;   // d_tile_count: two sets of ntiles + 2 counters; a call uses set `flip` and its scan
+                                                // kernel clears the other one for the next call (no memset launch per call)
+        int flip;
+        bool counting;                          // a call counted into set `flip` and its scan kernel was never launched (an error in between)
         int4 *d_work;               // [2 ntiles + kWorkExtra] work items of the tile kernel
         bfg::DeferredOut *d_defer;  // [2 ntiles + kWorkExtra][kDeferCap] pixels left to tile_deferred_kernel (paint)
         int32_t *d_defer_count;     // [2 ntiles + kWorkExtra]
@@ -128,6 +131,7 @@ struct bfg_ctx {
     bool tile_attr_set;             // MaxDynamicSharedMemorySize raised for the tile kernels on this device
     // timing: a growing pool of event pairs per kernel class, resolved lazily in bfg_timing_read
     bool timing;
+    unsigned timing_mask;           // classes that get events (bfg_timing_select)
     std::vector<hipEvent_t> *ev_a[kTimingSlots], *ev_b[kTimingSlots];
     size_t ev_used[kTimingSlots];
     double t_ms[kTimingSlots];
@@ -1459,7 +1463,7 @@ static void timing_fold(bfg_ctx *c, int which)
 
 static void timing_begin(bfg_ctx *c, int which)
 {
-    if (!c->timing) return;
+    if (!c->timing || !((c->timing_mask >> which) & 1u)) return;
     if (c->ev_used[which] >= 4096) timing_fold(c, which);
     if (c->ev_used[which] >= c->ev_a[which]->size()) {
         hipEvent_t a, b;
@@ -1471,7 +1475,7 @@ static void timing_begin(bfg_ctx *c, int which)
 
 static void timing_end(bfg_ctx *c, int which)
 {
-    if (!c->timing) return;
+    if (!c->timing || !((c->timing_mask >> which) & 1u)) return;
     (void)hipEventRecord((*c->ev_b[which])[c->ev_used[which]], c->stream);
     c->ev_used[which] += 1;
 }
@@ -1514,7 +1518,9 @@ static int ensure_tiles(bfg_ctx *c, int mode, int tr, int tw, int64_t nside, int
         HIP_TRY(hipMalloc((void **)&ts.d_geo, blob.size() * sizeof(int32_t)));
         HIP_TRY(hipMemcpyAsync(ts.d_geo, blob.data(), blob.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipMalloc((void **)&ts.d_tile_count, (size_t)(ntiles + 2) * sizeof(int32_t)));   // + the left-over list's length, + needs_scan
+        HIP_TRY(hipMalloc((void **)&ts.d_tile_count, (size_t)2 * (ntiles + 2) * sizeof(int32_t)));   // per set: + the left-over list's length, + needs_scan
+        HIP_TRY(hipMemsetAsync(ts.d_tile_count, 0, (size_t)2 * (ntiles + 2) * sizeof(int32_t), c->stream));
+        ts.flip = 0; ts.counting = false;
         HIP_TRY(hipMalloc((void **)&ts.d_tile_start, (size_t)(ntiles + 1) * sizeof(int32_t)));
         HIP_TRY(hipMalloc((void **)&ts.d_work, (size_t)(2 * ntiles + kWorkExtra) * 2 * sizeof(int4)));
         HIP_TRY(hipMalloc((void **)&ts.d_nwork, 2 * sizeof(int32_t)));     // [0] items in the work list, [1] the tile kernel's item counter
@@ -1649,22 +1655,28 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     pp.want_model_radius = (mode == MODE_BARYONIFY);
     pp.ht = tile ? c->d_ht : nullptr; pp.win_nodes = win_nodes; pp.pixfac_area = pixfac_area;
     if (tile) {
-        pp.bin.geo = c->tiles[mode].geo; pp.bin.tile_count = c->tiles[mode].d_tile_count;
+        bfg_ctx::TileSet &tsw = c->tiles[mode];
+        if (tsw.counting) {                     // left dirty by a call that failed half-way: start from clean counters
+            HIP_TRY(hipMemsetAsync(tsw.d_tile_count, 0, (size_t)2 * (tsw.geo.ntiles + 2) * sizeof(int32_t), c->stream));
+            tsw.flip = 0;
+        }
+        tsw.counting = true;
+        int32_t *const tile_count = tsw.d_tile_count + (size_t)tsw.flip * (tsw.geo.ntiles + 2);   // this call's counters (all zero)
+        pp.bin.geo = c->tiles[mode].geo; pp.bin.tile_count = tile_count;
         pp.bin.tile_start = c->tiles[mode].d_tile_start;
         pp.bin.pairs = c->d_pairs; pp.bin.pair_total = c->d_pair_total; pp.bin.pair_cap = c->pair_cap;
         pp.bin.cap_direct = c->tiles[mode].cap_direct; pp.bin.ovf_mask = c->d_ovf_mask;
         pp.bin.mode = mode;
         pp.hd = (mode == MODE_BARYONIFY) ? c->d_hd : nullptr;
         pp.eps_model = a->model_epsilon_max; pp.rdelta = a->rdelta_sampling;
-        // one memset: the tile counters and, right behind them, the length of the left-over list
-        HIP_TRY(hipMemsetAsync(c->tiles[mode].d_tile_count, 0, (size_t)(c->tiles[mode].geo.ntiles + 2) * sizeof(int32_t), c->stream));
-        pp.bin.needs_scan = c->tiles[mode].d_tile_count + c->tiles[mode].geo.ntiles + 1;
+        // the tile counters and, right behind them, the length of the left-over list and the needs_scan flag
+        pp.bin.needs_scan = tile_count + c->tiles[mode].geo.ntiles + 1;
         // tiles of up to 512 pairs are one work item each and need no scan (256: the 1e6-halo headline, ~115 pairs per tile with
         // a tail beyond 256, paid the 0.02 ms single-workgroup scan -- 0.043 ms on the offsets tiles -- for items no better balanced)
         pp.bin.direct_limit = std::min(c->tiles[mode].cap_direct, 512);
         if (const char *e = std::getenv("BFG_DIRECT_LIMIT")) pp.bin.direct_limit = std::min(c->tiles[mode].cap_direct, std::atoi(e));
         if (std::getenv("BFG_TILE_SCAN")) pp.bin.direct_limit = 0;                   // A/B: always the scan kernel
-        pp.left = c->d_left; pp.left_n = c->tiles[mode].d_tile_count + c->tiles[mode].geo.ntiles;
+        pp.left = c->d_left; pp.left_n = tile_count + c->tiles[mode].geo.ntiles;
     }
     // row windows of 4 k nodes are built by the prep kernel itself (BFG_ROWS=separate: by halo_row4_kernel, the A/B)
     bool fuse_rows = tile && !win_table && win_nodes % 4 == 0 && win_nodes >= 8;
@@ -1700,8 +1712,11 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         if (const char *e = std::getenv("BFG_TILE_PERSIST")) persist = std::atoi(e) > 1 ? std::atoi(e) : (std::atoi(e) ? persist : 0);
         const int tile_grid = persist > 0 ? std::min(persist, items_max) : items_max;
         hipLaunchKernelGGL(tile_scan_kernel, dim3((unsigned)(1 + (ts.geo.ntiles + 1023) / 1024)), dim3(1024), 0, c->stream, ts.geo,
-                           ts.cap_direct, ts.d_tile_count, ts.d_tile_start, ts.d_work, ts.d_nwork, ts.d_nwork + 1, 3 * tile_grid,
-                           overwrite ? 1 : 0, ts.d_shared, ts.d_tile_count + ts.geo.ntiles + 1);
+                           ts.cap_direct, pp.bin.tile_count, ts.d_tile_start, ts.d_work, ts.d_nwork, ts.d_nwork + 1, 3 * tile_grid,
+                           overwrite ? 1 : 0, ts.d_shared, pp.bin.tile_count + ts.geo.ntiles + 1,
+                           ts.d_tile_count + (size_t)(1 - ts.flip) * (ts.geo.ntiles + 2));
+        c->tiles[mode].flip = 1 - ts.flip;             // the next call counts in the set this scan kernel clears
+        c->tiles[mode].counting = false;
         FillParams fp;
         std::memset(&fp, 0, sizeof(fp));
         fp.overwrite = overwrite ? 1 : 0; fp.nacc = (mode == MODE_PAINT) ? 1 : 3; fp.shared_flag = ts.d_shared; fp.out = d_out;
@@ -1796,7 +1811,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
             timing_end(c, 5);
         }
         sp.only_flagged = 1;     // leftovers: halos the binning left to the global-atomic kernel
-        sp.left = c->d_left; sp.left_n = ts.d_tile_count + ts.geo.ntiles;
+        sp.left = c->d_left; sp.left_n = pp.left_n;
         sp.pair_total_ptr = ts.d_tile_start + ts.geo.ntiles; sp.pair_cap = c->pair_cap;
     }
     const int G = (variant == BFG_VARIANT_SCATTER_WAVE) ? 64 : 16;
@@ -1810,7 +1825,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     sp.win_nodes = win;
     const size_t lds = ring_bytes + (size_t)win * sizeof(double2) * (size_t)gpb;
     unsigned grid = (unsigned)((a->n_halo + gpb - 1) / gpb);
-    if (sp.left) grid = std::min(grid, 4096u);          // fixed grid striding over the left-over list
+    if (sp.left) grid = std::min(grid, 1024u);          // fixed grid striding over the left-over list (usually empty)
     timing_begin(c, tslot);
     if (mode == MODE_PAINT) {
         if (G == 64) hipLaunchKernelGGL((shell_scatter_kernel<64, MODE_PAINT>), dim3(grid), dim3(256), lds, c->stream, sp);
@@ -2320,7 +2335,18 @@ int bfg_timing_enable(bfg_ctx *c, int enable)
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->timing = enable != 0;
+    c->timing_mask = ~0u;
     for (int k = 0; k < kTimingSlots; ++k) { c->t_ms[k] = 0; c->t_n[k] = 0; c->ev_used[k] = 0; }
+    return BFG_OK;
+}
+
+int bfg_timing_select(bfg_ctx *c, unsigned which_mask)
+{
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));       // no begin without its end
+    c->timing_mask = which_mask;
     return BFG_OK;
 }
 

@@ -318,6 +318,8 @@ struct FillParams {
 
 __global__ __launch_bounds__(256) void tile_fill_kernel(const FillParams P)
 {
+    // no tile beyond its fixed slots (the count pass says so): no overflow lists to fill, no tile cut into shared items
+    if (!*P.bin.needs_scan) return;
     if (P.overwrite) {
         // Clear the tiles the tile kernel will add to with atomics (those cut into several work items: crowded catalogs,
         // compact multi-GPU shards).  Tile t belongs to workgroup t mod gridDim, so the clearing is spread over the whole
@@ -381,8 +383,15 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const FillParams P)
 constexpr int kWorkExtra = 4096;
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const TileGeom geo, int cap_direct, int32_t *count, int32_t *start, int4 *work,
                                                          int32_t *n_work, int32_t *work_counter, int first_dynamic,
-                                                         int overwrite, int32_t *shared_flag, const int32_t *needs_scan)
+                                                         int overwrite, int32_t *shared_flag, const int32_t *needs_scan,
+                                                         int32_t *next_count)
 {
+    // the other set of counters (ntiles + 2), for the next call
+    if (blockIdx.x != 0) {
+        const int t = ((int)blockIdx.x - 1) * 1024 + (int)threadIdx.x;
+        if (t < geo.ntiles) next_count[t] = 0;
+        if (t == 0) { next_count[geo.ntiles] = 0; next_count[geo.ntiles + 1] = 0; }
+    }
     // overwrite: the tile kernel initialises the map itself, so tiles without a single pair get an (empty) work item too,
     // and tiles cut into several items -- which add to the map with atomics -- are listed for tile_fill_kernel to clear first
     const int ntiles = geo.ntiles;

@@ -425,8 +425,11 @@ class Context(object):
                 "pixels_out_of_table": int(st.pixels_out_of_table), "halos_fallback4": int(st.halos_fallback4),
                 "warn_mask": int(st.warn_mask), "fallback_halos": int(st.halos_scatter_fallback)}
 
-    def timing_enable(self, on=True):
+    def timing_enable(self, on=True, which=None):
+        """hipEvents around the context's kernels; `which`: the kernel classes (bfg_timing_read's indices) to time, default all"""
         _lib.check(self.lib.bfg_timing_enable(self.handle, int(bool(on))))
+        if on and which is not None:
+            _lib.check(self.lib.bfg_timing_select(self.handle, sum(1 << int(k) for k in which)))
 
     def timing_read(self, which):
         ms, n = C.c_double(), C.c_int64()

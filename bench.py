@@ -333,7 +333,10 @@ def main():
     barrier()
     _mark("warmup done")
     ctx.stats_reset()
-    ctx.timing_enable(True)          # hipEvents around each kernel, on the kernels' own stream
+    # hipEvents around the dominant kernel (class 1), on the kernels' own stream, over the whole timed region.  The other
+    # kernel classes are timed in an extra, untimed leg below: an event pair costs a few microseconds of stream time, and
+    # six of them per step slowed the timed region by 0.04 ms per step (3 % at 1e6 halos, 17 % at 1e5).
+    ctx.timing_enable(True, which=[1])
     dt = timed(args.steps)
     _mark("timed region done")
     if dist is not None:
@@ -345,6 +348,9 @@ def main():
         dt = float(t.item())
     stats = ctx.stats()
     k_ms, k_n = ctx.timing_read(1)
+    n_extra = max(1, min(args.steps, 10))
+    ctx.timing_enable(True)          # every kernel class, outside the timed region
+    timed(n_extra, collective=False) if dist is not None else timed(n_extra)
     p_ms, p_n = ctx.timing_read(0)
     r_ms, r_n = ctx.timing_read(2)
     b_ms, b_n = ctx.timing_read(3)
@@ -405,6 +411,8 @@ def main():
                 "bytes_per_halo": kernel_bytes / max(idx.size, 1),
                 "pixel_updates_per_launch": ptot_step,
                 "pixel_updates_per_s": ptot_step / kernel_s if kernel_s > 0 else 0.0,
+                "other_kernels_timed_in": f"an extra untimed leg of {n_extra} steps with every kernel class timed (the timed "
+                                          "region carries events for the dominant kernel only)",
                 "prep_kernel_ms": p_ms / max(p_n, 1),
                 "tile_binning_ms": (b_ms / b_n) if b_n else None,
                 "leftover_scatter_kernel_ms": (l_ms / l_n) if l_n else None,

@@ -332,8 +332,12 @@ int bfg_stats_read(bfg_ctx *ctx, bfg_stats *out);   /* synchronises the stream *
  * (tile kernel, or the scatter kernel of the scatter variants), 2 = regrid kernel,
  * 3 = tile binning (work list + overflow fill + row windows), 4 = left-over scatter kernel of the tile
  * variant, 5 = the follow-up kernel that adds the tile kernel's deferred pixels (paint).
- * Returns the accumulated milliseconds and launch count since the last enable. */
+ * Returns the accumulated milliseconds and launch count since the last enable.
+ * bfg_timing_select restricts the events to the classes in `which_mask` (bit k = class k; the default, and what
+ * bfg_timing_enable restores, is all of them): every event pair costs a few microseconds of stream time, which a step of
+ * seven small launches feels (0.04 ms per shell call with all classes timed). */
 int bfg_timing_enable(bfg_ctx *ctx, int enable);
+int bfg_timing_select(bfg_ctx *ctx, unsigned which_mask);
 int bfg_timing_read(bfg_ctx *ctx, int which, double *ms_total, int64_t *launches);
 
 #ifdef __cplusplus

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--workloads", default="paint1e6,paint1e5,bary1e5,steep")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--no-timing", action="store_true", help="no per-kernel HIP events in the timed steps (the step time without them)")
     a = ap.parse_args()
     # "VAR=a,b" (one variable, several values) or "A=1 B=2;A=3" (';'-separated sets of assignments; '-' = nothing set)
     if ";" in a.modes or " " in a.modes or a.modes == "-":
@@ -96,7 +97,7 @@ def main():
                     step()
                 torch.cuda.synchronize()
                 ctx.stats_reset()
-                ctx.timing_enable(True)
+                ctx.timing_enable(not a.no_timing)
                 t0 = time.perf_counter()
                 for _ in range(a.steps):
                     step()
