@@ -1412,7 +1412,15 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
             const int pend = min(ptotal, pbase + kPixMax);
             const uint16_t *pp = ptab + tid;
             for (int q = pbase + tid; q < pend; q += NT, pp += NT) {
-                const Seg sg = *reinterpret_cast<const Seg *>(smem_raw + segs_off + *pp);     // by value: one burst of LDS reads
+                // by value: one burst of LDS reads; an absolute LDS address (the block starts at 0, checked above) -- through
+                // smem_raw the compiler adds the block's relocatable base to the loaded offset, one more VALU instruction per pixel
+                typedef int v4i_t __attribute__((ext_vector_type(4)));
+                typedef double v2d_t __attribute__((ext_vector_type(2)));
+                const unsigned sa = (unsigned)segs_off + (unsigned)*pp;
+                const v4i_t s0 = *lds_ptr<const v4i_t>(sa);
+                const v2d_t s1 = *lds_ptr<const v2d_t>(sa + 16), s2 = *lds_ptr<const v2d_t>(sa + 32);
+                Seg sg;
+                sg.excl = s0.x; sg.abyte = s0.y; sg.wbyte = s0.z; sg.pk = s0.w; sg.hstep = s1.x; sg.c0 = s1.y; sg.Aq = s2.x; sg.Bq = s2.y;
                 do_pixel(q, sg);
             }
         }
