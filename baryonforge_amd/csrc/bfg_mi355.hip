@@ -784,13 +784,21 @@ __device__ inline void sincos_2pi(double a, double &s, double &c)
     c = ((q + 1) & 2) ? -c0 : c0;
 }
 
-// 4 waves per SIMD (128 VGPRs, 172 B of scratch per lane) beat the spill-free 184-VGPR build at 2 waves per SIMD: 0.43 -> 0.33 ms;
-// the long dependent chain per pixel (sincos -> sqrt -> atan2 x 2 -> divisions) needs the extra wavefronts to overlap
-__global__ __launch_bounds__(256, 4) void regrid_tile_kernel(Hpx hp, TileGeom geo, const double *__restrict__ off,
+// Waves per SIMD: the long dependent chain per pixel (sincos -> sqrt -> atan2 x 2 -> divisions) needs wavefronts to overlap, spills
+// cost more.  Round 1's body: 184 VGPRs spill-free (2 waves) 0.43 ms, 128 VGPRs + 172 B of scratch (4 waves) 0.33 ms.  With the
+// table-driven atan2, the fast sqrt and multiplications by nr / 2 pi in place of four divisions the body fits 168 VGPRs without
+// scratch: 3 waves 0.29 ms, 4 waves (148 B of scratch) 0.30 ms (profiles/r02_regrid_ab.txt).
+#ifndef BFG_RG_WAVES
+#define BFG_RG_WAVES 3
+#endif
+__global__ __launch_bounds__(256, BFG_RG_WAVES) void regrid_tile_kernel(Hpx hp, TileGeom geo, const double *__restrict__ off,
                                                           const double *__restrict__ in_map,
-                                                          double *__restrict__ out_map, double *sums)
+                                                          double *__restrict__ out_map, double *sums,
+                                                          const double *__restrict__ atantab)
 {
     __shared__ double acc[kRgRows * kRgWidth];
+    __shared__ double s_atan[kAtanTab];
+    if (threadIdx.x < kAtanTab) s_atan[threadIdx.x] = atantab[threadIdx.x];
     __shared__ RgRow rows[kRgRows];
     __shared__ double s_in[4], s_dep[4];
     const int tile = blockIdx.x;
@@ -824,15 +832,17 @@ __global__ __launch_bounds__(256, 4) void regrid_tile_kernel(Hpx hp, TileGeom ge
 
     // one bilinear neighbour ring of get_interpol: (start, nr, theta, shift) from the LDS table when the ring is one
     // of the tile's rows (almost always), else recomputed
-    auto ring_of = [&](int ir, int64_t &sp, int &nr, double &th, bool &sh, int &lr) {
+    auto ring_of = [&](int ir, int64_t &sp, int &nr, double &th, bool &sh, int &lr, double &dphi) {
         lr = ir - row_ring0;
         if (lr >= 0 && lr < kRgRows && rows[lr].nr > 0) {
             const RgRow &t = rows[lr];
             sp = t.start; nr = t.nr; th = t.theta; sh = t.shifted != 0;
+            dphi = t.phistep;                                       // 2 pi / nr to a rounding error: moves a weight by as much
         } else {
             int64_t n64;
             ring_info2(hp, ir, sp, n64, th, sh);
             nr = (int)n64; lr = -1;
+            dphi = kTwoPi / (double)nr;
         }
     };
     // deposit d on ring index i of ring row lr (lr < 0: not an LDS row) / pixel sp + i
@@ -870,10 +880,12 @@ __global__ __launch_bounds__(256, 4) void regrid_tile_kernel(Hpx hp, TileGeom ge
         const double vx = sr.sth * cphi + off[3 * p + 0];              // :357
         const double vy = sr.sth * sphi + off[3 * p + 1];
         const double vz = sr.z + off[3 * p + 2];
-        const double dnorm = sqrt(vx * vx + vy * vy + vz * vz);        // hp.vec2ang :358
+        const double n2 = vx * vx + vy * vy + vz * vz;                 // |pixel vector + offset|^2: 1 + a small offset
+        const double dnorm = (n2 > 1e-200 && n2 < 1e200) ? sqrt_unit(n2) : sqrt(n2);   // hp.vec2ang :358
         const double z = vz / dnorm;                                   // = cos(theta) to rounding
-        const double theta = atan2_upper(sqrt((1.0 - z) * (1.0 + z)), z);     // acos(z)
-        const double aphi = (vx == 0.0 && vy == 0.0) ? 0.0 : atan2_upper(fabs(vy), vx);
+        const double s2 = (1.0 - z) * (1.0 + z);
+        const double theta = atan2_upper_tab((s2 > 1e-200) ? sqrt_unit(s2) : sqrt(s2), z, s_atan);     // acos(z)
+        const double aphi = (vx == 0.0 && vy == 0.0) ? 0.0 : atan2_upper_tab(fabs(vy), vx, s_atan);
         const double phi = (vy < 0.0) ? kTwoPi - aphi : aphi;          // atan2(vy, vx) brought to [0, 2 pi)
         // healpix_cxx get_interpol (:361), ring by ring, with (ring, index) kept instead of pixel numbers
         const int ir1 = (int)ring_above(hp, z), ir2 = ir1 + 1;
@@ -883,12 +895,17 @@ __global__ __launch_bounds__(256, 4) void regrid_tile_kernel(Hpx hp, TileGeom ge
         double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
         if (ir1 > 0) {
             bool sh;
-            ring_of(ir1, sp1, nr1, theta1, sh, lr1);
-            const double dphi = kTwoPi / (double)nr1;
+            double dphi;
+            ring_of(ir1, sp1, nr1, theta1, sh, lr1, dphi);
+            // phi / dphi as phi * (nr / 2 pi): the weights move by a rounding error and a pixel index can only flip where its
+            // weight is ~0 (the interpolation is continuous) -- except in healpix_cxx's phi == 2 pi case below, which is
+            // decided with the reference's own division
+            const double inv_dphi = (double)nr1 * kInvTwoPi;
             const double hs = sh ? 0.5 : 0.0;
-            const double tmp = phi / dphi - hs;
+            double tmp = phi * inv_dphi - hs;
+            if (phi >= kTwoPi) tmp = phi / (kTwoPi / (double)nr1) - hs;
             int ia = (tmp < 0) ? (int)tmp - 1 : (int)tmp;
-            const double ww = (phi - ((double)ia + hs) * dphi) / dphi;
+            const double ww = (phi - ((double)ia + hs) * dphi) * inv_dphi;
             int ib = ia + 1;
             if (ia < 0) ia += nr1;
             if (ib >= nr1) ib -= nr1;
@@ -900,12 +917,14 @@ __global__ __launch_bounds__(256, 4) void regrid_tile_kernel(Hpx hp, TileGeom ge
         }
         if (ir2 < nl4) {
             bool sh;
-            ring_of(ir2, sp2, nr2, theta2, sh, lr2);
-            const double dphi = kTwoPi / (double)nr2;
+            double dphi;
+            ring_of(ir2, sp2, nr2, theta2, sh, lr2, dphi);
+            const double inv_dphi = (double)nr2 * kInvTwoPi;
             const double hs = sh ? 0.5 : 0.0;
-            const double tmp = phi / dphi - hs;
+            double tmp = phi * inv_dphi - hs;
+            if (phi >= kTwoPi) tmp = phi / (kTwoPi / (double)nr2) - hs;
             int ia = (tmp < 0) ? (int)tmp - 1 : (int)tmp;
-            const double ww = (phi - ((double)ia + hs) * dphi) / dphi;
+            const double ww = (phi - ((double)ia + hs) * dphi) * inv_dphi;
             int ib = ia + 1;
             if (ia < 0) ia += nr2;
             if (ib >= nr2) ib -= nr2;
@@ -1868,7 +1887,7 @@ int bfg_regrid_shell(bfg_ctx *c, int64_t nside, const double *d_offsets, const d
     timing_begin(c, 2);
     if (use_tiles)
         hipLaunchKernelGGL(regrid_tile_kernel, dim3((unsigned)c->tiles[kRegridSet].geo.ntiles), dim3(256), 0, c->stream, hp,
-                           c->tiles[kRegridSet].geo, d_offsets, d_in_map, d_out_map, d_sums);
+                           c->tiles[kRegridSet].geo, d_offsets, d_in_map, d_out_map, d_sums, c->d_mathtab + 2 * kLogTab + kExpTab);
     else
         hipLaunchKernelGGL(regrid_kernel, dim3((unsigned)((hp.npix + 255) / 256)), dim3(256), 0, c->stream, hp,
                            d_offsets, d_in_map, d_out_map, d_sums);

@@ -776,15 +776,14 @@ __device__ inline double atan2_upper(double y, double x)
     return (x < 0.0) ? 3.14159265358979323846 - a : a;
 }
 
-// The same with the reduction constant from a table: c = k / 64 nearest to min / max (picked through a single-precision
+// The same with the reduction constant from a table: c = k / 64 nearest to min / max (picked through an approximate
 // quotient: any neighbour of the nearest will do), atan(c) from `tab` (LDS), |u| <= 1/128 + 2^-20 so the odd series stops at
 // u^7 (next term < 2e-18 relative).  One division as before; ~25 instructions fewer than the compare-and-select ladder.
 __device__ inline double atan2_upper_tab(double y, double x, const double *tab)
 {
     const double ax = fabs(x);
     const double mx = fmax(ax, y), mn = fmin(ax, y);
-    const float qf = (float)mn * __builtin_amdgcn_rcpf((float)mx);     // mx >= sin(theta_ring) / sqrt 2: never denormal as a float
-    int k = (int)fmaf(qf, 64.0f, 0.5f);
+    int k = (int)fma(mn * __builtin_amdgcn_rcp(mx), 64.0, 0.5);        // v_rcp_f64: ~1e-8 relative, good for any normal mx
     k = min(max(k, 0), 64);
     const double c = (double)k * 0.015625;
     const double num = fma(-c, mx, mn), den = fma(c, mn, mx);
