@@ -29,7 +29,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
 done
 cd $R
 # stage cycles (a -DBFG_STAGE_TIMING=1 build, made here)
-( cd baryonforge_amd && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics -ffp-contract=on -DBFG_STAGE_TIMING=1 -o /tmp/bfg_st.so csrc/bfg_mi355.hip 2>/dev/null )
+( cd baryonforge_amd && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics -ffp-contract=on -DBFG_STAGE_TIMING=2 -o /tmp/bfg_st.so csrc/bfg_mi355.hip 2>/dev/null )
 for n in 1000000 100000; do BFG_SO=/tmp/bfg_st.so python3 tools/stage_timing.py $n 1024 paint; done > $O/${tag}_stage_cycles.txt 2>&1
 BFG_SO=/tmp/bfg_st.so python3 tools/stage_timing.py 100000 1024 bary >> $O/${tag}_stage_cycles.txt 2>&1
 grep -v "^/opt" $O/${tag}_stage_cycles.txt
