@@ -957,8 +957,12 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     if (n_pairs != 0) {
     for (int i = tid; i < TR * TW * NACC; i += NT) acc[i] = 0.0;
     if (tid == 0) ctl[5] = 0;
-    if (tid < TR) {
-        const int ring = ring_lo + tid;
+    // the ring rows are wave 1's (stage b is their first reader): wave 0 goes straight to stage a of the first chunk, and the one
+    // barrier after stage a covers the cleared accumulator, the rows and the pair records alike
+    constexpr int kRowWave = (NT >= 128) ? 64 : 0;
+    if (tid >= kRowWave && tid < kRowWave + TR) {
+        const int rtid = tid - kRowWave;
+        const int ring = ring_lo + rtid;
         RingRow rr;
         rr.z = 0; rr.sth = 0; rr.phistep = 0; rr.phioff = 0; rr.nr = 1; rr.k0 = 0; rr.k1 = 0; rr.rowoff = 0; rr.start = 0; rr.pad = 0;
         if (ring <= ring_hi) {
@@ -967,9 +971,9 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
             rr.sth = g.sth; rr.phistep = g.phistep; rr.phioff = g.phioff; rr.nr = g.nr; rr.start = g.start;
             rr.k0 = (int)(((int64_t)sector * g.nr) / NS);
             rr.k1 = (int)(((int64_t)(sector + 1) * g.nr) / NS);
-            rr.rowoff = tid * TW - rr.k0;
+            rr.rowoff = rtid * TW - rr.k0;
         }
-        rows[tid] = rr;
+        rows[rtid] = rr;
     }
 
     unsigned long long my_pixels = 0;
@@ -999,7 +1003,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         nx_j = (lane < kPairMax) ? pjA : -1;
         load_records();
     }
-    lds_barrier();
+    // (no barrier here: stage a of the first chunk reads nothing the prologue wrote; the barrier after it orders the rest)
 
     unsigned int n_oob32 = 0;
 
