@@ -1408,3 +1408,74 @@ def test_snapshot_and_grid_edge_cases(cosmo):
     out = bfg.PaintProfilesGrid(Cat0, bfg.GriddedMap(map=np.zeros((N, N, N)), redshift=zs, bins=bins, cosmo=cosmo), 5, paint,
                                 verbose=False).process()
     assert out.shape == (N, N, N) and not out.any()
+
+
+def test_call_sequences_on_one_context_keep_the_tile_counters_clean(cosmo, monkeypatch):
+    """the tile counters come in two sets, each call's scan kernel clearing the set the next call counts in (no memset launch):
+    sequences of calls that differ in catalog size, resolution, workload and work-list path (scan-free / scan kernel) on the
+    process's one context must paint what each call paints on its own"""
+    import warnings
+    zax, Max, rax, T = syn.pressure_table()
+    zd, Md, rd, d = syn.displacement_table()
+    bm = bfg.Baryonification2D.from_arrays(zd, Md, rd, d, cosmo, epsilon_max=20)
+    cases = [(256, 30000, 3), (128, 40, 4), (256, 30000, 3), (512, 3000, 5), (128, 20000, 6), (128, 40, 4)]
+
+    def paint(nside, n, seed):
+        ra, dec, M, z = syn.catalog(n, seed=seed)
+        Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+        R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), 10,
+                                   _paint_model(zax, Max, rax, T), verbose=False)
+        out = R.process()
+        return out, R.last_stats["pixel_updates"]
+
+    def bary(nside, n, seed):
+        ra, dec, M, z = syn.catalog(n, seed=seed)
+        Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=syn.mass_map(nside), cosmo=cosmo), 10, bm, verbose=False).process()
+
+    first = {}
+    for rnd in range(2):
+        for k, (nside, n, seed) in enumerate(cases):
+            if k == 4:
+                monkeypatch.setenv("BFG_TILE_SCAN", "1")            # this call builds its work list with the scan kernel
+            got, ptot = paint(nside, n, seed)
+            gb = bary(nside, n, seed) if k % 2 == 0 else None
+            monkeypatch.delenv("BFG_TILE_SCAN", raising=False)
+            key = (nside, n, seed)
+            if key not in first:
+                ref, pref = oracle_paint(cosmo, *syn.catalog(n, seed=seed), (zax, Max, rax), T, nside, 10)
+                assert ptot == pref
+                assert_maps_close(got, ref, RTOL, what=f"call {k} of round {rnd}")
+                first[key] = (got, ptot, gb)
+            else:
+                assert ptot == first[key][1]
+                assert_maps_close(got, first[key][0], 1e-12, what=f"repeat of {key}")
+                if gb is not None and first[key][2] is not None:
+                    assert_maps_close(gb, first[key][2], 1e-8, floor=BFLOOR, what=f"baryonify repeat of {key}")
+
+
+def test_timing_select_times_only_the_chosen_kernel_classes(cosmo):
+    """bfg_timing_select: events for the chosen kernel classes only (bench.py times the dominant kernel in its timed region)"""
+    from baryonforge_amd.background import Background
+    from baryonforge_amd.engine import get_context
+    ctx = get_context(0)
+    nside, n = 256, 20000
+    ra, dec, M, z = syn.catalog(n, seed=12)
+    zax, Max, rax, T = syn.pressure_table()
+    bg = Background(cosmo)
+    d_cat = ctx.to_device(np.stack([M, z, ra, dec], axis=1))
+    table = ctx.table([zax, Max, rax], np.log(T), log_values=True)
+    spline = ctx.da_spline(bg, float(z.max()))
+    d_map = ctx.zeros(12 * nside * nside)
+    sargs = ctx.shell_args(nside, d_cat, n, 4, 0, 10.0, ctx.massdef_struct(bg, None), out_overwrite=True)
+    ctx.timing_enable(True, which=[1])
+    for _ in range(3):
+        ctx.paint_shell(sargs, table, spline, d_map)
+    assert ctx.timing_read(1)[1] == 3 and ctx.timing_read(1)[0] > 0
+    assert all(ctx.timing_read(k)[1] == 0 for k in (0, 2, 3, 4, 5))
+    ctx.timing_enable(True)                                           # all classes again
+    ctx.paint_shell(sargs, table, spline, d_map)
+    assert ctx.timing_read(0)[1] == 1 and ctx.timing_read(1)[1] == 1 and ctx.timing_read(3)[1] == 1
+    ctx.timing_enable(False)
