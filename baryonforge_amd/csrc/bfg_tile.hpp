@@ -1073,8 +1073,20 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
             const int64_t *con = reinterpret_cast<const int64_t *>(cwn + ncorner);
             B0 = 0.0; B1 = 0.0;
             if (in) {                                  // a cell outside the axis is the caller's business; never read there
-#pragma unroll 4
-                for (int c = 0; c < ncorner; ++c) {
+                // corners four at a time with all their loads in flight together (the plain loop waited for two corners' loads
+                // before it asked for the next two: two dependent L2 round trips per pixel, and this read-out is latency-bound);
+                // same order of additions
+                int c = 0;
+                for (; c + 4 <= ncorner; c += 4) {
+                    const double *r0 = T.values + con[c] + (ic - 1), *r1 = T.values + con[c + 1] + (ic - 1);
+                    const double *r2 = T.values + con[c + 2] + (ic - 1), *r3 = T.values + con[c + 3] + (ic - 1);
+                    const double a0 = r0[0], b0 = r0[1], a1 = r1[0], b1 = r1[1], a2 = r2[0], b2 = r2[1], a3 = r3[0], b3 = r3[1];
+                    B0 = fma(a0, cwn[c], B0); B1 = fma(b0, cwn[c], B1);
+                    B0 = fma(a1, cwn[c + 1], B0); B1 = fma(b1, cwn[c + 1], B1);
+                    B0 = fma(a2, cwn[c + 2], B0); B1 = fma(b2, cwn[c + 2], B1);
+                    B0 = fma(a3, cwn[c + 3], B0); B1 = fma(b3, cwn[c + 3], B1);
+                }
+                for (; c < ncorner; ++c) {
                     const double *row = T.values + con[c] + (ic - 1);
                     const double w = cwn[c];
                     B0 = fma(row[0], w, B0); B1 = fma(row[1], w, B1);
@@ -1414,16 +1426,20 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
             BFG_TICK(3);
             const int pend = min(ptotal, pbase + kPixMax);
             const uint16_t *pp = ptab + tid;
-            for (int q = pbase + tid; q < pend; q += NT, pp += NT) {
-                // by value: one burst of LDS reads; an absolute LDS address (the block starts at 0, checked above) -- through
-                // smem_raw the compiler adds the block's relocatable base to the loaded offset, one more VALU instruction per pixel
+            // by value: one burst of LDS reads; an absolute LDS address (the block starts at 0, checked above) -- through
+            // smem_raw the compiler adds the block's relocatable base to the loaded offset, one more VALU instruction per pixel
+            auto load_seg = [&](const uint16_t *pq) -> Seg {
                 typedef int v4i_t __attribute__((ext_vector_type(4)));
                 typedef double v2d_t __attribute__((ext_vector_type(2)));
-                const unsigned sa = (unsigned)segs_off + (unsigned)*pp;
+                const unsigned sa = (unsigned)segs_off + (unsigned)*pq;
                 const v4i_t s0 = *lds_ptr<const v4i_t>(sa);
                 const v2d_t s1 = *lds_ptr<const v2d_t>(sa + 16), s2 = *lds_ptr<const v2d_t>(sa + 32);
                 Seg sg;
                 sg.excl = s0.x; sg.abyte = s0.y; sg.wbyte = s0.z; sg.pk = s0.w; sg.hstep = s1.x; sg.c0 = s1.y; sg.Aq = s2.x; sg.Bq = s2.y;
+                return sg;
+            };
+            for (int q = pbase + tid; q < pend; q += NT, pp += NT) {
+                const Seg sg = load_seg(pp);
                 do_pixel(q, sg);
             }
         }
