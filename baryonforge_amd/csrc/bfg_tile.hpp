@@ -144,7 +144,7 @@ struct __align__(16) PairInfoDisp {  // ... baryonify (96 bytes)
     double a, D, xcut, tshift;
     int64_t hoff;
     int32_t win_lo, halo, ra, pad;
-    double pad2;
+    double a_over_D;                 // a / D
 };
 static_assert(sizeof(PairInfoDisp) == 96, "PairInfoDisp must be 96 bytes");
 
@@ -1116,6 +1116,22 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         const double h = fma((double)k, sg.hstep, sg.c0);
         const double h2 = h * h;
         if constexpr (MODE == MODE_PAINT) {
+            if constexpr (win_in_lds) {
+                // the common case behind ONE branch (small angle, cell inside the staged window, value inside exp's range); a
+                // pixel that fails any of the three falls through to the general code below, which starts over
+                const double xf = fma(sg.Bq, sin_squared_small(h2), sg.Aq);
+                const double t1f = fma(fast_log_biased(xf, logtab), t_m, t_c1);
+                const int i1f = (int)t1f;
+                const int icf = med3_i32(i1f, sg.pk, sg.pk + W - 2);
+                const lds_double *wpf = lds_ptr<double>(lds_base + sg.wbyte + 8 * icf);
+                const double B0f = wpf[0], B1f = wpf[1];
+                const double Lf = fma(t1f - (double)icf, B1f - B0f, B0f);
+                if ((h2 <= kSinSmall) && (icf == i1f) && (fabs(Lf) < 709.0)) {
+                    __hip_atomic_fetch_add(lds_ptr<double>(lds_base + sg.abyte + 8 * k), fast_exp(Lf, exptab), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                    return;
+                }
+            }
             double s2 = sin_squared_small(h2);
             if (__any(h2 > kSinSmall)) {                                   // wave-uniform branch: only near the poles
                 if (h2 > kSinSmall) s2 = sin_squared_wide(h);
@@ -1150,7 +1166,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
             const int pidx = sg.pk & 63, wl1 = sg.pk >> 12;
             const Pair &pi = pinfo[pidx];
             const RingRow &rr = rows[(sg.pk >> 6) & 63];
-            double sh = sin_small(h, h2), ch = sqrt(1.0 - sh * sh);        // sin, cos of dphi/2 (cos >= 0)
+            double sh = sin_small(h, h2), ch = sqrt_unit(1.0 - sh * sh);   // sin, cos of dphi/2 (cos >= 0; 1 - sh^2 > 0.9 here)
             if (__any(h2 > kSinSmall)) { if (h2 > kSinSmall) sincos_wide(h, sh, ch); }
             const double s2 = sh * sh;
             const double x = fma(sg.Bq, s2, sg.Aq);                        // r_com^2
@@ -1171,12 +1187,17 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
             const bool use = in && (x < pi.xcut) && (x > 0.0) && (fabs(d) < 1.0e300);
             d = use ? d * pi.a : 0.0;                                      // physical (HealpixRunner.py:345)
             if (d != 0.0) {
-                const double rc = sqrt(x);                                 // r_com; chord = rc a / D
-                const double chord = rc * pi.a / pi.D;
+                // (the offsets are continuous in all of this: the lean sqrt, a / D formed once per pair and one division
+                // shared by g and kk move them by rounding errors)
+                const double rc = (x > 1e-280 && x < 1e280) ? sqrt_unit(x) : sqrt(x);   // r_com; chord = rc a / D
+                const double chord = rc * pi.a_over_D;
                 const double qq = pi.D * d * chord + d * d;                // |pos + off|^2 - D^2
-                const double nwn = sqrt(fma(pi.D, pi.D, qq));
-                const double g = -qq / (nwn * (nwn + pi.D));               // D / |nw| - 1 without cancellation
-                const double kk = d / (chord * nwn);                       // offset along (vec - vec_j) / chord, / |nw|
+                const double n2 = fma(pi.D, pi.D, qq);
+                const double nwn = (n2 > 1e-280 && n2 < 1e280) ? sqrt_unit(n2) : sqrt(n2);
+                const double ga = nwn * (nwn + pi.D), kb = chord * nwn;
+                const double inv = 1.0 / (ga * kb);
+                const double g = -qq * kb * inv;                           // D / |nw| - 1 without cancellation: -qq / (nwn (nwn + D))
+                const double kk = d * ga * inv;                            // offset along (vec - vec_j) / chord, / |nw|: d / (chord nwn)
                 lds_double *ap = lds_ptr<double>(lds_base + sg.abyte + 24 * k);
                 __hip_atomic_fetch_add(ap + 0, fma(vx, g, dx * kk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(ap + 1, fma(vy, g, dy * kk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1268,7 +1289,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                 const HaloTile &h = P.ht[j];
                 const HaloDisp &hd = P.hd[j];
                 pi.cp0 = hd.cp0; pi.sp0 = hd.sp0; pi.st = h.st; pi.ct = h.ct;
-                pi.a = hd.a; pi.D = hd.D; pi.xcut = hd.xcut; pi.tshift = hd.tshift; pi.pad2 = 0.0;
+                pi.a = hd.a; pi.D = hd.D; pi.xcut = hd.xcut; pi.tshift = hd.tshift; pi.a_over_D = hd.a / hd.D;
             }
         }
         if (wave * 64 < nslots && !(P.debug & 8)) {                 // whole wavefronts: kSlotMax <= NT, one pass

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(kWaveThreads, 4) void shell_wave_kernel(const TileP
                 const HaloTile &h = P.ht[j];
                 const HaloDisp &hd = P.hd[j];
                 pi.cp0 = hd.cp0; pi.sp0 = hd.sp0; pi.st = h.st; pi.ct = h.ct;
-                pi.a = hd.a; pi.D = hd.D; pi.xcut = hd.xcut; pi.tshift = hd.tshift; pi.pad2 = 0.0;
+                pi.a = hd.a; pi.D = hd.D; pi.xcut = hd.xcut; pi.tshift = hd.tshift; pi.a_over_D = hd.a / hd.D;
             }
         }
         // row windows of the chunk's pairs: LDS-DMA, 16 lanes x 16 B per pair, asynchronous (waited for before the first pixel)
