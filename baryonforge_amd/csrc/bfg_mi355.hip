@@ -1844,7 +1844,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     sp.win_nodes = win;
     const size_t lds = ring_bytes + (size_t)win * sizeof(double2) * (size_t)gpb;
     unsigned grid = (unsigned)((a->n_halo + gpb - 1) / gpb);
-    if (sp.left) grid = std::min(grid, 1024u);          // fixed grid striding over the left-over list (usually empty)
+    if (sp.left) grid = std::min(grid, 512u);           // fixed grid striding over the left-over list (usually empty); two blocks per CU fit
     timing_begin(c, tslot);
     if (mode == MODE_PAINT) {
         if (G == 64) hipLaunchKernelGGL((shell_scatter_kernel<64, MODE_PAINT>), dim3(grid), dim3(256), lds, c->stream, sp);
