@@ -1775,7 +1775,12 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         tp.out_zero = out_zero ? 1 : 0;
         tp.overwrite = overwrite ? 1 : 0;
         tp.defer = (mode == MODE_PAINT) ? ts.d_defer : nullptr; tp.defer_count = ts.d_defer_count;
-        if (const char *e = std::getenv("BFG_FINAL_DRAIN")) if (e[0] == 'i') tp.defer = nullptr;  // "inline": drain in the tile kernel
+        tp.defer_cap_wg = (int)std::min<int64_t>(((int64_t)items_max * kDeferCap) / tile_grid, 1 << 20);   // the list, cut into one slice per workgroup
+        tp.defer_tail = 1;                                                   // the workgroups add their deferred pixels themselves
+        if (const char *e = std::getenv("BFG_FINAL_DRAIN")) {
+            if (e[0] == 'i') tp.defer = nullptr;                            // "inline": every item drains its own queue
+            if (e[0] == 'k') tp.defer_tail = 0;                             // "kernel": tile_deferred_kernel after the tile kernel
+        }
         if (!c->tile_attr_set) {
             const int lp = (int)tile_lds_bytes<MODE_PAINT>(), lb = (int)tile_lds_bytes<MODE_BARYONIFY>();
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_tile_kernel<MODE_PAINT, true>),
@@ -1822,10 +1827,9 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         }
         HIP_TRY(hipGetLastError());
         timing_end(c, 1);
-        if (mode == MODE_PAINT && tp.defer && !use_wave) {
+        if (mode == MODE_PAINT && tp.defer && !tp.defer_tail && !use_wave) {
             timing_begin(c, 5);
-            const int n_items = 2 * ts.geo.ntiles + kWorkExtra;
-            hipLaunchKernelGGL(tile_deferred_kernel, dim3((unsigned)std::min((n_items + 3) / 4, 8 * c->n_cu)), dim3(256), 0, c->stream, tp, n_items);
+            hipLaunchKernelGGL(tile_deferred_kernel, dim3((unsigned)std::min((tile_grid + 3) / 4, 8 * c->n_cu)), dim3(256), 0, c->stream, tp, tile_grid);
             HIP_TRY(hipGetLastError());
             timing_end(c, 5);
         }

@@ -197,8 +197,10 @@ struct TileParams {
     int debug;                       // ablation switches for profiling (BFG_DEBUG env; 0 in production)
     int out_zero;                    // BFG_SHELL_OUT_IS_ZERO: the caller cleared `out`; tiles are stored, not read-modify-written
     int overwrite;                   // BFG_SHELL_OUT_OVERWRITE: `out` is uninitialised; every tile (also one without halos) is stored in full
-    DeferredOut *defer;              // [grid][kDeferCap] deferred pixels a work item leaves to tile_deferred_kernel (paint)
-    int32_t *defer_count;            // [grid]
+    DeferredOut *defer;              // [grid][defer_cap_wg] pixels a workgroup's items left queued (paint): added by the workgroup itself
+                                     // after its last item (defer_tail) or by tile_deferred_kernel; null: every item drains its own
+    int32_t *defer_count;            // [grid] entries in the workgroup's slice (for tile_deferred_kernel)
+    int defer_cap_wg, defer_tail;
     int32_t *work_counter;           // persistent grid: the next work item to hand out (starts at 3 gridDim.x); null: one item per workgroup
 };
 
@@ -620,6 +622,43 @@ __global__ __launch_bounds__(256) void halo_row4_kernel(const RowParams P)
     *reinterpret_cast<double4 *>(P.hwin + j * W + e4) = out;   // 32-byte aligned: W and e4 are multiples of 4
 }
 
+// One deferred pixel: blend the halo's corner rows directly from the table (same corner order and arithmetic as
+// halo_row_kernel / the in-kernel drain) and add exp(.) to the map.  Several halos can leave the same pixel: an atomic.
+__device__ inline void deferred_add(const TileParams &P, const DeferredOut &e, const double *__restrict__ exptab)
+{
+    const DevTable &T = P.tab;
+    const int64_t j = e.halo;
+    const int i = min(max((int)e.t, 0), T.nr - 2);
+    const double f = e.t - (double)i;
+    // the halo's outer cell first (one round of independent loads), then all corner values (another): written as nested
+    // loops over corners and axes the compiler serialised 2^(ndim-1) x 2 dependent rounds per entry
+    int ci[BFG_MAX_DIM - 1];
+    double cy[BFG_MAX_DIM - 1];
+#pragma unroll
+    for (int k = 0; k < BFG_MAX_DIM - 1; ++k) {
+        ci[k] = (k < T.nouter) ? P.cidx[k * P.cap + j] : 0;
+        cy[k] = (k < T.nouter) ? P.cw[k * P.cap + j] : 0.0;
+    }
+    const double lnpf = P.ht[j].spare[0];
+    double c0v = 0.0, c1v = 0.0;
+    const int ncorner = 1 << T.nouter;
+    for (int c = 0; c < ncorner; ++c) {                            // corner order and products of halo_row_kernel
+        double w = 1.0; int64_t off = 0;
+#pragma unroll
+        for (int k = 0; k < BFG_MAX_DIM - 1; ++k) {
+            if (k < T.nouter) {
+                const int bit = (c >> (T.nouter - 1 - k)) & 1;
+                w = w * (bit ? cy[k] : 1.0 - cy[k]);
+                off += (int64_t)(ci[k] + bit) * T.ostride[k];
+            }
+        }
+        c0v = fma(T.values[off + i], w, c0v);
+        c1v = fma(T.values[off + i + 1], w, c1v);
+    }
+    const double L = fma(f, c1v - c0v, c0v) + lnpf;
+    if (fabs(L) < 709.0) unsafeAtomicAdd(P.out + e.pix, fast_exp(L, exptab));
+}
+
 #ifndef BFG_TILE_THREADS
 #define BFG_TILE_THREADS 512
 #endif
@@ -889,6 +928,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     const int n_work_total = uni(*P.n_work);
     // the binning gave up (pair buffer too small): every halo goes to the scatter kernel; an uninitialised map still has to be cleared
     const bool degraded = (long long)P.tile_start[P.geo.ntiles] > P.pair_cap;
+    if constexpr (Cfg::QCAP > 0) { if (P.defer && threadIdx.x == 0) P.defer_count[blockIdx.x] = 0; }   // (a workgroup that returns early left nothing)
     if (degraded && !P.overwrite) return;
     const Hpx &hp = P.hpx;
     const DevTable &T = P.tab;
@@ -916,6 +956,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     constexpr bool win_in_lds = WIN_LDS;     // row windows of <= kWinLds nodes live in LDS, longer ones stay in HBM/L2
     unsigned long long px_total = 0;
     unsigned int oob_total = 0;
+    int dfill = 0;                                    // entries in this workgroup's slice of the deferred-pixel list (uniform)
 
     // Work items are handed out by a counter (they differ in size: a static round-robin was 5 % slower) and pipelined three
     // deep, so that no item starts with the chain of dependent global loads counter -> work record -> pair list -> halo
@@ -1501,17 +1542,17 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     }
     if constexpr (kQCap > 0) {
         const int n = min(ctl[5], qcap);
-        if (P.defer) {
+        if (P.defer && dfill + n <= P.defer_cap_wg) {
             if (tid < n) {
                 const DeferredPixel e = rq[tid];
                 const int i = (e.abyte - acc_off) >> 3;                    // accumulator index = row * TW + column
                 const int row = i / TW, col = i % TW;
                 DeferredOut o;
                 o.pix = rows[row].start + rows[row].k0 + col; o.t = e.t; o.halo = e.halo; o.pad[0] = o.pad[1] = o.pad[2] = 0;
-                P.defer[(size_t)item * kDeferCap + tid] = o;
+                P.defer[(size_t)blockIdx.x * P.defer_cap_wg + dfill + tid] = o;
             }
-            if (tid == 0) P.defer_count[item] = n;
-        } else if (n > 0) drain();
+            dfill += n;
+        } else if (n > 0) drain();                                         // no list, or this workgroup's slice is full
     }
 #pragma unroll
     for (int u = 0; u < kPerThread; ++u) {
@@ -1549,7 +1590,6 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                 }
             }
         }
-        if constexpr (kQCap > 0) { if (P.defer && tid == 0) P.defer_count[item] = 0; }
     }
     // on to the next work item: every thread is done with the accumulator, the ring rows and the queue
     if (tid == 0) ctl[6] = item3;
@@ -1558,6 +1598,23 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     item = item1; item1 = item2; item2 = uni(ctl[6]);
     wk = wk1; wg = wg1; wk1 = wk2; wg1 = wg2;
     }   // work items
+    // The deferred pixels of this workgroup's items.  defer_tail: added here, by the workgroup that queued them -- its write-back
+    // stores of the same pixels have been acknowledged (the barrier waits for vmcnt(0)), other workgroups touch these pixels
+    // with atomics only (shared tiles); the entries are read back past the L1 (volatile: other wavefronts wrote them).  Else
+    // tile_deferred_kernel adds them after this kernel (BFG_FINAL_DRAIN=kernel: the A/B, 0.015 ms of launch and tail).
+    if constexpr (kQCap > 0) {
+        if (P.defer) {
+            if (P.defer_tail) {
+                __syncthreads();
+                const volatile DeferredOut *slice = P.defer + (size_t)blockIdx.x * P.defer_cap_wg;
+                for (int i = tid; i < dfill; i += NT) {
+                    DeferredOut e;
+                    e.pix = slice[i].pix; e.t = slice[i].t; e.halo = slice[i].halo;
+                    deferred_add(P, e, exptab);
+                }
+            } else if (tid == 0) P.defer_count[blockIdx.x] = dfill;
+        }
+    }
     // counters last, once per workgroup: nothing waits for these atomics
     if (px_total) atomicAdd((unsigned long long *)&P.stats->pixel_updates, px_total);
     if (oob_total) {
@@ -1569,51 +1626,15 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
 #endif
 }
 
-// The deferred pixels the paint tile workgroups left behind (DeferredOut): blend the halo's corner rows directly from the
-// table (same corner order and arithmetic as halo_row_kernel / the in-kernel drain) and add exp(.) to the map.  Several
-// halos can leave the same pixel: atomics.  One 64-lane workgroup per 4 work items.
-__global__ __launch_bounds__(256) void tile_deferred_kernel(const TileParams P, int n_items)
+// The deferred pixels the paint tile workgroups left in their slices, when they do not add them themselves (defer_tail = 0):
+// one wavefront per slice, striding over the slices of the tile kernel's grid.
+__global__ __launch_bounds__(256) void tile_deferred_kernel(const TileParams P, int n_slices)
 {
     if ((long long)P.tile_start[P.geo.ntiles] > P.pair_cap) return;
-    const int n_work = min(n_items, *P.n_work);
     const int lane = threadIdx.x & 63;
-    // a small grid (launching a workgroup per item costs more than the items: ~6 ns of dispatch each); one wavefront per
-    // item, striding over the work list
-    for (int item = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); item < n_work; item += (int)gridDim.x * 4) {
-    const int n = P.defer_count[item];
-    if (lane >= n) continue;
-    const DeferredOut e = P.defer[(size_t)item * kDeferCap + lane];
-    const DevTable &T = P.tab;
-    const int64_t j = e.halo;
-    const int i = min(max((int)e.t, 0), T.nr - 2);
-    const double f = e.t - (double)i;
-    // the halo's outer cell first (one round of independent loads), then all corner values (another): written as nested
-    // loops over corners and axes the compiler serialised 2^(ndim-1) x 2 dependent rounds per entry
-    int ci[BFG_MAX_DIM - 1];
-    double cy[BFG_MAX_DIM - 1];
-#pragma unroll
-    for (int k = 0; k < BFG_MAX_DIM - 1; ++k) {
-        ci[k] = (k < T.nouter) ? P.cidx[k * P.cap + j] : 0;
-        cy[k] = (k < T.nouter) ? P.cw[k * P.cap + j] : 0.0;
-    }
-    const double lnpf = P.ht[j].spare[0];
-    double c0v = 0.0, c1v = 0.0;
-    const int ncorner = 1 << T.nouter;
-    for (int c = 0; c < ncorner; ++c) {                            // corner order and products of halo_row_kernel
-        double w = 1.0; int64_t off = 0;
-#pragma unroll
-        for (int k = 0; k < BFG_MAX_DIM - 1; ++k) {
-            if (k < T.nouter) {
-                const int bit = (c >> (T.nouter - 1 - k)) & 1;
-                w = w * (bit ? cy[k] : 1.0 - cy[k]);
-                off += (int64_t)(ci[k] + bit) * T.ostride[k];
-            }
-        }
-        c0v = fma(T.values[off + i], w, c0v);
-        c1v = fma(T.values[off + i + 1], w, c1v);
-    }
-    const double L = fma(f, c1v - c0v, c0v) + lnpf;
-    if (fabs(L) < 709.0) unsafeAtomicAdd(P.out + e.pix, fast_exp(L, P.exptab));
+    for (int w = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); w < n_slices; w += (int)gridDim.x * 4) {
+        const int n = P.defer_count[w];
+        for (int i = lane; i < n; i += 64) deferred_add(P, P.defer[(size_t)w * P.defer_cap_wg + i], P.exptab);
     }
 }
 
