@@ -80,31 +80,33 @@ def estimate_disc_pixels(cosmo, M, z, epsilon_max, nside, mass_def=None, overhea
     return np.where(np.isfinite(est), est, 0.0) + overhead
 
 
-def shard_by_sky_patch(ra_deg, dec_deg, weights, world_size, nside_patch=8, nside_order=1024, layout="contiguous"):
+def shard_by_sky_patch(ra_deg, dec_deg, weights, world_size, nside_patch=64, nside_order=1024, layout="interleaved"):
     """
     Returns a list of `world_size` index arrays that partition the catalog by sky patch (= NEST pixel of the halo
     centre at `nside_patch`); every halo appears exactly once, all halos of a patch go to the same rank.  Deterministic.
+    Inside a shard the halos are sorted by fine NEST index (neighbouring halos in neighbouring lanes: their binning atomics on
+    the same tile counter merge, prep -12 %).
 
-    layout "contiguous" (default): contiguous NEST ranges of patches with ~equal total weight (one compact region per
-        rank), sorted by fine NEST index inside a shard.
-    layout "interleaved": the patches are dealt to the ranks round-robin in NEST order (use a fine nside_patch, e.g.
-        64), so every rank's shard covers the whole sky at 1/world_size of the density and keeps the caller's order.
+    layout "interleaved" (default, with fine patches: nside_patch 64 = 16 x 16 pixels at NSIDE 1024): the patches are dealt
+        to the ranks round-robin in NEST order, so every rank's shard covers the whole sky at 1/world_size of the density:
+        the single-GPU workload on every rank (`weights` is not used).
+    layout "contiguous" (use coarse patches, e.g. nside_patch 8): contiguous NEST ranges of patches with ~equal total
+        weight: one compact region per rank (its tiles crowd: the scan-built work list, tiles shared between work items,
+        the rest of the map written as empty items).
 
-    Measured per rank, 1e6 halos per rank at NSIDE 1024 (tools/shard_scale.py; ms per step at world size 1 / 2 / 4 / 8):
-        contiguous, first version of the kernels     1.65 / 2.6 / 3.3 / 4.4   the compact shard crowds into 1/N of the map
-                                                      tiles (784 eight-fold tiles on 512 workgroup slots) and its sorted
-                                                      halos hit the same tile counters from neighbouring lanes
-        interleaved (NSIDE-64 patches)                1.67 / 1.69 / 1.64-1.72 / 1.75-1.84   the single-GPU workload
-        contiguous, with wave-merged binning atomics and heavy tiles cut into work items
-                                                      1.67 / 1.55-1.59 / 1.51-1.53 / 1.55-1.58   sorted halos now help
+    Measured per rank at NSIDE 1024 with this round's kernels (tools/shard_scale.py; ms per step at world size 1 / 2 / 4 / 8):
+        weak scaling, 1e6 halos per rank     contiguous 1.32 / 1.38-1.42 / 1.42-1.48 / 1.48-1.58
+                                             interleaved 1.26 / - / 1.23-1.28 / 1.26-1.33
+        strong scaling, 1e6 halos in total   contiguous 1.32 / 0.74-0.81 / 0.50-0.54 / 0.40-0.42
+                                             interleaved 1.26 / 0.70 / 0.40 / 0.27
+    (Round 1's kernels had it the other way round: 1.55-1.58 contiguous against 1.75-1.84 interleaved at world size 8,
+    before the scan-free work list and the per-item costs that went since.)
     """
     ra_deg = np.asarray(ra_deg, dtype=np.float64)
     n = ra_deg.size
     if layout not in ("interleaved", "contiguous"):
         raise ValueError("layout must be 'interleaved' or 'contiguous'")
     if world_size <= 1:
-        if layout == "interleaved":
-            return [np.arange(n)]
         order = np.argsort(ang2pix_nest(nside_order, ra_deg, dec_deg), kind="stable") if n else np.arange(0)
         return [order]
     fine = ang2pix_nest(nside_order, ra_deg, dec_deg)
@@ -112,7 +114,9 @@ def shard_by_sky_patch(ra_deg, dec_deg, weights, world_size, nside_patch=8, nsid
     patch = fine >> shift
     if layout == "interleaved":
         owner = patch % world_size
-        return [np.nonzero(owner == r)[0] for r in range(world_size)]
+        order = np.argsort(fine, kind="stable")
+        owner_sorted = owner[order]
+        return [order[owner_sorted == r] for r in range(world_size)]
     npatch = 12 * nside_patch * nside_patch
     w_patch = np.bincount(patch, weights=np.asarray(weights, dtype=np.float64), minlength=npatch)
     cum = np.cumsum(w_patch)

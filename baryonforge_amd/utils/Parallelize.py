@@ -145,7 +145,7 @@ class SplitJoinParallel(object):
     local_process : older form of the seam, paint only: callable(runner_for_this_rank) -> np.ndarray
     """
 
-    def __init__(self, Runner, njobs=-1, seed=42, nside_patch=8, local_process=None, layout="contiguous",
+    def __init__(self, Runner, njobs=-1, seed=42, nside_patch=64, local_process=None, layout="interleaved",
                  collective="torch", local_ops=None):
         self.Runner = Runner
         self.seed = seed

@@ -217,7 +217,7 @@ def main():
     # this rank's sky-patch shard (the whole catalog at N = 1), resident in HBM before timing starts
     if world > 1:
         w = sharding.estimate_disc_pixels(cosmo, M, z, args.eps, nside)
-        idx = sharding.shard_by_sky_patch(ra, dec, w, world)[rank]
+        idx = sharding.shard_by_sky_patch(ra, dec, w, world)[rank]        # NSIDE-64 patches dealt round-robin: the whole sky per rank
     else:
         idx = np.arange(n_total)
     recs = np.stack([M[idx], z[idx], ra[idx], dec[idx]], axis=1)
@@ -423,7 +423,7 @@ def main():
                 "step_frac": step_bytes / (dt / args.steps) / HBM_PEAK if world == 1 else None}
     sharding_txt = "none"
     if world > 1:
-        sharding_txt = ("sky patch (contiguous NEST ranges of nside-8 patches, balanced by pixel work) + "
+        sharding_txt = ("sky patch (nside-64 patches dealt round-robin in NEST order: every rank's shard covers the sky; sorted by position) + "
                         + ("RCCL all-reduce of the map, overlapped with the next shell (two map buffers)"
                            if args.workload == "paint" else
                            "RCCL reduce-scatter of the offsets, regrid of the rank's pixel range, all-reduce of the map")

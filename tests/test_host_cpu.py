@@ -239,7 +239,7 @@ def test_shard_by_sky_patch_contiguous_partitions_and_balances(world):
     ra, dec, M, z = syn.catalog(20000, seed=3)
     w = sharding.estimate_disc_pixels(syn.COSMO, M, z, 10, 1024)
     assert np.all(w > 16) and np.isfinite(w).all()
-    shards = sharding.shard_by_sky_patch(ra, dec, w, world)               # the default layout
+    shards = sharding.shard_by_sky_patch(ra, dec, w, world, nside_patch=8, layout="contiguous")
     assert len(shards) == world
     allidx = np.concatenate(shards)
     assert np.array_equal(np.sort(allidx), np.arange(20000))            # disjoint and complete
@@ -257,14 +257,14 @@ def test_shard_by_sky_patch_contiguous_partitions_and_balances(world):
 def test_shard_by_sky_patch_interleaved_covers_the_sky_on_every_rank(world):
     ra, dec, M, z = syn.catalog(40000, seed=4)
     w = sharding.estimate_disc_pixels(syn.COSMO, M, z, 10, 1024)
-    shards = sharding.shard_by_sky_patch(ra, dec, w, world, nside_patch=64, layout="interleaved")
+    shards = sharding.shard_by_sky_patch(ra, dec, w, world)               # the default layout: NSIDE-64 patches, interleaved
     assert len(shards) == world
     assert np.array_equal(np.sort(np.concatenate(shards)), np.arange(40000))      # disjoint and complete
     loads = np.array([w[s].sum() for s in shards])
     assert loads.max() / loads.mean() < 1.1
     patch = sharding.ang2pix_nest(64, ra, dec)
     for r, s in enumerate(shards):
-        assert np.all(np.diff(s) > 0)                                   # the caller's halo order is kept
+        assert np.all(np.diff(sharding.ang2pix_nest(1024, ra[s], dec[s])) >= 0)   # sorted by position inside a shard
         if world > 1:
             assert np.all(patch[s] % world == r)                        # whole patches, dealt round-robin
             assert np.unique(sharding.ang2pix_nest(2, ra[s], dec[s])).size == 48   # every rank sees the whole sky

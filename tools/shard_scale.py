@@ -11,6 +11,7 @@ from baryonforge_amd.background import Background
 from baryonforge_amd.engine import get_context
 
 halos = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+strong = len(sys.argv) > 2 and sys.argv[2] == "strong"          # `halos` in total, cut into `world` shards
 nside, eps = 1024, 10.0
 cosmo = dict(syn.COSMO)
 ctx = get_context(0)
@@ -21,18 +22,17 @@ with np.errstate(all="ignore"):
     table = ctx.table([zax, Max, rax], np.log(T), log_values=True)
 d_map = ctx.zeros(12 * nside * nside)
 for world in (1, 2, 4, 8):
-    ra, dec, M, z = syn.catalog(halos * world, seed=42)
+    ra, dec, M, z = syn.catalog(halos if strong else halos * world, seed=42)
     spline = ctx.da_spline(bg, float(np.max(z)))
     if world > 1:
         w = sharding.estimate_disc_pixels(cosmo, M, z, eps, nside)
-        kw = {"layout": os.environ.get("LAYOUT", "contiguous")}
-        if os.environ.get("PATCH"):
-            kw["nside_patch"] = int(os.environ["PATCH"])
-        elif kw["layout"] == "interleaved":
-            kw["nside_patch"] = 64
+        kw = {}                                          # the library's default: NSIDE-64 patches, interleaved
+        if os.environ.get("LAYOUT"):
+            kw["layout"] = os.environ["LAYOUT"]
+            kw["nside_patch"] = int(os.environ.get("PATCH", 8 if kw["layout"] == "contiguous" else 64))
         shards = sharding.shard_by_sky_patch(ra, dec, w, world, **kw)
     else:
-        shards = [np.arange(halos)]
+        shards = [np.arange(ra.size)]                    # (the caller's order, as bench.py at N = 1)
     for rank in sorted(set([0, world // 2, world - 1])):
         idx = shards[rank]
         d_cat = ctx.to_device(np.stack([M[idx], z[idx], ra[idx], dec[idx]], axis=1))
