@@ -109,17 +109,27 @@ class DefaultRunner(object):
         z_m = max(z_m, getattr(self, "_spline_z_max", z_m))              # a shard of a split catalog: the whole catalog's max(z)
         bg = Background(self.cosmo)
         spline = ctx.da_spline(bg, z_m)                                  # :297-299 / :429-431
-        recs = self.HaloLightConeCatalog.records(keys) if hasattr(self.HaloLightConeCatalog, "records") else \
-            np.stack([np.asarray(cat[c], dtype=np.float64) for c in ["M", "z", "ra", "dec"] + keys], axis=1)
-        d_cat = ctx.to_device(recs)
-        return bg, spline, d_cat, recs.shape[1]
+        if hasattr(self.HaloLightConeCatalog, "device_records"):         # uploaded once per catalog object (utils/io.py)
+            d_cat, stride = self.HaloLightConeCatalog.device_records(ctx, keys)
+        else:                                                            # a catalog object of the real BaryonForge
+            recs = np.stack([np.asarray(cat[c], dtype=np.float64) for c in ["M", "z", "ra", "dec"] + keys], axis=1)
+            d_cat, stride = ctx.to_device(recs), recs.shape[1]
+        return bg, spline, d_cat, stride
 
 
 class PaintProfilesShell(DefaultRunner):
     """Paint a tabulated projected profile around every halo onto the shell (HealpixRunner.py:376-483)."""
 
-    def process_device(self, d_map=None):
-        """Paint into a device map (float64[Npix] torch tensor, zero-initialised if not given) and return it."""
+    def process_device(self, d_map=None, overwrite=None, slices=1, on_slice=None, sync_stats=True):
+        """Paint into a device map (float64[Npix] torch tensor) and return it.
+
+        d_map=None: a fresh map, defined entirely by the call.  A given map is accumulated INTO unless overwrite=True
+        (its previous contents are then ignored: BFG_SHELL_OUT_OVERWRITE).
+        slices, on_slice: bfg_paint_shell_sliced -- on_slice(k, n, lo, hi) is called after the k-th of n slices of the map,
+        d_map[lo:hi], has been enqueued: it is final once the current stream gets there, so an exchange of that slice can
+        start while the next one is painted (utils.Parallelize.SplitJoinParallel).
+        sync_stats=False: do not read the counters back (that synchronises the stream); `collect_stats()` does it later --
+        what a pipeline over several shells wants."""
         assert self.model is not None, "You must provide a model"         # :446
         keys = self._keys_checked()
         if not _is_paint_table(self.model):
@@ -141,12 +151,20 @@ class PaintProfilesShell(DefaultRunner):
             d_map = ctx.empty(12 * NSIDE * NSIDE)                         # :424 -- the zeros come from the kernels (OUT_OVERWRITE)
         args = ctx.shell_args(NSIDE, d_cat, d_cat.shape[0], stride, len(keys), self.epsilon_max,
                               ctx.massdef_struct(bg, self.mass_def), include_pixel_size=self.include_pixel_size,
-                              variant=self.variant, out_overwrite=fresh)
-        ctx.stats_reset()
-        ctx.paint_shell(args, table, spline, d_map)
-        self.last_stats = ctx.stats()
-        emit_fallback_warning(self.last_stats)
+                              variant=self.variant, out_overwrite=fresh if overwrite is None else bool(overwrite))
+        if sync_stats:
+            ctx.stats_reset()
+        ctx.paint_shell(args, table, spline, d_map, slices=slices, on_slice=on_slice)
+        self.last_stats = None
+        if sync_stats:
+            self.collect_stats()
         return d_map
+
+    def collect_stats(self):
+        """read the device counters (synchronises the stream), keep them in `last_stats`, emit the warnings"""
+        self.last_stats = get_context().stats()
+        emit_fallback_warning(self.last_stats)
+        return self.last_stats
 
     def process(self):
         """returns new_map : float64[Npix] (RING), the sum over halos of the painted profiles"""
@@ -298,10 +316,10 @@ class BaryonifyShell(DefaultRunner):
         in halos (:355), so it is summed across the ranks -- by a reduce-scatter, because every rank regrids only the
         sources of the pixel range it owns (:357-365 on that range) --, and the regridded maps, whose deposits can cross
         the range borders, are all-reduced."""
-        return _baryonify_process(self, _DeviceOps(self), distributed)
+        return _baryonify_process(self, _BaryonifyDeviceOps(self), distributed)
 
 
-class _DeviceOps(object):
+class _BaryonifyDeviceOps(object):
     """the GPU side of BaryonifyShell.process: HBM tensors and C-ABI calls"""
 
     def __init__(self, runner):
@@ -327,8 +345,8 @@ class _DeviceOps(object):
 
 
 def _baryonify_process(runner, ops, exchange):
-    """BaryonifyShell.process (HealpixRunner.py:252-373) over an `ops` object (the GPU, or the test seam of
-    utils.Parallelize) and an optional Exchange between ranks"""
+    """BaryonifyShell.process (HealpixRunner.py:252-373) over an `ops` object (the device side: _BaryonifyDeviceOps) and an
+    optional Exchange between ranks"""
     orig_map = runner.LightconeShell.map
     NSIDE = runner.LightconeShell.NSIDE
     if orig_map.size < (1 << 16) and np.allclose(orig_map, 0):         # small maps: decided on the host, as the reference

@@ -41,7 +41,11 @@ SYMBOLS = [
     "bfg_stats_reset", "bfg_stats_read", "bfg_timing_enable", "bfg_timing_select", "bfg_timing_read",
     "bfg_comm_unique_id", "bfg_comm_init", "bfg_comm_destroy", "bfg_comm_info",
     "bfg_allreduce_f64", "bfg_allreduce_f64_begin", "bfg_comm_wait", "bfg_reduce_scatter_f64", "bfg_allgather_f64",
+    "bfg_reduce_scatter_f64_begin", "bfg_paint_shell_sliced", "bfg_baryonify_offsets_sliced",
 ]
+ABI_VERSION = 2
+# bfg_slice_fn: int (*)(void *user, int slice, int n_slices, int64_t elem_begin, int64_t elem_end)
+SLICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64)
 BFG_COMM_ID_BYTES = 128
 
 
@@ -124,8 +128,9 @@ def load(build_if_missing=True):
     L.bfg_comm_destroy.argtypes = [_vp]
     L.bfg_comm_info.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.bfg_allreduce_f64.argtypes = [_vp, _vp, _i64]
-    L.bfg_allreduce_f64_begin.argtypes = [_vp, _vp, _i64]
-    L.bfg_comm_wait.argtypes = [_vp]
+    L.bfg_allreduce_f64_begin.argtypes = [_vp, _vp, _i64, C.POINTER(_i64)]
+    L.bfg_reduce_scatter_f64_begin.argtypes = [_vp, _vp, _i64, C.POINTER(_i64)]
+    L.bfg_comm_wait.argtypes = [_vp, _i64]
     L.bfg_reduce_scatter_f64.argtypes = [_vp, _vp, _i64]
     L.bfg_allgather_f64.argtypes = [_vp, _vp, _i64]
     L.bfg_ctx_synchronize.argtypes = [_vp]
@@ -154,6 +159,8 @@ def load(build_if_missing=True):
                                                C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_dbl), _vp,
                                                C.POINTER(C.c_int32)]
     L.bfg_baryonify_offsets.argtypes = [_vp, C.POINTER(ShellArgs), _vp, _vp, _vp]
+    L.bfg_paint_shell_sliced.argtypes = [_vp, C.POINTER(ShellArgs), _vp, _vp, _vp, C.c_int, SLICE_FN, _vp]
+    L.bfg_baryonify_offsets_sliced.argtypes = [_vp, C.POINTER(ShellArgs), _vp, _vp, _vp, C.c_int, SLICE_FN, _vp]
     L.bfg_regrid_shell.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp]
     L.bfg_reduce_absmax_sum.argtypes = [_vp, _i64, _vp, C.POINTER(_dbl), C.POINTER(_dbl)]
     L.bfg_stats_reset.argtypes = [_vp]
@@ -164,7 +171,7 @@ def load(build_if_missing=True):
     for name in SYMBOLS:
         if name not in ("bfg_status_string", "bfg_last_error"):
             getattr(L, name).restype = C.c_int
-    if L.bfg_abi_version() != 1:
+    if L.bfg_abi_version() != ABI_VERSION:
         raise BFGError("libbfg_mi355.so ABI version mismatch")
     _lib = L
     return L

@@ -7,15 +7,17 @@
 // users never load it.  One communicator per context = per GPU = per process.
 #pragma once
 #include <dlfcn.h>
+#include <mutex>
 #include <rccl/rccl.h>
 
+constexpr int kCommTickets = 32;   // ring of completion events; a recycled slot only ever makes a waiter wait longer
 struct bfg_comm_state {
     ncclComm_t comm;
     int rank, world;
-    hipStream_t side;        // the communication stream of bfg_allreduce_f64_begin (created on first use)
+    hipStream_t side;        // the communication stream of bfg_*_begin (created on first use)
     hipEvent_t ev_ready;     // context stream -> communication stream: the buffer has been produced
-    hipEvent_t ev_done;      // communication stream -> context stream: the collectives begun so far have finished
-    bool pending;
+    hipEvent_t ev_done[kCommTickets];   // communication stream -> context stream: collective `ticket` has finished
+    int64_t issued;          // tickets handed out so far (ticket k uses ev_done[k % kCommTickets])
 };
 
 namespace bfg_rccl {
@@ -30,21 +32,24 @@ struct Api {
     const char *(*GetErrorString)(ncclResult_t);
 };
 
-static Api g_api;
-static bool g_tried = false;
+static Api g_api;                 // handle == nullptr: not loaded
+static std::string g_load_error;  // why (set once, under the once-flag; copied into the caller's g_last_error)
+static std::once_flag g_once;
 
-static const Api *api()
+static void load_once()
 {
-    if (g_tried) return g_api.handle ? &g_api : nullptr;
-    g_tried = true;
     const char *names[] = {std::getenv("BFG_RCCL_SO"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;
+    std::string why;
     for (const char *n : names) {
         if (!n || !*n) continue;
         h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (h) break;
+        const char *e = dlerror();                    // one call: glibc clears the message when it is read
+        if (why.empty()) why = e ? e : "not found";   // the first candidate's reason (BFG_RCCL_SO if set)
+        if (n == names[0]) break;                     // an explicit BFG_RCCL_SO that does not load is an error, not a hint
     }
-    if (!h) { g_last_error = std::string("dlopen(librccl.so.1): ") + (dlerror() ? dlerror() : "not found"); return nullptr; }
+    if (!h) { g_load_error = "dlopen(librccl.so.1): " + (why.empty() ? std::string("not found") : why); return; }
     Api a;
     a.handle = h;
     a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
@@ -56,11 +61,18 @@ static const Api *api()
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
     if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.ReduceScatter || !a.AllGather ||
         !a.GetErrorString) {
-        g_last_error = "librccl.so.1 lacks one of the nccl* entry points";
-        return nullptr;
+        g_load_error = "librccl.so.1 lacks one of the nccl* entry points";
+        return;
     }
     g_api = a;
-    return &g_api;
+}
+
+static const Api *api()
+{
+    std::call_once(g_once, load_once);
+    if (g_api.handle) return &g_api;
+    g_last_error = g_load_error;
+    return nullptr;
 }
 }  // namespace bfg_rccl
 
@@ -78,7 +90,7 @@ static void bfg_comm_release(bfg_ctx *c)
     if (!c->comm) return;
     if (c->comm->side) { (void)hipStreamSynchronize(c->comm->side); (void)hipStreamDestroy(c->comm->side); }
     if (c->comm->ev_ready) (void)hipEventDestroy(c->comm->ev_ready);
-    if (c->comm->ev_done) (void)hipEventDestroy(c->comm->ev_done);
+    for (hipEvent_t e : c->comm->ev_done) if (e) (void)hipEventDestroy(e);
     if (const bfg_rccl::Api *A = bfg_rccl::api()) (void)A->CommDestroy(c->comm->comm);
     delete c->comm;
     c->comm = nullptr;
@@ -111,7 +123,8 @@ int bfg_comm_init(bfg_ctx *c, const char *id, size_t id_bytes, int rank, int wor
     std::memcpy(uid.internal, id, NCCL_UNIQUE_ID_BYTES);
     ncclComm_t comm;
     RCCL_TRY(A, A->CommInitRank(&comm, world, uid, rank));
-    c->comm = new bfg_comm_state{comm, rank, world, nullptr, nullptr, nullptr, false};
+    c->comm = new bfg_comm_state();
+    c->comm->comm = comm; c->comm->rank = rank; c->comm->world = world;
     return BFG_OK;
 }
 
@@ -149,41 +162,80 @@ int bfg_allreduce_f64(bfg_ctx *c, double *d_buf, int64_t count)
     return BFG_OK;
 }
 
-// The same sum on the context's COMMUNICATION stream, so that it overlaps whatever the caller enqueues next on the
-// context's stream (the painting of the next shell into another buffer): the collective is ordered after everything
-// enqueued on the context's stream so far; bfg_comm_wait makes the context's stream wait for all collectives begun so
-// far (before the buffer is read, zeroed or reused).
-int bfg_allreduce_f64_begin(bfg_ctx *c, double *d_buf, int64_t count)
+// The collectives below run on the context's COMMUNICATION stream, so that they overlap whatever the caller enqueues next on
+// the context's stream (the next slice of the same map, the next shell in another buffer): a collective is ordered after
+// everything enqueued on the context's stream so far and gets a ticket; bfg_comm_wait(ticket) makes the context's stream wait
+// for that collective only (and, the communication stream being in order, the ones begun before it).
+static int comm_side_begin(bfg_ctx *c, const bfg_rccl::Api *A, int64_t *ticket, hipEvent_t *done)
 {
-    DeviceGuard dg_;
-    int rc = ctx_enter(c, dg_);
-    if (rc) return rc;
-    if (count < 0 || (count > 0 && !d_buf)) return BFG_ERR_INVALID;
-    if (!c->comm || c->comm->world == 1 || count == 0) return BFG_OK;
-    const bfg_rccl::Api *A = bfg_rccl::api();
-    if (!A) return BFG_ERR_COMM;
+    (void)A;
     bfg_comm_state *m = c->comm;
     if (!m->side) {
         HIP_TRY(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&m->ev_ready, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&m->ev_done, hipEventDisableTiming));
     }
+    const int64_t tk = m->issued + 1;
+    hipEvent_t &ev = m->ev_done[tk % kCommTickets];
+    if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(m->ev_ready, c->stream));
     HIP_TRY(hipStreamWaitEvent(m->side, m->ev_ready, 0));
-    RCCL_TRY(A, A->AllReduce(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum, m->comm, m->side));
-    HIP_TRY(hipEventRecord(m->ev_done, m->side));
-    m->pending = true;
+    *ticket = tk; *done = ev;
     return BFG_OK;
 }
 
-int bfg_comm_wait(bfg_ctx *c)
+int bfg_allreduce_f64_begin(bfg_ctx *c, double *d_buf, int64_t count, int64_t *ticket)
 {
     DeviceGuard dg_;
     int rc = ctx_enter(c, dg_);
     if (rc) return rc;
-    if (!c->comm || !c->comm->pending) return BFG_OK;
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->comm->ev_done, 0));
-    c->comm->pending = false;
+    if (ticket) *ticket = 0;
+    if (count < 0 || (count > 0 && !d_buf)) return BFG_ERR_INVALID;
+    if (!c->comm || c->comm->world == 1 || count == 0) return BFG_OK;
+    const bfg_rccl::Api *A = bfg_rccl::api();
+    if (!A) return BFG_ERR_COMM;
+    int64_t tk; hipEvent_t done;
+    rc = comm_side_begin(c, A, &tk, &done);
+    if (rc) return rc;
+    RCCL_TRY(A, A->AllReduce(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum, c->comm->comm, c->comm->side));
+    HIP_TRY(hipEventRecord(done, c->comm->side));
+    c->comm->issued = tk;
+    if (ticket) *ticket = tk;
+    return BFG_OK;
+}
+
+int bfg_reduce_scatter_f64_begin(bfg_ctx *c, double *d_buf, int64_t count, int64_t *ticket)
+{
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
+    if (rc) return rc;
+    if (ticket) *ticket = 0;
+    if (count < 0 || (count > 0 && !d_buf)) return BFG_ERR_INVALID;
+    if (!c->comm || c->comm->world == 1 || count == 0) return BFG_OK;
+    if (count % c->comm->world) return BFG_ERR_INVALID;
+    const bfg_rccl::Api *A = bfg_rccl::api();
+    if (!A) return BFG_ERR_COMM;
+    int64_t tk; hipEvent_t done;
+    rc = comm_side_begin(c, A, &tk, &done);
+    if (rc) return rc;
+    const size_t chunk = (size_t)(count / c->comm->world);
+    RCCL_TRY(A, A->ReduceScatter(d_buf, d_buf + chunk * (size_t)c->comm->rank, chunk, ncclDouble, ncclSum, c->comm->comm,
+                                 c->comm->side));
+    HIP_TRY(hipEventRecord(done, c->comm->side));
+    c->comm->issued = tk;
+    if (ticket) *ticket = tk;
+    return BFG_OK;
+}
+
+int bfg_comm_wait(bfg_ctx *c, int64_t ticket)
+{
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
+    if (rc) return rc;
+    if (!c->comm || c->comm->issued == 0) return BFG_OK;
+    if (ticket < 0 || ticket > c->comm->issued) return BFG_ERR_INVALID;
+    if (ticket == 0) ticket = c->comm->issued;                   // everything begun so far
+    // a slot recycled by a later ticket makes this wait for that later collective: still correct, the stream is in order
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->comm->ev_done[ticket % kCommTickets], 0));
     return BFG_OK;
 }
 

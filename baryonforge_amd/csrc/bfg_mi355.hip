@@ -108,6 +108,7 @@ struct bfg_ctx {
         int cap_direct;             // fixed pair slots per tile of the current call
         int32_t *d_nwork;
         int32_t *d_shared;          // [ntiles] 1: the tile's pair list was cut into several work items (atomics on the map)
+        int32_t *d_slices;          // [3 kMaxSlices] sliced calls: item range per slice | work counter per slice
     } tiles[3];                     // [MODE_PAINT], [MODE_BARYONIFY], [2] = the regrid kernel's tiles
     int32_t *d_pairs;              // [ntiles * cap_direct] slots | [pair_cap] overflow lists
     unsigned long long *d_ovf_mask; // [cap_halo]
@@ -1175,6 +1176,7 @@ static void ctx_free_all(bfg_ctx *c)
         if (c->tiles[m].d_defer) (void)hipFree(c->tiles[m].d_defer);
         if (c->tiles[m].d_defer_count) (void)hipFree(c->tiles[m].d_defer_count);
         if (c->tiles[m].d_shared) (void)hipFree(c->tiles[m].d_shared);
+        if (c->tiles[m].d_slices) (void)hipFree(c->tiles[m].d_slices);
     }
     if (c->d_hd) (void)hipFree(c->d_hd);
     if (c->d_left) (void)hipFree(c->d_left);
@@ -1499,6 +1501,16 @@ static void timing_end(bfg_ctx *c, int which)
     c->ev_used[which] += 1;
 }
 
+// sectors per band: the longest ring of the band cut into pieces of at most tw pixels
+static int band_sectors_host(int64_t nside, int tr, int tw, int b)
+{
+    const int64_t nrings = 4 * nside - 1;
+    const int64_t lo = 1 + (int64_t)b * tr, hi = std::min<int64_t>(nrings, lo + tr - 1);
+    int64_t mx = 0;
+    for (int64_t r = lo; r <= hi; ++r) mx = std::max(mx, (r < nside) ? 4 * r : (r <= 3 * nside ? 4 * nside : 4 * (4 * nside - r)));
+    return (int)((mx + tw - 1) / tw);
+}
+
 // tile geometry of one (nside, rings-per-tile) (cached per mode) and the binning buffers
 constexpr int kRegridSet = 2, kRegridTR = 64;     // regrid_tile_kernel: 64-ring x kTileWidth tiles of source pixels
 static int ensure_tiles(bfg_ctx *c, int mode, int tr, int tw, int64_t nside, int64_t n_halo)
@@ -1509,7 +1521,8 @@ static int ensure_tiles(bfg_ctx *c, int mode, int tr, int tw, int64_t nside, int
         if (ts.d_geo) { (void)hipFree(ts.d_geo); (void)hipFree(ts.d_tile_count); (void)hipFree(ts.d_tile_start); (void)hipFree(ts.d_work); (void)hipFree(ts.d_nwork); }
         if (ts.d_defer) { (void)hipFree(ts.d_defer); (void)hipFree(ts.d_defer_count); }
         if (ts.d_shared) (void)hipFree(ts.d_shared);
-        ts.d_shared = nullptr;
+        if (ts.d_slices) (void)hipFree(ts.d_slices);
+        ts.d_shared = nullptr; ts.d_slices = nullptr;
         ts.d_geo = nullptr; ts.d_tile_count = nullptr; ts.d_tile_start = nullptr; ts.d_work = nullptr; ts.d_nwork = nullptr; ts.nside = 0;
         ts.d_defer = nullptr; ts.d_defer_count = nullptr;
         const int64_t nrings = 4 * nside - 1;
@@ -1544,6 +1557,7 @@ static int ensure_tiles(bfg_ctx *c, int mode, int tr, int tw, int64_t nside, int
         HIP_TRY(hipMalloc((void **)&ts.d_work, (size_t)(2 * ntiles + kWorkExtra) * 2 * sizeof(int4)));
         HIP_TRY(hipMalloc((void **)&ts.d_nwork, 2 * sizeof(int32_t)));     // [0] items in the work list, [1] the tile kernel's item counter
         HIP_TRY(hipMalloc((void **)&ts.d_shared, (size_t)ntiles * sizeof(int32_t)));
+        HIP_TRY(hipMalloc((void **)&ts.d_slices, (size_t)3 * kMaxSlices * sizeof(int32_t)));
         if (mode == MODE_PAINT) {
             // a failed allocation (the list is ~1 KB per work item) only means the tile workgroups drain their own queues
             const size_t items = (size_t)(2 * ntiles + kWorkExtra);
@@ -1593,8 +1607,29 @@ static int check_args(const bfg_shell_args *a, const bfg_table *t, const bfg_spl
     return BFG_OK;
 }
 
+// Sliced calls: the left-over scatter kernel runs BEFORE the tile kernels (a slice of the output must be final when its tile
+// launch ends).  If there is anything left over (usually not) the output is cleared here, the scatter kernel adds to it and the
+// tile kernels add their tiles instead of storing them (TileParams::accum_left); otherwise this kernel returns at once.
+__global__ __launch_bounds__(256) void out_clear_if_left_kernel(double *out, int64_t n, const int32_t *left_n, const int32_t *pair_total,
+                                                                long long pair_cap)
+{
+    if (!(*left_n > 0 || (long long)*pair_total > pair_cap)) return;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = 0.0;
+}
+
+// first RING pixel of ring `ring` (1 .. 4 nside - 1; 4 nside -> npix)
+static int64_t ring_first_pixel(int64_t nside, int64_t ring)
+{
+    const int64_t npix = 12 * nside * nside, ncap = 2 * nside * (nside - 1);
+    if (ring >= 4 * nside) return npix;
+    if (ring < nside) return 2 * ring * (ring - 1);
+    if (ring < 3 * nside) return ncap + (ring - nside) * 4 * nside;
+    const int64_t nr = 4 * nside - ring;
+    return npix - 2 * nr * (nr + 1);
+}
+
 static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, const bfg_spline *s,
-                     double *d_out, int mode)
+                     double *d_out, int mode, int n_slices = 1, bfg_slice_fn slice_fn = nullptr, void *slice_user = nullptr)
 {
     DeviceGuard dg_;
     int rc = ctx_enter(c, dg_);
@@ -1608,9 +1643,15 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     const size_t out_bytes = (size_t)12 * a->nside * a->nside * sizeof(double) * (mode == MODE_PAINT ? 1 : 3);
     bool overwrite = (a->flags & BFG_SHELL_OUT_OVERWRITE) != 0;
     bool out_zero = (a->flags & BFG_SHELL_OUT_IS_ZERO) != 0;
+    const int64_t out_elems = (int64_t)(out_bytes / sizeof(double));
+    // a call that is not cut into slices (no halos, scatter variants, the wave kernel) reports the whole output as one slice
+    auto whole_output = [&]() -> int {
+        if (slice_fn && slice_fn(slice_user, 0, 1, 0, out_elems) != 0) { g_last_error = "the slice callback failed"; return BFG_ERR_INVALID; }
+        return BFG_OK;
+    };
     if (a->n_halo == 0) {
         if (overwrite) HIP_TRY(hipMemsetAsync(d_out, 0, out_bytes, c->stream));
-        return BFG_OK;
+        return whole_output();
     }
     rc = ensure_workspace(c, a->n_halo);
     if (rc) return rc;
@@ -1717,6 +1758,33 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     sp.pixfac_area = pixfac_area;
     sp.out = d_out; sp.stats = c->d_stats;
 
+    // the global-atomic kernel: every halo (scatter variants) or the tile path's left-overs (sp.left, set below)
+    auto launch_scatter = [&]() -> int {
+        const int G = (variant == BFG_VARIANT_SCATTER_WAVE) ? 64 : 16;
+        const int tslot = (variant == BFG_VARIANT_TILE_LDS) ? 4 : 1;
+        const int gpb = 256 / G;
+        // LDS: ring records + per-group (axis, value) window; keep a block at or under 64 KiB
+        const size_t ring_bytes = (G == 64 ? sizeof(RingLds<64>) : sizeof(RingLds<16>)) * (size_t)gpb;
+        size_t budget = 64 * 1024 - ring_bytes;
+        int win = (int)std::min<int64_t>(t->dev.nr, (int64_t)(budget / (sizeof(double2) * (size_t)gpb)));
+        if (win < 2) return BFG_ERR_UNSUPPORTED;
+        sp.win_nodes = win;
+        const size_t lds = ring_bytes + (size_t)win * sizeof(double2) * (size_t)gpb;
+        unsigned grid = (unsigned)((a->n_halo + gpb - 1) / gpb);
+        if (sp.left) grid = std::min(grid, 512u);       // fixed grid striding over the left-over list (usually empty); two blocks per CU fit
+        timing_begin(c, tslot);
+        if (mode == MODE_PAINT) {
+            if (G == 64) hipLaunchKernelGGL((shell_scatter_kernel<64, MODE_PAINT>), dim3(grid), dim3(256), lds, c->stream, sp);
+            else hipLaunchKernelGGL((shell_scatter_kernel<16, MODE_PAINT>), dim3(grid), dim3(256), lds, c->stream, sp);
+        } else {
+            if (G == 64) hipLaunchKernelGGL((shell_scatter_kernel<64, MODE_BARYONIFY>), dim3(grid), dim3(256), lds, c->stream, sp);
+            else hipLaunchKernelGGL((shell_scatter_kernel<16, MODE_BARYONIFY>), dim3(grid), dim3(256), lds, c->stream, sp);
+        }
+        HIP_TRY(hipGetLastError());
+        timing_end(c, tslot);
+        return BFG_OK;
+    };
+
     if (tile) {
         timing_begin(c, 3);
         const bfg_ctx::TileSet &ts = c->tiles[mode];
@@ -1730,10 +1798,28 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         int persist = c->n_cu * (light ? 3 : 2);
         if (const char *e = std::getenv("BFG_TILE_PERSIST")) persist = std::atoi(e) > 1 ? std::atoi(e) : (std::atoi(e) ? persist : 0);
         const int tile_grid = persist > 0 ? std::min(persist, items_max) : items_max;
+        // sliced call: cut the tiles into n_slices runs of whole bands (contiguous ring ranges = contiguous RING pixel ranges)
+        SliceCuts cuts;
+        std::memset(&cuts, 0, sizeof(cuts));
+        int64_t slice_elem[kMaxSlices + 1];
+        const bool wave_requested = use_wave && win_nodes == kWinLds && !win_table;
+        if (slice_fn && n_slices > 1 && persist > 0 && !wave_requested) {
+            const int K = std::min(std::min(n_slices, kMaxSlices), ts.geo.nbands);
+            const int per = (mode == MODE_PAINT) ? 1 : 3;
+            int b = 0, tile0 = 0;
+            for (int k = 0; k <= K; ++k) {
+                const int bk = (int)((int64_t)ts.geo.nbands * k / K);
+                for (; b < bk; ++b) tile0 += band_sectors_host(a->nside, ts.geo.tr, ts.geo.tw, b);
+                cuts.tile[k] = tile0;
+                slice_elem[k] = per * ring_first_pixel(a->nside, 1 + (int64_t)bk * ts.geo.tr);
+            }
+            if (cuts.tile[K] != ts.geo.ntiles) { g_last_error = "slice cuts do not cover the tiles"; return BFG_ERR_INVALID; }
+            cuts.n = K; cuts.range = ts.d_slices; cuts.counter = ts.d_slices + 2 * kMaxSlices;
+        }
         hipLaunchKernelGGL(tile_scan_kernel, dim3((unsigned)(1 + (ts.geo.ntiles + 1023) / 1024)), dim3(1024), 0, c->stream, ts.geo,
                            ts.cap_direct, pp.bin.tile_count, ts.d_tile_start, ts.d_work, ts.d_nwork, ts.d_nwork + 1, 3 * tile_grid,
                            overwrite ? 1 : 0, ts.d_shared, pp.bin.tile_count + ts.geo.ntiles + 1,
-                           ts.d_tile_count + (size_t)(1 - ts.flip) * (ts.geo.ntiles + 2));
+                           ts.d_tile_count + (size_t)(1 - ts.flip) * (ts.geo.ntiles + 2), cuts);
         c->tiles[mode].flip = 1 - ts.flip;             // the next call counts in the set this scan kernel clears
         c->tiles[mode].counting = false;
         FillParams fp;
@@ -1802,6 +1888,22 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         const bool wl = win_nodes <= kWinLds;
         // wave-private chunks (bfg_wtile.hpp) need the 32-node LDS-staged windows
         use_wave = use_wave && wl && win_nodes == kWinLds && !win_table;
+        sp.only_flagged = 1;     // leftovers: halos the binning left to the global-atomic kernel
+        sp.left = c->d_left; sp.left_n = pp.left_n;
+        sp.pair_total_ptr = ts.d_tile_start + ts.geo.ntiles; sp.pair_cap = c->pair_cap;
+        if (cuts.n > 0) {
+            // sliced: left-overs first (into a cleared output, if there are any), then one tile launch per slice, each followed by
+            // the caller's callback -- which typically starts the exchange of that part of the output on another stream
+            hipLaunchKernelGGL(out_clear_if_left_kernel, dim3((unsigned)(4 * c->n_cu)), dim3(256), 0, c->stream, d_out, out_elems,
+                               pp.left_n, ts.d_tile_start + ts.geo.ntiles, (long long)c->pair_cap);
+            HIP_TRY(hipGetLastError());
+            rc = launch_scatter();
+            if (rc) return rc;
+            tp.accum_left = pp.left_n;
+        }
+        const int n_launch = cuts.n > 0 ? cuts.n : 1;
+        for (int islice = 0; islice < n_launch; ++islice) {
+        if (cuts.n > 0) { tp.slice = cuts.range + 2 * islice; tp.work_counter = cuts.counter + islice; }
         timing_begin(c, 1);
         if (use_wave) {
             const dim3 wblock(kWaveThreads), wgrid((unsigned)items_max);      // one workgroup per work item
@@ -1833,33 +1935,16 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
             HIP_TRY(hipGetLastError());
             timing_end(c, 5);
         }
-        sp.only_flagged = 1;     // leftovers: halos the binning left to the global-atomic kernel
-        sp.left = c->d_left; sp.left_n = pp.left_n;
-        sp.pair_total_ptr = ts.d_tile_start + ts.geo.ntiles; sp.pair_cap = c->pair_cap;
+        if (cuts.n > 0 && slice_fn(slice_user, islice, cuts.n, slice_elem[islice], slice_elem[islice + 1]) != 0) {
+            g_last_error = "the slice callback failed";
+            return BFG_ERR_INVALID;
+        }
+        }   // slices
+        if (cuts.n > 0) return BFG_OK;
     }
-    const int G = (variant == BFG_VARIANT_SCATTER_WAVE) ? 64 : 16;
-    const int tslot = (variant == BFG_VARIANT_TILE_LDS) ? 4 : 1;
-    const int gpb = 256 / G;
-    // LDS: ring records + per-group (axis, value) window; keep a block at or under 64 KiB
-    const size_t ring_bytes = (G == 64 ? sizeof(RingLds<64>) : sizeof(RingLds<16>)) * (size_t)gpb;
-    size_t budget = 64 * 1024 - ring_bytes;
-    int win = (int)std::min<int64_t>(t->dev.nr, (int64_t)(budget / (sizeof(double2) * (size_t)gpb)));
-    if (win < 2) return BFG_ERR_UNSUPPORTED;
-    sp.win_nodes = win;
-    const size_t lds = ring_bytes + (size_t)win * sizeof(double2) * (size_t)gpb;
-    unsigned grid = (unsigned)((a->n_halo + gpb - 1) / gpb);
-    if (sp.left) grid = std::min(grid, 512u);           // fixed grid striding over the left-over list (usually empty); two blocks per CU fit
-    timing_begin(c, tslot);
-    if (mode == MODE_PAINT) {
-        if (G == 64) hipLaunchKernelGGL((shell_scatter_kernel<64, MODE_PAINT>), dim3(grid), dim3(256), lds, c->stream, sp);
-        else hipLaunchKernelGGL((shell_scatter_kernel<16, MODE_PAINT>), dim3(grid), dim3(256), lds, c->stream, sp);
-    } else {
-        if (G == 64) hipLaunchKernelGGL((shell_scatter_kernel<64, MODE_BARYONIFY>), dim3(grid), dim3(256), lds, c->stream, sp);
-        else hipLaunchKernelGGL((shell_scatter_kernel<16, MODE_BARYONIFY>), dim3(grid), dim3(256), lds, c->stream, sp);
-    }
-    HIP_TRY(hipGetLastError());
-    timing_end(c, tslot);
-    return BFG_OK;
+    rc = launch_scatter();
+    if (rc) return rc;
+    return whole_output();
 }
 
 int bfg_paint_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, const bfg_spline *s, double *d_map)
@@ -1871,6 +1956,20 @@ int bfg_baryonify_offsets(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *
                           double *d_offsets)
 {
     return run_shell(c, a, t, s, d_offsets, MODE_BARYONIFY);
+}
+
+int bfg_paint_shell_sliced(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, const bfg_spline *s, double *d_map,
+                           int n_slices, bfg_slice_fn fn, void *user)
+{
+    if (n_slices < 1 || !fn) return BFG_ERR_INVALID;
+    return run_shell(c, a, t, s, d_map, MODE_PAINT, n_slices, fn, user);
+}
+
+int bfg_baryonify_offsets_sliced(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, const bfg_spline *s,
+                                 double *d_offsets, int n_slices, bfg_slice_fn fn, void *user)
+{
+    if (n_slices < 1 || !fn) return BFG_ERR_INVALID;
+    return run_shell(c, a, t, s, d_offsets, MODE_BARYONIFY, n_slices, fn, user);
 }
 
 int bfg_regrid_shell(bfg_ctx *c, int64_t nside, const double *d_offsets, const double *d_in_map,

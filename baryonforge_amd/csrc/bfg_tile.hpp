@@ -201,7 +201,14 @@ struct TileParams {
                                      // after its last item (defer_tail) or by tile_deferred_kernel; null: every item drains its own
     int32_t *defer_count;            // [grid] entries in the workgroup's slice (for tile_deferred_kernel)
     int defer_cap_wg, defer_tail;
-    int32_t *work_counter;           // persistent grid: the next work item to hand out (starts at 3 gridDim.x); null: one item per workgroup
+    int32_t *work_counter;           // persistent grid: the next work item to hand out (starts at first item + 3 gridDim.x); null: one item per workgroup
+    // Sliced calls (bfg_*_sliced): this launch takes the work items [slice[0], slice[1]) only -- the tiles of one band range, written
+    // by tile_scan_kernel -- so that the caller can start exchanging that part of the map while the next slice is painted.
+    const int32_t *slice;            // null: the whole work list
+    // Sliced calls run the left-over scatter kernel BEFORE the tile kernels (a slice must be final when its launch ends).  If there
+    // are left-over halos (*accum_left > 0, or the binning gave up) the output was cleared and scattered into beforehand, and the tiles
+    // are added to it instead of stored.
+    const int32_t *accum_left;       // null: not a sliced call
 };
 
 // sectors of band b whose phi range can intersect the disc: [s_lo, s_lo + n) modulo NS
@@ -383,10 +390,21 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const FillParams P)
 // that crowds into part of the sky (an octant light cone, a compact multi-GPU shard: 1/8 of the tiles with 8x the pairs)
 // still yields a few thousand items of similar size instead of 784 heavy ones on 512 workgroup slots.
 constexpr int kWorkExtra = 4096;
+// Sliced calls: the work list is cut at tile boundaries slices.tile[0] = 0 < tile[1] < ... < tile[n] = ntiles (whole bands); the scan
+// kernel writes the item range of slice k to slices.range[2 k .. 2 k + 1] and its work counter slices.counter[k] (= first item +
+// first_dynamic), which the k-th launch of the tile kernel reads.
+constexpr int kMaxSlices = 16;
+struct SliceCuts {
+    int n;                           // 0: not a sliced call
+    int tile[kMaxSlices + 1];
+    int32_t *range;                  // [2 n]
+    int32_t *counter;                // [n]
+};
+
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const TileGeom geo, int cap_direct, int32_t *count, int32_t *start, int4 *work,
                                                          int32_t *n_work, int32_t *work_counter, int first_dynamic,
                                                          int overwrite, int32_t *shared_flag, const int32_t *needs_scan,
-                                                         int32_t *next_count)
+                                                         int32_t *next_count, const SliceCuts slices)
 {
     // the other set of counters (ntiles + 2), for the next call
     if (blockIdx.x != 0) {
@@ -404,6 +422,10 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const TileGeom geo, int
         if (blockIdx.x == 0) return;
         const int t = ((int)blockIdx.x - 1) * 1024 + (int)threadIdx.x;
         if (t == 0) { *n_work = ntiles; *work_counter = first_dynamic; start[ntiles] = 0; }
+        if (t < slices.n) {                                      // item = tile: the cuts are the item ranges
+            slices.range[2 * t] = slices.tile[t]; slices.range[2 * t + 1] = slices.tile[t + 1];
+            slices.counter[t] = slices.tile[t] + first_dynamic;
+        }
         if (t >= ntiles) return;
         const int n = count[t];
         count[t] = 0; start[t] = 0;
@@ -468,6 +490,11 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const TileGeom geo, int
         int o = scan4(v);
         for (int k = 0; k < 4; ++k) {
             if (i0 + k >= ntiles) continue;
+            for (int q = 0; q < slices.n; ++q)                                               // the first item of a slice's first tile
+                if (slices.tile[q] == i0 + k) {
+                    slices.range[2 * q] = o; slices.counter[q] = o + first_dynamic;
+                    if (q > 0) slices.range[2 * q - 1] = o;
+                }
             count[i0 + k] = 0;                                                               // becomes the overflow cursor
             const int shared = v[k] > 1 ? 1 : 0;
             if (shared_flag) shared_flag[i0 + k] = shared;
@@ -488,7 +515,10 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const TileGeom geo, int
             }
         }
     }
-    if (threadIdx.x == 0) { *n_work = carry; *work_counter = first_dynamic; }   // the first items of a workgroup are static
+    if (threadIdx.x == 0) {
+        *n_work = carry; *work_counter = first_dynamic;          // the first items of a workgroup are static
+        if (slices.n > 0) slices.range[2 * slices.n - 1] = carry;
+    }
 }
 
 // Per-halo blended radial row: hwin[j][e] = B_i, i = win_lo_j + e, where
@@ -693,10 +723,21 @@ __device__ unsigned long long g_stage_cycles[16];     // profiling build only: b
 #else
 #define BFG_TICK(slot) do { } while (0)
 #endif
-#if BFG_STAGE_TIMING > 1
+#if BFG_STAGE_TIMING == 2
 #define BFG_SUBTICK(slot) do { if (tid == 64) { const long long now_ = clock64(); st_acc[8 + slot] += now_ - st_sub; st_sub = now_; } } while (0)
 #else
 #define BFG_SUBTICK(slot) do { } while (0)
+#endif
+// -DBFG_STAGE_TIMING=3: slots 8 .. 15 split a work item instead (thread BFG_TIMING_TID): top of the item (counter, work
+// record), accumulator clear, ring rows, first records, the chunk loop, write-back addresses + deferred pixels, stores,
+// end-of-item barrier
+#ifndef BFG_TIMING_TID
+#define BFG_TIMING_TID 64
+#endif
+#if BFG_STAGE_TIMING == 3
+#define BFG_ITICK(slot) do { if (tid == BFG_TIMING_TID) { const long long now_ = clock64(); st_acc[slot] += now_ - st_sub; st_sub = now_; } } while (0)
+#else
+#define BFG_ITICK(slot) do { } while (0)
 #endif
 constexpr int kTileThreads = BFG_TILE_THREADS;
 constexpr int kWinLds = 32;          // row windows up to this many nodes are staged in LDS
@@ -925,11 +966,15 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     // from it: pair counts, ring range, sector) in scalar registers instead of ~30 vector registers: -4 % at 1e5 halos
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
     auto uni4 = [&](int4 v) { return make_int4(uni(v.x), uni(v.y), uni(v.z), uni(v.w)); };
-    const int n_work_total = uni(*P.n_work);
+    const int item_first = P.slice ? uni(P.slice[0]) : 0;
+    const int n_work_total = P.slice ? uni(P.slice[1]) : uni(*P.n_work);
     // the binning gave up (pair buffer too small): every halo goes to the scatter kernel; an uninitialised map still has to be cleared
     const bool degraded = (long long)P.tile_start[P.geo.ntiles] > P.pair_cap;
+    // sliced call with left-over halos: they are in the (cleared) output already
+    const bool accum = P.accum_left && (uni(*P.accum_left) > 0 || degraded);
+    const int p_overwrite = accum ? 0 : P.overwrite, p_out_zero = accum ? 0 : P.out_zero;
     if constexpr (Cfg::QCAP > 0) { if (P.defer && threadIdx.x == 0) P.defer_count[blockIdx.x] = 0; }   // (a workgroup that returns early left nothing)
-    if (degraded && !P.overwrite) return;
+    if (degraded && !p_overwrite) return;
     const Hpx &hp = P.hpx;
     const DevTable &T = P.tab;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -970,14 +1015,17 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     [[maybe_unused]] double nx_lnpf = 0.0;
     bool primed = false;                              // wave 0 holds the first chunk's candidates of the item about to start
     constexpr int kNoItem = 0x7fffffff;
-    int item = blockIdx.x;
-    int item1 = P.work_counter ? (int)(blockIdx.x + gridDim.x) : kNoItem;
-    int item2 = P.work_counter ? (int)(blockIdx.x + 2 * gridDim.x) : kNoItem;
+    int item = item_first + (int)blockIdx.x;
+    int item1 = P.work_counter ? item_first + (int)(blockIdx.x + gridDim.x) : kNoItem;
+    int item2 = P.work_counter ? item_first + (int)(blockIdx.x + 2 * gridDim.x) : kNoItem;
     const int4 wzero = make_int4(0, 0, 0, 0);
     int4 wk = wzero, wg = wzero, wk1 = wzero, wg1 = wzero;
     if (item < n_work_total) { wk = uni4(P.work[2 * item]); wg = uni4(P.work[2 * item + 1]); }
     if (item1 < n_work_total) { wk1 = uni4(P.work[2 * item1]); wg1 = uni4(P.work[2 * item1 + 1]); }
     while (item < n_work_total) {
+#if BFG_STAGE_TIMING == 3
+    if (tid == BFG_TIMING_TID) st_sub = clock64();
+#endif
     int item3 = kNoItem;
     if (tid == 0 && P.work_counter) item3 = atomicAdd(P.work_counter, 1);
     const bool have_next = item1 < n_work_total;
@@ -995,9 +1043,11 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     const int ring_lo = 1 + band * TR;
     const int ring_hi = min((int)(4 * hp.nside - 1), ring_lo + TR - 1);
 
+    BFG_ITICK(8);
     if (n_pairs != 0) {
     for (int i = tid; i < TR * TW * NACC; i += NT) acc[i] = 0.0;
     if (tid == 0) ctl[5] = 0;
+    BFG_ITICK(9);
     // the ring rows are wave 1's (stage b is their first reader): wave 0 goes straight to stage a of the first chunk, and the one
     // barrier after stage a covers the cleared accumulator, the rows and the pair records alike
     constexpr int kRowWave = (NT >= 128) ? 64 : 0;
@@ -1016,6 +1066,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         }
         rows[rtid] = rr;
     }
+    BFG_ITICK(10);
 
     unsigned long long my_pixels = 0;
     const int32_t *plist = P.pairs + wk.y;
@@ -1250,6 +1301,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
 #if BFG_STAGE_TIMING
     BFG_TICK(6);                                       // prologue: LDS clear, tables, ring rows, first pair records
 #endif
+    BFG_ITICK(11);
     for (int base = 0; base < n_pairs;) {
         // ---- stage a: one lane per pair of the chunk (wave 0) ---------------------------------------
         if (wave == 0) {
@@ -1278,7 +1330,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         lds_barrier();
         const int n_take = ctl[0], nslots = ctl[1];
         BFG_TICK(0);
-#if BFG_STAGE_TIMING > 1
+#if BFG_STAGE_TIMING == 2
         if (tid == 64) st_sub = clock64();
 #endif
 
@@ -1367,7 +1419,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                 // fetched in one burst (a branch on irmin / irmax first serialises three L2 round trips); rings that
                 // lie entirely inside the disc (ring outside [irmin, irmax]) override the result.
                 const int irmin = h.irmin, irmax = h.irmax;
-#if BFG_STAGE_TIMING > 1
+#if BFG_STAGE_TIMING == 2
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 BFG_SUBTICK(1);                                      // halo record arrived
 #endif
@@ -1522,11 +1574,12 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     // owns TR * TW / NT pixels; their map values are fetched in one burst.  Deferred pixels still in the queue are not
     // drained here (two dependent rounds of global loads, 33 % of the kernel at 1e5 halos): they go to this work item's
     // slice of a global list and tile_deferred_kernel adds them after this kernel.
+    BFG_ITICK(12);
     constexpr int kPerThread = (TR * TW + NT - 1) / NT;
     int64_t wpix[kPerThread];
     double wold[kPerThread][NACC];
     const bool shared = wk.w && !degraded;
-    const bool rmw = !shared && !P.out_zero && !P.overwrite;
+    const bool rmw = !shared && !p_out_zero && !p_overwrite;
     if (!(P.debug & 128)) {                            // profiling: bit 128 skips the write-back (wrong results)
 #pragma unroll
     for (int u = 0; u < kPerThread; ++u) {
@@ -1554,6 +1607,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
             dfill += n;
         } else if (n > 0) drain();                                         // no list, or this workgroup's slice is full
     }
+    BFG_ITICK(13);
 #pragma unroll
     for (int u = 0; u < kPerThread; ++u) {
         if (wpix[u] < 0) continue;
@@ -1562,21 +1616,24 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         for (int c = 0; c < NACC; ++c) {
             const double v = acc[NACC * i + c];
             if (shared) { if (v != 0.0) unsafeAtomicAdd(P.out + NACC * wpix[u] + c, v); }   // the tile is shared with other workgroups
-            else if (P.overwrite) P.out[NACC * wpix[u] + c] = v;             // every pixel, zeros included: the map was not cleared
+            else if (p_overwrite) P.out[NACC * wpix[u] + c] = v;             // every pixel, zeros included: the map was not cleared
             else if (v != 0.0) P.out[NACC * wpix[u] + c] = wold[u][c] + v;
         }
     }
     }
     px_total += my_pixels;
     oob_total += n_oob32;
+    BFG_ITICK(14);
 #if BFG_STAGE_TIMING
+#if BFG_STAGE_TIMING != 3
     __syncthreads();
+#endif
     BFG_TICK(7);                                       // epilogue: final queue drain, write-back
 #endif
     } else {
         // an item without pairs (a tile no halo touches; every item when the binning gave up): nothing to paint.  An
         // uninitialised map still gets its zeros (tiles shared between items were cleared by tile_fill_kernel).
-        if (P.overwrite && !(wk.w && !degraded)) {
+        if (p_overwrite && !(wk.w && !degraded)) {
             for (int i = tid; i < TR * TW; i += NT) {
                 const int row = i / TW, col = i % TW;
                 const int ring = ring_lo + row;
@@ -1594,6 +1651,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     // on to the next work item: every thread is done with the accumulator, the ring rows and the queue
     if (tid == 0) ctl[6] = item3;
     lds_barrier();
+    BFG_ITICK(15);
     primed = handed;                                  // (an item without pairs has no last chunk to hand over in)
     item = item1; item1 = item2; item2 = uni(ctl[6]);
     wk = wk1; wg = wg1; wk1 = wk2; wg1 = wg2;

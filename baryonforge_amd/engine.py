@@ -125,6 +125,7 @@ class Context(object):
         self.handle = handle
         self._table_cache = {}
         self._spline_cache = {}
+        self._inflight = {}                # ticket -> tensor a collective on the communication stream still uses
         self.comm_world = 1
         self.comm_rank = 0
 
@@ -166,16 +167,36 @@ class Context(object):
                    "bfg_allreduce_f64")
 
     def allreduce_begin(self, d_tensor):
-        """the same sum on the context's communication stream (overlaps the work enqueued next); see comm_wait"""
+        """the same sum on the context's communication stream (overlaps the work enqueued next); returns the collective's
+        ticket for comm_wait.  The tensor is kept referenced until a comm_wait covers the ticket (the communication stream
+        is not one torch's caching allocator knows about)."""
         assert d_tensor.is_contiguous() and d_tensor.dtype == _torch().float64
         self._on_current_stream()
-        _lib.check(self.lib.bfg_allreduce_f64_begin(self.handle, C.c_void_p(d_tensor.data_ptr()), d_tensor.numel()),
-                   "bfg_allreduce_f64_begin")
+        ticket = C.c_int64(0)
+        _lib.check(self.lib.bfg_allreduce_f64_begin(self.handle, C.c_void_p(d_tensor.data_ptr()), d_tensor.numel(),
+                                                    C.byref(ticket)), "bfg_allreduce_f64_begin")
+        if ticket.value:
+            self._inflight[ticket.value] = d_tensor
+        return ticket.value
 
-    def comm_wait(self):
-        """the current stream waits for every collective begun with allreduce_begin"""
+    def reduce_scatter_begin(self, d_tensor):
+        """in place on the communication stream: rank r ends up owning [r n / world, (r + 1) n / world); returns a ticket"""
+        assert d_tensor.is_contiguous() and d_tensor.dtype == _torch().float64
         self._on_current_stream()
-        _lib.check(self.lib.bfg_comm_wait(self.handle), "bfg_comm_wait")
+        ticket = C.c_int64(0)
+        _lib.check(self.lib.bfg_reduce_scatter_f64_begin(self.handle, C.c_void_p(d_tensor.data_ptr()), d_tensor.numel(),
+                                                         C.byref(ticket)), "bfg_reduce_scatter_f64_begin")
+        if ticket.value:
+            self._inflight[ticket.value] = d_tensor
+        return ticket.value
+
+    def comm_wait(self, ticket=0):
+        """the current stream waits for the collective `ticket` (and those begun before it); 0: every collective begun so far"""
+        self._on_current_stream()
+        _lib.check(self.lib.bfg_comm_wait(self.handle, int(ticket)), "bfg_comm_wait")
+        # the stream now orders every later use (and torch's reuse of the memory) after the collective
+        for k in [k for k in self._inflight if ticket == 0 or k <= ticket]:
+            del self._inflight[k]
 
     def reduce_scatter(self, d_tensor):
         """in place: rank r ends up owning the summed elements [r n / world, (r + 1) n / world)"""
@@ -302,13 +323,36 @@ class Context(object):
         a.flags = (_lib.SHELL_OUT_IS_ZERO if out_is_zero else 0) | (_lib.SHELL_OUT_OVERWRITE if out_overwrite else 0)
         return a
 
-    def paint_shell(self, args, table, spline, d_map):
+    def _sliced(self, fn_name, args, table, spline, d_out, slices, on_slice):
+        """bfg_*_sliced: on_slice(k, n, elem_begin, elem_end) is called on this thread after the k-th slice of the output has
+        been enqueued (flat element range of d_out; final once the current stream gets there)"""
+        failure = []
+
+        def cb(_user, k, n, lo, hi):
+            try:
+                on_slice(int(k), int(n), int(lo), int(hi))
+                return 0
+            except BaseException as exc:          # never unwind through the C frames
+                failure.append(exc)
+                return 1
+        c_cb = _lib.SLICE_FN(cb)
+        status = getattr(self.lib, fn_name)(self.handle, C.byref(args), table.handle, spline.handle,
+                                            C.c_void_p(d_out.data_ptr()), int(slices), c_cb, None)
+        if failure:
+            raise failure[0]
+        _lib.check(status, fn_name)
+
+    def paint_shell(self, args, table, spline, d_map, slices=1, on_slice=None):
         self._on_current_stream()
+        if on_slice is not None:
+            return self._sliced("bfg_paint_shell_sliced", args, table, spline, d_map, slices, on_slice)
         _lib.check(self.lib.bfg_paint_shell(self.handle, C.byref(args), table.handle, spline.handle,
                                             C.c_void_p(d_map.data_ptr())), "bfg_paint_shell")
 
-    def baryonify_offsets(self, args, table, spline, d_offsets):
+    def baryonify_offsets(self, args, table, spline, d_offsets, slices=1, on_slice=None):
         self._on_current_stream()
+        if on_slice is not None:
+            return self._sliced("bfg_baryonify_offsets_sliced", args, table, spline, d_offsets, slices, on_slice)
         _lib.check(self.lib.bfg_baryonify_offsets(self.handle, C.byref(args), table.handle, spline.handle,
                                                   C.c_void_p(d_offsets.data_ptr())), "bfg_baryonify_offsets")
 

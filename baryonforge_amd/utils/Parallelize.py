@@ -9,8 +9,17 @@ one process per MI355X, backend "nccl" (= RCCL over xGMI) -- launched with
 
   * SplitJoinParallel shards the halo catalog BY SKY PATCH across the ranks
     (baryonforge_amd.sharding), every rank paints its shard onto a full-size
-    private map in its own HBM, and ONE all-reduce(sum, f64, Npix) replaces
-    the parent-side np.sum(outputs, axis=0) of Parallelize.py:318.
+    private map in its own HBM, and an all-reduce(sum, f64, Npix) replaces the
+    parent-side np.sum(outputs, axis=0) of Parallelize.py:318.  The exchange
+    is hidden behind the painting in two ways:
+      - inside one call the map is handed to the all-reduce in `slices` pieces
+        as the tile kernel finishes them (bfg_paint_shell_sliced), so only the
+        last piece's exchange is exposed;
+      - given a LIST of shell runners (what the reference's SimpleParallel
+        takes, Parallelize.py:92-113: the shells of a light cone, or several
+        models on one shell) every shell is split over all ranks and shell
+        k + 1 is painted while shell k's all-reduce and its copy to the host
+        are still in flight (rotating map buffers).
   * Unlike the reference (Parallelize.py:206-209) Baryonify runners ARE
     supported: the offset field Npix x 3 is linear in halos (HealpixRunner.py:355),
     so it is summed across ranks -- a reduce-scatter: every rank only needs the
@@ -25,7 +34,7 @@ import numpy as np
 
 from ..sharding import estimate_disc_pixels, shard_by_sky_patch
 
-__all__ = ["SimpleParallel", "SplitJoinParallel", "Exchange", "HostOps"]
+__all__ = ["SimpleParallel", "SplitJoinParallel", "Exchange"]
 
 
 def _dist():
@@ -44,8 +53,8 @@ class Exchange(object):
     collective = "torch": torch.distributed's own collectives (backend "nccl" = RCCL over xGMI on device tensors; "gloo"
                           for CPU tensors and for rehearsals of the multi-rank path on a one-GPU box, where device
                           tensors are staged through the host);
-    collective = "bfg":   the library's communicator (bfg_comm_init / bfg_allreduce_f64 / bfg_reduce_scatter_f64 of
-                          include/bfg_mi355.h: RCCL on the context's stream) -- what a C-ABI consumer without torch uses;
+    collective = "bfg":   the library's communicator (bfg_comm_init / bfg_allreduce_f64[_begin] / bfg_reduce_scatter_f64 of
+                          include/bfg_mi355.h: RCCL on the context's streams) -- what a C-ABI consumer without torch uses;
                           needs one GPU per rank.
     """
 
@@ -73,7 +82,7 @@ class Exchange(object):
         return t.is_cuda and self.backend == "gloo"
 
     def allreduce(self, t):
-        """t <- sum over ranks (in place)"""
+        """t <- sum over ranks (in place), ordered on the current stream"""
         if self.collective == "bfg" and t.is_cuda:
             self.ctx.allreduce(t)
         elif self._staged(t):
@@ -83,6 +92,26 @@ class Exchange(object):
         else:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t
+
+    def allreduce_begin(self, t):
+        """start t <- sum over ranks so that it overlaps what is enqueued next on the current stream; returns a handle for
+        `wait`.  t must stay alive (and untouched) until then."""
+        if self.collective == "bfg" and t.is_cuda:
+            return ("bfg", self.ctx.allreduce_begin(t))         # on the context's communication stream; a ticket
+        if self._staged(t):                                     # gloo rehearsal on one GPU: synchronous
+            self.allreduce(t)
+            return None
+        return ("torch", self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, async_op=True))
+
+    def wait(self, handle):
+        """order the current stream (CPU tensors: the host) after the collective of `handle`"""
+        if handle is None:
+            return
+        kind, h = handle
+        if kind == "bfg":
+            self.ctx.comm_wait(h)
+        else:
+            h.wait()
 
     def reduce_scatter(self, t):
         """in place: afterwards the elements own_range(t.numel()) of the flattened t hold the sum over ranks; the rest of
@@ -101,20 +130,85 @@ class Exchange(object):
         return t
 
 
-class SimpleParallel(object):
-    """Run several independent Runners (Parallelize.py:8-113).  Runners are dealt round-robin to the
-    ranks of the process group; every rank returns the full list of outputs (gathered)."""
+class _DeviceOps(object):
+    """The GPU side of one rank: HBM tensors, C-ABI calls through the runners, copies to the host.  (The CPU tests of the
+    multi-rank control flow replace this class -- `Parallelize._DeviceOps` -- by one that computes with the oracle.)"""
 
-    def __init__(self, Runner_list, njobs=-1, seed=42):
+    def __init__(self):
+        from ..engine import get_context
+        self.ctx = get_context()
+        self._copy_stream = None
+
+    def new_map(self, npix):
+        return self.ctx.empty(npix)
+
+    def paint(self, runner, d_map, slices, on_slice):
+        runner.process_device(d_map=d_map, overwrite=True, slices=slices, on_slice=on_slice, sync_stats=False)
+
+    def collect(self, runners):
+        """the counters of everything painted since the last collect (one read-back = one synchronisation)"""
+        stats = runners[0].collect_stats()
+        for r in runners[1:]:
+            r.last_stats = stats
+        self.ctx.stats_reset()
+        return stats
+
+    def reset_stats(self):
+        self.ctx.stats_reset()
+
+    def to_host(self, d_map):
+        return self.ctx.to_host(d_map)
+
+    def to_host_begin(self, d_map):
+        """copy d_map to page-locked host memory on a copy stream of its own, ordered after what the current stream holds;
+        returns (host tensor, event): the event marks the end of the copy (before the buffer may be repainted)"""
+        import torch
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=self.ctx.device)
+        try:
+            h = torch.empty(d_map.shape, dtype=d_map.dtype, pin_memory=True)
+        except RuntimeError:
+            h = torch.empty(d_map.shape, dtype=d_map.dtype)
+        self._copy_stream.wait_stream(torch.cuda.current_stream(self.ctx.device))
+        with torch.cuda.stream(self._copy_stream):
+            h.copy_(d_map, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._copy_stream)
+        return h, ev
+
+    def wait_event(self, ev):
+        """the current stream waits for `ev` (a buffer is about to be repainted)"""
+        import torch
+        torch.cuda.current_stream(self.ctx.device).wait_event(ev)
+
+    def host_ready(self, h, ev):
+        ev.synchronize()
+        return h.numpy()
+
+
+class SimpleParallel(object):
+    """Run several independent Runners (Parallelize.py:8-113).
+
+    split=False (default, the reference's scheme): whole runners are dealt round-robin to the ranks of the process group
+    and every rank returns the full list of outputs (gathered through the host).
+    split=True: every runner's catalog is split over ALL ranks instead (SplitJoinParallel over the list): shell k + 1 is
+    painted while shell k's all-reduce is in flight, no rank idles when there are fewer runners than GPUs, and the
+    results never leave HBM before they are final."""
+
+    def __init__(self, Runner_list, njobs=-1, seed=42, split=False, **splitjoin_args):
         self.Runner_list = list(Runner_list)
         self.njobs = njobs
         self.seed = seed
+        self.split = split
+        self.splitjoin_args = splitjoin_args
 
     def single_run(self, Runner):
         return Runner.process()
 
     def process(self):
         dist = _dist()
+        if self.split:
+            return SplitJoinParallel(self.Runner_list, self.njobs, self.seed, **self.splitjoin_args).process()
         if dist is None or dist.get_world_size() == 1:
             return [self.single_run(R) for R in self.Runner_list]
         rank, world = dist.get_rank(), dist.get_world_size()
@@ -129,50 +223,51 @@ class SimpleParallel(object):
 
 class SplitJoinParallel(object):
     """
-    Split one Runner's halo catalog across GPUs and join (sum) the results (Parallelize.py:116-320).
+    Split a Runner's halo catalog across GPUs and join (sum) the results (Parallelize.py:116-320).
 
     Parameters
     ----------
-    Runner : PaintProfilesShell or BaryonifyShell
+    Runner : PaintProfilesShell or BaryonifyShell, or a list of them (every one is split over all ranks; `process()`
+        then returns the list of maps)
     njobs : ignored when a process group exists (the world size is used); kept for API parity
     seed : kept for API parity (the sky-patch split is deterministic and needs no shuffle)
     nside_patch, layout : NSIDE of the sky patches and how they are dealt to the ranks (sharding.shard_by_sky_patch)
     collective : "torch" (torch.distributed: RCCL with the nccl backend) or "bfg" (the library's own RCCL communicator,
         bfg_allreduce_f64 & co.); see Exchange
-    local_ops : test seam -- an object replacing the GPU work of the per-rank runner (`paint(runner)`,
-        `offsets(runner)`, `regrid(nside, offsets, in_map)`, all on numpy arrays), so that the sharding and the
-        exchange steps -- the very code the GPU ranks run -- can be exercised with the gloo backend on CPU-only machines.
-    local_process : older form of the seam, paint only: callable(runner_for_this_rank) -> np.ndarray
+    slices : pieces in which a painted map is handed to the all-reduce while the rest is still being painted
+        (bfg_paint_shell_sliced); 1 = one all-reduce after the call
     """
 
-    def __init__(self, Runner, njobs=-1, seed=42, nside_patch=64, local_process=None, layout="interleaved",
-                 collective="torch", local_ops=None):
+    def __init__(self, Runner, njobs=-1, seed=42, nside_patch=64, layout="interleaved", collective="torch", slices=4):
+        self.is_list = isinstance(Runner, (list, tuple))
+        self.Runners = list(Runner) if self.is_list else [Runner]
         self.Runner = Runner
         self.seed = seed
         self.njobs = njobs
         self.nside_patch = nside_patch
         self.layout = layout
         self.collective = collective
-        if local_process is not None and local_ops is None:
-            local_ops = _PaintOnlyOps(local_process)
-        self.local_ops = local_ops
+        self.slices = max(1, int(slices))
         dist = _dist()
         self.rank = dist.get_rank() if dist else 0
         self.world = dist.get_world_size() if dist else 1
-        self.Runner_list = self.split_run(self.Runner)
+        self.shard_indices_list = []
+        self.Runner_list = [self.split_run(R) for R in self.Runners]     # this rank's runner of every input runner
+        self.shard_indices = self.shard_indices_list[0] if self.shard_indices_list else np.arange(0)
 
     def split_run(self, Runner):
-        """the Runner of THIS rank (list of length 1, mirroring the reference's attribute name)"""
+        """the Runner of THIS rank for one input Runner"""
         HaloCat = Runner.HaloLightConeCatalog
         cat = HaloCat.cat
         if self.world == 1:
-            self.shard_indices = np.arange(cat.size)
-            return [Runner]
+            self.shard_indices_list.append(np.arange(cat.size))
+            return Runner
         w = estimate_disc_pixels(Runner.cosmo, cat["M"], cat["z"], Runner.epsilon_max, Runner.LightconeShell.NSIDE,
                                  Runner.mass_def)
         shards = shard_by_sky_patch(cat["ra"], cat["dec"], w, self.world, self.nside_patch, layout=self.layout)
-        self.shard_indices = shards[self.rank]
-        New_HaloCatalog = HaloCat[self.shard_indices]
+        idx = shards[self.rank]
+        self.shard_indices_list.append(idx)
+        New_HaloCatalog = HaloCat[idx]
         New_Runner = type(Runner)(New_HaloCatalog, Runner.LightconeShell, Runner.epsilon_max, Runner.model,
                                   Runner.use_ellipticity, Runner.mass_def,
                                   include_pixel_size=Runner.include_pixel_size, verbose=False)
@@ -181,76 +276,97 @@ class SplitJoinParallel(object):
         # every rank builds the D_A spline the serial run would build (knots up to max(z) of the WHOLE catalog,
         # HealpixRunner.py:297-299): a halo then gets bit-identical scalars whichever rank it lands on
         New_Runner._spline_z_max = float(np.max(cat["z"])) if cat.size else 0.0
-        return [New_Runner]
+        return New_Runner
 
     def single_run(self, Runner):
         return Runner.process()
 
-    def process(self):
+    # ---- the pipeline ---------------------------------------------------------------------------------
+    def _exchange(self):
         dist = _dist()
-        local = self.Runner_list[0]
-        ops = self.local_ops
-        is_baryonify = hasattr(local, "offsets_device")
-        if self.world == 1:
-            if ops is None:
-                return local.process()
-            return ops.baryonify(local, None) if is_baryonify else ops.paint(local)
-        ex = Exchange(dist, self.collective if ops is None else "torch")
-        if ops is not None:                                         # CPU test seam (gloo): same steps, numpy arrays
-            import torch
-            if is_baryonify:
-                return ops.baryonify(local, ex)
-            part = torch.from_numpy(np.ascontiguousarray(ops.paint(local), dtype=np.float64))
-            return ex.allreduce(part).numpy()
-        if is_baryonify:
-            return local.process(distributed=ex)
-        d_map = local.process_device()
-        ex.allreduce(d_map)                                         # RCCL over xGMI
-        from ..engine import get_context
-        return get_context().to_host(d_map).reshape(np.shape(local.LightconeShell.map))
+        if dist is None or self.world == 1:
+            return None
+        return Exchange(dist, self.collective)
 
+    def process_device(self, consume=None, ops=None):
+        """Paint every runner's shard of this rank, summed over the ranks, leaving the maps ON THE DEVICE.
 
-class _PaintOnlyOps(object):
-    def __init__(self, fn):
-        self.paint = fn
+        consume=None: returns the list of device maps (one buffer per runner), ordered on the current stream.
+        consume=callable(k, d_map): called once per runner, in order, when the current stream holds everything map k
+        needs (painting and exchange); the map's buffer is recycled afterwards (two buffers rotate), so the callable must
+        enqueue or finish what it does with it.  Returns None.
+        Only PaintProfilesShell runners (a BaryonifyShell's regrid needs the exchanged offsets first: see process())."""
+        ops = ops or _DeviceOps()
+        ex = self._exchange()
+        n = len(self.Runner_list)
+        nbuf = n if consume is None else min(2, n)
+        bufs, pend = [None] * nbuf, [None] * nbuf
 
+        def retire(b):
+            if pend[b] is None:
+                return
+            k, handles = pend[b]
+            for h in handles:
+                ex.wait(h)
+            pend[b] = None
+            if consume is not None:
+                consume(k, bufs[b])
+        ops.reset_stats()
+        for k, R in enumerate(self.Runner_list):
+            b = k % nbuf
+            retire(b)
+            if bufs[b] is None:
+                bufs[b] = ops.new_map(12 * R.LightconeShell.NSIDE ** 2)
+            handles = []
+            if ex is None:
+                ops.paint(R, bufs[b], 1, None)
+            else:
+                buf = bufs[b]
+                ops.paint(R, buf, self.slices, lambda i, m, lo, hi, buf=buf, handles=handles:
+                          handles.append(ex.allreduce_begin(buf[lo:hi])))
+            pend[b] = (k, handles)
+        for k in range(max(0, n - nbuf), n):
+            retire(k % nbuf)
+        ops.collect(self.Runner_list)
+        return list(bufs) if consume is None else None
 
-class HostOps(object):
-    """Test seam of SplitJoinParallel (`local_ops`): the per-rank GPU work replaced by host callables on numpy arrays --
-    paint(runner) -> [Npix], offsets(runner) -> [Npix, 3], regrid(nside, offsets, in_map) -> [Npix] -- e.g. the CPU oracle
-    in tests/.  Everything else (sharding, the reduce-scatter / all-reduce sequence, the pixel ranges, the mass
-    assertion) is the code the GPU ranks run."""
+    def process(self, ops=None):
+        """The summed map(s) on the host: float64[Npix] for one Runner, a list for a list of Runners."""
+        first = self.Runner_list[0] if self.Runner_list else None
+        if first is not None and hasattr(first, "offsets_device"):
+            outs = [self._baryonify(R, ops) for R in self.Runner_list]
+            return outs if self.is_list else outs[0]
+        ops = ops or _DeviceOps()
+        n = len(self.Runner_list)
+        host = [None] * n
+        if n == 1:
+            d_map = self.process_device(ops=ops)[0]
+            host[0] = ops.to_host(d_map)
+        else:
+            # copies to the host run on their own stream: shell k's copy overlaps shell k + 1's painting; a buffer is only
+            # repainted after its copy has finished
+            copied = {}
 
-    def __init__(self, paint=None, offsets=None, regrid=None):
-        self.paint, self._offsets, self._regrid = paint, offsets, regrid
+            def consume(k, d_map):
+                h, ev = ops.to_host_begin(d_map)
+                host[k] = (h, ev)
+                copied[id(d_map)] = ev
+            orig_paint = ops.paint
 
-    def baryonify(self, runner, exchange):
-        from ..Runners.HealpixRunner import _baryonify_process
-        return _baryonify_process(runner, _BoundHostOps(self, runner), exchange)
+            def paint_after_copy(R, d_map, slices, on_slice):
+                ev = copied.pop(id(d_map), None)
+                if ev is not None:
+                    ops.wait_event(ev)
+                orig_paint(R, d_map, slices, on_slice)
+            ops.paint = paint_after_copy
+            try:
+                self.process_device(consume=consume, ops=ops)
+            finally:
+                ops.paint = orig_paint
+            host = [ops.host_ready(h, ev) for h, ev in host]
+        outs = [m.reshape(np.shape(R.LightconeShell.map)) for m, R in zip(host, self.Runner_list)]
+        return outs if self.is_list else outs[0]
 
-
-class _BoundHostOps(object):
-    def __init__(self, host, runner):
-        self.host, self.runner = host, runner
-
-    def upload(self, flat):
-        import torch
-        return torch.from_numpy(np.array(flat, dtype=np.float64))
-
-    def zeros(self, *shape):
-        import torch
-        return torch.zeros(*shape, dtype=torch.float64)
-
-    def absmax_sum(self, t):
-        return float(t.abs().max()), float(t.sum())
-
-    def offsets(self):
-        import torch
-        return torch.from_numpy(np.ascontiguousarray(self.host._offsets(self.runner), dtype=np.float64))
-
-    def regrid(self, nside, d_off, d_in, d_out):
-        import torch
-        d_out += torch.from_numpy(np.ascontiguousarray(self.host._regrid(nside, d_off.numpy(), d_in.numpy())))
-
-    def to_host(self, t):
-        return t.numpy()
+    def _baryonify(self, local, ops):
+        from ..Runners.HealpixRunner import _baryonify_process, _BaryonifyDeviceOps
+        return _baryonify_process(local, ops or _BaryonifyDeviceOps(local), self._exchange())

@@ -93,6 +93,42 @@ class HaloLightConeCatalog(object):
             out[:, i] = self.cat[c]
         return out
 
+    def device_records(self, ctx, extra_keys=()):
+        """(device record matrix, doubles per record) on the GPU of `ctx`, uploaded once per catalog.
+
+        The reference re-reads `cat` on every process() call.  To keep that guarantee without re-uploading 32 B per halo
+        per call, the structured array is made READ-ONLY while a device copy exists (numpy then refuses in-place edits
+        with a ValueError instead of letting the copy go stale); `unlock()` makes it writable again and drops the copies,
+        and replacing `self.cat` by another array is noticed by identity.  BFG_CATALOG_CACHE=0 uploads on every call."""
+        import os
+        recs = self.records(extra_keys)
+        if os.environ.get("BFG_CATALOG_CACHE", "1") == "0":
+            return ctx.to_device(recs), recs.shape[1]
+        cache = self.__dict__.setdefault("_device_copies", {})
+        key = (ctx.device_index, tuple(extra_keys))
+        hit = cache.get(key)
+        if hit is not None and hit[0] is self.cat and not self.cat.flags.writeable:
+            return hit[1], hit[2]
+        if hit is None or hit[0] is not self.cat or self.cat.flags.writeable:
+            cache.clear()                                                # another array, or it was writable in between
+        d = ctx.to_device(recs)
+        try:
+            self.cat.setflags(write=False)
+        except ValueError:                                               # a view of someone else's buffer: cannot lock it
+            return d, recs.shape[1]
+        cache[key] = (self.cat, d, recs.shape[1])
+        return d, recs.shape[1]
+
+    def unlock(self):
+        """make `cat` writable again and forget its device copies (see device_records)"""
+        self.__dict__.pop("_device_copies", None)
+        self.cat.setflags(write=True)
+
+    def __getstate__(self):                                              # device tensors do not travel
+        st = dict(self.__dict__)
+        st.pop("_device_copies", None)
+        return st
+
     def __str__(self):
         return (f"HaloLightConeCatalog with {self.cat.size} halos; fields {self.cat.dtype.names}; "
                 f"cosmology {self.cosmo}")

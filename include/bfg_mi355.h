@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BFG_ABI_VERSION 1
+#define BFG_ABI_VERSION 2
 
 typedef enum {
     BFG_OK = 0,
@@ -282,6 +282,24 @@ int bfg_paint_shell(bfg_ctx *ctx, const bfg_shell_args *args, const bfg_table *t
 int bfg_baryonify_offsets(bfg_ctx *ctx, const bfg_shell_args *args, const bfg_table *table,
                           const bfg_spline *da_spline, double *d_offsets);
 
+/* The same two loops with the output handed over IN SLICES while the call is still being enqueued -- the building block of
+ * the multi-GPU join inside one process() call.  The sky tiles are cut into n_slices runs of whole ring bands (n_slices is
+ * clamped to 16 and to the number of bands); the tile kernel is launched once per run and after each launch the library calls
+ *     fn(user, slice, n, elem_begin, elem_end)
+ * on the calling thread: once the context's stream reaches this point, d_out[elem_begin .. elem_end) (elements = doubles;
+ * contiguous RING pixel ranges, x 3 for the offset field) holds its final values, so the callback can start that part of the
+ * exchange on another stream -- e.g. bfg_allreduce_f64_begin(ctx, d_out + elem_begin, elem_end - elem_begin, &ticket), which
+ * replaces, slice by slice, the parent-side np.sum(outputs, axis=0) of utils/Parallelize.py:318 -- while the next slice is
+ * painted.  The slices cover the output exactly once, in ascending order.  Calls that cannot be cut (no halos, the scatter
+ * variants) report the whole output as one slice (slice 0 of 1) after their last launch.  A non-zero return of fn aborts the
+ * call with BFG_ERR_INVALID.  Halos the tile path leaves to the scatter kernel are handled BEFORE the first slice (into a
+ * cleared output, to which the tiles are then added), so every slice is final when it is reported.                    */
+typedef int (*bfg_slice_fn)(void *user, int slice, int n_slices, int64_t elem_begin, int64_t elem_end);
+int bfg_paint_shell_sliced(bfg_ctx *ctx, const bfg_shell_args *args, const bfg_table *table,
+                           const bfg_spline *da_spline, double *d_map, int n_slices, bfg_slice_fn fn, void *user);
+int bfg_baryonify_offsets_sliced(bfg_ctx *ctx, const bfg_shell_args *args, const bfg_table *table,
+                                 const bfg_spline *da_spline, double *d_offsets, int n_slices, bfg_slice_fn fn, void *user);
+
 /* Final regrid (Runners/HealpixRunner.py:357-365 + regrid_pixels_hpix :17-71):
  * every pixel with d_in_map != 0 is moved to pix2vec(p) + d_offsets[p] and
  * deposited on its 4 bilinear neighbours into d_out_map (accumulated INTO).
@@ -303,9 +321,13 @@ int bfg_regrid_shell(bfg_ctx *ctx, int64_t nside, const double *d_offsets, const
  * bfg_allreduce_f64    d_buf[count] <- sum over ranks, in place, asynchronous on the context's stream; a context
  *                      without a communicator is a world of one (no-op);
  * bfg_allreduce_f64_begin / bfg_comm_wait   the same sum on the context's own communication stream, ordered after what
- *                      the context's stream holds so far, so that it overlaps the work enqueued next (the next shell,
- *                      painted into another buffer); bfg_comm_wait makes the context's stream wait for every
- *                      collective begun so far -- call it before the buffer is read, zeroed or reused;
+ *                      the context's stream holds so far, so that it overlaps the work enqueued next (the next slice of
+ *                      the same map, or the next shell painted into another buffer).  *ticket (may be NULL) receives
+ *                      the collective's ticket, a positive number; bfg_comm_wait(ctx, ticket) makes the context's stream
+ *                      wait for THAT collective (and, the communication stream being in order, those begun before it)
+ *                      but not for later ones; ticket 0 = every collective begun so far.  Call it before the buffer is
+ *                      read, zeroed or reused; the buffer must stay allocated until then.  bfg_reduce_scatter_f64_begin:
+ *                      the same for the reduce-scatter half;
  * bfg_reduce_scatter_f64 / bfg_allgather_f64   the two halves, in place: rank r owns elements
  *                      [r count / world, (r + 1) count / world); count must be a multiple of world.
  * RCCL is loaded at the first of these calls (dlopen "librccl.so.1"; override with BFG_RCCL_SO): the library has no
@@ -316,8 +338,9 @@ int bfg_comm_init(bfg_ctx *ctx, const char *id, size_t id_bytes, int rank, int w
 int bfg_comm_destroy(bfg_ctx *ctx);
 int bfg_comm_info(bfg_ctx *ctx, int *rank, int *world);
 int bfg_allreduce_f64(bfg_ctx *ctx, double *d_buf, int64_t count);
-int bfg_allreduce_f64_begin(bfg_ctx *ctx, double *d_buf, int64_t count);
-int bfg_comm_wait(bfg_ctx *ctx);
+int bfg_allreduce_f64_begin(bfg_ctx *ctx, double *d_buf, int64_t count, int64_t *ticket);
+int bfg_reduce_scatter_f64_begin(bfg_ctx *ctx, double *d_buf, int64_t count, int64_t *ticket);
+int bfg_comm_wait(bfg_ctx *ctx, int64_t ticket);
 int bfg_reduce_scatter_f64(bfg_ctx *ctx, double *d_buf, int64_t count);
 int bfg_allgather_f64(bfg_ctx *ctx, double *d_buf, int64_t count);
 

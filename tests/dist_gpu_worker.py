@@ -16,6 +16,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
 NSIDE, N_PAINT, N_BARY, EPS = 256, 4000, 3000, 10.0
+LIST_CUTS = [(0, 1500), (1500, 4000), (500, 2500), (0, 4000)]
 
 
 def inputs():
@@ -58,11 +59,25 @@ def main():
         R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(npix), cosmo=cosmo), EPS,
                                    bfg.TabulatedProfile.from_arrays(zax, Max, rax, T), verbose=False)
         SJ = bfg.SplitJoinParallel(R, collective=coll)
-        assert SJ.world == a.world and SJ.rank == a.rank and SJ.local_ops is None
+        assert SJ.world == a.world and SJ.rank == a.rank
         out = SJ.process()
         np.save(os.path.join(a.out, f"paint_{coll}_{a.rank}.npy"), out)
         np.save(os.path.join(a.out, f"idx_{coll}_{a.rank}.npy"), SJ.shard_indices)
         info[f"paint_{coll}_pixel_updates"] = int(SJ.Runner_list[0].last_stats["pixel_updates"])
+
+        # a LIST of shells, every one split over all ranks and pipelined (sliced exchange, rotating buffers, async copies)
+        model = bfg.TabulatedProfile.from_arrays(zax, Max, rax, T)
+        shells = []
+        for lo, hi in LIST_CUTS:
+            c = bfg.HaloLightConeCatalog(I["ra"][lo:hi], I["dec"][lo:hi], I["M"][lo:hi], I["z"][lo:hi], cosmo)
+            shells.append(bfg.PaintProfilesShell(c, bfg.LightconeShell(map=np.zeros(npix), cosmo=cosmo), EPS, model, verbose=False))
+        LSJ = bfg.SplitJoinParallel(shells, collective=coll, slices=3)
+        louts = LSJ.process()
+        info[f"list_{coll}_pixel_updates"] = int(LSJ.Runner_list[0].last_stats["pixel_updates"])
+        for k, o in enumerate(louts):
+            np.save(os.path.join(a.out, f"list{k}_{coll}_{a.rank}.npy"), o)
+        louts2 = bfg.SimpleParallel(shells, split=True, collective=coll, slices=1).process()
+        assert all(np.allclose(x, y, rtol=1e-12, atol=0) for x, y in zip(louts, louts2))   # atomics reorder: rounding only
 
         dz, dM, dr, dtab = I["disp"]
         sub = bfg.HaloLightConeCatalog(I["ra"][:N_BARY], I["dec"][:N_BARY], I["M"][:N_BARY], I["z"][:N_BARY], cosmo)

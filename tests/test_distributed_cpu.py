@@ -2,7 +2,9 @@
 World-size-2 (and 3) tests of the multi-GPU path on CPU (gloo): sky-patch sharding of the catalog across ranks +
 the exchange steps (paint: all-reduce of the per-rank maps; baryonify: reduce-scatter of the offset field, regrid of the
 rank's own pixel range, all-reduce of the output maps), exactly the code path SplitJoinParallel takes under RCCL, with the
-per-rank kernels replaced through the documented test seam (`local_ops`) by the CPU oracle.
+per-rank device work done by the CPU oracle (tests/host_ops.py passed as `ops`).  Covered: the single-runner call with the
+map exchanged in slices, the pipelined call over a LIST of shell runners (rotating buffers, exchange of shell k behind the
+painting of shell k + 1, asynchronous copies to the host), SimpleParallel(split=True).
 Checks: every halo handled exactly once, reduced map == serial oracle map on every rank, mass conserved.
 (tests/test_gpu_distributed.py runs the same with the real HIP kernels in the ranks.)
 """
@@ -52,11 +54,36 @@ def _worker(rank, world, port, out_dir):
         m, _ = orc.paint_shell(nside, c["ra"], c["dec"], c["M"], a, D, R, (zax, Max, rax), np.log(T), 10,
                                include_pixel_size=True)
         return m
-    SJ = bfg.SplitJoinParallel(Runner, njobs=-1, local_process=oracle_local)
+    from host_ops import OracleBaryonifyOps, OraclePaintOps
+    ops = OraclePaintOps(oracle_local)
+    SJ = bfg.SplitJoinParallel(Runner, njobs=-1, slices=5)
     assert SJ.world == world and SJ.rank == rank
-    out = SJ.process()
+    out = SJ.process(ops=ops)
+    assert ops.log[0][0] == "paint" and ops.log[0][2] == 5 and ops.collected == 1   # sliced exchange inside the one call
     np.save(os.path.join(out_dir, f"map_{rank}.npy"), out)
     np.save(os.path.join(out_dir, f"idx_{rank}.npy"), SJ.shard_indices)
+
+    # ---- a LIST of shells (three catalogs): every shell split over all ranks, pipelined
+    runners, subs = [], [slice(0, 250), slice(250, 600), slice(100, 400)]
+    for sl in subs:
+        sub = bfg.HaloLightConeCatalog(ra[sl], dec[sl], M[sl], z[sl], cosmo)
+        runners.append(bfg.PaintProfilesShell(sub, Shell, 10, model, include_pixel_size=True, verbose=False))
+    ops = OraclePaintOps(oracle_local)
+    LSJ = bfg.SplitJoinParallel(runners, slices=3)
+    outs = LSJ.process(ops=ops)
+    assert isinstance(outs, list) and len(outs) == 3
+    paints = [e for e in ops.log if e[0] == "paint"]
+    assert len(paints) == 3 and len({e[1] for e in paints}) == 2          # two map buffers rotate
+    assert sum(e[0] == "copy" for e in ops.log) == 3 and sum(e[0] == "wait_copy" for e in ops.log) == 1
+    for k, o in enumerate(outs):
+        np.save(os.path.join(out_dir, f"lmap{k}_{rank}.npy"), o)
+    # the same through SimpleParallel(split=True), maps left on the "device"
+    dev = bfg.SplitJoinParallel(runners, slices=2).process_device(ops=OraclePaintOps(oracle_local))
+    assert len(dev) == 3 and all(np.array_equal(d.numpy(), o) for d, o in zip(dev, outs))
+    consumed = []
+    bfg.SplitJoinParallel(runners, slices=1).process_device(consume=lambda k, d: consumed.append((k, d.numpy().copy())),
+                                                             ops=OraclePaintOps(oracle_local))
+    assert [k for k, _ in consumed] == [0, 1, 2] and all(np.array_equal(c, o) for (_, c), o in zip(consumed, outs))
 
     # ---- BaryonifyShell, which the reference's splitter refuses (Parallelize.py:206-209): offsets are linear in halos
     dz, dM, dr, dtab = syn.displacement_table(5, 8, 50)
@@ -76,8 +103,8 @@ def _worker(rank, world, port, out_dir):
     def oracle_regrid(ns, off, in_map):
         calls["regrid_sources"] = np.flatnonzero(in_map)
         return orc.regrid_shell(ns, off, in_map)
-    BSJ = bfg.SplitJoinParallel(BR, local_ops=bfg.HostOps(offsets=oracle_offsets, regrid=oracle_regrid))
-    bout = BSJ.process()
+    BSJ = bfg.SplitJoinParallel(BR)
+    bout = BSJ.process(ops=OracleBaryonifyOps(BSJ.Runner_list[0], oracle_offsets, oracle_regrid))
     np.save(os.path.join(out_dir, f"bmap_{rank}.npy"), bout)
     np.save(os.path.join(out_dir, f"bidx_{rank}.npy"), BSJ.shard_indices)
     np.save(os.path.join(out_dir, f"bsrc_{rank}.npy"), calls["regrid_sources"])
@@ -112,6 +139,11 @@ def test_splitjoin_ranks_gloo(tmp_path, world):
     for m in maps:                                                            # all-reduce: same map everywhere
         np.testing.assert_allclose(m, ref, rtol=1e-9, atol=0)
     assert np.array_equal(maps[0], maps[1])
+    for k, sl in enumerate([slice(0, 250), slice(250, 600), slice(100, 400)]):     # the list API: every shell == its serial oracle
+        lref, _ = oracle_paint(dict(syn.COSMO), ra[sl], dec[sl], M[sl], z[sl], (zax, Max, rax), T, 64, 10,
+                               include_pixel_size=True)
+        for r in range(world):
+            np.testing.assert_allclose(np.load(tmp_path / f"lmap{k}_{r}.npy"), lref, rtol=1e-9, atol=0)
     # distributed BaryonifyShell == the serial oracle run, on every rank; mass conserved; every source pixel regridded once
     from util import oracle_baryonify
     dz, dM, dr, dtab = syn.displacement_table(5, 8, 50)
@@ -136,6 +168,10 @@ def test_splitjoin_single_process_is_passthrough():
     Cat = bfg.HaloLightConeCatalog(*syn.catalog(10), syn.COSMO)
     Shell = bfg.LightconeShell(map=np.zeros(12), cosmo=syn.COSMO)
     R = bfg.PaintProfilesShell(Cat, Shell, 10, None, verbose=False)
-    SJ = bfg.SplitJoinParallel(R, njobs=4, local_process=lambda r: np.arange(12.0))
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from host_ops import OraclePaintOps
+    SJ = bfg.SplitJoinParallel(R, njobs=4)
     assert SJ.world == 1 and SJ.Runner_list[0] is R
-    assert np.array_equal(SJ.process(), np.arange(12.0))
+    assert np.array_equal(SJ.process(ops=OraclePaintOps(lambda r: np.arange(12.0))), np.arange(12.0))
+    outs = bfg.SplitJoinParallel([R, R, R]).process(ops=OraclePaintOps(lambda r: np.arange(12.0)))
+    assert len(outs) == 3 and all(np.array_equal(o, np.arange(12.0)) for o in outs)

@@ -204,6 +204,13 @@ def test_cabi_comm_world_of_one_and_collectives():
     _lib.check(L.bfg_reduce_scatter_f64(ctx, d.p, x.size), "reduce-scatter")
     _lib.check(L.bfg_allgather_f64(ctx, d.p, x.size), "all-gather")
     assert L.bfg_allreduce_f64(ctx, None, 8) == -1
+    # the overlapped forms: in a world of one there is nothing to exchange, the ticket is 0 and waiting is a no-op
+    tk = C.c_int64(-5)
+    _lib.check(L.bfg_allreduce_f64_begin(ctx, d.p, x.size, C.byref(tk)), "allreduce begin")
+    assert tk.value == 0
+    _lib.check(L.bfg_reduce_scatter_f64_begin(ctx, d.p, x.size, None), "reduce-scatter begin, no ticket wanted")
+    _lib.check(L.bfg_comm_wait(ctx, 0), "wait for everything")
+    assert L.bfg_comm_wait(ctx, 7) in (0, -1)                                      # a ticket never issued
     _lib.check(L.bfg_ctx_synchronize(ctx))
     assert np.array_equal(d.down(x.shape), x)
     _lib.check(L.bfg_comm_destroy(ctx))
@@ -243,6 +250,53 @@ def test_cabi_set_stream_orders_work_across_streams(cosmo):
     a, R, D = orc.halo_scalars(cosmo, M, z)
     ref, _ = orc.paint_shell(nside, ra, dec, M, a, D, R, (zax, Max, rax), np.log(T), 10.0)
     assert_maps_close(d_map.down(npix), ref, 1e-5, what="paint after a stream switch")
+    d_cat.free(); d_map.free()
+    _lib.check(L.bfg_table_destroy(ctx, tab))
+    _lib.check(L.bfg_spline_destroy(ctx, spl))
+    _lib.check(L.bfg_ctx_destroy(ctx))
+
+
+def test_cabi_sliced_paint_through_ctypes(cosmo):
+    """bfg_paint_shell_sliced driven from plain ctypes: the callback sees n ascending slices that cover the map; copying
+    each slice out (bfg_memcpy_d2h is synchronous on the context's stream) the moment it is reported gives the plain map"""
+    from scipy import interpolate
+    L = _lib.load()
+    ctx = C.c_void_p()
+    _lib.check(L.bfg_ctx_create(0, C.c_void_p(-1), C.byref(ctx)), "ctx")
+    nside, npix, n = 128, 12 * 128 * 128, 3000
+    ra, dec, M, z = syn.catalog(n, seed=18)
+    bg = Background(cosmo)
+    z_t = np.linspace(0, z.max() + 0.1, 1000)
+    cs = interpolate.CubicSpline(z_t, bg.angular_diameter_distance(1 / (1 + z_t)))
+    knots, coef = np.ascontiguousarray(cs.x), np.ascontiguousarray(cs.c)
+    spl = C.c_void_p()
+    _lib.check(L.bfg_spline_create(ctx, knots.size, _dp(knots), _dp(coef), C.byref(spl)), "spline")
+    zax, Max, rax, T = syn.pressure_table()
+    tab = _table(L, ctx, (zax, Max, rax), np.log(T), _lib.BFG_TABLE_LOG_VALUES)
+    d_cat = Dev(L, ctx, n * 32).up(np.stack([M, z, ra, dec], 1))
+    args = _lib.ShellArgs()
+    args.nside, args.n_halo, args.d_catalog, args.cat_stride, args.n_extra = nside, n, d_cat.p.value, 4, 0
+    args.epsilon_max, args.runner_md, args.model_md, args.variant = 10.0, _massdef(bg), _massdef(bg), 0
+    args.flags = _lib.SHELL_OUT_OVERWRITE
+    d_map = Dev(L, ctx, npix * 8).up(np.full(npix, np.nan))
+    out = np.full(npix, np.nan)
+    seen = []
+
+    def cb(user, k, nsl, lo, hi):
+        seen.append((k, nsl, lo, hi))
+        L.bfg_memcpy_d2h(ctx, out[lo:hi].ctypes.data_as(C.c_void_p), C.c_void_p(d_map.p.value + 8 * lo), 8 * (hi - lo))
+        return 0
+    fn = _lib.SLICE_FN(cb)
+    _lib.check(L.bfg_paint_shell_sliced(ctx, C.byref(args), tab, spl, d_map.p, 4, fn, None), "sliced paint")
+    assert L.bfg_paint_shell_sliced(ctx, C.byref(args), tab, spl, d_map.p, 0, fn, None) == -1     # n_slices < 1
+    _lib.check(L.bfg_ctx_synchronize(ctx))
+    assert [s[0] for s in seen] == [0, 1, 2, 3] and seen[0][2] == 0 and seen[-1][3] == npix
+    a, R, D = orc.halo_scalars(cosmo, M, z)
+    ref, _ = orc.paint_shell(nside, ra, dec, M, a, D, R, (zax, Max, rax), np.log(T), 10.0)
+    assert_maps_close(out, ref, 1e-5, what="sliced paint through ctypes")
+    assert np.array_equal(d_map.down(npix), out)
+    fail = _lib.SLICE_FN(lambda user, k, nsl, lo, hi: 1)
+    assert L.bfg_paint_shell_sliced(ctx, C.byref(args), tab, spl, d_map.p, 4, fail, None) == -1  # the callback's veto
     d_cat.free(); d_map.free()
     _lib.check(L.bfg_table_destroy(ctx, tab))
     _lib.check(L.bfg_spline_destroy(ctx, spl))

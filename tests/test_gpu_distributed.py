@@ -80,3 +80,14 @@ def test_two_ranks_real_kernels_paint_and_baryonify(tmp_path):
             assert_maps_close(bgot, bref, 1e-5, floor=1e-9, what=f"2-rank baryonify ({backend}/{coll}), rank {r}")
             assert np.isclose(bgot.sum(), I["m_in"].sum(), rtol=1e-10)            # mass conservation (:368-370)
         assert np.array_equal(np.load(tmp_path / f"paint_{coll}_0.npy"), np.load(tmp_path / f"paint_{coll}_1.npy"))
+        # the list API: every shell equals its own serial oracle run on every rank; every (halo, pixel) pair painted once
+        ptot_list = 0
+        for k, (lo, hi) in enumerate(W.LIST_CUTS):
+            lref, lp = oracle_paint(I["cosmo"], I["ra"][lo:hi], I["dec"][lo:hi], I["M"][lo:hi], I["z"][lo:hi],
+                                    (zax, Max, rax), T, W.NSIDE, W.EPS)
+            ptot_list += lp
+            for r in range(world):
+                lgot = np.load(tmp_path / f"list{k}_{coll}_{r}.npy")
+                assert np.array_equal(lgot != 0, lref != 0)
+                assert_maps_close(lgot, lref, 1e-5, what=f"2-rank list shell {k} ({backend}/{coll}), rank {r}")
+        assert sum(info[f"list_{coll}_pixel_updates"] for info in infos) == ptot_list

@@ -1481,3 +1481,141 @@ def test_timing_select_times_only_the_chosen_kernel_classes(cosmo):
     ctx.paint_shell(sargs, table, spline, d_map)
     assert ctx.timing_read(0)[1] == 1 and ctx.timing_read(1)[1] == 1 and ctx.timing_read(3)[1] == 1
     ctx.timing_enable(False)
+
+
+# --------------------------------------------------------------------------- sliced calls (the multi-GPU join inside one call)
+def _sliced_paint(runner, slices, poison=True):
+    """process_device through bfg_paint_shell_sliced; every slice is copied out the moment it is reported (stream order), and
+    the slice is then poisoned: a later launch that still wrote into a reported slice would be caught"""
+    import torch
+    ctx = bfg.engine.get_context()
+    npix = 12 * runner.LightconeShell.NSIDE ** 2
+    d_map = ctx.empty(npix)
+    got = torch.empty(npix, dtype=torch.float64, device=d_map.device)
+    seen = []
+
+    def on_slice(k, n, lo, hi):
+        seen.append((k, n, lo, hi))
+        got[lo:hi] = d_map[lo:hi]                  # stream-ordered: what the exchange of this slice would read
+        if poison:
+            d_map[lo:hi] = float("nan")
+    runner.process_device(d_map=d_map, overwrite=True, slices=slices, on_slice=on_slice)
+    return got.cpu().numpy(), seen
+
+
+@pytest.mark.parametrize("case", ["plain", "scan", "leftover", "degraded", "scatter_variant"])
+def test_sliced_paint_equals_the_plain_call(cosmo, case, monkeypatch):
+    """bfg_paint_shell_sliced: the slices cover the map exactly once in ascending order, each is final when it is reported,
+    and their union equals the plain call's map (to the rounding of reordered atomic adds) -- on the scan-free path, with the scan-built work list
+    (shared tiles), with a left-over halo (the scatter kernel then runs first and the tiles are added), with the pair
+    buffer exhausted (everything through the scatter kernel) and for a scatter variant (one slice)."""
+    import warnings
+    nside, n = 256, 5000
+    ra, dec, M, z = syn.catalog(n, seed=77)
+    if case == "leftover":                                    # one disc over more than 64 sky tiles
+        ra, dec, M, z = np.append(ra, 10.0), np.append(dec, 5.0), np.append(M, 5e15), np.append(z, 0.012)
+    zax, Max, rax, T = syn.pressure_table()
+    if case == "scan":
+        monkeypatch.setenv("BFG_TILE_CAP", "3")               # overflow lists + tiles cut into several (shared) items
+        monkeypatch.setenv("BFG_TILE_SCAN", "1")
+    if case == "degraded":
+        monkeypatch.setenv("BFG_TILE_CAP", "2")
+        monkeypatch.setenv("BFG_PAIR_CAP", "100")
+    ref, ptot = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax), T, nside, 10)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    Shell = bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo)
+    variant = "scatter_quarter" if case == "scatter_variant" else "tile_lds"
+    R = bfg.PaintProfilesShell(Cat, Shell, 10, _paint_model(zax, Max, rax, T), verbose=False, variant=variant)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        plain = R.process()
+        assert R.last_stats["pixel_updates"] == ptot
+        for slices in (1, 3, 7, 64):
+            got, seen = _sliced_paint(R, slices)
+            assert R.last_stats["pixel_updates"] == ptot
+            nrep = seen[0][1]
+            assert [s[0] for s in seen] == list(range(nrep)) and all(s[1] == nrep for s in seen)
+            assert seen[0][2] == 0 and seen[-1][3] == got.size
+            assert all(a[3] == b[2] and a[2] < a[3] for a, b in zip(seen, seen[1:]))      # contiguous, ascending, non-empty
+            if case == "scatter_variant":
+                assert nrep == 1
+            else:
+                assert nrep == min(slices, 16, (4 * nside - 1 + 31) // 32)
+            # equal up to the order in which atomics add (deferred pixels, shared tiles, the scatter kernel): rounding only
+            assert np.array_equal(got != 0, plain != 0)
+            np.testing.assert_allclose(got, plain, rtol=1e-12, atol=0, err_msg=f"{case}: {slices} slices vs the plain call")
+    assert_maps_close(plain, ref, RTOL, what=f"sliced paint ({case})")
+
+
+def test_sliced_offsets_equal_the_plain_call(cosmo):
+    """bfg_baryonify_offsets_sliced: element ranges are 3 doubles per pixel; union == the plain call's offset field"""
+    import torch
+    import warnings
+    nside = 128
+    ra, dec, M, z = syn.catalog(2500, seed=78)
+    zd, Md, rd, d = syn.displacement_table()
+    ctx = bfg.engine.get_context()
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    model = bfg.Baryonification2D.from_arrays(zd, Md, rd, d, cosmo, epsilon_max=20)
+    R = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=syn.mass_map(nside), cosmo=cosmo), 10, model, verbose=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        plain = R.offsets_device().cpu().numpy()
+        keys = R._checked_model_keys()
+        bg, spline, d_cat, stride = R._device_inputs(ctx, keys)
+        table = ctx.table(bfg.Runners.HealpixRunner._table_axes(model, keys), np.asarray(model.raw_input_d), log_values=False)
+        md = ctx.massdef_struct(bg, R.mass_def)
+        args = ctx.shell_args(nside, d_cat, d_cat.shape[0], stride, 0, 10, md, model_md=md, model_epsilon_max=20.0,
+                              out_overwrite=True)
+        d_off = ctx.empty(12 * nside * nside, 3)
+        got = torch.empty_like(d_off)
+        seen = []
+
+        def on_slice(k, n, lo, hi):
+            seen.append((lo, hi))
+            got.view(-1)[lo:hi] = d_off.view(-1)[lo:hi]
+            d_off.view(-1)[lo:hi] = float("nan")
+        ctx.baryonify_offsets(args, table, spline, d_off, slices=5, on_slice=on_slice)
+    assert len(seen) == 5 and seen[0][0] == 0 and seen[-1][1] == 3 * 12 * nside * nside
+    assert all(lo % 3 == 0 and hi % 3 == 0 for lo, hi in seen)
+    got = got.cpu().numpy()
+    # 4-neighbour fallback halos (< 4 pixels) go through the scatter kernel, whose atomics reorder the sums
+    assert np.array_equal(got != 0, plain != 0)
+    np.testing.assert_allclose(got, plain, rtol=1e-11, atol=1e-18)
+
+
+def test_slice_callback_failure_aborts_the_call(cosmo):
+    ra, dec, M, z = syn.catalog(300, seed=5)
+    zax, Max, rax, T = syn.pressure_table()
+    R = bfg.PaintProfilesShell(bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo),
+                               bfg.LightconeShell(map=np.zeros(12 * 64 * 64), cosmo=cosmo), 10,
+                               _paint_model(zax, Max, rax, T), verbose=False)
+
+    def boom(k, n, lo, hi):
+        raise KeyError("from the callback")
+    with pytest.raises(KeyError, match="from the callback"):
+        R.process_device(slices=4, on_slice=boom)
+    got = R.process()                                         # the context is usable afterwards
+    ref, _ = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax), T, 64, 10)
+    assert_maps_close(got, ref, RTOL, what="after a failed callback")
+
+
+def test_catalog_device_copy_is_locked_not_stale(cosmo):
+    """the device copy of a catalog is reused between calls; numpy refuses in-place edits while it exists, unlock() drops it"""
+    ra, dec, M, z = syn.catalog(400, seed=6)
+    zax, Max, rax, T = syn.pressure_table()
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * 64 * 64), cosmo=cosmo), 10,
+                               _paint_model(zax, Max, rax, T), verbose=False)
+    a = R.process()
+    with pytest.raises(ValueError):
+        Cat.cat["M"][0] = 1e15
+    assert np.array_equal(R.process(), a)
+    Cat.unlock()
+    Cat.cat["M"] *= 2.0
+    ref, _ = oracle_paint(cosmo, ra, dec, 2 * M, z, (zax, Max, rax), T, 64, 10)
+    assert_maps_close(R.process(), ref, RTOL, what="after unlock + edit")
+    Cat.cat = Cat.cat.copy()                                  # another array object: noticed by identity
+    Cat.cat["M"] /= 2.0
+    ref, _ = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax), T, 64, 10)
+    assert_maps_close(R.process(), ref, RTOL, what="after replacing cat")

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.bfg_abi_version() == 1
+    assert L.bfg_abi_version() == _lib.ABI_VERSION == 2
     assert L.bfg_status_string(0) == b"ok" and b"invalid" in L.bfg_status_string(-1)
 
 
@@ -42,7 +42,7 @@ def test_header_is_plain_c(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)])
     out = subprocess.check_output([str(exe)]).decode().split()
     assert [int(x) for x in out] == [ctypes.sizeof(_lib.MassDefStruct), ctypes.sizeof(_lib.ShellArgs),
-                                     ctypes.sizeof(_lib.Stats), 1, ctypes.sizeof(_lib.SnapshotArgs),
+                                     ctypes.sizeof(_lib.Stats), _lib.ABI_VERSION, ctypes.sizeof(_lib.SnapshotArgs),
                                      ctypes.sizeof(_lib.GridArgs)]
 
 
@@ -469,3 +469,22 @@ def test_grid_and_snapshot_runners_use_lcdm_like_the_reference():
     a = 1 / 1.5
     assert Background(lcdm(c)).E2(a) != Background(c).E2(a)
     assert Background(lcdm(c)).E2(a) == Background(dict(c, w0=-1.0)).E2(a)
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash(tmp_path):
+    """with no loadable librccl the communicator entry points must return BFG_ERR_COMM (-6) and leave a message
+    in bfg_last_error() -- not crash on a null dlerror().  A fresh process: the load is attempted once per process."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        f"L = C.CDLL({_lib.so_path()!r})\n"
+        "L.bfg_last_error.restype = C.c_char_p\n"
+        "buf = C.create_string_buffer(128)\n"
+        "L.bfg_comm_unique_id.argtypes = [C.c_char_p, C.c_size_t]\n"
+        "rc = [L.bfg_comm_unique_id(buf, 128) for _ in range(3)]\n"
+        "print(rc, L.bfg_last_error().decode())\n")
+    env = dict(os.environ, BFG_RCCL_SO=str(tmp_path / "no_such_librccl.so"))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.startswith("[-6, -6, -6]") and "no_such_librccl" in out.stdout, out.stdout

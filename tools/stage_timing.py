@@ -55,7 +55,14 @@ print(f"workload {workload} n={n} nside={nside}: {tot:.4g} cycles summed over wo
 for nm, x in zip(names, v):
     if x:
         print(f"  {nm:45s} {x:12.4g}  {100 * x / tot:5.1f} %")
-if sub.sum():
+if sub.sum() and os.environ.get("BFG_ST_MODE") == "3":
+    subn = ["i0: top of the item (counter atomic, work record, list prefetch)", "i1: accumulator clear", "i2: ring rows",
+            "i3: first records / wave-0 priming", "i4: chunk loop", "i5: write-back addresses, deferred pixels",
+            "i6: write-back stores", "i7: end-of-item barrier"]
+    print(f"  inside a work item (thread {os.environ.get('BFG_ST_TID', '64')} of every workgroup; a -DBFG_STAGE_TIMING=3 build):")
+    for nm, x in zip(subn, sub):
+        print(f"    {nm:62s} {x:12.4g}  {100 * x / sub.sum():5.1f} %")
+elif sub.sum():
     subn = ["b0: window DMA issued, pair of the slot found", "b1: halo record arrived", "b2: ring window, clipping, segment constants",
             "b3: pixel-list offsets (scan + LDS atomics)", "b4: segment records + pixel->segment table", "b5: barrier (other waves, window DMA)"]
     print("  inside stage b (wave 1 of every workgroup; a -DBFG_STAGE_TIMING=2 build):")
