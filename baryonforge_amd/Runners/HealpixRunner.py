@@ -104,7 +104,10 @@ class DefaultRunner(object):
 
     def _device_inputs(self, ctx, keys):
         cat = self.HaloLightConeCatalog.cat
-        z_m = np.max(cat["z"]) if cat.size else 0.0
+        if hasattr(self.HaloLightConeCatalog, "z_max"):
+            z_m = self.HaloLightConeCatalog.z_max()
+        else:
+            z_m = np.max(cat["z"]) if cat.size else 0.0
         assert z_m <= 30, f"We assume max(z) = 30, but your catalog has max(z) = {z_m}"   # :301 / :433
         z_m = max(z_m, getattr(self, "_spline_z_max", z_m))              # a shard of a split catalog: the whole catalog's max(z)
         bg = Background(self.cosmo)
@@ -120,6 +123,17 @@ class DefaultRunner(object):
 class PaintProfilesShell(DefaultRunner):
     """Paint a tabulated projected profile around every halo onto the shell (HealpixRunner.py:376-483)."""
 
+    def _validated_keys(self):
+        """the reference's argument checks, before anything touches the GPU"""
+        assert self.model is not None, "You must provide a model"         # :446
+        keys = self._keys_checked()
+        if not _is_paint_table(self.model):
+            if hasattr(self.model, "setup_interpolator"):
+                raise NameError("No Table created. Run setup_interpolator() method first")
+            raise TypeError(f"PaintProfilesShell on the MI355X path needs a tabulated model (TabulatedProfile / "
+                            f"ParamTabulatedProfile with raw_input_2D); got {type(self.model)}")
+        return keys
+
     def process_device(self, d_map=None, overwrite=None, slices=1, on_slice=None, sync_stats=True):
         """Paint into a device map (float64[Npix] torch tensor) and return it.
 
@@ -130,13 +144,7 @@ class PaintProfilesShell(DefaultRunner):
         start while the next one is painted (utils.Parallelize.SplitJoinParallel).
         sync_stats=False: do not read the counters back (that synchronises the stream); `collect_stats()` does it later --
         what a pipeline over several shells wants."""
-        assert self.model is not None, "You must provide a model"         # :446
-        keys = self._keys_checked()
-        if not _is_paint_table(self.model):
-            if hasattr(self.model, "setup_interpolator"):
-                raise NameError("No Table created. Run setup_interpolator() method first")
-            raise TypeError(f"PaintProfilesShell on the MI355X path needs a tabulated model (TabulatedProfile / "
-                            f"ParamTabulatedProfile with raw_input_2D); got {type(self.model)}")
+        keys = self._validated_keys()
         ctx = get_context()
         NSIDE = self.LightconeShell.NSIDE
         bg, spline, d_cat, stride = self._device_inputs(ctx, keys)
@@ -166,11 +174,44 @@ class PaintProfilesShell(DefaultRunner):
         emit_fallback_warning(self.last_stats)
         return self.last_stats
 
-    def process(self):
-        """returns new_map : float64[Npix] (RING), the sum over halos of the painted profiles"""
-        d_map = self.process_device()                                      # validates the model first
-        new_map = get_context().to_host(d_map)
-        return new_map.reshape(np.shape(self.LightconeShell.map))
+    def process(self, out=None):
+        """returns new_map : float64[Npix] (RING), the sum over halos of the painted profiles.
+
+        out: optional float64 numpy array of the map's size to receive the result -- page-locked memory if the copy is to run
+        at PCIe speed (engine.pinned_empty; a pageable array costs ~3 ms more per 101 MB); by default the result lands in
+        page-locked memory from torch's caching host allocator.
+        The map leaves the GPU in slices while it is being painted (bfg_paint_shell_sliced + a copy stream): the copy of slice k
+        overlaps the painting of slice k + 1 (measured at the headline size: 3.9 ms with one slice, 2.6 ms with eight)."""
+        import os
+        import torch
+        self._validated_keys()
+        ctx = get_context()
+        npix = 12 * self.LightconeShell.NSIDE ** 2
+        shape = np.shape(self.LightconeShell.map)
+        if out is not None:
+            if not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.size == npix and out.flags["C_CONTIGUOUS"]):
+                raise ValueError("out must be a C-contiguous float64 array with one element per pixel")
+            h = torch.from_numpy(out.reshape(-1))
+        else:
+            try:
+                h = torch.empty(npix, dtype=torch.float64, pin_memory=True)
+            except RuntimeError:                                           # no page-locked memory to be had
+                h = torch.empty(npix, dtype=torch.float64)
+        d_map = ctx.empty(npix)
+        main, side = torch.cuda.current_stream(ctx.device), ctx.copy_stream()
+
+        def on_slice(k, n, lo, hi):
+            ev = torch.cuda.Event()
+            ev.record(main)                                                # slice k has been painted when this fires
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                h[lo:hi].copy_(d_map[lo:hi], non_blocking=True)
+        ctx.stats_reset()
+        self.process_device(d_map=d_map, overwrite=True, slices=int(os.environ.get("BFG_D2H_SLICES", "8")), on_slice=on_slice,
+                            sync_stats=False)
+        side.synchronize()                                                 # every slice is on the host; d_map may go
+        self.collect_stats()
+        return (out if out is not None else h.numpy()).reshape(shape)
 
 
 class _ProductTable(object):

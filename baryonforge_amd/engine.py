@@ -240,6 +240,12 @@ class Context(object):
             return torch.full(shape, float("nan"), dtype=torch.float64, device=self.device)
         return torch.empty(*shape, dtype=torch.float64, device=self.device)
 
+    def copy_stream(self):
+        """a stream of this context's GPU for device <-> host copies that overlap the kernels of the current stream"""
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = _torch().cuda.Stream(device=self.device)
+        return self._copy_stream
+
     def to_host(self, d_tensor):
         """device tensor -> numpy array.  Up to 1 GiB the copy lands in page-locked memory from torch's caching host
         allocator and the array is a view of it: 1.8 ms instead of 11 ms for a 101 MB map once a block is being
@@ -479,6 +485,12 @@ class Context(object):
         ms, n = C.c_double(), C.c_int64()
         _lib.check(self.lib.bfg_timing_read(self.handle, int(which), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+def pinned_empty(n):
+    """float64 numpy array of n elements in page-locked host memory (for PaintProfilesShell.process(out=...)): device -> host
+    copies into it run at PCIe speed and asynchronously"""
+    return require_gpu().empty(int(n), dtype=_torch().float64, pin_memory=True).numpy()
 
 
 def get_context(device=None):

@@ -131,8 +131,8 @@ class Exchange(object):
 
 
 class _DeviceOps(object):
-    """The GPU side of one rank: HBM tensors, C-ABI calls through the runners, copies to the host.  (The CPU tests of the
-    multi-rank control flow replace this class -- `Parallelize._DeviceOps` -- by one that computes with the oracle.)"""
+    """The GPU side of one rank: HBM tensors, C-ABI calls through the runners, copies to the host (the default `ops` of
+    SplitJoinParallel.process / process_device)."""
 
     def __init__(self):
         from ..engine import get_context
@@ -252,6 +252,7 @@ class SplitJoinParallel(object):
         self.rank = dist.get_rank() if dist else 0
         self.world = dist.get_world_size() if dist else 1
         self.shard_indices_list = []
+        self._shards = {}                                                # id(catalog) -> (indices, this rank's sub-catalog)
         self.Runner_list = [self.split_run(R) for R in self.Runners]     # this rank's runner of every input runner
         self.shard_indices = self.shard_indices_list[0] if self.shard_indices_list else np.arange(0)
 
@@ -262,12 +263,15 @@ class SplitJoinParallel(object):
         if self.world == 1:
             self.shard_indices_list.append(np.arange(cat.size))
             return Runner
-        w = estimate_disc_pixels(Runner.cosmo, cat["M"], cat["z"], Runner.epsilon_max, Runner.LightconeShell.NSIDE,
-                                 Runner.mass_def)
-        shards = shard_by_sky_patch(cat["ra"], cat["dec"], w, self.world, self.nside_patch, layout=self.layout)
-        idx = shards[self.rank]
+        # runners that share a catalog object (several models on one shell) share its shard -- and its one device copy
+        key = (id(HaloCat), float(Runner.epsilon_max), int(Runner.LightconeShell.NSIDE), id(Runner.mass_def))
+        if key not in self._shards:
+            w = estimate_disc_pixels(Runner.cosmo, cat["M"], cat["z"], Runner.epsilon_max, Runner.LightconeShell.NSIDE,
+                                     Runner.mass_def)
+            shards = shard_by_sky_patch(cat["ra"], cat["dec"], w, self.world, self.nside_patch, layout=self.layout)
+            self._shards[key] = (shards[self.rank], HaloCat[shards[self.rank]], HaloCat)   # (keeps HaloCat alive: id() stays unique)
+        idx, New_HaloCatalog, _ = self._shards[key]
         self.shard_indices_list.append(idx)
-        New_HaloCatalog = HaloCat[idx]
         New_Runner = type(Runner)(New_HaloCatalog, Runner.LightconeShell, Runner.epsilon_max, Runner.model,
                                   Runner.use_ellipticity, Runner.mass_def,
                                   include_pixel_size=Runner.include_pixel_size, verbose=False)
@@ -288,8 +292,9 @@ class SplitJoinParallel(object):
             return None
         return Exchange(dist, self.collective)
 
-    def process_device(self, consume=None, ops=None):
+    def process_device(self, consume=None, ops=None, exchange=True):
         """Paint every runner's shard of this rank, summed over the ranks, leaving the maps ON THE DEVICE.
+        (exchange=False: no sum over the ranks -- every rank keeps the map of its own shard.)
 
         consume=None: returns the list of device maps (one buffer per runner), ordered on the current stream.
         consume=callable(k, d_map): called once per runner, in order, when the current stream holds everything map k
@@ -297,7 +302,7 @@ class SplitJoinParallel(object):
         enqueue or finish what it does with it.  Returns None.
         Only PaintProfilesShell runners (a BaryonifyShell's regrid needs the exchanged offsets first: see process())."""
         ops = ops or _DeviceOps()
-        ex = self._exchange()
+        ex = self._exchange() if exchange else None
         n = len(self.Runner_list)
         nbuf = n if consume is None else min(2, n)
         bufs, pend = [None] * nbuf, [None] * nbuf

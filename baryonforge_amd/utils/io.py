@@ -119,14 +119,26 @@ class HaloLightConeCatalog(object):
         cache[key] = (self.cat, d, recs.shape[1])
         return d, recs.shape[1]
 
+    def z_max(self):
+        """max(z) of the catalog (HealpixRunner.py:297 / :429 take it on every call: 0.5 ms per 1e6 halos); remembered while the
+        array is locked by device_records(), recomputed otherwise"""
+        hit = self.__dict__.get("_zmax")
+        if hit is not None and hit[0] is self.cat and not self.cat.flags.writeable:
+            return hit[1]
+        z_m = float(np.max(self.cat["z"])) if self.cat.size else 0.0
+        self.__dict__["_zmax"] = (self.cat, z_m)
+        return z_m
+
     def unlock(self):
         """make `cat` writable again and forget its device copies (see device_records)"""
         self.__dict__.pop("_device_copies", None)
+        self.__dict__.pop("_zmax", None)
         self.cat.setflags(write=True)
 
     def __getstate__(self):                                              # device tensors do not travel
         st = dict(self.__dict__)
         st.pop("_device_copies", None)
+        st.pop("_zmax", None)
         return st
 
     def __str__(self):

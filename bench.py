@@ -16,8 +16,15 @@ and -- for N > 1 -- the RCCL all-reduce of the per-rank maps.
 BASELINE.json's metric reads: one 1e6-halo catalog at 1/2/4/8 GPUs).  Either way value = all halos painted by all ranks
 / max-over-ranks time, and the N = 1 run is the same workload.
 --collective torch (default): torch.distributed's all_reduce (backend nccl = RCCL), asynchronous on RCCL's stream;
---collective bfg: the library's own RCCL communicator (bfg_allreduce_f64_begin / bfg_comm_wait of include/bfg_mi355.h).
-Both overlap the all-reduce of shell k with the painting of shell k + 1 (two map buffers).
+--collective bfg: the library's own RCCL communicator (bfg_allreduce_f64_begin / bfg_comm_wait(ticket) of include/bfg_mi355.h).
+For N > 1 the paint workload runs through the PRODUCT API: the K timed steps are K shell runners handed as a list to
+baryonforge_amd.SplitJoinParallel (utils/Parallelize.py), which paints shell k + 1 while the all-reduce of shell k is in
+flight (two rotating map buffers) and hands every map to the all-reduce in --slices pieces as the tile kernel finishes them
+(bfg_paint_shell_sliced).  `api_single_call_ms` = one SplitJoinParallel(runner).process_device() on its own (nothing to
+overlap with but its own slices; `api_single_call_unsliced_ms`: one all-reduce after the call).
+The run exits non-zero with a one-line reason -- it never hangs -- when fewer than N GPUs are visible, when RCCL cannot be
+loaded, when a rank fails (collective timeout BFG_BENCH_TIMEOUT_S, default 180 s) or when the whole run exceeds
+BFG_BENCH_DEADLINE_S (default 1500 s).
 
 Rank 0 prints ONE JSON line (see the contract in the task statement) with these extra objects:
   "roofline":     algorithmic bytes of the dominant kernel / its mean duration (HIP events on the
@@ -54,6 +61,8 @@ def parse():
     p.add_argument("--halos", type=int, default=1_000_000, help="halos per GPU (weak scaling) / in total (strong scaling)")
     p.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     p.add_argument("--collective", choices=["torch", "bfg"], default="torch")
+    p.add_argument("--slices", type=int, default=4, help="N > 1: pieces in which a painted map is handed to the all-reduce")
+    p.add_argument("--layout", choices=["interleaved", "contiguous"], default="interleaved", help="sky-patch sharding layout")
     p.add_argument("--nside", type=int, default=1024)
     p.add_argument("--eps", type=float, default=10.0)
     p.add_argument("--workload", choices=["paint", "baryonify"], default="paint")
@@ -175,28 +184,73 @@ def _mark(msg):
         print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
 
 
+def die(reason, code=1):
+    """one line on stderr, non-zero exit; never a hang, never an exec"""
+    print(f"bench.py: FAILED (rank {os.environ.get('RANK', '0')}): {reason}", file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    os._exit(code)        # not sys.exit: a rank stuck in a collective's destructor would keep the job alive
+
+
+def agree(dist, ok, reason, backend):
+    """every rank learns whether ALL ranks are fine (a MIN all-reduce over the group); if not, all of them stop together --
+    a rank that fails alone would leave the others waiting in the next collective"""
+    import torch
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if int(t.item()) == 0:
+        die(reason if not ok else "another rank failed during set-up (see its message)")
+
+
 def main():
     args = parse()
+    import datetime
+    import signal
+    # the whole run has a deadline: a wedged collective or GPU ends as an error line, not as a hang
+    deadline = int(os.environ.get("BFG_BENCH_DEADLINE_S", "1500"))
+    signal.signal(signal.SIGALRM, lambda *_: die(f"deadline of {deadline} s exceeded", 3))
+    signal.alarm(deadline)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X GPU (no CPU fallback for the product path)")
     # BFG_BENCH_BACKEND=gloo + BFG_BENCH_ONE_DEVICE=1: rehearsal of the multi-rank path on a one-GPU box
     # (all ranks on cuda:0, gloo all-reduce); the driver's runs use one GPU per rank and nccl (= RCCL).
     backend = os.environ.get("BFG_BENCH_BACKEND", "nccl")
-    if os.environ.get("BFG_BENCH_ONE_DEVICE"):
+    one_device = bool(os.environ.get("BFG_BENCH_ONE_DEVICE"))
+    if world != args.gpus:
+        die(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with python -m torch.distributed.run --nproc-per-node "
+            f"{args.gpus} (N > 1) or plain python (N = 1)")
+    n_dev = torch.cuda.device_count()            # counts devices without initialising the runtime
+    if n_dev < (1 if one_device else world):
+        die(f"{n_dev} GPU(s) visible, {world} needed (one process per GPU)")
+    if not torch.cuda.is_available():
+        die("no usable MI355X GPU (torch.cuda.is_available() is False); there is no CPU fallback for the product path")
+    if one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        tmo = datetime.timedelta(seconds=int(os.environ.get("BFG_BENCH_TIMEOUT_S", "180")))
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
+            else:
+                dist.init_process_group(backend, timeout=tmo)
+        except Exception as exc:
+            die(f"init_process_group({backend}) failed: {exc!r}")
+    try:
+        _main(args, torch, dist, rank, local_rank, world, backend)
+    except SystemExit:
+        raise
+    except BaseException as exc:                 # a dead peer surfaces here as a collective timeout / RCCL error
+        import traceback
+        traceback.print_exc()
+        die(f"{type(exc).__name__}: {str(exc).splitlines()[0] if str(exc) else ''}")
+
+
+def _main(args, torch, dist, rank, local_rank, world, backend):
 
     _mark("process group up")
     from baryonforge_amd import sharding, synthetic as syn
@@ -212,12 +266,19 @@ def main():
     bg = Background(cosmo)
     use_bfg = dist is not None and args.collective == "bfg" and backend == "nccl"
     if use_bfg:
-        ctx.comm_init(dist)                      # the library's own RCCL communicator (id broadcast through the group)
+        # the library's own RCCL communicator (id broadcast through the group).  Can RCCL be loaded at all?  Ask before the
+        # id broadcast, on every rank, and stop together if not (bfg_comm_unique_id is the cheapest call that dlopens it)
+        import ctypes
+        from baryonforge_amd import _lib
+        probe = ctypes.create_string_buffer(_lib.BFG_COMM_ID_BYTES)
+        st = ctx.lib.bfg_comm_unique_id(probe, _lib.BFG_COMM_ID_BYTES)
+        agree(dist, st == 0, f"RCCL unavailable: {ctx.lib.bfg_last_error().decode()} (status {st})", backend)
+        ctx.comm_init(dist)
 
     # this rank's sky-patch shard (the whole catalog at N = 1), resident in HBM before timing starts
     if world > 1:
         w = sharding.estimate_disc_pixels(cosmo, M, z, args.eps, nside)
-        idx = sharding.shard_by_sky_patch(ra, dec, w, world)[rank]        # NSIDE-64 patches dealt round-robin: the whole sky per rank
+        idx = sharding.shard_by_sky_patch(ra, dec, w, world, layout=args.layout)[rank]   # default: NSIDE-64 patches dealt round-robin
     else:
         idx = np.arange(n_total)
     recs = np.stack([M[idx], z[idx], ra[idx], dec[idx]], axis=1)
@@ -237,7 +298,44 @@ def main():
             return lambda: None
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True).wait
 
-    if args.workload == "paint":
+    api = None           # N > 1, paint: the product API (SplitJoinParallel over a list of shell runners)
+    if args.workload == "paint" and dist is not None:
+        import baryonforge_amd as bfg
+        from baryonforge_amd.utils.Parallelize import Exchange
+        zax, Max, rax, T = syn.pressure_table(*shape)
+        Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+        Shell = bfg.LightconeShell(map=np.zeros(npix), cosmo=cosmo)
+        R = bfg.PaintProfilesShell(Cat, Shell, args.eps, bfg.TabulatedProfile.from_arrays(zax, Max, rax, T), verbose=False,
+                                   variant=args.variant)
+        pipes = {}
+
+        def pipe(n, slices=None):
+            key = (n, slices or args.slices)
+            if key not in pipes:                                  # sharding + the per-rank runners: outside every timed region
+                pipes[key] = bfg.SplitJoinParallel([R] * n if n > 1 else R, collective="bfg" if use_bfg else "torch",
+                                                   slices=key[1], layout=args.layout)
+            return pipes[key]
+        api = pipe(args.steps)
+        pipe(max(args.warmup, 1))
+        idx = api.shard_indices
+        ex_only = Exchange(dist, "bfg" if use_bfg else "torch", ctx)
+        d_probe = ctx.zeros(npix)
+        last = {"stats": None}
+
+        def run_steps(n, collective=True, do_compute=True):
+            if do_compute:
+                sj = pipe(n)
+                sj.process_device(consume=lambda k, d: None, exchange=collective)
+                last["stats"] = sj.Runner_list[0].last_stats
+            else:                                                # the exchange alone: n maps, each in --slices pieces
+                k = max(1, min(args.slices, 16))
+                cuts = [npix * i // k for i in range(k + 1)]
+                for _ in range(n):
+                    hs = [ex_only.allreduce_begin(d_probe[cuts[i]:cuts[i + 1]]) for i in range(k)]
+                    for h in hs:
+                        ex_only.wait(h)
+        exchange_bytes = 8.0 * npix
+    elif args.workload == "paint":
         zax, Max, rax, T = syn.pressure_table(*shape)
         with np.errstate(all="ignore"):
             table = ctx.table([zax, Max, rax], np.log(T), log_values=True)
@@ -246,7 +344,7 @@ def main():
         # N > 1: consecutive shells go to alternating map buffers, so the all-reduce of shell k (async, on RCCL's own
         # stream) overlaps the painting of shell k+1; every collective is waited for before its buffer is reused and
         # before the timed region ends (finish()).
-        nbuf = 2 if dist is not None else 1
+        nbuf = 1
         d_maps = [ctx.zeros(npix) for _ in range(nbuf)]
         pending = [None] * nbuf
         counter = [0]
@@ -316,19 +414,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if api is None:
+        def run_steps(n, **kw):
+            for _ in range(n):
+                step(**kw)
+            finish()                     # every outstanding collective has completed inside the timed region
+
     def timed(n, **kw):
         barrier()
         t0 = time.perf_counter()
-        for _ in range(n):
-            step(**kw)
-        finish()                         # every outstanding collective has completed inside the timed region
+        run_steps(n, **kw)
         barrier()
         return time.perf_counter() - t0
 
     _mark("inputs resident")
-    for _ in range(args.warmup):
-        step()
-    finish()
+    if args.warmup > 0 or api is not None:
+        run_steps(max(args.warmup, 1) if api is not None else args.warmup)
     _mark("warmup issued")
     barrier()
     _mark("warmup done")
@@ -346,8 +447,10 @@ def main():
         else:
             h = t.cpu(); dist.all_reduce(h, op=dist.ReduceOp.MAX); t.copy_(h)
         dt = float(t.item())
-    stats = ctx.stats()
+    stats = ctx.stats() if api is None else last["stats"]
     k_ms, k_n = ctx.timing_read(1)
+    if api is not None:
+        k_n = args.steps                 # a sliced call launches the tile kernel once per slice: per-shell time = total / shells
     n_extra = max(1, min(args.steps, 10))
     ctx.timing_enable(True)          # every kernel class, outside the timed region
     timed(n_extra, collective=False) if dist is not None else timed(n_extra)
@@ -367,6 +470,20 @@ def main():
         mine = {"rank": rank, "shard_halos": int(idx.size), "pixel_updates_per_step": ptot_step,
                 "compute_ms": t_comp, "allreduce_ms": t_coll, "kernel_ms": k_ms / max(k_n, 1),
                 "prep_kernel_ms": p_ms / max(p_n, 1), "tile_binning_ms": (b_ms / b_n) if b_n else None}
+        if api is not None:
+            # one product call on its own: SplitJoinParallel(runner).process_device() -- painting + exchange of ONE shell, with
+            # the map handed to the all-reduce in --slices pieces, and with a single all-reduce after the call
+            def single(slices, reps=5):
+                sj = pipe(1, slices)
+                sj.process_device()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    sj.process_device()
+                barrier()
+                return (time.perf_counter() - t0) / reps * 1e3
+            mine["api_single_call_ms"] = single(args.slices)
+            mine["api_single_call_unsliced_ms"] = single(1)
         ranks = [None] * world
         dist.all_gather_object(ranks, mine)
         ptot_all = float(sum(r["pixel_updates_per_step"] for r in ranks))
@@ -423,8 +540,10 @@ def main():
                 "step_frac": step_bytes / (dt / args.steps) / HBM_PEAK if world == 1 else None}
     sharding_txt = "none"
     if world > 1:
-        sharding_txt = ("sky patch (nside-64 patches dealt round-robin in NEST order: every rank's shard covers the sky; sorted by position) + "
-                        + ("RCCL all-reduce of the map, overlapped with the next shell (two map buffers)"
+        sharding_txt = (f"sky patch, layout {args.layout} (interleaved: nside-64 patches dealt round-robin in NEST order, every rank's "
+                        "shard covers the sky; contiguous: one compact region per rank; sorted by position) + "
+                        + (f"product API SplitJoinParallel over the list of {args.steps} shell runners: RCCL all-reduce of every map "
+                           f"in {args.slices} slices as the tile kernel finishes them, overlapped with the next shell (two map buffers)"
                            if args.workload == "paint" else
                            "RCCL reduce-scatter of the offsets, regrid of the rank's pixel range, all-reduce of the map")
                         + f"; collective = {'libbfg_mi355 communicator (bfg_allreduce_f64*)' if use_bfg else 'torch.distributed ' + backend}")
@@ -450,11 +569,37 @@ def main():
         for r in ranks:
             r["overlap_ms"] = max(0.0, r["compute_ms"] + r["allreduce_ms"] - ms_per_step)   # collective time hidden behind compute
         out["ranks"] = ranks
+        if api is not None:
+            out["api_single_call_ms"] = max(r["api_single_call_ms"] for r in ranks)
+            out["api_single_call_unsliced_ms"] = max(r["api_single_call_unsliced_ms"] for r in ranks)
+            out["slices"] = args.slices
         out["exchange"] = {"bytes_per_rank_per_step": exchange_bytes, "backend": backend,
                            "collective": "bfg" if use_bfg else "torch",
                            "busbw_GBps": 2.0 * (world - 1) / world * exchange_bytes /
                            max(max(r["allreduce_ms"] for r in ranks) * 1e-3, 1e-9) / 1e9}
     if world == 1 and not args.no_e2e and args.workload == "paint":
+        try:
+            # the product API with everything left on the device: SplitJoinParallel over a list of shell runners (the call the
+            # N > 1 runs time), here with a world of one -- what the Python layer adds to a resident-input step
+            import baryonforge_amd as bfg
+            Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+            Rn = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(npix), cosmo=cosmo), args.eps,
+                                        bfg.TabulatedProfile.from_arrays(zax, Max, rax, T), verbose=False, variant=args.variant)
+            sj = bfg.SplitJoinParallel([Rn] * args.steps)
+            sj.process_device(consume=lambda k, d: None)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sj.process_device(consume=lambda k, d: None)
+            torch.cuda.synchronize()
+            out["api_pipelined_ms_per_shell"] = (time.perf_counter() - t0) / args.steps * 1e3
+            t0 = time.perf_counter()
+            for _ in range(5):
+                Rn.process_device()
+            torch.cuda.synchronize()
+            out["api_process_device_ms"] = (time.perf_counter() - t0) / 5 * 1e3
+            del sj, Rn, Cat
+        except Exception as exc:
+            out["api_error"] = repr(exc)
         try:
             out["e2e_ms_python_api"] = e2e_python_api(args, cosmo, ra, dec, M, z, zax, Max, rax, T)
         except Exception as exc:                       # never lose the line to the side measurement
