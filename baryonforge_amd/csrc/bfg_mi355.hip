@@ -397,8 +397,10 @@ __global__ __launch_bounds__(256, BFG_PREP_WAVES) void halo_prep_kernel(const Pr
             hd.pad[0] = hd.pad[1] = 0.0;
             P.hd[j] = hd;
         }
-        h.win_lo = win_lo; h.flags = flags; h.pad0 = 0; h.pad1 = 0;
-        h.spare[0] = lnpf; h.spare[1] = h.spare[2] = h.spare[3] = 0.0;
+        h.win_lo = win_lo; h.flags = flags;
+        h.ci0 = s_ci[0][threadIdx.x]; h.ci1 = (P.tab.nouter > 1) ? s_ci[1][threadIdx.x] : 0;
+        h.spare[0] = lnpf; h.spare[1] = s_cy[0][threadIdx.x]; h.spare[2] = (P.tab.nouter > 1) ? s_cy[1][threadIdx.x] : 0.0;
+        h.spare[3] = 0.0;
         P.ht[j] = h;
         s_wl[threadIdx.x] = win_lo; s_fl[threadIdx.x] = flags; s_ln[threadIdx.x] = lnpf;
     }
@@ -1690,7 +1692,10 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         rc = ensure_tiles(c, mode, mode == MODE_PAINT ? TileCfg<MODE_PAINT>::TR : TileCfg<MODE_BARYONIFY>::TR,
                           mode == MODE_PAINT ? TileCfg<MODE_PAINT>::TW : TileCfg<MODE_BARYONIFY>::TW, a->nside, a->n_halo);
         if (rc) return rc;
-        const int64_t want = win_table ? 0 : a->n_halo * (int64_t)win_nodes;
+        bool blend_early = !win_table && win_nodes == kWinLds && t->dev.nouter == 2;
+        if (const char *e = std::getenv("BFG_BLEND")) blend_early = blend_early && std::atoi(e) != 0;
+        if (use_wave) blend_early = false;
+        const int64_t want = (win_table || blend_early) ? 0 : a->n_halo * (int64_t)win_nodes;
         if (want > c->hwin_cap) {
             HIP_TRY(hipStreamSynchronize(c->stream));
             if (c->d_hwin) (void)hipFree(c->d_hwin);
@@ -1738,8 +1743,13 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         if (std::getenv("BFG_TILE_SCAN")) pp.bin.direct_limit = 0;                   // A/B: always the scan kernel
         pp.left = c->d_left; pp.left_n = tile_count + c->tiles[mode].geo.ntiles;
     }
+    // 3-D tables with 32-node windows: no row windows in HBM at all, the tile kernel blends them per pair from the L2-resident
+    // table (TileParams::blend; BFG_BLEND=0: the windows of round 2, the A/B)
+    bool blend = tile && !win_table && win_nodes == kWinLds && t->dev.nouter == 2;
+    if (const char *e = std::getenv("BFG_BLEND")) blend = blend && std::atoi(e) != 0;
+    if (const char *tk = std::getenv("BFG_TILE_KERNEL")) if (tk[0] == 'w') blend = false;      // the wave kernel reads hwin
     // row windows of 4 k nodes are built by the prep kernel itself (BFG_ROWS=separate: by halo_row4_kernel, the A/B)
-    bool fuse_rows = tile && !win_table && win_nodes % 4 == 0 && win_nodes >= 8;
+    bool fuse_rows = tile && !win_table && !blend && win_nodes % 4 == 0 && win_nodes >= 8;
     if (const char *e = std::getenv("BFG_ROWS")) if (!std::strcmp(e, "separate")) fuse_rows = false;
     pp.hwin = fuse_rows ? c->d_hwin : nullptr;
     const size_t prep_lds = fuse_rows ? (size_t)64 * ((size_t)1 << t->dev.nouter) * 16 : 0;
@@ -1832,8 +1842,8 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         std::memset(&rp, 0, sizeof(rp));
         rp.n_halo = a->n_halo; rp.cap = c->cap_halo; rp.ht = c->d_ht; rp.cidx = c->d_cidx; rp.cw = c->d_cw;
         rp.tab = t->dev; rp.win_nodes = win_nodes; rp.hwin = c->d_hwin;
-        if (win_table || fuse_rows) {
-            // no row windows / built by halo_prep_kernel
+        if (win_table || fuse_rows || blend) {
+            // no row windows / built by halo_prep_kernel / blended in the tile kernel
         } else if (win_nodes % 4 == 0 && win_nodes >= 8) {
             const int hpb = std::min(256 / (win_nodes / 4), 64);
             const size_t rlds = (size_t)64 * ((size_t)1 << t->dev.nouter) * 16;           // weights + offsets of 64 halos
@@ -1860,6 +1870,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         { const char *dbg = std::getenv("BFG_DEBUG"); tp.debug = dbg ? std::atoi(dbg) : 0; }
         tp.out_zero = out_zero ? 1 : 0;
         tp.overwrite = overwrite ? 1 : 0;
+        tp.blend = blend ? 1 : 0;
         tp.defer = (mode == MODE_PAINT) ? ts.d_defer : nullptr; tp.defer_count = ts.d_defer_count;
         tp.defer_cap_wg = (int)std::min<int64_t>(((int64_t)items_max * kDeferCap) / tile_grid, 1 << 20);   // the list, cut into one slice per workgroup
         tp.defer_tail = 1;                                                   // the workgroups add their deferred pixels themselves

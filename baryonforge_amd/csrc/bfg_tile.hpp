@@ -108,8 +108,8 @@ struct __align__(16) HaloTile {
     double st, ct, pphi, S;          // sin/cos of the halo colatitude, longitude, (D/a)^2
     double cosr, z0, xa, pixfac;     // query_disc constants, pixarea * D^2 (or 1)
     int32_t rfirst, rlast, irmin, irmax;
-    int32_t win_lo, flags, pad0, pad1;
-    double spare[4];                 // [0] = ln(pixfac)
+    int32_t win_lo, flags, ci0, ci1; // ci0 / ci1: the halo's cell on the z and M axes of the table (3-D tables)
+    double spare[4];                 // [0] = ln(pixfac), [1] / [2] = the halo's weights on the z / M axes (3-D tables)
 };
 static_assert(sizeof(HaloTile) == 128, "HaloTile must be one 128-byte line");
 
@@ -133,10 +133,11 @@ struct __align__(16) HaloDisp {
 };
 static_assert(sizeof(HaloDisp) == 64, "HaloDisp must be 64 bytes");
 
-struct __align__(16) PairInfo {      // per (halo, tile) pair of the current chunk, paint (32 bytes)
+struct __align__(16) PairInfo {      // per (halo, tile) pair of the current chunk, paint (48 bytes)
     double lnpf;                     // ln(pixarea D^2), already folded into the row window (used by the rare direct read-out)
-    int64_t hoff;                    // index of the halo's row window in hwin
+    int64_t hoff;                    // index of the halo's row window in hwin; blend mode: ci0 | ci1 << 32 (the halo's table cell)
     int32_t win_lo, halo, ra, pad;
+    double w0, w1;                   // blend mode: the halo's weights on the z / M axes
 };
 
 struct __align__(16) PairInfoDisp {  // ... baryonify (96 bytes)
@@ -145,8 +146,9 @@ struct __align__(16) PairInfoDisp {  // ... baryonify (96 bytes)
     int64_t hoff;
     int32_t win_lo, halo, ra, pad;
     double a_over_D;                 // a / D
+    double w0, w1;                   // blend mode (as PairInfo)
 };
-static_assert(sizeof(PairInfoDisp) == 96, "PairInfoDisp must be 96 bytes");
+static_assert(sizeof(PairInfoDisp) == 112, "PairInfoDisp must be 112 bytes");
 
 struct __align__(16) DeferredPixel { // a pixel whose table cell lies outside the staged row window (queued, see drain)
     int32_t halo, abyte;             // halo index, LDS byte offset of the pixel's accumulator
@@ -201,6 +203,8 @@ struct TileParams {
                                      // after its last item (defer_tail) or by tile_deferred_kernel; null: every item drains its own
     int32_t *defer_count;            // [grid] entries in the workgroup's slice (for tile_deferred_kernel)
     int defer_cap_wg, defer_tail;
+    int blend;                       // 1: no pre-blended row windows in HBM -- stage b blends every pair's 32-node window from the four
+                                     // corner rows of the halo's (z, M) cell, straight from the (L2-resident) table, into LDS
     int32_t *work_counter;           // persistent grid: the next work item to hand out (starts at first item + 3 gridDim.x); null: one item per workgroup
     // Sliced calls (bfg_*_sliced): this launch takes the work items [slice[0], slice[1]) only -- the tiles of one band range, written
     // by tile_scan_kernel -- so that the caller can start exchanging that part of the map while the next slice is painted.
@@ -709,7 +713,7 @@ __device__ inline void deferred_add(const TileParams &P, const DeferredOut &e, c
 #endif
 // offsets tiles (3 accumulators per pixel, 1024 pixels): 16 x 64 instead of 32 x 32, tile kernel -5 %
 #ifndef BFG_PAINT_PIXMAX
-#define BFG_PAINT_PIXMAX 6912      // pixel -> segment table entries per round of stage c: what the LDS left by the 32-ring rows holds
+#define BFG_PAINT_PIXMAX 6400      // pixel -> segment table entries per round of stage c: what the LDS left by the 32-ring rows holds
 #endif
 #ifndef BFG_BARY_TR
 #define BFG_BARY_TR 16
@@ -761,7 +765,7 @@ template <> struct TileCfg<MODE_PAINT, 0> {
 };
 template <> struct TileCfg<MODE_BARYONIFY, 0> {
     static constexpr int NT = kTileThreads, WPS = BFG_TILE_WAVES_PER_SIMD, LDS_MAX = 81920;
-    static constexpr int TR = BFG_BARY_TR, TW = BFG_BARY_TW, NACC = 3, SLOTMAX = 448, PAIRMAX = 48, PIXMAX = 4096, QCAP = 0;
+    static constexpr int TR = BFG_BARY_TR, TW = BFG_BARY_TW, NACC = 3, SLOTMAX = 448, PAIRMAX = 48, PIXMAX = 3712, QCAP = 0;
     static constexpr int SEGMAX = SLOTMAX + kSegExtra;
     using Pair = PairInfoDisp;
 };
@@ -1013,6 +1017,8 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     int pjA = -1, pjB = -1, pjA1 = -1, pjB1 = -1;
     int nx_j = -1, nx_first = 0, nx_last = -1, nx_wl = 0;
     [[maybe_unused]] double nx_lnpf = 0.0;
+    [[maybe_unused]] int nx_c0 = 0, nx_c1 = 0;        // blend mode: table cell and weights of the candidate's halo
+    [[maybe_unused]] double nx_w0 = 0.0, nx_w1 = 0.0;
     bool primed = false;                              // wave 0 holds the first chunk's candidates of the item about to start
     constexpr int kNoItem = 0x7fffffff;
     int item = item_first + (int)blockIdx.x;
@@ -1088,6 +1094,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
             const HaloTile &h = P.ht[nx_j];
             nx_first = h.rfirst; nx_last = h.rlast; nx_wl = h.win_lo;
             if constexpr (MODE == MODE_PAINT) nx_lnpf = h.spare[0];
+            if constexpr (win_in_lds) { if (P.blend) { nx_c0 = h.ci0; nx_c1 = h.ci1; nx_w0 = h.spare[1]; nx_w1 = h.spare[2]; } }
         }
     };
     if (wave == 0 && !primed) {
@@ -1319,6 +1326,9 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                 Pair &pi = pinfo[lane];
                 pi.hoff = (int64_t)j * W; pi.win_lo = nx_wl; pi.halo = j; pi.ra = ra; pi.pad = 0;
                 if constexpr (MODE == MODE_PAINT) pi.lnpf = nx_lnpf;   // baryonify: the rest is filled in stage b
+                if constexpr (win_in_lds) {
+                    if (P.blend) { pi.hoff = (int64_t)(uint32_t)nx_c0 | ((int64_t)nx_c1 << 32); pi.w0 = nx_w0; pi.w1 = nx_w1; }
+                }
             }
             pr_off[lane] = (lane < n_take) ? cum - nrings : 0x7fffffff;
             if (lane == n_take - 1) { ctl[0] = n_take; ctl[1] = cum; ctl[2] = 0; ctl[3] = 0; }
@@ -1339,6 +1349,35 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         // drained by the barrier that ends stage b).  dest = wave-uniform base + lane * 16 B == pwin[2 * tid].
         if constexpr (win_in_lds) {
             if (P.debug & 64) {                                       // profiling: no window copy at all (wrong results)
+            } else if (P.blend) {
+                // No windows in HBM: one thread per (pair, 4 nodes) blends them from the four corner rows of the halo's (z, M)
+                // cell -- the table is L2-resident -- with the arithmetic of halo_row4_kernel (corner order, fma chain from
+                // 0, + ln(pixarea D^2)): the same bits.  All eight 16-byte loads of a thread are in flight together.
+                typedef double double2u __attribute__((ext_vector_type(2), aligned(8)));
+                const int i = tid;
+                if (i < n_take * (kWinLds / 4)) {
+                    const int p = i >> 3, q = i & 7;
+                    const Pair &pi = pinfo[p];
+                    const int c0 = (int)(uint32_t)pi.hoff, c1 = (int)(pi.hoff >> 32);
+                    const double y0 = pi.w0, y1 = pi.w1;
+                    const double *r0 = T.values + (int64_t)c0 * T.ostride[0] + (int64_t)c1 * T.ostride[1] + (pi.win_lo + 4 * q);
+                    const double *r1 = r0 + T.ostride[1], *r2 = r0 + T.ostride[0], *r3 = r2 + T.ostride[1];
+                    const double2u a0 = *reinterpret_cast<const double2u *>(r0), b0 = *reinterpret_cast<const double2u *>(r0 + 2);
+                    const double2u a1 = *reinterpret_cast<const double2u *>(r1), b1 = *reinterpret_cast<const double2u *>(r1 + 2);
+                    const double2u a2 = *reinterpret_cast<const double2u *>(r2), b2 = *reinterpret_cast<const double2u *>(r2 + 2);
+                    const double2u a3 = *reinterpret_cast<const double2u *>(r3), b3 = *reinterpret_cast<const double2u *>(r3 + 2);
+                    const double w0 = (1.0 * (1.0 - y0)) * (1.0 - y1), w1 = (1.0 * (1.0 - y0)) * y1;
+                    const double w2 = (1.0 * y0) * (1.0 - y1), w3 = (1.0 * y0) * y1;
+                    double add = 0.0;
+                    if constexpr (MODE == MODE_PAINT) add = pi.lnpf;
+                    double2 o0, o1;
+                    o0.x = fma(a3.x, w3, fma(a2.x, w2, fma(a1.x, w1, fma(a0.x, w0, 0.0)))) + add;
+                    o0.y = fma(a3.y, w3, fma(a2.y, w2, fma(a1.y, w1, fma(a0.y, w0, 0.0)))) + add;
+                    o1.x = fma(b3.x, w3, fma(b2.x, w2, fma(b1.x, w1, fma(b0.x, w0, 0.0)))) + add;
+                    o1.y = fma(b3.y, w3, fma(b2.y, w2, fma(b1.y, w1, fma(b0.y, w0, 0.0)))) + add;
+                    double2 *dst = reinterpret_cast<double2 *>(pwin + p * kWinLds + 4 * q);
+                    dst[0] = o0; dst[1] = o1;
+                }
             } else if (W == kWinLds) {
                 for (int i = tid; i - lane < n_take * (kWinLds / 2); i += NT) {          // whole wavefronts step together
                     if (i < n_take * (kWinLds / 2)) {
