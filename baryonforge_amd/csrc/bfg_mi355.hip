@@ -196,11 +196,28 @@ struct PrepParams {
     int rdelta;
     double *hwin;            // tile variant, row windows of 4 k nodes: the kernel also builds the halos' blended rows (null: a
                              // separate halo_row*_kernel does)
+    int lazy_soa;            // tile path, 3-D table: the SoA workspace rows only of halos the scatter kernel / the fill pass will read
 };
 
 #define MODE_PAINT 0
 #define MODE_BARYONIFY 1
 constexpr int kMaxCorner = 1 << (BFG_MAX_DIM - 1);
+// Everything halo_prep_kernel derives from one catalog record.  A pure function of the record (no atomics, no stores), so
+// that tile_fill_kernel can redo it for the rare call that degrades to the scatter kernel after the fact (see `lazy_soa`).
+struct HaloCalc {
+    double x0, y0, z0v, ptheta, pphi, D, a, Rm, radius;     // what the scatter kernel reads (F_* columns of the SoA workspace)
+    double st, sp, cp, lnpf, pixfac, Rm_com;
+    int32_t flags, rfirst, rlast, irmin, irmax;
+    uint32_t warn;
+    bool oob;
+};
+
+// axis(k): the k-th non-radial table axis (LDS or global); cell(k, i, y): receives the halo's cell index and weight on it
+// (functors, not arrays: private arrays indexed by k end up in scratch memory)
+template <class AxisFn, class CellFn>
+__device__ inline void halo_calc(const PrepParams &P, int64_t j, const double *__restrict__ knots, AxisFn axis, CellFn cell,
+                                 HaloCalc &o);
+__device__ inline void halo_write_soa(const PrepParams &P, int64_t j, const HaloCalc &o, int32_t flags);
 #include "bfg_tile.hpp"
 #include "bfg_wtile.hpp"
 
@@ -235,6 +252,93 @@ constexpr int kPrepKnots = 1024;     // D_A spline knots staged in LDS (the refe
 constexpr int kPrepAxis = 64;        // nodes of a non-radial table axis staged in LDS
 constexpr int kPrepRadial = 512;     // nodes of the radial axis staged in LDS (the window search is one more bisection)
 
+// knots / axes: the D_A spline knots and the non-radial table axes, in LDS (the prep kernel stages them) or in global memory
+template <class AxisFn, class CellFn>
+__device__ inline void halo_calc(const PrepParams &P, int64_t j, const double *__restrict__ knots, AxisFn axis, CellFn cell,
+                                 HaloCalc &o)
+{
+    const double *c = P.cat + j * (int64_t)P.cat_stride;
+    const double M = c[0], zred = c[1], ra = c[2], dec = c[3];
+    const double a = 1.0 / (1.0 + zred);                                   // HealpixRunner.py:319/:453
+    const double R = massdef_radius(P.md_run, M, a);                        // :320/:454
+    const double D = spline_eval(P.spl_n, knots, P.spl_coef, zred);         // :321/:455
+    // hp.ang2vec(ra, dec, lonlat=True)                                      // :327/:460
+    const double theta = kHalfPi - dec * kDeg2Rad, phi = ra * kDeg2Rad;
+    double st, ct, sp, cp;
+    sincos(theta, &st, &ct);
+    sincos(phi, &sp, &cp);
+    const double x0 = st * cp, y0 = st * sp, z0v = ct;
+    // pointing(vec3) inside query_disc
+    double ptheta = atan2(sqrt(x0 * x0 + y0 * y0), z0v);
+    double pphi = (x0 == 0.0 && y0 == 0.0) ? 0.0 : atan2(y0, x0);
+    if (pphi < 0.0) pphi += kTwoPi;
+    const double radius = R * P.eps_run / D;                                 // :329/:462
+    o.x0 = x0; o.y0 = y0; o.z0v = z0v; o.ptheta = ptheta; o.pphi = pphi; o.D = D; o.a = a; o.radius = radius;
+    o.st = st; o.sp = sp; o.cp = cp;
+    o.Rm = P.want_model_radius ? massdef_radius(P.md_model, M, a) / a : 0.0;   // BaryonCorrection.py:399
+    o.Rm_com = P.want_model_radius ? o.Rm : 1.0;
+    const double lnM = log(M), lnz = log(1.0 / a);                           // Tabulate.py:308,312
+
+    // disc ring range (query_disc_internal, fact = 0)
+    int32_t flags = 0, rfirst = 1, rlast = 0, irmin = 1, irmax = 0;
+    const int64_t nl4 = 4 * P.hpx.nside;
+    if (!(radius >= 0.0) || !isfinite(ptheta)) {
+        flags |= HF_SKIP;   // NaN radius: every healpy comparison is false -> empty disc
+    } else if (radius >= kPi) {
+        rfirst = 1; rlast = (int32_t)(nl4 - 1); irmin = (int32_t)nl4; irmax = (int32_t)nl4;  // every ring complete
+    } else {
+        const double rlat1 = ptheta - radius;
+        const double zmax = cos(rlat1);
+        int64_t imin = ring_above(P.hpx, zmax) + 1;
+        const double rlat2 = ptheta + radius;
+        const double zmin = cos(rlat2);
+        int64_t imax = ring_above(P.hpx, zmin);
+        bool north = (rlat1 <= 0) && (imin > 1);
+        bool south = (rlat2 >= kPi) && (imax + 1 < nl4);
+        irmin = (int32_t)imin; irmax = (int32_t)imax;
+        rfirst = north ? 1 : irmin;
+        rlast = south ? (int32_t)(nl4 - 1) : irmax;
+    }
+    // table cell of the halo in the outer (non-radial) dimensions
+    bool oob = false;
+    uint32_t warn = 0;
+    for (int k = 0; k < P.tab.nouter; ++k) {
+        double x = (k == 0) ? lnz : (k == 1) ? lnM : c[4 + (k - 2)];
+        int n = P.tab.oshape[k];
+        const double *g = axis(k);
+        if (!(x >= g[0]) || !(x <= g[n - 1])) {
+            oob = true;
+            if (k == 0) warn |= BFG_WARN_Z_RANGE;
+            if (k == 1) warn |= BFG_WARN_M_RANGE;
+        }
+        int i = find_interval(g, n, x);
+        cell(k, i, (x - g[i]) / (g[i + 1] - g[i]));
+    }
+    if (oob) flags |= HF_OOB;
+    // paint: the tile path folds ln(pixarea D^2) into the halo's row window; keep exp() range handling exact
+    o.pixfac = (P.pixfac_area != 0.0) ? P.pixfac_area * (D * D) : 1.0;
+    o.lnpf = (P.pixfac_area != 0.0) ? log(o.pixfac) : 0.0;
+    if (P.ht && P.bin.mode == MODE_PAINT && !(fabs(o.lnpf) < 50.0)) flags |= HF_SCATTER | HF_SLOW;
+    o.flags = flags; o.rfirst = rfirst; o.rlast = rlast; o.irmin = irmin; o.irmax = irmax;
+    o.warn = warn; o.oob = oob;
+}
+
+// the SoA workspace row of one halo (what shell_scatter_kernel and the fill pass of the binning read)
+__device__ inline void halo_write_soa(const PrepParams &P, int64_t j, const HaloCalc &o, int32_t flags)
+{
+    const int64_t cap = P.cap;
+    double *rec = P.rec + j;
+    rec[F_X0 * cap] = o.x0; rec[F_Y0 * cap] = o.y0; rec[F_Z0 * cap] = o.z0v;
+    rec[F_PTHETA * cap] = o.ptheta; rec[F_PPHI * cap] = o.pphi;
+    rec[F_D * cap] = o.D; rec[F_A * cap] = o.a;
+    rec[F_RM * cap] = o.Rm;
+    rec[F_RADIUS * cap] = o.radius;
+    int32_t *irec = P.irec + j;
+    irec[I_RFIRST * cap] = o.rfirst; irec[I_RLAST * cap] = o.rlast;
+    irec[I_IRMIN * cap] = o.irmin; irec[I_IRMAX * cap] = o.irmax;
+    irec[I_FLAGS * cap] = flags;
+}
+
 #ifndef BFG_PREP_WAVES
 #define BFG_PREP_WAVES 1
 #endif
@@ -262,81 +366,18 @@ __global__ __launch_bounds__(256, BFG_PREP_WAVES) void halo_prep_kernel(const Pr
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     s_fl[threadIdx.x] = HF_SKIP; s_wl[threadIdx.x] = 0; s_ln[threadIdx.x] = 0.0;
     if (j < P.n_halo) {
-    const double *c = P.cat + j * (int64_t)P.cat_stride;
-    const double M = c[0], zred = c[1], ra = c[2], dec = c[3];
-    const double a = 1.0 / (1.0 + zred);                                   // HealpixRunner.py:319/:453
-    const double R = massdef_radius(P.md_run, M, a);                        // :320/:454
-    const double D = spline_eval(P.spl_n, knots_lds ? s_knots : P.spl_knots, P.spl_coef, zred);   // :321/:455
-    // hp.ang2vec(ra, dec, lonlat=True)                                      // :327/:460
-    const double theta = kHalfPi - dec * kDeg2Rad, phi = ra * kDeg2Rad;
-    double st, ct, sp, cp;
-    sincos(theta, &st, &ct);
-    sincos(phi, &sp, &cp);
-    const double x0 = st * cp, y0 = st * sp, z0v = ct;
-    // pointing(vec3) inside query_disc
-    double ptheta = atan2(sqrt(x0 * x0 + y0 * y0), z0v);
-    double pphi = (x0 == 0.0 && y0 == 0.0) ? 0.0 : atan2(y0, x0);
-    if (pphi < 0.0) pphi += kTwoPi;
-    const double radius = R * P.eps_run / D;                                 // :329/:462
-
-    double *rec = P.rec + j;
-    const int64_t cap = P.cap;
-    rec[F_X0 * cap] = x0; rec[F_Y0 * cap] = y0; rec[F_Z0 * cap] = z0v;
-    rec[F_PTHETA * cap] = ptheta; rec[F_PPHI * cap] = pphi;
-    rec[F_D * cap] = D; rec[F_A * cap] = a;
-    rec[F_RM * cap] = P.want_model_radius ? massdef_radius(P.md_model, M, a) / a : 0.0;  // BaryonCorrection.py:399
-    rec[F_RADIUS * cap] = radius;
-    const double lnM = log(M), lnz = log(1.0 / a);                           // Tabulate.py:308,312
-
-    // disc ring range (query_disc_internal, fact = 0)
-    int32_t flags = 0, rfirst = 1, rlast = 0, irmin = 1, irmax = 0;
-    const int64_t nl4 = 4 * P.hpx.nside;
-    if (!(radius >= 0.0) || !isfinite(ptheta)) {
-        flags |= HF_SKIP;   // NaN radius: every healpy comparison is false -> empty disc
-    } else if (radius >= kPi) {
-        rfirst = 1; rlast = (int32_t)(nl4 - 1); irmin = (int32_t)nl4; irmax = (int32_t)nl4;  // every ring complete
-    } else {
-        const double rlat1 = ptheta - radius;
-        const double zmax = cos(rlat1);
-        int64_t imin = ring_above(P.hpx, zmax) + 1;
-        const double rlat2 = ptheta + radius;
-        const double zmin = cos(rlat2);
-        int64_t imax = ring_above(P.hpx, zmin);
-        bool north = (rlat1 <= 0) && (imin > 1);
-        bool south = (rlat2 >= kPi) && (imax + 1 < nl4);
-        irmin = (int32_t)imin; irmax = (int32_t)imax;
-        rfirst = north ? 1 : irmin;
-        rlast = south ? (int32_t)(nl4 - 1) : irmax;
-    }
-    int32_t *irec = P.irec + j;
-    // table cell of the halo in the outer (non-radial) dimensions
-    bool oob = false;
-    uint32_t warn = 0;
-    for (int k = 0; k < P.tab.nouter; ++k) {
-        double x = (k == 0) ? lnz : (k == 1) ? lnM : c[4 + (k - 2)];
-        int n = P.tab.oshape[k];
-        const double *g = (n <= kPrepAxis) ? s_axis[k] : P.tab.oaxis[k];
-        if (!(x >= g[0]) || !(x <= g[n - 1])) {
-            oob = true;
-            if (k == 0) warn |= BFG_WARN_Z_RANGE;
-            if (k == 1) warn |= BFG_WARN_M_RANGE;
-        }
-        int i = find_interval(g, n, x);
-        const double y = (x - g[i]) / (g[i + 1] - g[i]);
-        P.cidx[k * cap + j] = i;
-        P.cw[k * cap + j] = y;
-        s_ci[k][threadIdx.x] = i; s_cy[k][threadIdx.x] = y;
-    }
-    if (oob) {
-        flags |= HF_OOB;
+    HaloCalc hc;
+    halo_calc(P, j, knots_lds ? s_knots : P.spl_knots,
+              [&](int k) -> const double * { return (P.tab.oshape[k] <= kPrepAxis) ? s_axis[k] : P.tab.oaxis[k]; },
+              [&](int k, int i, double y) { s_ci[k][threadIdx.x] = i; s_cy[k][threadIdx.x] = y; }, hc);
+    if (hc.oob) {
         atomicAdd((unsigned long long *)&P.stats->halos_out_of_table, 1ull);
-        atomicOr(&P.stats->warn_mask, warn);
+        atomicOr(&P.stats->warn_mask, hc.warn);
     }
-    const double Rm_com = P.want_model_radius ? massdef_radius(P.md_model, M, a) / a : 1.0;
-    // paint: the tile path folds ln(pixarea D^2) into the halo's row window; keep exp() range handling exact
-    const double pixfac = (P.pixfac_area != 0.0) ? P.pixfac_area * (D * D) : 1.0;
-    const double lnpf = (P.pixfac_area != 0.0) ? log(pixfac) : 0.0;
-    if (P.ht && P.bin.mode == MODE_PAINT && !(fabs(lnpf) < 50.0)) flags |= HF_SCATTER | HF_SLOW;
+    int32_t flags = hc.flags;
+    const int32_t rfirst = hc.rfirst, rlast = hc.rlast, irmin = hc.irmin, irmax = hc.irmax;
+    const double radius = hc.radius, ptheta = hc.ptheta, pphi = hc.pphi, D = hc.D, a = hc.a;
+    unsigned long long ovf = 0ull;
     if (P.ht) {
         if (P.bin.mode == MODE_BARYONIFY && !(flags & HF_SKIP) && rlast >= rfirst && rlast - rfirst < 8) {
             // small disc: count its pixels exactly; fewer than 4 -> 4-neighbour fallback (HealpixRunner.py:333-334),
@@ -363,46 +404,50 @@ __global__ __launch_bounds__(256, BFG_PREP_WAVES) void halo_prep_kernel(const Pr
             }
             if (total < 4) flags |= HF_SCATTER;
         }
-        unsigned long long ovf = 0ull;
         if (!(flags & HF_SCATTER))
             flags = tile_bin_halo(P.bin, false, j, flags, rfirst, rlast, irmin, irmax, ptheta, pphi, radius, ovf);
         P.bin.ovf_mask[j] = ovf;
     }
-    irec[I_RFIRST * cap] = rfirst; irec[I_RLAST * cap] = rlast;
-    irec[I_IRMIN * cap] = irmin; irec[I_IRMAX * cap] = irmax;
-    irec[I_FLAGS * cap] = flags;
+    // The SoA workspace is what the scatter kernel and the fill pass of the binning read.  On the tile path with a 3-D table
+    // (lazy_soa) only the halos they will touch get it: the ones left to the scatter kernel and the ones with pairs in overflow
+    // lists -- none at all for a catalog spread over the sky: 124 B per halo less to write.  (Should the call degrade to the
+    // scatter kernel after the fact -- pair buffer exhausted -- tile_fill_kernel recomputes the rows: halo_calc is pure.)
+    if (!P.lazy_soa || (flags & HF_SCATTER) || ovf != 0ull) {
+        halo_write_soa(P, j, hc, flags);
+        for (int k = 0; k < P.tab.nouter; ++k) { P.cidx[k * P.cap + j] = s_ci[k][threadIdx.x]; P.cw[k * P.cap + j] = s_cy[k][threadIdx.x]; }
+    }
     if (P.left && (flags & HF_SCATTER) && !(flags & HF_SKIP)) P.left[1 + atomicAdd(P.left_n, 1)] = (int32_t)j;
     if ((flags & HF_SLOW) && !(flags & (HF_SKIP | HF_OOB))) atomicAdd(&P.stats->halos_scatter_fallback, 1u);
     if (P.ht) {
         HaloTile h;
-        h.st = st; h.ct = z0v; h.pphi = pphi;
+        h.st = hc.st; h.ct = hc.z0v; h.pphi = pphi;
         h.S = (D / a) * (D / a);
         h.cosr = cos(radius);
         h.z0 = cos(ptheta);
         h.xa = 1.0 / sqrt((1.0 - h.z0) * (1.0 + h.z0));
-        h.pixfac = pixfac;
+        h.pixfac = hc.pixfac;
         h.rfirst = rfirst; h.rlast = rlast; h.irmin = irmin; h.irmax = irmax;
         // staged row window: ends at the node above the largest radius of the disc (on the table's radial axis)
         const double sr = sin(0.5 * fmin(radius, kPi));
-        const double axis_shift = (P.hd && P.rdelta) ? log(Rm_com) : 0.0;
+        const double axis_shift = (P.hd && P.rdelta) ? log(hc.Rm_com) : 0.0;
         const double rho_max = 0.5 * log(4.0 * h.S * sr * sr) - axis_shift;
         int win_lo = find_interval(raxis_lds ? s_raxis : P.tab.raxis, P.tab.nr, rho_max) + 1 - (P.win_nodes - 1);
         if (win_lo > P.tab.nr - P.win_nodes) win_lo = P.tab.nr - P.win_nodes;
         if (win_lo < 0) win_lo = 0;
         if (P.hd) {
             HaloDisp hd;
-            hd.cp0 = cp; hd.sp0 = sp; hd.a = a; hd.D = D;
-            hd.xcut = (P.eps_model * Rm_com) * (P.eps_model * Rm_com);
+            hd.cp0 = hc.cp; hd.sp0 = hc.sp; hd.a = a; hd.D = D;
+            hd.xcut = (P.eps_model * hc.Rm_com) * (P.eps_model * hc.Rm_com);
             hd.tshift = -axis_shift * P.tab.inv_dr;
             hd.pad[0] = hd.pad[1] = 0.0;
             P.hd[j] = hd;
         }
         h.win_lo = win_lo; h.flags = flags;
         h.ci0 = s_ci[0][threadIdx.x]; h.ci1 = (P.tab.nouter > 1) ? s_ci[1][threadIdx.x] : 0;
-        h.spare[0] = lnpf; h.spare[1] = s_cy[0][threadIdx.x]; h.spare[2] = (P.tab.nouter > 1) ? s_cy[1][threadIdx.x] : 0.0;
+        h.spare[0] = hc.lnpf; h.spare[1] = s_cy[0][threadIdx.x]; h.spare[2] = (P.tab.nouter > 1) ? s_cy[1][threadIdx.x] : 0.0;
         h.spare[3] = 0.0;
         P.ht[j] = h;
-        s_wl[threadIdx.x] = win_lo; s_fl[threadIdx.x] = flags; s_ln[threadIdx.x] = lnpf;
+        s_wl[threadIdx.x] = win_lo; s_fl[threadIdx.x] = flags; s_ln[threadIdx.x] = hc.lnpf;
     }
     }   // j < n_halo
     // ---- row phase (what halo_row4_kernel does, same arithmetic): hwin[j][e] = sum over the corners of the halo's outer cell of
@@ -1680,6 +1725,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     }
     // row window of the tile path: ~3.5 e-folds of radius below the disc edge (r_max/33 .. r_max)
     int win_nodes = 0;
+    bool blend = false;          // row windows blended per pair inside the tile kernel (set below)
     bool win_table = false;      // finely sampled radial axis: no row windows, the pixel stage reads the table (bfg_tile.hpp)
     if (tile) {
         win_nodes = (int)std::ceil(3.5 * t->dev.inv_dr) + 2;
@@ -1692,10 +1738,15 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         rc = ensure_tiles(c, mode, mode == MODE_PAINT ? TileCfg<MODE_PAINT>::TR : TileCfg<MODE_BARYONIFY>::TR,
                           mode == MODE_PAINT ? TileCfg<MODE_PAINT>::TW : TileCfg<MODE_BARYONIFY>::TW, a->nside, a->n_halo);
         if (rc) return rc;
-        bool blend_early = !win_table && win_nodes == kWinLds && t->dev.nouter == 2;
-        if (const char *e = std::getenv("BFG_BLEND")) blend_early = blend_early && std::atoi(e) != 0;
-        if (use_wave) blend_early = false;
-        const int64_t want = (win_table || blend_early) ? 0 : a->n_halo * (int64_t)win_nodes;
+        // Paint, 3-D tables with 32-node windows: no row windows in HBM at all, the tile kernel's stage b blends them per pair from the
+        // L2-resident table (the BLEND instantiation of shell_tile_kernel; BFG_BLEND=0: the windows of round 2, built by the prep
+        // kernel and fetched by LDS-DMA).  Measured (profiles/r03_blend_ab.txt): 1e6 halos step 1.27 -> 1.14 ms (prep 0.223 ->
+        // 0.156, tile kernel 1.01 -> 0.95), 1e5 halos 0.242 -> 0.235, steep mass function 0.533 -> 0.446.
+        const bool can_blend = mode == MODE_PAINT && !win_table && win_nodes == kWinLds && t->dev.nouter == 2 && !use_wave &&
+                               !(std::getenv("BFG_TILE_LIGHT") && std::atoi(std::getenv("BFG_TILE_LIGHT")) != 0);
+        blend = can_blend;
+        if (const char *e = std::getenv("BFG_BLEND")) blend = can_blend && std::atoi(e) != 0;
+        const int64_t want = (win_table || blend) ? 0 : a->n_halo * (int64_t)win_nodes;
         if (want > c->hwin_cap) {
             HIP_TRY(hipStreamSynchronize(c->stream));
             if (c->d_hwin) (void)hipFree(c->d_hwin);
@@ -1743,15 +1794,11 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         if (std::getenv("BFG_TILE_SCAN")) pp.bin.direct_limit = 0;                   // A/B: always the scan kernel
         pp.left = c->d_left; pp.left_n = tile_count + c->tiles[mode].geo.ntiles;
     }
-    // 3-D tables with 32-node windows: no row windows in HBM at all, the tile kernel blends them per pair from the L2-resident
-    // table (TileParams::blend; BFG_BLEND=0: the windows of round 2, the A/B)
-    bool blend = tile && !win_table && win_nodes == kWinLds && t->dev.nouter == 2;
-    if (const char *e = std::getenv("BFG_BLEND")) blend = blend && std::atoi(e) != 0;
-    if (const char *tk = std::getenv("BFG_TILE_KERNEL")) if (tk[0] == 'w') blend = false;      // the wave kernel reads hwin
     // row windows of 4 k nodes are built by the prep kernel itself (BFG_ROWS=separate: by halo_row4_kernel, the A/B)
     bool fuse_rows = tile && !win_table && !blend && win_nodes % 4 == 0 && win_nodes >= 8;
     if (const char *e = std::getenv("BFG_ROWS")) if (!std::strcmp(e, "separate")) fuse_rows = false;
     pp.hwin = fuse_rows ? c->d_hwin : nullptr;
+    pp.lazy_soa = (tile && t->dev.nouter == 2 && !std::getenv("BFG_EAGER_SOA")) ? 1 : 0;
     const size_t prep_lds = fuse_rows ? (size_t)64 * ((size_t)1 << t->dev.nouter) * 16 : 0;
     timing_begin(c, 0);
     hipLaunchKernelGGL(halo_prep_kernel, dim3((unsigned)((a->n_halo + 255) / 256)), dim3(256), prep_lds, c->stream, pp);
@@ -1836,7 +1883,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         std::memset(&fp, 0, sizeof(fp));
         fp.overwrite = overwrite ? 1 : 0; fp.nacc = (mode == MODE_PAINT) ? 1 : 3; fp.shared_flag = ts.d_shared; fp.out = d_out;
         fp.hpx = pp.hpx;
-        fp.stats = c->d_stats; fp.n_halo = a->n_halo; fp.cap = c->cap_halo; fp.rec = c->d_rec; fp.irec = c->d_irec; fp.ht = c->d_ht; fp.bin = pp.bin;
+        fp.stats = c->d_stats; fp.n_halo = a->n_halo; fp.cap = c->cap_halo; fp.rec = c->d_rec; fp.irec = c->d_irec; fp.ht = c->d_ht; fp.bin = pp.bin; fp.prep = pp;
         hipLaunchKernelGGL(tile_fill_kernel, dim3((unsigned)((a->n_halo + 255) / 256)), dim3(256), 0, c->stream, fp);
         RowParams rp;
         std::memset(&rp, 0, sizeof(rp));
@@ -1883,6 +1930,8 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_tile_kernel<MODE_PAINT, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lp));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_tile_kernel<MODE_PAINT, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lp));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_tile_kernel<MODE_PAINT, true, 0, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lp));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_tile_kernel<MODE_BARYONIFY, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lb));
@@ -1931,7 +1980,8 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
                 hipLaunchKernelGGL((shell_tile_kernel<MODE_BARYONIFY, true, 1>), tgrid, dim3(ntb), ldb, c->stream, tp);
         } else if (mode == MODE_PAINT) {
             const size_t tlds = tile_lds_bytes<MODE_PAINT>();
-            if (wl) hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, true>), tgrid, tblock, tlds, c->stream, tp);
+            if (wl && blend) hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, true, 0, true>), tgrid, tblock, tlds, c->stream, tp);
+            else if (wl) hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, true>), tgrid, tblock, tlds, c->stream, tp);
             else hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, false>), tgrid, tblock, tlds, c->stream, tp);
         } else {
             const size_t tlds = tile_lds_bytes<MODE_BARYONIFY>();

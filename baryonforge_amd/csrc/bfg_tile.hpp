@@ -113,6 +113,49 @@ struct __align__(16) HaloTile {
 };
 static_assert(sizeof(HaloTile) == 128, "HaloTile must be one 128-byte line");
 
+// The halo's cell (index, weight) on non-radial table axis k: from its HaloTile line for 3-D tables (the SoA arrays are only
+// written for halos the scatter kernel / the fill pass read: PrepParams::lazy_soa), from the SoA arrays for tables with extra
+// p_keys axes.  Scalar selects on purpose: private arrays indexed by the axis number end up in scratch memory.
+__device__ inline int halo_cell_index(const HaloTile *ht, const int32_t *cidx, int64_t cap, int nouter, int64_t j, int k)
+{
+    return (nouter == 2) ? (k == 0 ? ht[j].ci0 : ht[j].ci1) : cidx[k * cap + j];
+}
+__device__ inline double halo_cell_weight(const HaloTile *ht, const double *cw, int64_t cap, int nouter, int64_t j, int k)
+{
+    return (nouter == 2) ? (k == 0 ? ht[j].spare[1] : ht[j].spare[2]) : cw[k * cap + j];
+}
+
+// Nodes i, i + 1 of the blended row of halo j straight from the table, corners in index order (the arithmetic of halo_row_kernel)
+__device__ inline void halo_row_pair(const DevTable &T, const HaloTile *ht, const int32_t *cidx, const double *cw, int64_t cap,
+                                     int64_t j, int i, double &c0v, double &c1v)
+{
+    c0v = 0.0; c1v = 0.0;
+    if (T.nouter == 2) {
+        const HaloTile &h = ht[j];
+        const double y0 = h.spare[1], y1 = h.spare[2];
+        const double *r0 = T.values + (int64_t)h.ci0 * T.ostride[0] + (int64_t)h.ci1 * T.ostride[1] + i;
+        const double *r1 = r0 + T.ostride[1], *r2 = r0 + T.ostride[0], *r3 = r2 + T.ostride[1];
+        const double a0 = r0[0], b0 = r0[1], a1 = r1[0], b1 = r1[1], a2 = r2[0], b2 = r2[1], a3 = r3[0], b3 = r3[1];
+        const double w0 = (1.0 * (1.0 - y0)) * (1.0 - y1), w1 = (1.0 * (1.0 - y0)) * y1;
+        const double w2 = (1.0 * y0) * (1.0 - y1), w3 = (1.0 * y0) * y1;
+        c0v = fma(a3, w3, fma(a2, w2, fma(a1, w1, fma(a0, w0, 0.0))));
+        c1v = fma(b3, w3, fma(b2, w2, fma(b1, w1, fma(b0, w0, 0.0))));
+        return;
+    }
+    const int ncorner = 1 << T.nouter;
+    for (int c = 0; c < ncorner; ++c) {
+        double w = 1.0; int64_t off = 0;
+        for (int k = 0; k < T.nouter; ++k) {
+            const int bit = (c >> (T.nouter - 1 - k)) & 1;
+            const double y = cw[k * cap + j];
+            w = w * (bit ? y : 1.0 - y);
+            off += (int64_t)(cidx[k * cap + j] + bit) * T.ostride[k];
+        }
+        c0v = fma(T.values[off + i], w, c0v);
+        c1v = fma(T.values[off + i + 1], w, c1v);
+    }
+}
+
 struct __align__(16) Seg {           // one ring segment of one halo inside one tile (48 bytes)
     int32_t excl;                    // offset of the segment's first pixel in the chunk's flattened pixel list
     int32_t abyte;                   // LDS byte offset of the accumulator of the segment's first pixel
@@ -133,11 +176,10 @@ struct __align__(16) HaloDisp {
 };
 static_assert(sizeof(HaloDisp) == 64, "HaloDisp must be 64 bytes");
 
-struct __align__(16) PairInfo {      // per (halo, tile) pair of the current chunk, paint (48 bytes)
+struct __align__(16) PairInfo {      // per (halo, tile) pair of the current chunk, paint (32 bytes)
     double lnpf;                     // ln(pixarea D^2), already folded into the row window (used by the rare direct read-out)
-    int64_t hoff;                    // index of the halo's row window in hwin; blend mode: ci0 | ci1 << 32 (the halo's table cell)
+    int64_t hoff;                    // index of the halo's row window in hwin
     int32_t win_lo, halo, ra, pad;
-    double w0, w1;                   // blend mode: the halo's weights on the z / M axes
 };
 
 struct __align__(16) PairInfoDisp {  // ... baryonify (96 bytes)
@@ -146,9 +188,8 @@ struct __align__(16) PairInfoDisp {  // ... baryonify (96 bytes)
     int64_t hoff;
     int32_t win_lo, halo, ra, pad;
     double a_over_D;                 // a / D
-    double w0, w1;                   // blend mode (as PairInfo)
 };
-static_assert(sizeof(PairInfoDisp) == 112, "PairInfoDisp must be 112 bytes");
+static_assert(sizeof(PairInfoDisp) == 96, "PairInfoDisp must be 96 bytes");
 
 struct __align__(16) DeferredPixel { // a pixel whose table cell lies outside the staged row window (queued, see drain)
     int32_t halo, abyte;             // halo index, LDS byte offset of the pixel's accumulator
@@ -327,6 +368,7 @@ struct FillParams {
     int32_t *irec;
     HaloTile *ht;
     BinCtx bin;
+    PrepParams prep;                 // lazy_soa: what halo_calc needs to rebuild a halo's SoA row
 };
 
 __global__ __launch_bounds__(256) void tile_fill_kernel(const FillParams P)
@@ -372,8 +414,15 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const FillParams P)
     if (j >= P.n_halo) return;
     const int64_t cap = P.cap;
     if ((long long)P.bin.tile_start[P.bin.geo.ntiles] > P.bin.pair_cap) {        // overflow lists too long: all to scatter
-        const int f0 = P.irec[I_FLAGS * cap + j], f = f0 | HF_SCATTER;
-        P.irec[I_FLAGS * cap + j] = f; P.ht[j].flags = f;
+        const int f0 = P.ht[j].flags, f = f0 | HF_SCATTER;
+        if (P.prep.lazy_soa) {
+            // the prep kernel wrote the SoA rows of the halos it knew would need them; now every halo does
+            HaloCalc hc;
+            halo_calc(P.prep, j, P.prep.spl_knots, [&](int k) -> const double * { return P.prep.tab.oaxis[k]; },
+                      [&](int k, int i, double y) { P.prep.cidx[k * cap + j] = i; P.prep.cw[k * cap + j] = y; }, hc);
+            halo_write_soa(P.prep, j, hc, f);
+        } else P.irec[I_FLAGS * cap + j] = f;
+        P.ht[j].flags = f;
         if (!(f0 & (HF_SCATTER | HF_SKIP))) atomicAdd(&P.stats->halos_scatter_fallback, 1u);
         return;
     }
@@ -562,8 +611,8 @@ __global__ __launch_bounds__(256) void halo_row_kernel(const RowParams P)
             int64_t off = 0;
             for (int k = 0; k < T.nouter; ++k) {
                 const int bit = (c >> (T.nouter - 1 - k)) & 1;
-                const double y = P.cw[k * P.cap + j];
-                const int i = P.cidx[k * P.cap + j];
+                const double y = halo_cell_weight(P.ht, P.cw, P.cap, T.nouter, j, k);
+                const int i = halo_cell_index(P.ht, P.cidx, P.cap, T.nouter, j, k);
                 w = w * (bit ? y : 1.0 - y);
                 off += (int64_t)(i + bit) * T.ostride[k];
             }
@@ -637,8 +686,8 @@ __global__ __launch_bounds__(256) void halo_row4_kernel(const RowParams P)
             int64_t off = 0;
             for (int k = 0; k < T.nouter; ++k) {
                 const int bit = (c >> (T.nouter - 1 - k)) & 1;
-                const double y = P.cw[k * P.cap + j];
-                const int i = P.cidx[k * P.cap + j];
+                const double y = halo_cell_weight(P.ht, P.cw, P.cap, T.nouter, j, k);
+                const int i = halo_cell_index(P.ht, P.cidx, P.cap, T.nouter, j, k);
                 w = w * (bit ? y : 1.0 - y);
                 off += (int64_t)(i + bit) * T.ostride[k];
             }
@@ -664,31 +713,9 @@ __device__ inline void deferred_add(const TileParams &P, const DeferredOut &e, c
     const int64_t j = e.halo;
     const int i = min(max((int)e.t, 0), T.nr - 2);
     const double f = e.t - (double)i;
-    // the halo's outer cell first (one round of independent loads), then all corner values (another): written as nested
-    // loops over corners and axes the compiler serialised 2^(ndim-1) x 2 dependent rounds per entry
-    int ci[BFG_MAX_DIM - 1];
-    double cy[BFG_MAX_DIM - 1];
-#pragma unroll
-    for (int k = 0; k < BFG_MAX_DIM - 1; ++k) {
-        ci[k] = (k < T.nouter) ? P.cidx[k * P.cap + j] : 0;
-        cy[k] = (k < T.nouter) ? P.cw[k * P.cap + j] : 0.0;
-    }
     const double lnpf = P.ht[j].spare[0];
-    double c0v = 0.0, c1v = 0.0;
-    const int ncorner = 1 << T.nouter;
-    for (int c = 0; c < ncorner; ++c) {                            // corner order and products of halo_row_kernel
-        double w = 1.0; int64_t off = 0;
-#pragma unroll
-        for (int k = 0; k < BFG_MAX_DIM - 1; ++k) {
-            if (k < T.nouter) {
-                const int bit = (c >> (T.nouter - 1 - k)) & 1;
-                w = w * (bit ? cy[k] : 1.0 - cy[k]);
-                off += (int64_t)(ci[k] + bit) * T.ostride[k];
-            }
-        }
-        c0v = fma(T.values[off + i], w, c0v);
-        c1v = fma(T.values[off + i + 1], w, c1v);
-    }
+    double c0v, c1v;
+    halo_row_pair(T, P.ht, P.cidx, P.cw, P.cap, j, i, c0v, c1v);
     const double L = fma(f, c1v - c0v, c0v) + lnpf;
     if (fabs(L) < 709.0) unsafeAtomicAdd(P.out + e.pix, fast_exp(L, exptab));
 }
@@ -713,7 +740,7 @@ __device__ inline void deferred_add(const TileParams &P, const DeferredOut &e, c
 #endif
 // offsets tiles (3 accumulators per pixel, 1024 pixels): 16 x 64 instead of 32 x 32, tile kernel -5 %
 #ifndef BFG_PAINT_PIXMAX
-#define BFG_PAINT_PIXMAX 6400      // pixel -> segment table entries per round of stage c: what the LDS left by the 32-ring rows holds
+#define BFG_PAINT_PIXMAX 6912      // pixel -> segment table entries per round of stage c: what the LDS left by the 32-ring rows holds
 #endif
 #ifndef BFG_BARY_TR
 #define BFG_BARY_TR 16
@@ -765,7 +792,7 @@ template <> struct TileCfg<MODE_PAINT, 0> {
 };
 template <> struct TileCfg<MODE_BARYONIFY, 0> {
     static constexpr int NT = kTileThreads, WPS = BFG_TILE_WAVES_PER_SIMD, LDS_MAX = 81920;
-    static constexpr int TR = BFG_BARY_TR, TW = BFG_BARY_TW, NACC = 3, SLOTMAX = 448, PAIRMAX = 48, PIXMAX = 3712, QCAP = 0;
+    static constexpr int TR = BFG_BARY_TR, TW = BFG_BARY_TW, NACC = 3, SLOTMAX = 448, PAIRMAX = 48, PIXMAX = 4096, QCAP = 0;
     static constexpr int SEGMAX = SLOTMAX + kSegExtra;
     using Pair = PairInfoDisp;
 };
@@ -919,9 +946,13 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int MODE, bool WIN_LDS, int LIGHT = 0>
+// BLEND: the instantiation whose stage b blends the pairs' row windows from the table itself (TileParams::blend; paint, 3-D
+// tables, dense catalogs).  A template parameter, not a run-time branch: the blend code costs the other path registers (20 -> 36 B
+// of scratch and + 4 % on the 1e5-halo run when it was a branch).
+template <int MODE, bool WIN_LDS, int LIGHT = 0, bool BLEND = false>
 __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::WPS)) void shell_tile_kernel(const TileParams P)
 {
+    static_assert(!BLEND || (MODE == MODE_PAINT && WIN_LDS && LIGHT == 0), "the blend instantiation is paint with LDS windows");
     using Cfg = TileCfg<MODE, LIGHT>;
     using Pair = typename Cfg::Pair;
     constexpr int TR = Cfg::TR, TW = Cfg::TW, NT = Cfg::NT, NACC = Cfg::NACC;
@@ -1017,8 +1048,6 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     int pjA = -1, pjB = -1, pjA1 = -1, pjB1 = -1;
     int nx_j = -1, nx_first = 0, nx_last = -1, nx_wl = 0;
     [[maybe_unused]] double nx_lnpf = 0.0;
-    [[maybe_unused]] int nx_c0 = 0, nx_c1 = 0;        // blend mode: table cell and weights of the candidate's halo
-    [[maybe_unused]] double nx_w0 = 0.0, nx_w1 = 0.0;
     bool primed = false;                              // wave 0 holds the first chunk's candidates of the item about to start
     constexpr int kNoItem = 0x7fffffff;
     int item = item_first + (int)blockIdx.x;
@@ -1094,7 +1123,6 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
             const HaloTile &h = P.ht[nx_j];
             nx_first = h.rfirst; nx_last = h.rlast; nx_wl = h.win_lo;
             if constexpr (MODE == MODE_PAINT) nx_lnpf = h.spare[0];
-            if constexpr (win_in_lds) { if (P.blend) { nx_c0 = h.ci0; nx_c1 = h.ci1; nx_w0 = h.spare[1]; nx_w1 = h.spare[2]; } }
         }
     };
     if (wave == 0 && !primed) {
@@ -1110,19 +1138,8 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     auto direct_row_halo = [&](int64_t j, double t) -> double {
         const int i = min(max((int)t, 0), NRm1 - 1);
         const double f = t - (double)i;
-        double c0v = 0.0, c1v = 0.0;
-        const int ncorner = 1 << T.nouter;
-        for (int c = 0; c < ncorner; ++c) {
-            double w = 1.0; int64_t off = 0;
-            for (int k = 0; k < T.nouter; ++k) {
-                const int bit = (c >> (T.nouter - 1 - k)) & 1;
-                const double y = P.cw[k * P.cap + j];
-                w = w * (bit ? y : 1.0 - y);
-                off += (int64_t)(P.cidx[k * P.cap + j] + bit) * T.ostride[k];
-            }
-            c0v = fma(T.values[off + i], w, c0v);
-            c1v = fma(T.values[off + i + 1], w, c1v);
-        }
+        double c0v, c1v;
+        halo_row_pair(T, P.ht, P.cidx, P.cw, P.cap, j, i, c0v, c1v);
         return fma(f, c1v - c0v, c0v);
     };
     auto direct_row = [&](int pidx, double t) -> double {
@@ -1326,9 +1343,6 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                 Pair &pi = pinfo[lane];
                 pi.hoff = (int64_t)j * W; pi.win_lo = nx_wl; pi.halo = j; pi.ra = ra; pi.pad = 0;
                 if constexpr (MODE == MODE_PAINT) pi.lnpf = nx_lnpf;   // baryonify: the rest is filled in stage b
-                if constexpr (win_in_lds) {
-                    if (P.blend) { pi.hoff = (int64_t)(uint32_t)nx_c0 | ((int64_t)nx_c1 << 32); pi.w0 = nx_w0; pi.w1 = nx_w1; }
-                }
             }
             pr_off[lane] = (lane < n_take) ? cum - nrings : 0x7fffffff;
             if (lane == n_take - 1) { ctl[0] = n_take; ctl[1] = cum; ctl[2] = 0; ctl[3] = 0; }
@@ -1349,7 +1363,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         // drained by the barrier that ends stage b).  dest = wave-uniform base + lane * 16 B == pwin[2 * tid].
         if constexpr (win_in_lds) {
             if (P.debug & 64) {                                       // profiling: no window copy at all (wrong results)
-            } else if (P.blend) {
+            } else if constexpr (BLEND) {
                 // No windows in HBM: one thread per (pair, 4 nodes) blends them from the four corner rows of the halo's (z, M)
                 // cell -- the table is L2-resident -- with the arithmetic of halo_row4_kernel (corner order, fma chain from
                 // 0, + ln(pixarea D^2)): the same bits.  All eight 16-byte loads of a thread are in flight together.
@@ -1358,8 +1372,9 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                 if (i < n_take * (kWinLds / 4)) {
                     const int p = i >> 3, q = i & 7;
                     const Pair &pi = pinfo[p];
-                    const int c0 = (int)(uint32_t)pi.hoff, c1 = (int)(pi.hoff >> 32);
-                    const double y0 = pi.w0, y1 = pi.w1;
+                    const HaloTile &hb = P.ht[pi.halo];                // the line the slot threads of this pair fetch as well
+                    const int c0 = hb.ci0, c1 = hb.ci1;
+                    const double y0 = hb.spare[1], y1 = hb.spare[2];
                     const double *r0 = T.values + (int64_t)c0 * T.ostride[0] + (int64_t)c1 * T.ostride[1] + (pi.win_lo + 4 * q);
                     const double *r1 = r0 + T.ostride[1], *r2 = r0 + T.ostride[0], *r3 = r2 + T.ostride[1];
                     const double2u a0 = *reinterpret_cast<const double2u *>(r0), b0 = *reinterpret_cast<const double2u *>(r0 + 2);
@@ -1369,7 +1384,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                     const double w0 = (1.0 * (1.0 - y0)) * (1.0 - y1), w1 = (1.0 * (1.0 - y0)) * y1;
                     const double w2 = (1.0 * y0) * (1.0 - y1), w3 = (1.0 * y0) * y1;
                     double add = 0.0;
-                    if constexpr (MODE == MODE_PAINT) add = pi.lnpf;
+                    if constexpr (MODE == MODE_PAINT) add = hb.spare[0];
                     double2 o0, o1;
                     o0.x = fma(a3.x, w3, fma(a2.x, w2, fma(a1.x, w1, fma(a0.x, w0, 0.0)))) + add;
                     o0.y = fma(a3.y, w3, fma(a2.y, w2, fma(a1.y, w1, fma(a0.y, w0, 0.0)))) + add;
@@ -1405,9 +1420,9 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                     int64_t off = 0;
                     for (int k = 0; k < T.nouter; ++k) {
                         const int bit = (c >> (T.nouter - 1 - k)) & 1;
-                        const double y = P.cw[k * P.cap + j];
+                        const double y = halo_cell_weight(P.ht, P.cw, P.cap, T.nouter, j, k);
                         w = w * (bit ? y : 1.0 - y);
-                        off += (int64_t)(P.cidx[k * P.cap + j] + bit) * T.ostride[k];
+                        off += (int64_t)(halo_cell_index(P.ht, P.cidx, P.cap, T.nouter, j, k) + bit) * T.ostride[k];
                     }
                     cwn[c] = w; con[c] = off;
                 }

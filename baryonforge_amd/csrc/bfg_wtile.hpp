@@ -153,19 +153,8 @@ __global__ __launch_bounds__(kWaveThreads, 4) void shell_wave_kernel(const TileP
     auto direct_row_halo = [&](int64_t j, double t) -> double {
         const int i = min(max((int)t, 0), NRm1 - 1);
         const double f = t - (double)i;
-        double c0v = 0.0, c1v = 0.0;
-        const int ncorner = 1 << T.nouter;
-        for (int c = 0; c < ncorner; ++c) {
-            double w = 1.0; int64_t off = 0;
-            for (int k = 0; k < T.nouter; ++k) {
-                const int bit = (c >> (T.nouter - 1 - k)) & 1;
-                const double y = P.cw[k * P.cap + j];
-                w = w * (bit ? y : 1.0 - y);
-                off += (int64_t)(P.cidx[k * P.cap + j] + bit) * T.ostride[k];
-            }
-            c0v = fma(T.values[off + i], w, c0v);
-            c1v = fma(T.values[off + i + 1], w, c1v);
-        }
+        double c0v, c1v;
+        halo_row_pair(T, P.ht, P.cidx, P.cw, P.cap, j, i, c0v, c1v);
         return fma(f, c1v - c0v, c0v);
     };
     auto direct_row = [&](int pidx, double t) -> double {
