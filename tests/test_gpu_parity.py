@@ -1048,7 +1048,7 @@ def test_paint_and_baryonify_any_nside(cosmo, nside, variant):
 
 @pytest.mark.parametrize("switch", ["BFG_TILE_KERNEL=wave", "BFG_TILE_LIGHT=1", "BFG_TILE_PERSIST=0", "BFG_TILE_PERSIST=7",
                                     "BFG_FINAL_DRAIN=inline", "BFG_FINAL_DRAIN=kernel", "BFG_TILE_SCAN=1", "BFG_OUT_OVERWRITE=0",
-                                    "BFG_ROWS=separate"])
+                                    "BFG_ROWS=separate", "BFG_BLEND=0", "BFG_BLEND=0 BFG_ROWS=separate", "BFG_EAGER_SOA=1"])
 def test_tile_kernel_switches_agree(cosmo, switch, monkeypatch):
     """every A/B switch of the tile path paints the default build's map: the wave-private-chunk kernel, the
     256-thread instantiation, one workgroup per item / a tiny persistent grid, the deferred pixels drained by every item / added by
@@ -1076,8 +1076,9 @@ def test_tile_kernel_switches_agree(cosmo, switch, monkeypatch):
             gotb = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo), eps, bm, verbose=False).process()
         return got, gotb
     base, baseb = run()
-    k, v = switch.split("=")
-    monkeypatch.setenv(k, v)
+    for kv in switch.split():
+        k, v = kv.split("=")
+        monkeypatch.setenv(k, v)
     got, gotb = run()
     assert np.array_equal(got != 0, ref != 0)
     assert_maps_close(got, ref, RTOL, what=f"paint with {switch}")
