@@ -1926,7 +1926,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
             if (e[0] == 'k') tp.defer_tail = 0;                             // "kernel": tile_deferred_kernel after the tile kernel
         }
         if (!c->tile_attr_set) {
-            const int lp = (int)tile_lds_bytes<MODE_PAINT>(), lb = (int)tile_lds_bytes<MODE_BARYONIFY>();
+            const int lp = (int)tile_lds_bytes<MODE_PAINT>() + (BFG_STAGE_TIMING == 4 ? 128 : 0), lb = (int)tile_lds_bytes<MODE_BARYONIFY>();
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_tile_kernel<MODE_PAINT, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lp));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_tile_kernel<MODE_PAINT, false>),
@@ -1979,7 +1979,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
             else
                 hipLaunchKernelGGL((shell_tile_kernel<MODE_BARYONIFY, true, 1>), tgrid, dim3(ntb), ldb, c->stream, tp);
         } else if (mode == MODE_PAINT) {
-            const size_t tlds = tile_lds_bytes<MODE_PAINT>();
+            const size_t tlds = tile_lds_bytes<MODE_PAINT>() + (BFG_STAGE_TIMING == 4 ? 128 : 0);
             if (wl && blend) hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, true, 0, true>), tgrid, tblock, tlds, c->stream, tp);
             else if (wl) hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, true>), tgrid, tblock, tlds, c->stream, tp);
             else hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, false>), tgrid, tblock, tlds, c->stream, tp);

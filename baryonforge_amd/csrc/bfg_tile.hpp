@@ -750,6 +750,8 @@ __device__ inline void deferred_add(const TileParams &P, const DeferredOut &e, c
 #endif
 #if BFG_STAGE_TIMING
 __device__ unsigned long long g_stage_cycles[16];     // profiling build only: barrier-to-barrier cycles per stage ([8..]: inside stage b)
+#endif
+#if BFG_STAGE_TIMING && BFG_STAGE_TIMING != 4
 #define BFG_TICK(slot) do { if (tid == 64) { const long long now_ = clock64(); st_acc[slot] += now_ - st_t; st_t = now_; } } while (0)
 #else
 #define BFG_TICK(slot) do { } while (0)
@@ -764,6 +766,16 @@ __device__ unsigned long long g_stage_cycles[16];     // profiling build only: b
 // end-of-item barrier
 #ifndef BFG_TIMING_TID
 #define BFG_TIMING_TID 64
+#endif
+// -DBFG_STAGE_TIMING=4: the timeline of a work item as thread BFG_TIMING_TID sees it, accumulated in LDS (two registers instead
+// of the 32 of st_acc, whose spills and their vmcnt(0) waits distort modes 1-3): slots 0 .. 9 = top of the item -> work record
+// arrived -> accumulator cleared / rows -> stage a + barrier -> stage b -> its barrier -> pixel loop -> end-of-chunk barrier ->
+// write-back issued -> end-of-item barrier
+#if BFG_STAGE_TIMING == 4
+#define BFG_LTICK(slot) do { if (tid == BFG_TIMING_TID) { const long long now_ = clock64(); \
+    atomicAdd(reinterpret_cast<unsigned long long *>(smem_raw + lt_off) + (slot), (unsigned long long)(now_ - lt_last)); lt_last = now_; } } while (0)
+#else
+#define BFG_LTICK(slot) do { } while (0)
 #endif
 #if BFG_STAGE_TIMING == 3
 #define BFG_ITICK(slot) do { if (tid == BFG_TIMING_TID) { const long long now_ = clock64(); st_acc[slot] += now_ - st_sub; st_sub = now_; } } while (0)
@@ -817,7 +829,7 @@ __host__ __device__ constexpr size_t tile_lds_bytes()
            (kExpTab + kAtanTab) * sizeof(double) + Cfg::TR * sizeof(RingRow) + Cfg::SEGMAX * sizeof(Seg) +
            Cfg::PAIRMAX * sizeof(typename Cfg::Pair) + (size_t)Cfg::PAIRMAX * kWinLds * sizeof(double) +
            Cfg::PIXMAX * sizeof(uint16_t) + kPrOff * sizeof(int32_t) + Cfg::SEGMAX * sizeof(uint8_t) +
-           Cfg::QCAP * sizeof(DeferredPixel) + 8 * sizeof(int32_t);
+           Cfg::QCAP * sizeof(DeferredPixel) + 24 * sizeof(int32_t);
 }
 
 // two (LIGHT: three) tile workgroups share a CU's 160 KB of LDS
@@ -949,6 +961,14 @@ __device__ __forceinline__ void lds_barrier()
 // BLEND: the instantiation whose stage b blends the pairs' row windows from the table itself (TileParams::blend; paint, 3-D
 // tables, dense catalogs).  A template parameter, not a run-time branch: the blend code costs the other path registers (20 -> 36 B
 // of scratch and + 4 % on the 1e5-halo run when it was a branch).
+// Hand-over of the persistent loop's look-ahead through LDS.  On gfx9 vector loads and stores share the one in-order vmcnt
+// counter: a wavefront that waits for a vector load (or a returning atomic) after it has issued its write-back stores waits for
+// those stores to be acknowledged first -- ~1-2 us per work item, 17-27 % of a sparse catalog's item (profiles/r03_item_timeline.txt).
+// So the look-ahead never passes through a wavefront's registers after its stores: at the top of item k thread 0 requests the
+// index of item k + 3 (a returning atomic; parked in LDS right BEFORE the write-back, when it has long arrived and no store is in
+// flight) and wave 0 sends the record of item k + 2 straight into LDS by LDS-DMA (two lanes x 16 B; landed by the time the
+// barrier that ends stage b has drained wave 0's vmcnt; two alternating slots, so the next item's DMA cannot overtake a slow
+// reader); every wavefront picks both up from LDS after the end-of-item barrier.
 template <int MODE, bool WIN_LDS, int LIGHT = 0, bool BLEND = false>
 __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::WPS)) void shell_tile_kernel(const TileParams P)
 {
@@ -991,7 +1011,8 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     [[maybe_unused]] DeferredPixel *rq = reinterpret_cast<DeferredPixel *>(smem_raw + rq_off);
     int32_t *ctl = reinterpret_cast<int32_t *>(smem_raw + ctl_off);
     static_assert(sizeof(RingRow) % 16 == 0 && sizeof(Pair) % 16 == 0, "16-byte aligned LDS records");
-    static_assert(ctl_off + 8 * sizeof(int32_t) == tile_lds_bytes<MODE, LIGHT>(), "layout and tile_lds_bytes() must agree");
+    static_assert(ctl_off + 24 * sizeof(int32_t) == tile_lds_bytes<MODE, LIGHT>(), "layout and tile_lds_bytes() must agree");
+    static_assert(ctl_off % 16 == 0, "the work records parked in ctl[8 .. 23] are 16-byte accesses");
 
     // Persistent workgroups: the grid is a few workgroups per CU and every workgroup takes work items from a counter until
     // the list is empty.  (One workgroup per item -- 16 640 launches at NSIDE 1024, 10 368 of them with nothing to do --
@@ -1013,9 +1034,14 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     const Hpx &hp = P.hpx;
     const DevTable &T = P.tab;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#if BFG_STAGE_TIMING
+#if BFG_STAGE_TIMING && BFG_STAGE_TIMING != 4
     long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = clock64();
     [[maybe_unused]] long long st_sub = st_t;
+#endif
+#if BFG_STAGE_TIMING == 4
+    constexpr int lt_off = ctl_off + 24 * (int)sizeof(int32_t);      // 16 x 8 B behind the layout (the host asks for 128 B more)
+    long long lt_last = 0;
+    if (tid < 16) reinterpret_cast<unsigned long long *>(smem_raw + lt_off)[tid] = 0ull;
 #endif
     if (tid < kLogTab) logtab[tid] = P.logtab[tid];
     if (tid < kExpTab) exptab[tid] = P.exptab[tid];
@@ -1057,15 +1083,20 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     int4 wk = wzero, wg = wzero, wk1 = wzero, wg1 = wzero;
     if (item < n_work_total) { wk = uni4(P.work[2 * item]); wg = uni4(P.work[2 * item + 1]); }
     if (item1 < n_work_total) { wk1 = uni4(P.work[2 * item1]); wg1 = uni4(P.work[2 * item1 + 1]); }
+    int par = 0;                                      // which of the two LDS slots this iteration's record DMA uses
     while (item < n_work_total) {
 #if BFG_STAGE_TIMING == 3
     if (tid == BFG_TIMING_TID) st_sub = clock64();
 #endif
+#if BFG_STAGE_TIMING == 4
+    if (tid == BFG_TIMING_TID) lt_last = clock64();
+#endif
     int item3 = kNoItem;
     if (tid == 0 && P.work_counter) item3 = atomicAdd(P.work_counter, 1);
     const bool have_next = item1 < n_work_total;
-    int4 wk2 = wzero, wg2 = wzero;
-    if (item2 < n_work_total) { wk2 = uni4(P.work[2 * item2]); wg2 = uni4(P.work[2 * item2 + 1]); }
+    if (wave == 0 && lane < 2 && item2 < n_work_total)    // the record of item k + 2 -> ctl[8 + 8 par ..] (see the hand-over above)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(P.work + 2 * item2 + lane),
+                                         (__attribute__((address_space(3))) void *)(ctl + 8 + 8 * par), 16, 0, 0);
     if (wave == 0 && have_next) {                     // first pair-list windows of the next item
         const int32_t *plist1 = P.pairs + wk1.y;
         const int n1 = wk1.z - wk1.y;
@@ -1079,6 +1110,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     const int ring_hi = min((int)(4 * hp.nside - 1), ring_lo + TR - 1);
 
     BFG_ITICK(8);
+    BFG_LTICK(0);
     if (n_pairs != 0) {
     for (int i = tid; i < TR * TW * NACC; i += NT) acc[i] = 0.0;
     if (tid == 0) ctl[5] = 0;
@@ -1326,6 +1358,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     BFG_TICK(6);                                       // prologue: LDS clear, tables, ring rows, first pair records
 #endif
     BFG_ITICK(11);
+    BFG_LTICK(1);
     for (int base = 0; base < n_pairs;) {
         // ---- stage a: one lane per pair of the chunk (wave 0) ---------------------------------------
         if (wave == 0) {
@@ -1354,6 +1387,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         lds_barrier();
         const int n_take = ctl[0], nslots = ctl[1];
         BFG_TICK(0);
+        BFG_LTICK(2);
 #if BFG_STAGE_TIMING == 2
         if (tid == 64) st_sub = clock64();
 #endif
@@ -1564,7 +1598,9 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
             }
         }
         BFG_SUBTICK(4);                                              // segment records + pixel -> segment table written
+        BFG_LTICK(3);
         __syncthreads();
+        BFG_LTICK(4);
         BFG_SUBTICK(5);                                              // wait for the other wavefronts and the window DMA
         BFG_TICK(1);
         const int nseg = min(nslots + ctl[2], kSegMax);
@@ -1618,8 +1654,10 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         }
         handed = handed || (last_chunk && have_next);
         BFG_TICK(4);
+        BFG_LTICK(5);
         lds_barrier();
         BFG_TICK(5);
+        BFG_LTICK(6);
         base += n_take;
         if constexpr (kQCap > 0) { if (ctl[5] >= qcap / 2) drain(); }     // uniform: ctl[5] is stable between the barriers
     }
@@ -1629,12 +1667,51 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     // drained here (two dependent rounds of global loads, 33 % of the kernel at 1e5 halos): they go to this work item's
     // slice of a global list and tile_deferred_kernel adds them after this kernel.
     BFG_ITICK(12);
+    // the look-ahead of the persistent loop goes to LDS BEFORE the write-back stores (see the hand-over above)
+    if (tid == 0) ctl[6] = item3;
     constexpr int kPerThread = (TR * TW + NT - 1) / NT;
     int64_t wpix[kPerThread];
     double wold[kPerThread][NACC];
     const bool shared = wk.w && !degraded;
     const bool rmw = !shared && !p_out_zero && !p_overwrite;
-    if (!(P.debug & 128)) {                            // profiling: bit 128 skips the write-back (wrong results)
+    // Overwrite mode, tile not shared (the runners' and the bench's case): plain stores of every pixel and NOT ONE vector load in
+    // this stretch of code -- a load here (the read-modify-write path's) leaves the compiler a pending destination register to
+    // protect with s_waitcnt vmcnt(0) after the stores, i.e. a wait for their acknowledgement at the end of every item.
+    const bool plain = p_overwrite && !shared;
+    if (plain && !(P.debug & 128)) {
+        if constexpr (kQCap > 0) {
+            const int n = min(ctl[5], qcap);
+            if (P.defer && dfill + n <= P.defer_cap_wg) {
+                if (tid < n) {
+                    const DeferredPixel e = rq[tid];
+                    const int i = (e.abyte - acc_off) >> 3;                // accumulator index = row * TW + column
+                    const int row = i / TW, col = i % TW;
+                    DeferredOut o;
+                    o.pix = rows[row].start + rows[row].k0 + col; o.t = e.t; o.halo = e.halo; o.pad[0] = o.pad[1] = o.pad[2] = 0;
+                    P.defer[(size_t)blockIdx.x * P.defer_cap_wg + dfill + tid] = o;
+                }
+                dfill += n;
+            } else if (n > 0) drain();                                     // no list, or this workgroup's slice is full
+        }
+        // (the thread index through an opaque asm: otherwise the compiler hoists the per-u row addresses out of the persistent
+        // loop, spills some of them, and reloads them here with s_waitcnt vmcnt(0) -- between the stores, i.e. waiting for their
+        // acknowledgement after all)
+        int wt = tid;
+        asm volatile("" : "+v"(wt));
+#pragma unroll
+        for (int u = 0; u < kPerThread; ++u) {
+            const int i = wt + u * NT;
+            if (i < TR * TW) {
+                const int row = i / TW, col = i % TW;
+                const RingRow &rr = rows[row];
+                if (ring_lo + row <= ring_hi && rr.k0 + col < rr.k1) {
+                    double *dst = P.out + NACC * (rr.start + rr.k0 + col);
+#pragma unroll
+                    for (int c = 0; c < NACC; ++c) dst[c] = acc[NACC * i + c];
+                }
+            }
+        }
+    } else if (!(P.debug & 128)) {                     // profiling: bit 128 skips the write-back (wrong results)
 #pragma unroll
     for (int u = 0; u < kPerThread; ++u) {
         const int i = tid + u * NT;
@@ -1678,7 +1755,8 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     px_total += my_pixels;
     oob_total += n_oob32;
     BFG_ITICK(14);
-#if BFG_STAGE_TIMING
+    BFG_LTICK(7);
+#if BFG_STAGE_TIMING && BFG_STAGE_TIMING != 4
 #if BFG_STAGE_TIMING != 3
     __syncthreads();
 #endif
@@ -1687,6 +1765,8 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     } else {
         // an item without pairs (a tile no halo touches; every item when the binning gave up): nothing to paint.  An
         // uninitialised map still gets its zeros (tiles shared between items were cleared by tile_fill_kernel).
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the record DMA has landed (no stage-b barrier here)
+        if (tid == 0) ctl[6] = item3;
         if (p_overwrite && !(wk.w && !degraded)) {
             for (int i = tid; i < TR * TW; i += NT) {
                 const int row = i / TW, col = i % TW;
@@ -1703,12 +1783,14 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         }
     }
     // on to the next work item: every thread is done with the accumulator, the ring rows and the queue
-    if (tid == 0) ctl[6] = item3;
     lds_barrier();
     BFG_ITICK(15);
+    BFG_LTICK(8);
     primed = handed;                                  // (an item without pairs has no last chunk to hand over in)
     item = item1; item1 = item2; item2 = uni(ctl[6]);
-    wk = wk1; wg = wg1; wk1 = wk2; wg1 = wg2;
+    wk = wk1; wg = wg1;
+    wk1 = uni4(*reinterpret_cast<const int4 *>(ctl + 8 + 8 * par)); wg1 = uni4(*reinterpret_cast<const int4 *>(ctl + 12 + 8 * par));
+    par ^= 1;
     }   // work items
     // The deferred pixels of this workgroup's items.  defer_tail: added here, by the workgroup that queued them -- its write-back
     // stores of the same pixels have been acknowledged (the barrier waits for vmcnt(0)), other workgroups touch these pixels
@@ -1733,8 +1815,12 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         atomicAdd((unsigned long long *)&P.stats->pixels_out_of_table, (unsigned long long)oob_total);
         atomicOr(&P.stats->warn_mask, BFG_WARN_R_RANGE);
     }
-#if BFG_STAGE_TIMING
+#if BFG_STAGE_TIMING && BFG_STAGE_TIMING != 4
     if (tid == 64) for (int i = 0; i < 16; ++i) atomicAdd(&g_stage_cycles[i], (unsigned long long)st_acc[i]);
+#endif
+#if BFG_STAGE_TIMING == 4
+    __syncthreads();
+    if (tid < 16) atomicAdd(&g_stage_cycles[tid], reinterpret_cast<unsigned long long *>(smem_raw + lt_off)[tid]);
 #endif
 }
 

@@ -55,6 +55,18 @@ print(f"workload {workload} n={n} nside={nside}: {tot:.4g} cycles summed over wo
 for nm, x in zip(names, v):
     if x:
         print(f"  {nm:45s} {x:12.4g}  {100 * x / tot:5.1f} %")
+if os.environ.get("BFG_ST_MODE") == "4":
+    allv = np.array(list(out), dtype=np.float64) / reps
+    lab = ["t0: top of the item: counter atomic issued, work record of item k + 2 arrived, list prefetch issued",
+           "t1: accumulator clear, ring rows (wave 1), first records (wave 0)", "t2: stage a + its barrier (first chunk incl. wait for the records)",
+           "t3: stage b: blend / window DMA issue, halo records, ring windows, segments", "t4: barrier after stage b (vmcnt(0): loads, DMA, earlier stores)",
+           "t5: next records issued, pixel loop", "t6: end-of-chunk barrier (+ queue drain check)", "t7: write-back: addresses, deferred pixels, stores issued",
+           "t8: end-of-item barrier"]
+    tot = allv[:9].sum()
+    print(f"workload {workload} n={n} nside={nside}: thread {os.environ.get('BFG_ST_TID', '64')}: {tot:.4g} cycles per launch summed over workgroups")
+    for nm, x in zip(lab, allv[:9]):
+        print(f"    {nm:100s} {x:12.4g}  {100 * x / tot:5.1f} %")
+    sys.exit(0)
 if sub.sum() and os.environ.get("BFG_ST_MODE") == "3":
     subn = ["i0: top of the item (counter atomic, work record, list prefetch)", "i1: accumulator clear", "i2: ring rows",
             "i3: first records / wave-0 priming", "i4: chunk loop", "i5: write-back addresses, deferred pixels",
