@@ -1696,19 +1696,30 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         // (the thread index through an opaque asm: otherwise the compiler hoists the per-u row addresses out of the persistent
         // loop, spills some of them, and reloads them here with s_waitcnt vmcnt(0) -- between the stores, i.e. waiting for their
         // acknowledgement after all)
-        int wt = tid;
+        unsigned wt = (unsigned)tid;
         asm volatile("" : "+v"(wt));
+        // all LDS reads of the thread's pixels first (ring rows and accumulator values in flight together, one wait), then the
+        // stores: read -> wait -> read -> wait per pixel cost ~3 LDS round trips x 4 pixels on the critical path of every item.
+        // (Tried: wave 0, whose loads pace the next item, issuing no stores at all -- no change: profiles/r03_writeback_ab.txt.)
+        int wk0[kPerThread], wk1[kPerThread];
+        int64_t wst[kPerThread];
+        double wv[kPerThread][NACC];
 #pragma unroll
         for (int u = 0; u < kPerThread; ++u) {
-            const int i = wt + u * NT;
-            if (i < TR * TW) {
-                const int row = i / TW, col = i % TW;
-                const RingRow &rr = rows[row];
-                if (ring_lo + row <= ring_hi && rr.k0 + col < rr.k1) {
-                    double *dst = P.out + NACC * (rr.start + rr.k0 + col);
+            const unsigned i = min(wt + (unsigned)(u * NT), (unsigned)(TR * TW - 1));
+            const RingRow &rr = rows[i / TW];
+            wk0[u] = rr.k0; wk1[u] = rr.k1; wst[u] = rr.start;
 #pragma unroll
-                    for (int c = 0; c < NACC; ++c) dst[c] = acc[NACC * i + c];
-                }
+            for (int c = 0; c < NACC; ++c) wv[u][c] = acc[NACC * i + c];
+        }
+#pragma unroll
+        for (int u = 0; u < kPerThread; ++u) {
+            const unsigned i = wt + (unsigned)(u * NT);
+            const int row = (int)(i / TW), col = (int)(i % TW);
+            if (i < (unsigned)(TR * TW) && ring_lo + row <= ring_hi && wk0[u] + col < wk1[u]) {
+                double *dst = P.out + NACC * (wst[u] + wk0[u] + col);
+#pragma unroll
+                for (int c = 0; c < NACC; ++c) dst[c] = wv[u][c];
             }
         }
     } else if (!(P.debug & 128)) {                     // profiling: bit 128 skips the write-back (wrong results)
