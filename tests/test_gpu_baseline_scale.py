@@ -89,6 +89,60 @@ def test_baryonify_shell_config4_per_rank_share_properties(cosmo):
     assert abs(ptot_all / n - ptot_ref / ns) < 0.05 * ptot_ref / ns
 
 
+def test_baryonify_shell_config4_whole_catalog_one_gpu(cosmo):
+    """BASELINE config[3] on ONE GPU (the N = 1 anchor of the 8-GPU configuration): the whole 1e7-halo catalog at NSIDE 2048,
+    1.1e10 pixel-updates -- mass conserved (HealpixRunner.py:368-370), finite and non-negative output, no halo through the
+    scatter fallback, P_tot equal to the oracle's count on a 2e4-halo sample of the same catalog and the full count the
+    sample's scaled up (same mass function), and the eighth of it that is rank 0's shard reproduces that shard's own run
+    when the offsets are summed over the eight shards (the linearity the multi-GPU join relies on, :355)."""
+    import torch
+    from baryonforge_amd import sharding
+    from baryonforge_amd.engine import get_context
+    nside, n, eps = 2048, 10_000_000, 10.0
+    npix = 12 * nside * nside
+    ra, dec, M, z = syn.catalog(n, seed=42)
+    zd, Md, rd, d = syn.displacement_table()
+    model = bfg.Baryonification2D.from_arrays(zd, Md, rd, d, cosmo, epsilon_max=20)
+    m_in = syn.mass_map(nside)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    R = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in, cosmo=cosmo), eps, model, verbose=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = R.process()
+    assert got.shape == (npix,) and np.all(np.isfinite(got)) and got.min() >= 0.0
+    assert np.isclose(got.sum(), m_in.sum(), rtol=1e-9)
+    assert R.last_stats["fallback_halos"] == 0 and R.last_stats["halos_out_of_table"] == 0
+    ptot_all = R.last_stats["pixel_updates"]
+    ns = 20000
+    a, Rr, D = orc.halo_scalars(cosmo, M[:ns], z[:ns])
+    _, ptot_ref = orc.baryonify_offsets(nside, ra[:ns], dec[:ns], M[:ns], a, D, Rr, Rr / a, (zd, Md, rd), d, eps, 20.0, False, None)
+    Rs = bfg.BaryonifyShell(bfg.HaloLightConeCatalog(ra[:ns], dec[:ns], M[:ns], z[:ns], cosmo),
+                            bfg.LightconeShell(map=m_in, cosmo=cosmo), eps, model, verbose=False)
+    Rs._spline_z_max = float(z.max())                               # the whole catalog's D_A spline, as a shard would use
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        Rs.offsets_device()
+    assert Rs.last_stats["pixel_updates"] == ptot_ref
+    assert abs(ptot_all / n - ptot_ref / ns) < 0.03 * ptot_ref / ns
+    # linearity over sky-patch shards: sum of the eight shards' offset fields == the whole catalog's (to summation rounding)
+    w = sharding.estimate_disc_pixels(cosmo, M, z, eps, nside)
+    shards = sharding.shard_by_sky_patch(ra, dec, w, 8)
+    assert sum(s.size for s in shards) == n
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        d_full = R.offsets_device()
+        d_sum = torch.zeros_like(d_full)
+        for idx in shards:
+            Rk = bfg.BaryonifyShell(bfg.HaloLightConeCatalog(ra[idx], dec[idx], M[idx], z[idx], cosmo),
+                                    bfg.LightconeShell(map=m_in, cosmo=cosmo), eps, model, verbose=False)
+            Rk._spline_z_max = float(z.max())
+            d_sum += Rk.offsets_device()
+    scale = float(d_full.abs().max())
+    assert float((d_sum - d_full).abs().max()) < 1e-9 * scale
+    del d_full, d_sum
+    get_context().synchronize()
+
+
 def test_snapshot_config5_full_size_properties(cosmo, monkeypatch):
     """BASELINE config[4]: 512^3 particles (a jittered lattice, built on the device), 1e5 halos, L = 1000 Mpc, eps = 10,
     + CIC deposit on a 512^3 grid"""

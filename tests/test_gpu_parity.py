@@ -1620,3 +1620,50 @@ def test_catalog_device_copy_is_locked_not_stale(cosmo):
     Cat.cat["M"] /= 2.0
     ref, _ = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax), T, 64, 10)
     assert_maps_close(R.process(), ref, RTOL, what="after replacing cat")
+
+
+# --------------------------------------------------------------------------- a8 pin at the BASELINE resolutions
+@pytest.mark.parametrize("nside", [1024, 2048])
+def test_painted_pixel_sets_equal_brute_force_over_all_pixels(cosmo, nside):
+    """Disc membership of the HIP kernels against an INDEPENDENT criterion at the workloads' resolutions:
+    a table of T = 1 makes every (halo, pixel) pair paint exactly 1, so the painted map is the number of discs covering each
+    pixel; the reference count is sum_j [ n_p . n_j > cos(theta_j) ] over ALL 12 nside^2 pixel centres, computed with torch
+    from the closed-form ring formulae (tests/closed_form.py -- neither csrc/bfg_device.hpp nor the oracle).  ~500 halos incl.
+    both poles and the phi = 0 seam; pixels within 1e-12 rad of a disc's rim are exempt."""
+    import torch
+    from closed_form import ring_pixel_vectors
+    n, eps = 500, 10.0
+    rng = np.random.default_rng(nside)
+    ra, dec, M, z = syn.catalog(n, seed=nside)
+    res_deg = np.degrees(np.sqrt(4 * np.pi / (12 * nside * nside)))
+    dec[:30] = 90 - np.abs(rng.normal(0, 4 * res_deg, 30))                # north pole (the container clips |dec| = 90)
+    dec[30:60] = -90 + np.abs(rng.normal(0, 4 * res_deg, 30))             # south pole
+    ra[60:110] = rng.normal(0, 3 * res_deg, 50) % 360                      # the seam
+    M[110:130] = 10 ** rng.uniform(11.0, 11.6, 20)                         # discs of a pixel or less (some empty)
+    zax = np.log(1 + np.array([0.01, 1.0]))
+    Max = np.log(np.array([1e10, 1e17]))
+    rax = np.log(np.geomspace(1e-6, 1e4, 100))
+    T = np.ones((2, 2, 100))
+    model = bfg.TabulatedProfile.from_arrays(zax, Max, rax, T)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), eps, model, verbose=False)
+    d_map = R.process_device()
+    assert R.last_stats["fallback_halos"] == 0 and R.last_stats["pixels_out_of_table"] == 0
+    a, Rr, D = orc.halo_scalars(cosmo, M, Cat.cat["z"])
+    theta = torch.tensor(Rr * eps / D, dtype=torch.float64, device=d_map.device)
+    dr = np.radians(Cat.cat["dec"]); rr = np.radians(Cat.cat["ra"])
+    c = torch.tensor(np.stack([np.cos(dr) * np.cos(rr), np.cos(dr) * np.sin(rr), np.sin(dr)], 1), dtype=torch.float64,
+                     device=d_map.device)
+    v = ring_pixel_vectors(nside, xp=torch)
+    count = torch.zeros(v.shape[0], dtype=torch.float64, device=d_map.device)
+    rim = torch.zeros(v.shape[0], dtype=torch.bool, device=d_map.device)
+    cos_t, sin_t = torch.cos(theta), torch.sin(theta)
+    for j0 in range(0, n, 4):
+        dot = v @ c[j0:j0 + 4].T                                           # [npix, 4]
+        count += (dot > cos_t[j0:j0 + 4]).sum(dim=1).to(torch.float64)
+        # |angle - theta| < 1e-12  <=>  |dot - cos(theta)| < 1e-12 sin(theta) (to first order)
+        rim |= ((dot - cos_t[j0:j0 + 4]).abs() < 1e-12 * sin_t[j0:j0 + 4] + 4e-16).any(dim=1)
+    ok = ~rim
+    assert int(rim.sum()) < 50                                             # the exemption is a handful of pixels
+    assert torch.equal(d_map[ok], count[ok]), int((d_map[ok] != count[ok]).sum())
+    assert float(count.sum()) > 1e4 * n / 500 and abs(R.last_stats["pixel_updates"] - float(count.sum())) <= int(rim.sum())

@@ -488,3 +488,44 @@ def test_missing_rccl_is_an_error_code_not_a_crash(tmp_path):
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.startswith("[-6, -6, -6]") and "no_such_librccl" in out.stdout, out.stdout
+
+
+def test_background_against_independent_quadrature_and_closed_form():
+    """a9 pins: D_A(z) = a c/H0 int_a^1 da' / (a'^2 E(a')) against a high-order Gauss-Legendre quadrature
+    written here from the CCL parameter definitions, and R_200c against its closed form, at 50 redshifts, to 1e-12 -- for the
+    product's Background, the oracle's background and the device-side spline knots' source alike"""
+    from numpy.polynomial.legendre import leggauss
+    cosmo = {"Omega_m": 0.31, "Omega_b": 0.045, "h": 0.68, "sigma8": 0.8, "n_s": 0.96, "w0": -0.9}
+    bg = Background(cosmo)
+    h = cosmo["h"]
+    # photons + 3.044 massless neutrinos (CCL defaults: T_CMB 2.7255 K, T_ncdm 0.71611), from first principles
+    sigma_sb, c, G_Msun, Mpc = 5.670374419e-8, 299792458.0, 1.3271244e20, 3.085677581491367e22
+    rho_crit_si = 3 * (100e3 * h / Mpc) ** 2 / (8 * np.pi) * (1.98840987e30 / 1.3271244e20) ** 0 / (G_Msun / 1.98840987e30)
+    rho_g = 4 * sigma_sb / c ** 3 * 2.7255 ** 4
+    Og = rho_g / rho_crit_si
+    Onu = 3.044 * 7.0 / 8.0 * (0.71611 ** 4) * Og
+    Or = Og + Onu
+    Ol = 1 - cosmo["Omega_m"] - Or
+
+    def E(a):
+        return np.sqrt(cosmo["Omega_m"] / a ** 3 + Ol * a ** (-3 * (1 + cosmo["w0"])) + Or / a ** 4)
+    np.testing.assert_allclose(bg.Omega_r, Or, rtol=1e-9)                    # same radiation content from independent constants
+    x, w = leggauss(96)
+    zs = np.linspace(0.01, 3.0, 50)
+    chi = np.empty_like(zs)
+    for k, zz in enumerate(zs):
+        a0 = 1 / (1 + zz)
+        aa = 0.5 * (1 - a0) * x + 0.5 * (1 + a0)
+        chi[k] = 0.5 * (1 - a0) * np.sum(w / (aa ** 2 * np.sqrt(cosmo["Omega_m"] / aa ** 3 + bg.Omega_l * aa ** (-3 * (1 + cosmo["w0"])) + bg.Omega_r / aa ** 4)))
+    DA_ref = chi * (c / 1e3 / (100 * h)) / (1 + zs)
+    np.testing.assert_allclose(bg.angular_diameter_distance(1 / (1 + zs)), DA_ref, rtol=1e-12)
+    np.testing.assert_allclose(orc.angular_diameter_distance(cosmo, 1 / (1 + zs)), DA_ref, rtol=1e-12)
+    M = 10 ** np.linspace(12, 15.5, 50)
+    a = 1 / (1 + zs)
+    E2 = cosmo["Omega_m"] / a ** 3 + bg.Omega_l * a ** (-3 * (1 + cosmo["w0"])) + bg.Omega_r / a ** 4
+    R_ref = (M / (4.18879020479 * 200 * 2.775366e11 * h * h * E2)) ** (1 / 3)
+    np.testing.assert_allclose(MassDef(200, "critical").get_radius(cosmo, M, a), R_ref, rtol=2e-7)   # CCL's rounded RHO_CRITICAL
+    from baryonforge_amd.background import RHO_CRITICAL
+    R_exact = (M / (4.18879020479 * 200 * RHO_CRITICAL * h * h * E2)) ** (1 / 3)
+    np.testing.assert_allclose(MassDef(200, "critical").get_radius(cosmo, M, a), R_exact, rtol=1e-12)
+    np.testing.assert_allclose(orc.get_radius(cosmo, M, a), R_exact, rtol=1e-12)

@@ -114,3 +114,78 @@ def test_interp_weights_properties():
         z = np.stack(o.pix2vec(nside, p.ravel()), 1)[:, 2].reshape(4, -1)
         if nside >= 16:
             np.testing.assert_allclose((w * z).sum(0), np.sin(np.radians(lat)), atol=3.0 / nside ** 2 + 1e-12)
+
+
+# ---------------------------------------------------------------- pins at the resolutions the workloads run at
+@pytest.mark.parametrize("nside", [128, 1024, 2048])
+def test_pix2vec_equals_the_closed_form_ring_formulae(nside):
+    """every pixel centre of the oracle == the closed-form ring formulae evaluated independently (tests/closed_form.py)"""
+    from closed_form import ring_pixel_vectors
+    v = ring_pixel_vectors(nside)
+    step = 1 if nside <= 1024 else 3
+    idx = np.arange(0, 12 * nside * nside, step)
+    ref = np.stack(o.pix2vec(nside, idx), axis=1)
+    np.testing.assert_allclose(ref, v[idx], rtol=0, atol=2e-14)
+
+
+@pytest.mark.parametrize("nside", [128, 512, 1024, 2048])
+def test_interp_weights_reproduce_linear_functions(nside):
+    """get_interp_weights is the bilinear ring interpolation: between two rings it reproduces the colatitude exactly
+    (sum_k w_k theta_k = theta) and inside each ring the longitude (sum over the ring's two pixels of w_k phi_k / their weight
+    = phi, away from the phi = 0 seam), to 1e-12 -- at the resolutions of the BASELINE workloads"""
+    from closed_form import ring_pixel_z_phi, ring_theta
+    rng = np.random.default_rng(nside)
+    n = 20000
+    th_r = ring_theta(nside)
+    theta = rng.uniform(th_r[0] * 1.0001, th_r[-1] * 0.9999, n)            # between the first and the last ring
+    phi = rng.uniform(0.0, 2 * np.pi, n)
+    pix, w = o.get_interp_weights(nside, theta, phi)
+    np.testing.assert_allclose(w.sum(axis=0), 1.0, rtol=0, atol=1e-13)
+    assert np.all(w >= -1e-15)
+    z, ph = ring_pixel_z_phi(nside)
+    tk = np.arccos(z[pix])                                                  # colatitudes of the four pixels
+    np.testing.assert_allclose((w * tk).sum(axis=0), theta, rtol=0, atol=1e-12)
+    # the two pixels of each ring: pix[0:2] upper ring, pix[2:4] lower ring
+    for a, b in ((0, 1), (2, 3)):
+        pa, pb = ph[pix[a]], ph[pix[b]]
+        pb = np.where(pb < pa - np.pi, pb + 2 * np.pi, pb)                  # the pair straddles phi = 2 pi
+        pa2 = np.where(pa > pb + np.pi, pa - 2 * np.pi, pa)
+        wsum = w[a] + w[b]
+        ok = wsum > 1e-9
+        got = (w[a] * pa2 + w[b] * pb)[ok] / wsum[ok]
+        want = phi[ok]
+        d = np.mod(got - want + np.pi, 2 * np.pi) - np.pi                    # compare on the circle
+        assert np.max(np.abs(d)) < 1e-12, np.max(np.abs(d))
+
+
+@pytest.mark.parametrize("nside", [1024, 2048])
+def test_query_disc_equals_brute_force_at_workload_resolution(nside):
+    """disc membership at NSIDE 1024 / 2048 (the existing brute-force test stops at 64): for 60 discs incl. the poles and the
+    seam, query_disc == { p : n_p . n_j > cos(theta) } over the pixels of a generous ring band around the disc, centres from
+    the closed-form formulae; pixels within 1e-12 rad of the rim are exempt"""
+    from closed_form import ring_pixel_vectors
+    v = ring_pixel_vectors(nside)
+    rng = np.random.default_rng(5 + nside)
+    res = np.sqrt(4 * np.pi / (12 * nside * nside))
+    cases = []
+    for k in range(60):
+        th = np.arccos(rng.uniform(-1, 1))
+        ph = rng.uniform(0, 2 * np.pi)
+        if k < 6:
+            th = rng.uniform(0, 3 * res)                 # around the north pole
+        elif k < 12:
+            th = np.pi - rng.uniform(0, 3 * res)         # south pole
+        elif k < 20:
+            ph = rng.normal(0, 2 * res) % (2 * np.pi)    # the phi = 0 seam
+        cases.append((th, ph, res * 10 ** rng.uniform(-0.3, 1.7)))            # radii 0.5 .. 50 pixels
+    for th, ph, rad in cases:
+        c = np.array([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)])
+        got = o.query_disc(nside, c, rad)
+        zlo, zhi = np.cos(min(np.pi, th + rad + 3 * res)), np.cos(max(0.0, th - rad - 3 * res))
+        band = np.flatnonzero((v[:, 2] >= zlo) & (v[:, 2] <= zhi))
+        dot = v[band] @ c
+        margin = np.abs(np.arccos(np.clip(dot, -1, 1)) - rad)
+        inside = band[dot > np.cos(rad)]
+        rim = band[margin < 1e-12]
+        assert np.array_equal(np.setdiff1d(got, rim), np.setdiff1d(inside, rim)), (th, ph, rad)
+        assert np.all(np.diff(got) > 0)
