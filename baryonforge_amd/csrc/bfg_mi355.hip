@@ -1797,6 +1797,9 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     // row windows of 4 k nodes are built by the prep kernel itself (BFG_ROWS=separate: by halo_row4_kernel, the A/B)
     bool fuse_rows = tile && !win_table && !blend && win_nodes % 4 == 0 && win_nodes >= 8;
     if (const char *e = std::getenv("BFG_ROWS")) if (!std::strcmp(e, "separate")) fuse_rows = false;
+    // the row phase needs 64 x 2^nouter x 16 B of dynamic LDS on top of the kernel's 34 KB of static LDS: tables with three extra
+    // axes would pass 64 KB -- those take the separate row kernel
+    if (fuse_rows && 34816 + (size_t)64 * ((size_t)1 << t->dev.nouter) * 16 > std::min<size_t>(c->max_dyn_lds, 65536)) fuse_rows = false;
     pp.hwin = fuse_rows ? c->d_hwin : nullptr;
     pp.lazy_soa = (tile && t->dev.nouter == 2 && !std::getenv("BFG_EAGER_SOA")) ? 1 : 0;
     const size_t prep_lds = fuse_rows ? (size_t)64 * ((size_t)1 << t->dev.nouter) * 16 : 0;

@@ -1810,7 +1810,13 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     if constexpr (kQCap > 0) {
         if (P.defer) {
             if (P.defer_tail) {
+                // every wavefront's write-back stores and list entries are visible device-wide before any wavefront of this
+                // workgroup adds to those pixels / reads those entries: an explicit release fence + vmcnt(0), not an assumption
+                // about what __syncthreads() happens to wait for
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 const volatile DeferredOut *slice = P.defer + (size_t)blockIdx.x * P.defer_cap_wg;
                 for (int i = tid; i < dfill; i += NT) {
                     DeferredOut e;

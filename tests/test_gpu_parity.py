@@ -1667,3 +1667,29 @@ def test_painted_pixel_sets_equal_brute_force_over_all_pixels(cosmo, nside):
     assert int(rim.sum()) < 50                                             # the exemption is a handful of pixels
     assert torch.equal(d_map[ok], count[ok]), int((d_map[ok] != count[ok]).sum())
     assert float(count.sum()) > 1e4 * n / 500 and abs(R.last_stats["pixel_updates"] - float(count.sum())) <= int(rim.sum())
+
+
+@pytest.mark.parametrize("rows", ["fused", "separate"])
+def test_paint_three_extra_table_axes(cosmo, rows, monkeypatch):
+    """a 6-D table (three p_keys axes: BFG_MAX_EXTRA, 32 corners per halo): the prep kernel's fused row phase would need more
+    than 64 KB of LDS there and hands the rows to halo_row4_kernel; against the oracle's N-linear read-out"""
+    if rows == "separate":
+        monkeypatch.setenv("BFG_ROWS", "separate")
+    nside, n, eps = 256, 3000, 10.0
+    ra, dec, M, z = syn.catalog(n, seed=271)
+    rng = np.random.default_rng(6)
+    p1, p2, p3 = rng.uniform(0.7, 1.4, n), rng.uniform(-1.0, 2.0, n), rng.uniform(10.0, 20.0, n)
+    zax, Max, rax, T = syn.pressure_table(3, 8, 100)
+    a1, a2, a3 = np.array([0.6, 1.0, 1.5]), np.array([-1.5, 0.0, 2.5]), np.array([5.0, 25.0])
+    T6 = (T[..., None, None, None] * (1.0 + 0.3 * (a1 - 1.0))[None, None, None, :, None, None]
+          * (1.0 + 0.05 * a2 ** 2)[None, None, None, None, :, None] * (a3 / 10.0)[None, None, None, None, None, :])
+    ref, ptot = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax, a1, a2, a3), T6, nside, eps, extra=np.stack([p1, p2, p3], 1))
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo, pa=p1, pb=p2, pc=p3)
+    model = bfg.ParamTabulatedProfile.from_arrays(zax, Max, rax, T6, other_params={"pa": a1, "pb": a2, "pc": a3})
+    for variant in ("tile_lds", "scatter_quarter"):
+        R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), eps, model,
+                                   verbose=False, variant=variant)
+        got = R.process()
+        assert R.last_stats["pixel_updates"] == ptot
+        assert np.array_equal(got != 0, ref != 0)
+        assert_maps_close(got, ref, RTOL, what=f"three extra axes ({rows}, {variant})")
