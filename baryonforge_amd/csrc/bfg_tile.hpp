@@ -1402,7 +1402,10 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                 // cell -- the table is L2-resident -- with the arithmetic of halo_row4_kernel (corner order, fma chain from
                 // 0, + ln(pixarea D^2)): the same bits.  All eight 16-byte loads of a thread are in flight together.
                 typedef double double2u __attribute__((ext_vector_type(2), aligned(8)));
-                const int i = tid;
+                // from the LAST thread down: the (pair, ring) slots below are dealt from thread 0 up, so in a chunk that does not
+                // fill the workgroup (sparse catalogs) the blend -- two dependent L2 round trips -- runs in wavefronts that have
+                // no slot, beside the slot work instead of in front of it
+                const int i = NT - 1 - tid;
                 if (i < n_take * (kWinLds / 4)) {
                     const int p = i >> 3, q = i & 7;
                     const Pair &pi = pinfo[p];
@@ -1810,13 +1813,13 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     if constexpr (kQCap > 0) {
         if (P.defer) {
             if (P.defer_tail) {
-                // every wavefront's write-back stores and list entries are visible device-wide before any wavefront of this
-                // workgroup adds to those pixels / reads those entries: an explicit release fence + vmcnt(0), not an assumption
-                // about what __syncthreads() happens to wait for
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                // Every wavefront's write-back stores and list entries have been acknowledged by the L2 -- an explicit
+                // s_waitcnt vmcnt(0), not an assumption about what __syncthreads() happens to wait for -- before any wavefront of
+                // this workgroup adds to those pixels (atomics, resolved in that same L2: one CU, one XCD) or reads those entries
+                // (volatile: past the L1).  (An agent-scope release / acquire fence pair is NOT what is wanted here: on this part
+                // it writes back and invalidates the whole L2 -- the 1e5-halo tile kernel went from 0.151 to 0.226 ms with it.)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 const volatile DeferredOut *slice = P.defer + (size_t)blockIdx.x * P.defer_cap_wg;
                 for (int i = tid; i < dfill; i += NT) {
                     DeferredOut e;
