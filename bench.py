@@ -513,7 +513,10 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
-            traffic = tj.get(f"{args.workload}_{args.variant}_n{idx.size}_nside{nside}")
+            key = f"{args.workload}_{args.variant}_n{idx.size}_nside{nside}"
+            if args.table != "default" or args.steep or args.eps != 10.0:      # only the default catalog / table / eps were measured
+                key += f"_{args.table}{'_steep' if args.steep else ''}_eps{args.eps:g}"
+            traffic = tj.get(key)
             if traffic is not None:
                 traffic_source = f"stored: {tj.get('_source', 'profiles/pmc_traffic.json')}"
         except Exception:

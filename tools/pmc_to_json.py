@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""profiles/pmc_traffic.json from the two rocprofv3 --pmc summaries (tools/pmc_summary.py output) of the headline run:
-HBM-side bytes per launch of the dominant kernel = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 B.  FETCH_SIZE is doubled per the
-gfx950 wide-read correction of MI355X_MICROARCH.md (an upper bound: not every read of this kernel is a wide coalesced
-stream); WRITE_SIZE is exact for 16-B-per-lane stores.   usage: pmc_to_json.py FETCH.txt WRITE.txt TAG [out.json]"""
+"""profiles/pmc_traffic.json from rocprofv3 --pmc summaries (tools/pmc_summary.py output): HBM-side bytes per launch of the
+dominant kernel of each measured workload = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 B.  FETCH_SIZE is doubled per the gfx950
+wide-read correction of MI355X_MICROARCH.md (an upper bound: not every read of these kernels is a wide coalesced stream);
+WRITE_SIZE is taken as is.
+usage: pmc_to_json.py TAG out.json  key=FETCH.txt,WRITE.txt[,kernel] ...   (key = bench.py's <workload>_<variant>_n<halos>_nside<nside>)"""
 import json
 import re
 import sys
@@ -19,15 +20,21 @@ def mean_of(path, kernel, counter):
     raise SystemExit(f"{counter} of {kernel} not found in {path}")
 
 
-fetch, nf = mean_of(sys.argv[1], "shell_tile_kernel", "FETCH_SIZE")
-write, nw = mean_of(sys.argv[2], "shell_tile_kernel", "WRITE_SIZE")
-tag = sys.argv[3]
-out = sys.argv[4] if len(sys.argv) > 4 else "profiles/pmc_traffic.json"
-j = {"paint_auto_n1000000_nside1024": (2.0 * fetch + write) * 1024.0,
-     "_source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes) of `bench.py --steps 3` on the {tag} build: "
-                f"profiles/{tag}_pmc_FETCH_SIZE.txt, profiles/{tag}_pmc_WRITE_SIZE.txt",
-     "_note": "shell_tile_kernel per launch: (2*FETCH_SIZE + WRITE_SIZE)*1024 B; FETCH_SIZE doubled per the gfx950 wide-read "
-              "correction of MI355X_MICROARCH.md (an upper bound); WRITE_SIZE = the 101 MB map written once + the deferred-pixel lists",
-     "_raw": {"FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "launches_averaged": [nf, nw]}}
+tag, out = sys.argv[1], sys.argv[2]
+j = {"_source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --steps 3` on the {tag} build; summaries "
+                f"profiles/{tag}_pmc_<workload>_<counter>.txt",
+     "_note": "dominant kernel (shell_tile_kernel) per launch: (2*FETCH_SIZE + WRITE_SIZE)*1024 B; FETCH_SIZE doubled per the gfx950 "
+              "wide-read correction of MI355X_MICROARCH.md (an upper bound)", "_raw": {}}
+for spec in sys.argv[3:]:
+    key, files = spec.split("=")
+    parts = files.split(",")
+    kernel = parts[2] if len(parts) > 2 else "shell_tile_kernel"
+    fetch, nf = mean_of(parts[0], kernel, "FETCH_SIZE")
+    write, nw = mean_of(parts[1], kernel, "WRITE_SIZE")
+    if key.startswith("_"):                                    # not a bench key: kept under _raw only (e.g. the prep kernel)
+        j["_raw"][key] = {"kernel": kernel, "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "launches_averaged": [nf, nw]}
+        continue
+    j[key] = (2.0 * fetch + write) * 1024.0
+    j["_raw"][key] = {"kernel": kernel, "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "launches_averaged": [nf, nw]}
 json.dump(j, open(out, "w"), indent=1)
 print(json.dumps(j))
