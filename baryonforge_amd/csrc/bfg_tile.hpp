@@ -1290,6 +1290,30 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                     return;
                 }
             }
+            if constexpr (!win_in_lds) {
+                // the same for the table-direct read-out of a 3-D table (finely sampled radial axes): the pair's four corner weights,
+                // the offset of its first corner row and ln(pixarea D^2) come from ONE 72-byte LDS record (stage b), the other three
+                // rows are strides away; the four 16-byte loads go out together and the cell is clamped, so they need no guard
+                if (P.win_table && T.nouter == 2) {
+                    const double xf = fma(sg.Bq, sin_squared_small(h2), sg.Aq);
+                    const double t1f = fma(fast_log_biased(xf, logtab), t_m, t_c1);
+                    const int i1f = (int)t1f;
+                    const int icf = med3_i32(i1f, sg.pk, sg.pk + W - 2);
+                    const double *rec = pwin + sg.wbyte * kWinLds;
+                    const double w0 = rec[0], w1 = rec[1], w2 = rec[2], w3 = rec[3], addf = rec[8];
+                    const double *r0 = T.values + reinterpret_cast<const int64_t *>(rec)[4] + (icf - 1);
+                    const double *r1 = r0 + T.ostride[1], *r2 = r0 + T.ostride[0], *r3 = r2 + T.ostride[1];
+                    const double a0 = r0[0], b0 = r0[1], a1 = r1[0], b1 = r1[1], a2 = r2[0], b2 = r2[1], a3 = r3[0], b3 = r3[1];
+                    const double B0f = fma(a3, w3, fma(a2, w2, fma(a1, w1, fma(a0, w0, 0.0)))) + addf;
+                    const double B1f = fma(b3, w3, fma(b2, w2, fma(b1, w1, fma(b0, w0, 0.0)))) + addf;
+                    const double Lf = fma(t1f - (double)icf, B1f - B0f, B0f);
+                    if ((h2 <= kSinSmall) && (icf == i1f) && (fabs(Lf) < 709.0)) {
+                        __hip_atomic_fetch_add(lds_ptr<double>(lds_base + sg.abyte + 8 * k), fast_exp(Lf, exptab), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                        return;
+                    }
+                }
+            }
             double s2 = sin_squared_small(h2);
             if (__any(h2 > kSinSmall)) {                                   // wave-uniform branch: only near the poles
                 if (h2 > kSinSmall) s2 = sin_squared_wide(h);
@@ -1473,6 +1497,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                     }
                     cwn[c] = w; con[c] = off;
                 }
+                if constexpr (MODE == MODE_PAINT) { if (ncorner == 4) cwn[8] = pinfo[lane].lnpf; }   // the fast path's record
             }
         }
         if constexpr (MODE == MODE_BARYONIFY) {
