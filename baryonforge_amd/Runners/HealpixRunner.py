@@ -325,8 +325,10 @@ class BaryonifyShell(DefaultRunner):
                             f"got {type(self.model)}")
         return keys
 
-    def offsets_device(self):
-        """Accumulate the unit-vector offsets of all halos (:313-355); returns float64[Npix, 3] on the device."""
+    def offsets_device(self, slices=1, on_slice=None):
+        """Accumulate the unit-vector offsets of all halos (:313-355); returns float64[Npix, 3] on the device.
+        slices, on_slice: bfg_baryonify_offsets_sliced -- on_slice(k, n, lo, hi) after the k-th band slice of the field has been
+        enqueued; lo / hi are ELEMENT indices of the flattened field (3 per pixel)."""
         keys = self._checked_model_keys()
         ctx = get_context()
         NSIDE = self.LightconeShell.NSIDE
@@ -343,7 +345,12 @@ class BaryonifyShell(DefaultRunner):
                               out_overwrite=True)
         d_off = ctx.empty(12 * NSIDE * NSIDE, 3)                          # :313 -- the zeros come from the kernels
         ctx.stats_reset()
-        ctx.baryonify_offsets(args, table, spline, d_off)                 # :315-355
+        if on_slice is not None:
+            flat = d_off.view(-1)
+            ctx.baryonify_offsets(args, table, spline, d_off, slices=slices,
+                                  on_slice=lambda k, n, lo, hi: on_slice(k, n, lo, hi, flat))
+        else:
+            ctx.baryonify_offsets(args, table, spline, d_off)             # :315-355
         self.last_stats = ctx.stats()
         emit_range_warnings(self.last_stats, "table")                     # BaryonCorrection.py:382-394
         emit_fallback_warning(self.last_stats)
@@ -375,8 +382,8 @@ class _BaryonifyDeviceOps(object):
     def absmax_sum(self, t):
         return get_context().absmax_sum(t)
 
-    def offsets(self):
-        return self.runner.offsets_device()
+    def offsets(self, slices=1, on_slice=None):
+        return self.runner.offsets_device(slices=slices, on_slice=on_slice)
 
     def regrid(self, nside, d_off, d_in, d_out):
         get_context().regrid_shell(nside, d_off, d_in, d_out, None)
@@ -385,9 +392,11 @@ class _BaryonifyDeviceOps(object):
         return get_context().to_host(t)
 
 
-def _baryonify_process(runner, ops, exchange):
+def _baryonify_process(runner, ops, exchange, slices=1):
     """BaryonifyShell.process (HealpixRunner.py:252-373) over an `ops` object (the device side: _BaryonifyDeviceOps) and an
-    optional Exchange between ranks"""
+    optional Exchange between ranks.  slices > 1: the offset field is exchanged in band slices while the rest is still being
+    accumulated -- every slice is reduce-scattered (rank r ends up owning the r-th part of EVERY slice; all-reduced instead if
+    its length does not divide by the world size), and a rank regrids the sources of the pixels it owns."""
     orig_map = runner.LightconeShell.map
     NSIDE = runner.LightconeShell.NSIDE
     if orig_map.size < (1 << 16) and np.allclose(orig_map, 0):         # small maps: decided on the host, as the reference
@@ -403,8 +412,30 @@ def _baryonify_process(runner, ops, exchange):
     if exchange is not None and not hasattr(exchange, "reduce_scatter"):
         from ..utils.Parallelize import Exchange
         exchange = Exchange(exchange)
-    d_off = ops.offsets()                                             # :313-355, this rank's halos
-    if exchange is not None and exchange.world > 1:
+    if exchange is not None and exchange.world > 1 and slices > 1:
+        rank, world = exchange.rank, exchange.world
+        owned, handles = [], []
+
+        def on_slice(k, n, lo, hi, flat):                             # element range [lo, hi) of the flattened field: final
+            plo, phi = lo // 3, hi // 3
+            npx = phi - plo
+            if npx % world == 0:
+                handles.append(exchange.reduce_scatter_begin(flat[lo:hi]))
+            else:
+                handles.append(exchange.allreduce_begin(flat[lo:hi]))
+            owned.append((plo + npx * rank // world, plo + npx * (rank + 1) // world))
+        d_off = ops.offsets(slices=slices, on_slice=on_slice)          # :313-355, this rank's halos
+        for h in handles:
+            exchange.wait(h)
+        d_in = ops.zeros(npix)
+        for lo, hi in owned:
+            d_in[lo:hi] = d_orig[lo:hi]                               # sources this rank does not own have no mass here
+        assert sum(hi - lo for lo, hi in owned) > 0 or npix < world
+    else:
+        d_off = ops.offsets()                                         # :313-355, this rank's halos
+    if exchange is not None and exchange.world > 1 and slices > 1:
+        pass
+    elif exchange is not None and exchange.world > 1:
         rank, world = exchange.rank, exchange.world
         if npix % world == 0:
             exchange.reduce_scatter(d_off)                            # summed offsets of the pixels this rank owns

@@ -103,6 +103,21 @@ class Exchange(object):
             return None
         return ("torch", self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, async_op=True))
 
+    def reduce_scatter_begin(self, t):
+        """start the in-place reduce-scatter of the flat tensor t (numel a multiple of the world size: rank r ends up owning the
+        r-th part); returns a handle for `wait`"""
+        n = t.numel()
+        assert n % self.world == 0
+        if self.collective == "bfg" and t.is_cuda:
+            return ("bfg", self.ctx.reduce_scatter_begin(t))
+        if self.backend == "nccl" and t.is_cuda:
+            import torch
+            lo, hi = self.own_range(n)
+            out = torch.empty(hi - lo, dtype=t.dtype, device=t.device)
+            work = self.dist.reduce_scatter_tensor(out, t, op=self.dist.ReduceOp.SUM, async_op=True)
+            return ("torch_rs", (work, out, t[lo:hi]))
+        return self.allreduce_begin(t)                             # gloo has no reduce-scatter
+
     def wait(self, handle):
         """order the current stream (CPU tensors: the host) after the collective of `handle`"""
         if handle is None:
@@ -110,6 +125,10 @@ class Exchange(object):
         kind, h = handle
         if kind == "bfg":
             self.ctx.comm_wait(h)
+        elif kind == "torch_rs":
+            work, out, dest = h
+            work.wait()
+            dest.copy_(out)
         else:
             h.wait()
 
@@ -374,4 +393,4 @@ class SplitJoinParallel(object):
 
     def _baryonify(self, local, ops):
         from ..Runners.HealpixRunner import _baryonify_process, _BaryonifyDeviceOps
-        return _baryonify_process(local, ops or _BaryonifyDeviceOps(local), self._exchange())
+        return _baryonify_process(local, ops or _BaryonifyDeviceOps(local), self._exchange(), slices=self.slices)

@@ -70,8 +70,17 @@ class OracleBaryonifyOps(object):
     def absmax_sum(self, t):
         return float(t.abs().max()), float(t.sum())
 
-    def offsets(self):
-        return torch.from_numpy(np.ascontiguousarray(self.offsets_fn(self.runner), dtype=np.float64))
+    def offsets(self, slices=1, on_slice=None):
+        d = torch.from_numpy(np.ascontiguousarray(self.offsets_fn(self.runner), dtype=np.float64))
+        if on_slice is not None:
+            flat = d.view(-1)
+            npix = d.shape[0]
+            # cuts on pixel boundaries, some lengths divisible by the world size and some not (both exchange paths)
+            cuts = sorted(set([0, npix] + [int(npix * (i / slices) ** 1.2) // 4 * 4 + (i % 2) for i in range(1, slices)]))
+            self.cuts = cuts
+            for k in range(len(cuts) - 1):
+                on_slice(k, len(cuts) - 1, 3 * cuts[k], 3 * cuts[k + 1], flat)
+        return d
 
     def regrid(self, nside, d_off, d_in, d_out):
         d_out += torch.from_numpy(np.ascontiguousarray(self.regrid_fn(nside, d_off.numpy(), d_in.numpy())))

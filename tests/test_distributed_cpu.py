@@ -103,12 +103,21 @@ def _worker(rank, world, port, out_dir):
     def oracle_regrid(ns, off, in_map):
         calls["regrid_sources"] = np.flatnonzero(in_map)
         return orc.regrid_shell(ns, off, in_map)
-    BSJ = bfg.SplitJoinParallel(BR)
+    BSJ = bfg.SplitJoinParallel(BR, slices=1)
     bout = BSJ.process(ops=OracleBaryonifyOps(BSJ.Runner_list[0], oracle_offsets, oracle_regrid))
+    # the same with the offset field exchanged in 5 slices (owned pixels = one part of every slice)
+    calls2 = dict(calls)
+    BSJ5 = bfg.SplitJoinParallel(BR, slices=5)
+    bops = OracleBaryonifyOps(BSJ5.Runner_list[0], oracle_offsets, oracle_regrid)
+    bout5 = BSJ5.process(ops=bops)
+    assert len(bops.cuts) == 6
+    np.testing.assert_allclose(bout5, bout, rtol=1e-12, atol=1e-12 * np.abs(bout).max())
+    np.save(os.path.join(out_dir, f"bsrc5_{rank}.npy"), calls["regrid_sources"])
+    calls["regrid_sources"] = calls2["regrid_sources"]
     np.save(os.path.join(out_dir, f"bmap_{rank}.npy"), bout)
     np.save(os.path.join(out_dir, f"bidx_{rank}.npy"), BSJ.shard_indices)
     np.save(os.path.join(out_dir, f"bsrc_{rank}.npy"), calls["regrid_sources"])
-    assert calls["offsets"] == 1
+    assert calls["offsets"] == 1 + 1
     # SimpleParallel: runners dealt round-robin, every rank gets every output
     class Fake(object):
         def __init__(self, k):
@@ -155,6 +164,8 @@ def test_splitjoin_ranks_gloo(tmp_path, world):
     bsrc = [np.load(tmp_path / f"bsrc_{r}.npy") for r in range(world)]
     assert np.array_equal(np.sort(np.concatenate(bidx)), np.arange(600))
     assert np.array_equal(np.sort(np.concatenate(bsrc)), np.flatnonzero(m_in))   # pixel ranges partition the sources
+    bsrc5 = [np.load(tmp_path / f"bsrc5_{r}.npy") for r in range(world)]
+    assert np.array_equal(np.sort(np.concatenate(bsrc5)), np.flatnonzero(m_in))  # ... also when every slice is cut N ways
     assert all(s.size > 0 for s in bsrc)
     assert not np.allclose(bref, m_in)
     for m in bmaps:

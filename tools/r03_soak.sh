@@ -1,0 +1,16 @@
+#!/bin/bash
+# GPU box: randomised soak of the round's final build against the oracle (default paths -- PaintProfilesShell.process() goes
+# through the sliced call with 8 slices --, then the A/B paths)
+cd ${GRAFT_REPO_ROOT:-.}
+O=gpurun_out/r03_soak.txt
+: > $O
+run() { echo "== $1 ($2 s, seed $3)" >> $O; env $1 timeout -k 10 $(( $2 + 120 )) python3 tests/soak/soak.py $2 $3 2>&1 | grep -v "^ok\|amdgpu.ids" | tail -3 >> $O; }
+run "BFG_X=0" 240 3001
+run "BFG_BLEND=0" 90 3002
+run "BFG_TILE_CAP=3 BFG_TILE_SCAN=1" 90 3003
+run "BFG_D2H_SLICES=1 BFG_EAGER_SOA=1" 60 3004
+run "BFG_TILE_CAP=2 BFG_PAIR_CAP=100" 45 3005
+run "BFG_TILE_KERNEL=wave" 45 3006
+echo "== aux (snapshot / deposit / grid)" >> $O
+timeout -k 10 200 python3 tests/soak/soak_aux.py 60 3007 2>&1 | grep -v "^ok\|amdgpu.ids" | tail -3 >> $O
+cat $O
