@@ -1693,3 +1693,33 @@ def test_paint_three_extra_table_axes(cosmo, rows, monkeypatch):
         assert R.last_stats["pixel_updates"] == ptot
         assert np.array_equal(got != 0, ref != 0)
         assert_maps_close(got, ref, RTOL, what=f"three extra axes ({rows}, {variant})")
+
+
+def test_list_of_shells_on_one_gpu_pipelined(cosmo):
+    """SplitJoinParallel over a list of shell runners without a process group: rotating map buffers, copies to the host on a copy
+    stream (a buffer is repainted only after its copy has finished), stats collected once -- every map equals the runner's own
+    process(), and SimpleParallel(split=True) is the same call"""
+    nside = 256
+    zax, Max, rax, T = syn.pressure_table()
+    model = _paint_model(zax, Max, rax, T)
+    runners, refs, ptots = [], [], 0
+    for k, n in enumerate((3000, 10, 5000, 1, 2000)):
+        ra, dec, M, z = syn.catalog(n, seed=500 + k)
+        ref, ptot = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax), T, nside, 10)
+        refs.append(ref); ptots += ptot
+        runners.append(bfg.PaintProfilesShell(bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo),
+                                              bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), 10, model, verbose=False))
+    SJ = bfg.SplitJoinParallel(runners)
+    outs = SJ.process()
+    assert len(outs) == 5 and SJ.Runner_list[0].last_stats["pixel_updates"] == ptots
+    for o, ref in zip(outs, refs):
+        assert np.array_equal(o != 0, ref != 0)
+        assert_maps_close(o, ref, RTOL, what="list of shells")
+    outs2 = bfg.SimpleParallel(runners, split=True).process()
+    assert all(np.allclose(a, b, rtol=1e-12, atol=0) for a, b in zip(outs, outs2))
+    seen = []
+    SJ.process_device(consume=lambda k, d: seen.append((k, d.cpu().numpy())))
+    assert [k for k, _ in seen] == [0, 1, 2, 3, 4]
+    assert all(np.allclose(m, o, rtol=1e-12, atol=0) for (_, m), o in zip(seen, outs))
+    devs = SJ.process_device()
+    assert len(devs) == 5 and all(np.allclose(d.cpu().numpy(), o, rtol=1e-12, atol=0) for d, o in zip(devs, outs))
