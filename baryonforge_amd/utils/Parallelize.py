@@ -32,9 +32,9 @@ Without an initialised process group both wrappers simply run on the one GPU.
 """
 import numpy as np
 
-from ..sharding import estimate_disc_pixels, shard_by_sky_patch
+from ..sharding import disc_radius, estimate_disc_pixels, shard_by_sky_patch, shard_by_stripes, stripe_extent
 
-__all__ = ["SimpleParallel", "SplitJoinParallel", "Exchange"]
+__all__ = ["SimpleParallel", "SplitJoinParallel", "Exchange", "OwnerExchange"]
 
 
 def _dist():
@@ -149,6 +149,81 @@ class Exchange(object):
         return t
 
 
+class OwnerExchange(object):
+    """The owner-computes join of per-rank maps (the alternative to a full all-reduce; DESIGN.md section 5, column C1).
+
+    The RING-ordered map is cut into `world` equal parts; rank r OWNS part r.  With the catalog sharded by declination stripes
+    (sharding.shard_by_stripes) a rank's discs touch its own part plus a border of a few rings -- its EXTENT, known on the host
+    from the catalog alone.  The join is then
+      1. border exchange: every rank sends what it painted inside another rank's part (extent_s intersected with part_r: a few
+         per cent of the map, neighbours only) point to point, and adds what it receives to its own part;
+      2. all-gather of the owned parts, if every rank is to hold the whole map (`gather=True`) -- (N - 1) / N of the map per
+         rank, HALF the bytes of the all-reduce it replaces.
+    Correct for ANY extents (a rank whose discs reach three stripes just sends more); needs Npix divisible by the world size.
+    Collectives: torch.distributed point-to-point (batch_isend_irecv) + all_gather_into_tensor; gloo with device tensors (the
+    one-GPU rehearsal) is staged through the host.
+    """
+
+    def __init__(self, exchange, npix, extent):
+        self.ex = exchange
+        self.dist = exchange.dist
+        self.rank, self.world = exchange.rank, exchange.world
+        if npix % self.world:
+            raise ValueError("the owner-computes join needs 12 NSIDE^2 divisible by the number of ranks")
+        self.npix, self.part = int(npix), int(npix) // self.world
+        extents = [None] * self.world
+        self.dist.all_gather_object(extents, (int(extent[0]), int(extent[1])))
+        self.extents = extents
+        # what this rank sends to / receives from every other rank: RING pixel ranges
+        self.sends, self.recvs = [], []
+        for s in range(self.world):
+            if s == self.rank:
+                continue
+            lo, hi = max(extents[self.rank][0], s * self.part), min(extents[self.rank][1], (s + 1) * self.part)
+            if hi > lo:
+                self.sends.append((s, lo, hi))
+            lo, hi = max(extents[s][0], self.rank * self.part), min(extents[s][1], (self.rank + 1) * self.part)
+            if hi > lo:
+                self.recvs.append((s, lo, hi))
+        self.border_bytes = 8 * sum(hi - lo for _, lo, hi in self.sends)
+
+    def begin(self, t, gather=True):
+        """t: this rank's map float64[npix], defined everywhere (zeros where it painted nothing).  Starts the join; after
+        wait(handle) t holds the summed map (gather=True) or its owned part t[rank * part : (rank + 1) * part] does."""
+        import torch
+        staged = t.is_cuda and self.ex.backend == "gloo"
+        w = t.cpu() if staged else t
+        dist = self.dist
+        ops, bufs = [], []
+        for s, lo, hi in self.sends:
+            ops.append(dist.P2POp(dist.isend, w[lo:hi], s))
+        for s, lo, hi in self.recvs:
+            b = torch.empty(hi - lo, dtype=w.dtype, device=w.device)
+            bufs.append((lo, hi, b))
+            ops.append(dist.P2POp(dist.irecv, b, s))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()                                  # nccl: the current stream waits; gloo: the host
+        for lo, hi, b in bufs:
+            w[lo:hi] += b
+        work = None
+        if gather:
+            own = w[self.rank * self.part:(self.rank + 1) * self.part].clone()
+            if staged or not w.is_cuda:                     # gloo: the list form
+                parts = [w[r * self.part:(r + 1) * self.part] for r in range(self.world)]
+                dist.all_gather(parts, own)
+            else:
+                work = dist.all_gather_into_tensor(w, own, async_op=True)
+        if staged:
+            t.copy_(w)
+        return ("owner", (work, bufs))                      # (the receive buffers live until the wait)
+
+    def wait(self, handle):
+        work, _ = handle[1]
+        if work is not None:
+            work.wait()
+
+
 class _DeviceOps(object):
     """The GPU side of one rank: HBM tensors, C-ABI calls through the runners, copies to the host (the default `ops` of
     SplitJoinParallel.process / process_device)."""
@@ -255,9 +330,12 @@ class SplitJoinParallel(object):
         bfg_allreduce_f64 & co.); see Exchange
     slices : pieces in which a painted map is handed to the all-reduce while the rest is still being painted
         (bfg_paint_shell_sliced); 1 = one all-reduce after the call
+    exchange : "allreduce" (default) or "owner": the owner-computes join (OwnerExchange: declination-stripe shards, border
+        exchange + all-gather -- half the bytes of the all-reduce; paint runners; `layout` is then "stripes")
     """
 
-    def __init__(self, Runner, njobs=-1, seed=42, nside_patch=64, layout="interleaved", collective="torch", slices=4):
+    def __init__(self, Runner, njobs=-1, seed=42, nside_patch=64, layout="interleaved", collective="torch", slices=4,
+                 exchange="allreduce"):
         self.is_list = isinstance(Runner, (list, tuple))
         self.Runners = list(Runner) if self.is_list else [Runner]
         self.Runner = Runner
@@ -267,6 +345,12 @@ class SplitJoinParallel(object):
         self.layout = layout
         self.collective = collective
         self.slices = max(1, int(slices))
+        if exchange not in ("allreduce", "owner"):
+            raise ValueError("exchange must be 'allreduce' or 'owner'")
+        self.exchange = exchange
+        if exchange == "owner":
+            self.layout = "stripes"
+        self._owner = {}                                                 # id(catalog) -> OwnerExchange
         dist = _dist()
         self.rank = dist.get_rank() if dist else 0
         self.world = dist.get_world_size() if dist else 1
@@ -281,16 +365,29 @@ class SplitJoinParallel(object):
         cat = HaloCat.cat
         if self.world == 1:
             self.shard_indices_list.append(np.arange(cat.size))
+            self._owner_of_runner = getattr(self, "_owner_of_runner", [])
+            self._owner_of_runner.append(None)
             return Runner
         # runners that share a catalog object (several models on one shell) share its shard -- and its one device copy
         key = (id(HaloCat), float(Runner.epsilon_max), int(Runner.LightconeShell.NSIDE), id(Runner.mass_def))
         if key not in self._shards:
             w = estimate_disc_pixels(Runner.cosmo, cat["M"], cat["z"], Runner.epsilon_max, Runner.LightconeShell.NSIDE,
                                      Runner.mass_def)
-            shards = shard_by_sky_patch(cat["ra"], cat["dec"], w, self.world, self.nside_patch, layout=self.layout)
+            if self.layout == "stripes":
+                shards = shard_by_stripes(cat["ra"], cat["dec"], self.world)
+            else:
+                shards = shard_by_sky_patch(cat["ra"], cat["dec"], w, self.world, self.nside_patch, layout=self.layout)
             self._shards[key] = (shards[self.rank], HaloCat[shards[self.rank]], HaloCat)   # (keeps HaloCat alive: id() stays unique)
+            if self.exchange == "owner" and not hasattr(Runner, "offsets_device"):
+                idx = shards[self.rank]
+                th = disc_radius(Runner.cosmo, cat["M"][idx], cat["z"][idx], Runner.epsilon_max, Runner.mass_def)
+                nside = int(Runner.LightconeShell.NSIDE)
+                self._owner[key] = OwnerExchange(Exchange(_dist(), "torch"), 12 * nside * nside,
+                                                 stripe_extent(nside, cat["dec"][idx], th))
         idx, New_HaloCatalog, _ = self._shards[key]
         self.shard_indices_list.append(idx)
+        self._owner_of_runner = getattr(self, "_owner_of_runner", [])
+        self._owner_of_runner.append(self._owner.get(key))
         New_Runner = type(Runner)(New_HaloCatalog, Runner.LightconeShell, Runner.epsilon_max, Runner.model,
                                   Runner.use_ellipticity, Runner.mass_def,
                                   include_pixel_size=Runner.include_pixel_size, verbose=False)
@@ -331,7 +428,10 @@ class SplitJoinParallel(object):
                 return
             k, handles = pend[b]
             for h in handles:
-                ex.wait(h)
+                if h is not None and h[0] == "owner":
+                    self._owner_of_runner[k].wait(h)
+                else:
+                    ex.wait(h)
             pend[b] = None
             if consume is not None:
                 consume(k, bufs[b])
@@ -342,8 +442,12 @@ class SplitJoinParallel(object):
             if bufs[b] is None:
                 bufs[b] = ops.new_map(12 * R.LightconeShell.NSIDE ** 2)
             handles = []
+            owner = self._owner_of_runner[k] if ex is not None else None
             if ex is None:
                 ops.paint(R, bufs[b], 1, None)
+            elif owner is not None:                                 # owner-computes join: borders + all-gather after the call
+                ops.paint(R, bufs[b], 1, None)
+                handles.append(owner.begin(bufs[b]))
             else:
                 buf = bufs[b]
                 ops.paint(R, buf, self.slices, lambda i, m, lo, hi, buf=buf, handles=handles:

@@ -63,6 +63,10 @@ def parse():
     p.add_argument("--collective", choices=["torch", "bfg"], default="torch")
     p.add_argument("--slices", type=int, default=4, help="N > 1: pieces in which a painted map is handed to the all-reduce")
     p.add_argument("--layout", choices=["interleaved", "contiguous"], default="interleaved", help="sky-patch sharding layout")
+    p.add_argument("--exchange", choices=["auto", "allreduce", "owner"], default="auto",
+                   help="N > 1, paint: all-reduce of the replicated maps (sliced, behind the painting) or the owner-computes join "
+                        "(declination stripes, border exchange + all-gather: half the bytes); auto = owner if its map equals the "
+                        "all-reduce's in a warm-up self-check on every rank, else all-reduce")
     p.add_argument("--nside", type=int, default=1024)
     p.add_argument("--eps", type=float, default=10.0)
     p.add_argument("--workload", choices=["paint", "baryonify"], default="paint")
@@ -299,6 +303,7 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True).wait
 
     api = None           # N > 1, paint: the product API (SplitJoinParallel over a list of shell runners)
+    mode = {"exchange": "allreduce", "selfcheck": None}
     if args.workload == "paint" and dist is not None:
         import baryonforge_amd as bfg
         from baryonforge_amd.utils.Parallelize import Exchange
@@ -308,13 +313,33 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
         R = bfg.PaintProfilesShell(Cat, Shell, args.eps, bfg.TabulatedProfile.from_arrays(zax, Max, rax, T), verbose=False,
                                    variant=args.variant)
         pipes = {}
+        mode["exchange"] = "allreduce" if args.exchange == "auto" else args.exchange
 
-        def pipe(n, slices=None):
-            key = (n, slices or args.slices)
+        def pipe(n, slices=None, exchange=None):
+            exchange = exchange or mode["exchange"]
+            key = (n, slices or args.slices, exchange)
             if key not in pipes:                                  # sharding + the per-rank runners: outside every timed region
                 pipes[key] = bfg.SplitJoinParallel([R] * n if n > 1 else R, collective="bfg" if use_bfg else "torch",
-                                                   slices=key[1], layout=args.layout)
+                                                   slices=key[1], layout=args.layout, exchange=exchange)
             return pipes[key]
+        if args.exchange == "auto":
+            # the owner-computes join moves half the bytes; it is used if -- on every rank -- it reproduces the all-reduce's map
+            ok, why = True, ""
+            try:
+                if npix % world:
+                    raise ValueError("12 NSIDE^2 does not divide by the number of ranks")
+                ref_map = pipe(1, args.slices, "allreduce").process_device()[0].clone()
+                own_map = pipe(1, 1, "owner").process_device()[0]
+                torch.cuda.synchronize()
+                ok = bool(torch.allclose(own_map, ref_map, rtol=1e-10, atol=0.0)) and bool(torch.equal(own_map != 0, ref_map != 0))
+                why = "" if ok else "maps differ"
+                del ref_map, own_map
+            except Exception as exc:                              # (a failure on one rank only ends in the collective timeout)
+                ok, why = False, repr(exc)
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            mode["exchange"] = "owner" if int(flag.item()) == 1 else "allreduce"
+            mode["selfcheck"] = "passed" if int(flag.item()) == 1 else f"failed ({why or 'on another rank'})"
         api = pipe(args.steps)
         pipe(max(args.warmup, 1))
         idx = api.shard_indices
@@ -327,6 +352,10 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
                 sj = pipe(n)
                 sj.process_device(consume=lambda k, d: None, exchange=collective)
                 last["stats"] = sj.Runner_list[0].last_stats
+            elif mode["exchange"] == "owner":                    # the join alone: borders + all-gather of n maps
+                own = api._owner_of_runner[0]
+                for _ in range(n):
+                    own.wait(own.begin(d_probe))
             else:                                                # the exchange alone: n maps, each in --slices pieces
                 k = max(1, min(args.slices, 16))
                 cuts = [npix * i // k for i in range(k + 1)]
@@ -484,6 +513,8 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
                 return (time.perf_counter() - t0) / reps * 1e3
             mine["api_single_call_ms"] = single(args.slices)
             mine["api_single_call_unsliced_ms"] = single(1)
+            if mode["exchange"] == "owner":
+                mine["border_bytes_sent"] = api._owner_of_runner[0].border_bytes
         ranks = [None] * world
         dist.all_gather_object(ranks, mine)
         ptot_all = float(sum(r["pixel_updates_per_step"] for r in ranks))
@@ -545,8 +576,11 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
     if world > 1:
         sharding_txt = (f"sky patch, layout {args.layout} (interleaved: nside-64 patches dealt round-robin in NEST order, every rank's "
                         "shard covers the sky; contiguous: one compact region per rank; sorted by position) + "
-                        + (f"product API SplitJoinParallel over the list of {args.steps} shell runners: RCCL all-reduce of every map "
-                           f"in {args.slices} slices as the tile kernel finishes them, overlapped with the next shell (two map buffers)"
+                        + (f"product API SplitJoinParallel over the list of {args.steps} shell runners: "
+                           + ("declination-stripe shards, owner-computes join (border exchange + all-gather), overlapped with the next "
+                              "shell (two map buffers)" if mode["exchange"] == "owner" else
+                              f"RCCL all-reduce of every map in {args.slices} slices as the tile kernel finishes them, overlapped with "
+                              "the next shell (two map buffers)")
                            if args.workload == "paint" else
                            "RCCL reduce-scatter of the offsets, regrid of the rank's pixel range, all-reduce of the map")
                         + f"; collective = {'libbfg_mi355 communicator (bfg_allreduce_f64*)' if use_bfg else 'torch.distributed ' + backend}")
@@ -576,10 +610,15 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
             out["api_single_call_ms"] = max(r["api_single_call_ms"] for r in ranks)
             out["api_single_call_unsliced_ms"] = max(r["api_single_call_unsliced_ms"] for r in ranks)
             out["slices"] = args.slices
-        out["exchange"] = {"bytes_per_rank_per_step": exchange_bytes, "backend": backend,
+        owner_mode = api is not None and mode["exchange"] == "owner"
+        sent = ((world - 1) / world * exchange_bytes + max(r.get("border_bytes_sent", 0) for r in ranks)) if owner_mode else \
+            2.0 * (world - 1) / world * exchange_bytes
+        out["exchange"] = {"mode": ("owner-computes: border exchange (point to point) + all-gather of the owned parts" if owner_mode
+                                    else "all-reduce of the replicated maps"),
+                           "selfcheck": mode["selfcheck"] if api is not None else None,
+                           "bytes_per_rank_per_step": exchange_bytes, "bytes_sent_per_rank_per_step": sent, "backend": backend,
                            "collective": "bfg" if use_bfg else "torch",
-                           "busbw_GBps": 2.0 * (world - 1) / world * exchange_bytes /
-                           max(max(r["allreduce_ms"] for r in ranks) * 1e-3, 1e-9) / 1e9}
+                           "busbw_GBps": sent / max(max(r["allreduce_ms"] for r in ranks) * 1e-3, 1e-9) / 1e9}
     if world == 1 and not args.no_e2e and args.workload == "paint":
         try:
             # the product API with everything left on the device: SplitJoinParallel over a list of shell runners (the call the

@@ -79,6 +79,16 @@ def main():
         louts2 = bfg.SimpleParallel(shells, split=True, collective=coll, slices=1).process()
         assert all(np.allclose(x, y, rtol=1e-12, atol=0) for x, y in zip(louts, louts2))   # atomics reorder: rounding only
 
+        if coll == "torch":
+            # the owner-computes join with the real kernels: declination stripes, border exchange, all-gather
+            OSJ = bfg.SplitJoinParallel(shells, exchange="owner")
+            oouts = OSJ.process()
+            assert all(np.allclose(x, y, rtol=1e-12, atol=0) for x, y in zip(oouts, louts))
+            assert all(np.array_equal(x != 0, y != 0) for x, y in zip(oouts, louts))
+            own = OSJ._owner_of_runner[-1]
+            info["owner_border_fraction"] = own.border_bytes / (8.0 * npix)
+            info["owner_pixel_updates"] = int(OSJ.Runner_list[0].last_stats["pixel_updates"])
+
         dz, dM, dr, dtab = I["disp"]
         sub = bfg.HaloLightConeCatalog(I["ra"][:N_BARY], I["dec"][:N_BARY], I["M"][:N_BARY], I["z"][:N_BARY], cosmo)
         BR = bfg.BaryonifyShell(sub, bfg.LightconeShell(map=I["m_in"].copy(), cosmo=cosmo), EPS,

@@ -85,6 +85,16 @@ def _worker(rank, world, port, out_dir):
                                                              ops=OraclePaintOps(oracle_local))
     assert [k for k, _ in consumed] == [0, 1, 2] and all(np.array_equal(c, o) for (_, c), o in zip(consumed, outs))
 
+    # ---- the owner-computes join (declination stripes, border exchange + all-gather) gives the same maps
+    if (12 * nside * nside) % world == 0:
+        OSJ = bfg.SplitJoinParallel(runners + [Runner], exchange="owner")
+        assert OSJ.layout == "stripes" and all(o is not None for o in OSJ._owner_of_runner)
+        oouts = OSJ.process(ops=OraclePaintOps(oracle_local))
+        for k, o in enumerate(oouts):
+            np.save(os.path.join(out_dir, f"omap{k}_{rank}.npy"), o)
+        np.save(os.path.join(out_dir, f"oinfo_{rank}.npy"), np.array([OSJ._owner_of_runner[-1].border_bytes, 8 * 12 * nside * nside,
+                                                                      OSJ.shard_indices_list[-1].size]))
+
     # ---- BaryonifyShell, which the reference's splitter refuses (Parallelize.py:206-209): offsets are linear in halos
     dz, dM, dr, dtab = syn.displacement_table(5, 8, 50)
     bmodel = bfg.Baryonification2D.from_arrays(dz, dM, dr, dtab, cosmo, epsilon_max=20)
@@ -130,7 +140,7 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_splitjoin_ranks_gloo(tmp_path, world):
     import torch.multiprocessing as mp
     port = _free_port()
@@ -153,6 +163,15 @@ def test_splitjoin_ranks_gloo(tmp_path, world):
                                include_pixel_size=True)
         for r in range(world):
             np.testing.assert_allclose(np.load(tmp_path / f"lmap{k}_{r}.npy"), lref, rtol=1e-9, atol=0)
+    # the owner-computes join: the same maps as the all-reduce; only a border travels point to point
+    if (12 * 64 * 64) % world == 0:
+        for r in range(world):
+            for k in range(3):
+                np.testing.assert_allclose(np.load(tmp_path / f"omap{k}_{r}.npy"), np.load(tmp_path / f"lmap{k}_{r}.npy"), rtol=1e-12, atol=0)
+            np.testing.assert_allclose(np.load(tmp_path / f"omap3_{r}.npy"), ref, rtol=1e-9, atol=0)
+        info = [np.load(tmp_path / f"oinfo_{r}.npy") for r in range(world)]
+        assert sum(int(i[2]) for i in info) == 600
+        assert all(0 < i[0] < 0.6 * i[1] for i in info)                           # (NSIDE 64: the discs are large against a stripe)
     # distributed BaryonifyShell == the serial oracle run, on every rank; mass conserved; every source pixel regridded once
     from util import oracle_baryonify
     dz, dM, dr, dtab = syn.displacement_table(5, 8, 50)

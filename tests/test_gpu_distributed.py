@@ -91,3 +91,6 @@ def test_two_ranks_real_kernels_paint_and_baryonify(tmp_path):
                 assert np.array_equal(lgot != 0, lref != 0)
                 assert_maps_close(lgot, lref, 1e-5, what=f"2-rank list shell {k} ({backend}/{coll}), rank {r}")
         assert sum(info[f"list_{coll}_pixel_updates"] for info in infos) == ptot_list
+    # the owner-computes join painted every (halo, pixel) pair once as well, and only a border travelled point to point
+    assert sum(info["owner_pixel_updates"] for info in infos) == ptot_list
+    assert all(0 < info["owner_border_fraction"] < 0.2 for info in infos)

@@ -7,6 +7,8 @@ run 29611 --steps 6 --warmup 2 --halos 200000 --scaling strong > gpurun_out/r03_
 echo "strong rc=$?"
 run 29612 --steps 6 --warmup 2 --halos 200000 --scaling weak --slices 8 > gpurun_out/r03_rehearsal_n2_weak.json 2> gpurun_out/r03_rehearsal_n2_weak.err
 echo "weak rc=$?"
+run 29615 --steps 6 --warmup 2 --halos 200000 --scaling strong --exchange allreduce > gpurun_out/r03_rehearsal_n2_strong_allreduce.json 2> gpurun_out/r03_rehearsal_n2_strong_allreduce.err
+echo "strong allreduce rc=$?"
 run 29613 --steps 4 --warmup 1 --halos 100000 --workload baryonify > gpurun_out/r03_rehearsal_n2_bary.json 2> gpurun_out/r03_rehearsal_n2_bary.err
 echo "bary rc=$?"
 # failure modes: must exit non-zero with one line, quickly
