@@ -65,8 +65,8 @@ def parse():
     p.add_argument("--layout", choices=["interleaved", "contiguous"], default="interleaved", help="sky-patch sharding layout")
     p.add_argument("--exchange", choices=["auto", "allreduce", "owner"], default="auto",
                    help="N > 1, paint: all-reduce of the replicated maps (sliced, behind the painting) or the owner-computes join "
-                        "(declination stripes, border exchange + all-gather: half the bytes); auto = owner if its map equals the "
-                        "all-reduce's in a warm-up self-check on every rank, else all-reduce")
+                        "(declination stripes, border exchange + all-gather: half the bytes); auto = both are tried in the warm-up: the "
+                        "owner-computes join is used if its map equals the all-reduce's on every rank AND it is the faster of the two")
     p.add_argument("--nside", type=int, default=1024)
     p.add_argument("--eps", type=float, default=10.0)
     p.add_argument("--workload", choices=["paint", "baryonify"], default="paint")
@@ -338,8 +338,24 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
                 ok, why = False, repr(exc)
             flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            mode["exchange"] = "owner" if int(flag.item()) == 1 else "allreduce"
             mode["selfcheck"] = "passed" if int(flag.item()) == 1 else f"failed ({why or 'on another rank'})"
+            if int(flag.item()) == 1:
+                # both joins are correct here: take the faster one for THIS workload (a few shells each, max over ranks).  Compute-
+                # bound runs (weak scaling: the all-reduce hides behind 1e6 halos per rank, and interleaved shards paint faster
+                # than crowded stripes) tend to the all-reduce, exchange-bound ones (strong scaling) to the owner-computes join.
+                trial = {}
+                for name, sl in (("allreduce", args.slices), ("owner", 1)):
+                    sj = pipe(3, sl, name)
+                    sj.process_device(consume=lambda k, d: None)
+                    dist.barrier(); torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    sj.process_device(consume=lambda k, d: None)
+                    torch.cuda.synchronize()
+                    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    trial[name] = float(tt.item()) / 3 * 1e3
+                mode["exchange"] = "owner" if trial["owner"] < trial["allreduce"] else "allreduce"
+                mode["trial_ms_per_shell"] = trial
         api = pipe(args.steps)
         pipe(max(args.warmup, 1))
         idx = api.shard_indices
@@ -616,6 +632,7 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
         out["exchange"] = {"mode": ("owner-computes: border exchange (point to point) + all-gather of the owned parts" if owner_mode
                                     else "all-reduce of the replicated maps"),
                            "selfcheck": mode["selfcheck"] if api is not None else None,
+                           "auto_trial_ms_per_shell": mode.get("trial_ms_per_shell"),
                            "bytes_per_rank_per_step": exchange_bytes, "bytes_sent_per_rank_per_step": sent, "backend": backend,
                            "collective": "bfg" if use_bfg else "torch",
                            "busbw_GBps": sent / max(max(r["allreduce_ms"] for r in ranks) * 1e-3, 1e-9) / 1e9}
