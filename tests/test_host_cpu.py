@@ -529,3 +529,28 @@ def test_background_against_independent_quadrature_and_closed_form():
     R_exact = (M / (4.18879020479 * 200 * RHO_CRITICAL * h * h * E2)) ** (1 / 3)
     np.testing.assert_allclose(MassDef(200, "critical").get_radius(cosmo, M, a), R_exact, rtol=1e-12)
     np.testing.assert_allclose(orc.get_radius(cosmo, M, a), R_exact, rtol=1e-12)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_stripe_shards_partition_and_extents_cover_the_painted_pixels(world):
+    """sharding.shard_by_stripes: every halo exactly once, equal-area stripes get ~equal counts; stripe_extent: a RING pixel
+    range that contains every pixel the oracle paints for the shard (incl. shards that reach a pole), tight to a few rings"""
+    from util import oracle_paint
+    cosmo = dict(syn.COSMO)
+    nside, n = 128, 8000
+    ra, dec, M, z = syn.catalog(n, seed=77)
+    dec[:3] = [89.5, -89.7, 0.01]
+    shards = sharding.shard_by_stripes(ra, dec, world)
+    assert np.array_equal(np.sort(np.concatenate(shards)), np.arange(n))
+    assert min(s.size for s in shards) > 0.7 * n / world
+    th = sharding.disc_radius(cosmo, M, z, 10.0)
+    zax, Max, rax, T = syn.pressure_table(4, 8, 40)
+    npix = 12 * nside * nside
+    for r, idx in enumerate(shards):
+        e0, e1 = sharding.stripe_extent(nside, dec[idx], th[idx])
+        m, _ = oracle_paint(cosmo, ra[idx], dec[idx], M[idx], z[idx], (zax, Max, rax), T, nside, 10.0)
+        nz = np.flatnonzero(m)
+        assert 0 <= e0 <= nz.min() and nz.max() < e1 <= npix, (r, e0, e1, nz.min(), nz.max())
+        assert (e1 - e0) < (1.0 / world + 0.25) * npix                     # own part + borders (NSIDE 128: large discs)
+    assert sharding.stripe_extent(nside, np.array([]), np.array([])) == (0, 0)
+    assert sharding.stripe_extent(nside, np.array([10.0]), np.array([np.pi])) == (0, npix)     # a disc over the whole sky
