@@ -107,8 +107,9 @@ struct bfg_ctx {
         int32_t *d_defer_count;     // [2 ntiles + kWorkExtra]
         int cap_direct;             // fixed pair slots per tile of the current call
         int32_t *d_nwork;
+        int32_t *d_counters;        // [kCounterInts] item counters of the persistent tile kernel (bfg_tile.hpp)
         int32_t *d_shared;          // [ntiles] 1: the tile's pair list was cut into several work items (atomics on the map)
-        int32_t *d_slices;          // [3 kMaxSlices] sliced calls: item range per slice | work counter per slice
+        int32_t *d_slices;          // [2 kMaxSlices] sliced calls: item range per slice
     } tiles[3];                     // [MODE_PAINT], [MODE_BARYONIFY], [2] = the regrid kernel's tiles
     int32_t *d_pairs;              // [ntiles * cap_direct] slots | [pair_cap] overflow lists
     unsigned long long *d_ovf_mask; // [cap_halo]
@@ -1220,6 +1221,7 @@ static void ctx_free_all(bfg_ctx *c)
         if (c->tiles[m].d_tile_start) (void)hipFree(c->tiles[m].d_tile_start);
         if (c->tiles[m].d_work) (void)hipFree(c->tiles[m].d_work);
         if (c->tiles[m].d_nwork) (void)hipFree(c->tiles[m].d_nwork);
+        if (c->tiles[m].d_counters) (void)hipFree(c->tiles[m].d_counters);
         if (c->tiles[m].d_defer) (void)hipFree(c->tiles[m].d_defer);
         if (c->tiles[m].d_defer_count) (void)hipFree(c->tiles[m].d_defer_count);
         if (c->tiles[m].d_shared) (void)hipFree(c->tiles[m].d_shared);
@@ -1569,7 +1571,8 @@ static int ensure_tiles(bfg_ctx *c, int mode, int tr, int tw, int64_t nside, int
         if (ts.d_defer) { (void)hipFree(ts.d_defer); (void)hipFree(ts.d_defer_count); }
         if (ts.d_shared) (void)hipFree(ts.d_shared);
         if (ts.d_slices) (void)hipFree(ts.d_slices);
-        ts.d_shared = nullptr; ts.d_slices = nullptr;
+        if (ts.d_counters) (void)hipFree(ts.d_counters);
+        ts.d_shared = nullptr; ts.d_slices = nullptr; ts.d_counters = nullptr;
         ts.d_geo = nullptr; ts.d_tile_count = nullptr; ts.d_tile_start = nullptr; ts.d_work = nullptr; ts.d_nwork = nullptr; ts.nside = 0;
         ts.d_defer = nullptr; ts.d_defer_count = nullptr;
         const int64_t nrings = 4 * nside - 1;
@@ -1602,9 +1605,10 @@ static int ensure_tiles(bfg_ctx *c, int mode, int tr, int tw, int64_t nside, int
         ts.flip = 0; ts.counting = false;
         HIP_TRY(hipMalloc((void **)&ts.d_tile_start, (size_t)(ntiles + 1) * sizeof(int32_t)));
         HIP_TRY(hipMalloc((void **)&ts.d_work, (size_t)(2 * ntiles + kWorkExtra) * 2 * sizeof(int4)));
-        HIP_TRY(hipMalloc((void **)&ts.d_nwork, 2 * sizeof(int32_t)));     // [0] items in the work list, [1] the tile kernel's item counter
+        HIP_TRY(hipMalloc((void **)&ts.d_nwork, 2 * sizeof(int32_t)));     // [0] items in the work list
+        HIP_TRY(hipMalloc((void **)&ts.d_counters, kCounterInts * sizeof(int32_t)));
         HIP_TRY(hipMalloc((void **)&ts.d_shared, (size_t)ntiles * sizeof(int32_t)));
-        HIP_TRY(hipMalloc((void **)&ts.d_slices, (size_t)3 * kMaxSlices * sizeof(int32_t)));
+        HIP_TRY(hipMalloc((void **)&ts.d_slices, (size_t)2 * kMaxSlices * sizeof(int32_t)));
         if (mode == MODE_PAINT) {
             // a failed allocation (the list is ~1 KB per work item) only means the tile workgroups drain their own queues
             const size_t items = (size_t)(2 * ntiles + kWorkExtra);
@@ -1858,6 +1862,10 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         int persist = c->n_cu * (light ? 3 : 2);
         if (const char *e = std::getenv("BFG_TILE_PERSIST")) persist = std::atoi(e) > 1 ? std::atoi(e) : (std::atoi(e) ? persist : 0);
         const int tile_grid = persist > 0 ? std::min(persist, items_max) : items_max;
+        // item counters of the persistent grid (bfg_tile.hpp: one address serialises the hand-out); BFG_ITEM_COUNTERS=1: the A/B
+        int n_counters = 8;
+        if (const char *e = std::getenv("BFG_ITEM_COUNTERS")) n_counters = std::atoi(e);
+        n_counters = std::max(1, std::min(std::min(n_counters, kMaxCounters), tile_grid));
         // sliced call: cut the tiles into n_slices runs of whole bands (contiguous ring ranges = contiguous RING pixel ranges)
         SliceCuts cuts;
         std::memset(&cuts, 0, sizeof(cuts));
@@ -1874,10 +1882,10 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
                 slice_elem[k] = per * ring_first_pixel(a->nside, 1 + (int64_t)bk * ts.geo.tr);
             }
             if (cuts.tile[K] != ts.geo.ntiles) { g_last_error = "slice cuts do not cover the tiles"; return BFG_ERR_INVALID; }
-            cuts.n = K; cuts.range = ts.d_slices; cuts.counter = ts.d_slices + 2 * kMaxSlices;
+            cuts.n = K; cuts.range = ts.d_slices;
         }
         hipLaunchKernelGGL(tile_scan_kernel, dim3((unsigned)(1 + (ts.geo.ntiles + 1023) / 1024)), dim3(1024), 0, c->stream, ts.geo,
-                           ts.cap_direct, pp.bin.tile_count, ts.d_tile_start, ts.d_work, ts.d_nwork, ts.d_nwork + 1, 3 * tile_grid,
+                           ts.cap_direct, pp.bin.tile_count, ts.d_tile_start, ts.d_work, ts.d_nwork, ts.d_counters, n_counters, 3 * tile_grid,
                            overwrite ? 1 : 0, ts.d_shared, pp.bin.tile_count + ts.geo.ntiles + 1,
                            ts.d_tile_count + (size_t)(1 - ts.flip) * (ts.geo.ntiles + 2), cuts);
         c->tiles[mode].flip = 1 - ts.flip;             // the next call counts in the set this scan kernel clears
@@ -1947,7 +1955,8 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
             c->tile_attr_set = true;
         }
         const dim3 tgrid((unsigned)tile_grid), tblock(kTileThreads);
-        tp.work_counter = persist > 0 ? ts.d_nwork + 1 : nullptr;
+        tp.work_counter = persist > 0 ? ts.d_counters : nullptr;
+        tp.n_counters = n_counters;
         const bool wl = win_nodes <= kWinLds;
         // wave-private chunks (bfg_wtile.hpp) need the 32-node LDS-staged windows
         use_wave = use_wave && wl && win_nodes == kWinLds && !win_table;
@@ -1966,7 +1975,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         }
         const int n_launch = cuts.n > 0 ? cuts.n : 1;
         for (int islice = 0; islice < n_launch; ++islice) {
-        if (cuts.n > 0) { tp.slice = cuts.range + 2 * islice; tp.work_counter = cuts.counter + islice; }
+        if (cuts.n > 0) { tp.slice = cuts.range + 2 * islice; tp.work_counter = ts.d_counters + (size_t)(1 + islice) * kMaxCounters * kCounterStride; }
         timing_begin(c, 1);
         if (use_wave) {
             const dim3 wblock(kWaveThreads), wgrid((unsigned)items_max);      // one workgroup per work item

@@ -246,7 +246,9 @@ struct TileParams {
     int defer_cap_wg, defer_tail;
     int blend;                       // 1: no pre-blended row windows in HBM -- stage b blends every pair's 32-node window from the four
                                      // corner rows of the halo's (z, M) cell, straight from the (L2-resident) table, into LDS
-    int32_t *work_counter;           // persistent grid: the next work item to hand out (starts at first item + 3 gridDim.x); null: one item per workgroup
+    int32_t *work_counter;           // persistent grid: the item counters of this launch ([n_counters], kCounterStride apart; see the kernel);
+                                     // null: one item per workgroup
+    int n_counters;
     // Sliced calls (bfg_*_sliced): this launch takes the work items [slice[0], slice[1]) only -- the tiles of one band range, written
     // by tile_scan_kernel -- so that the caller can start exchanging that part of the map while the next slice is painted.
     const int32_t *slice;            // null: the whole work list
@@ -444,18 +446,27 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const FillParams P)
 // still yields a few thousand items of similar size instead of 784 heavy ones on 512 workgroup slots.
 constexpr int kWorkExtra = 4096;
 // Sliced calls: the work list is cut at tile boundaries slices.tile[0] = 0 < tile[1] < ... < tile[n] = ntiles (whole bands); the scan
-// kernel writes the item range of slice k to slices.range[2 k .. 2 k + 1] and its work counter slices.counter[k] (= first item +
-// first_dynamic), which the k-th launch of the tile kernel reads.
+// kernel writes the item range of slice k to slices.range[2 k .. 2 k + 1], which the k-th launch of the tile kernel reads.
 constexpr int kMaxSlices = 16;
 struct SliceCuts {
     int n;                           // 0: not a sliced call
     int tile[kMaxSlices + 1];
     int32_t *range;                  // [2 n]
-    int32_t *counter;                // [n]
 };
 
+// Item counters of the persistent tile kernel: set 0 for a whole-list launch, set 1 + k for the launch of slice k; K counters per
+// set, kCounterStride ints apart.  Counter c of a set hands out the LOCAL item indices c + K v, v = its value; the first
+// first_dynamic (= 3 x grid) local indices are the workgroups' static items.
+constexpr int kMaxCounters = 16, kCounterStride = 256;
+constexpr size_t kCounterInts = (size_t)(1 + kMaxSlices) * kMaxCounters * kCounterStride;
+__device__ inline void init_item_counter(int32_t *counters, int t, int first_dynamic, int K)
+{
+    const int set = t / K, c = t - set * K;
+    counters[((size_t)set * kMaxCounters + c) * kCounterStride] = (first_dynamic - c + K - 1) / K;
+}
+
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const TileGeom geo, int cap_direct, int32_t *count, int32_t *start, int4 *work,
-                                                         int32_t *n_work, int32_t *work_counter, int first_dynamic,
+                                                         int32_t *n_work, int32_t *counters, int n_counters, int first_dynamic,
                                                          int overwrite, int32_t *shared_flag, const int32_t *needs_scan,
                                                          int32_t *next_count, const SliceCuts slices)
 {
@@ -474,10 +485,10 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const TileGeom geo, int
     if (!*needs_scan) {
         if (blockIdx.x == 0) return;
         const int t = ((int)blockIdx.x - 1) * 1024 + (int)threadIdx.x;
-        if (t == 0) { *n_work = ntiles; *work_counter = first_dynamic; start[ntiles] = 0; }
+        if (t == 0) { *n_work = ntiles; start[ntiles] = 0; }
+        if (t < (1 + slices.n) * n_counters) init_item_counter(counters, t, first_dynamic, n_counters);
         if (t < slices.n) {                                      // item = tile: the cuts are the item ranges
             slices.range[2 * t] = slices.tile[t]; slices.range[2 * t + 1] = slices.tile[t + 1];
-            slices.counter[t] = slices.tile[t] + first_dynamic;
         }
         if (t >= ntiles) return;
         const int n = count[t];
@@ -545,7 +556,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const TileGeom geo, int
             if (i0 + k >= ntiles) continue;
             for (int q = 0; q < slices.n; ++q)                                               // the first item of a slice's first tile
                 if (slices.tile[q] == i0 + k) {
-                    slices.range[2 * q] = o; slices.counter[q] = o + first_dynamic;
+                    slices.range[2 * q] = o;
                     if (q > 0) slices.range[2 * q - 1] = o;
                 }
             count[i0 + k] = 0;                                                               // becomes the overflow cursor
@@ -568,8 +579,9 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const TileGeom geo, int
             }
         }
     }
+    if ((int)threadIdx.x < (1 + slices.n) * n_counters) init_item_counter(counters, (int)threadIdx.x, first_dynamic, n_counters);
     if (threadIdx.x == 0) {
-        *n_work = carry; *work_counter = first_dynamic;          // the first items of a workgroup are static
+        *n_work = carry;                                         // (the first items of a workgroup are static)
         if (slices.n > 0) slices.range[2 * slices.n - 1] = carry;
     }
 }
@@ -1076,6 +1088,13 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     [[maybe_unused]] double nx_lnpf = 0.0;
     bool primed = false;                              // wave 0 holds the first chunk's candidates of the item about to start
     constexpr int kNoItem = 0x7fffffff;
+    // The items after a workgroup's first three are handed out by counters -- several of them: every returning atomic on ONE
+    // address costs the memory side ~12.6 ns, i.e. 0.079 ms for the 6 272 items of an NSIDE-1024 map whatever the items hold (the
+    // whole tile kernel takes 0.15 ms at 1e5 halos), and under that load its latency sits in front of every later load of wave 0
+    // (one in-order vmcnt).  Counter c, 1 KB from the next, hands out the items c, c + K, c + 2 K, ... (interleaved: neighbouring
+    // tiles cost about the same) to the workgroups with blockIdx = c mod K.
+    const int n_counters = uni(P.n_counters), my_c = (int)blockIdx.x % n_counters;
+    int32_t *my_counter = P.work_counter + my_c * kCounterStride;
     int item = item_first + (int)blockIdx.x;
     int item1 = P.work_counter ? item_first + (int)(blockIdx.x + gridDim.x) : kNoItem;
     int item2 = P.work_counter ? item_first + (int)(blockIdx.x + 2 * gridDim.x) : kNoItem;
@@ -1092,7 +1111,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     if (tid == BFG_TIMING_TID) lt_last = clock64();
 #endif
     int item3 = kNoItem;
-    if (tid == 0 && P.work_counter) item3 = atomicAdd(P.work_counter, 1);
+    if (tid == 0 && P.work_counter) item3 = atomicAdd(my_counter, 1);      // (the counter's value; made an item index where it is parked)
     const bool have_next = item1 < n_work_total;
     if (wave == 0 && lane < 2 && item2 < n_work_total)    // the record of item k + 2 -> ctl[8 + 8 par ..] (see the hand-over above)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(P.work + 2 * item2 + lane),
@@ -1706,7 +1725,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     // slice of a global list and tile_deferred_kernel adds them after this kernel.
     BFG_ITICK(12);
     // the look-ahead of the persistent loop goes to LDS BEFORE the write-back stores (see the hand-over above)
-    if (tid == 0) ctl[6] = item3;
+    if (tid == 0) ctl[6] = P.work_counter ? item_first + item3 * n_counters + my_c : kNoItem;
     constexpr int kPerThread = (TR * TW + NT - 1) / NT;
     int64_t wpix[kPerThread];
     double wold[kPerThread][NACC];
@@ -1815,7 +1834,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         // an item without pairs (a tile no halo touches; every item when the binning gave up): nothing to paint.  An
         // uninitialised map still gets its zeros (tiles shared between items were cleared by tile_fill_kernel).
         if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the record DMA has landed (no stage-b barrier here)
-        if (tid == 0) ctl[6] = item3;
+        if (tid == 0) ctl[6] = P.work_counter ? item_first + item3 * n_counters + my_c : kNoItem;
         if (p_overwrite && !(wk.w && !degraded)) {
             for (int i = tid; i < TR * TW; i += NT) {
                 const int row = i / TW, col = i % TW;

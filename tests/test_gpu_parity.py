@@ -1048,12 +1048,14 @@ def test_paint_and_baryonify_any_nside(cosmo, nside, variant):
 
 @pytest.mark.parametrize("switch", ["BFG_TILE_KERNEL=wave", "BFG_TILE_LIGHT=1", "BFG_TILE_PERSIST=0", "BFG_TILE_PERSIST=7",
                                     "BFG_FINAL_DRAIN=inline", "BFG_FINAL_DRAIN=kernel", "BFG_TILE_SCAN=1", "BFG_OUT_OVERWRITE=0",
-                                    "BFG_ROWS=separate", "BFG_BLEND=0", "BFG_BLEND=0 BFG_ROWS=separate", "BFG_EAGER_SOA=1"])
+                                    "BFG_ROWS=separate", "BFG_BLEND=0", "BFG_BLEND=0 BFG_ROWS=separate", "BFG_EAGER_SOA=1",
+                                    "BFG_ITEM_COUNTERS=1", "BFG_ITEM_COUNTERS=3", "BFG_ITEM_COUNTERS=16 BFG_TILE_PERSIST=40"])
 def test_tile_kernel_switches_agree(cosmo, switch, monkeypatch):
     """every A/B switch of the tile path paints the default build's map: the wave-private-chunk kernel, the
     256-thread instantiation, one workgroup per item / a tiny persistent grid, the deferred pixels drained by every item / added by
     the follow-up kernel instead of by the workgroups after their last item, the scan-built work
-    list, a cleared instead of an overwritten output, row windows from halo_row4_kernel instead of the prep kernel -- paint and
+    list, a cleared instead of an overwritten output, row windows from halo_row4_kernel instead of the prep kernel, one / three /
+    sixteen item counters (the last with a grid they do not divide) -- paint and
     baryonify, against the default path and the oracle"""
     import warnings
     nside, n, eps = 512, 20000, 10.0
