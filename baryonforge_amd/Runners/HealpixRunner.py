@@ -11,10 +11,14 @@ kernels of libbfg_mi355.so (one launch for all halos):
     range, table cell) -> shell kernel (query_disc ring windows, LDS-staged
     profile row, trilinear read-out, f64 atomic scatter-add) [-> regrid_kernel]
 
-There is no CPU fallback.  Models must be tabulated (TabulatedProfile,
-ParamTabulatedProfile, BaryonificationClass -- ours or objects from the real
-BaryonForge exposing the same raw_input_* attributes); analytic pyccl profiles
-evaluated per halo are outside the scope of this build.
+There is no CPU fallback for the loops.  The fast path is the tabulated one
+(TabulatedProfile, ParamTabulatedProfile, BaryonificationClass -- ours or objects
+from the real BaryonForge exposing the same raw_input_* attributes).  A model that
+is NOT tabulated -- any object with .projected(cosmo, r, M, a) / .displacement(r, M, a),
+which the reference calls once per halo (:472, :345) -- is still a Python callable and
+is evaluated on the host, per halo, exactly as the reference does; the GPU does
+everything around it (disc enumeration and distances, the scatter-add, the offset
+geometry, the regrid): `_callable_batches`.
 """
 import numpy as np
 
@@ -120,6 +124,36 @@ class DefaultRunner(object):
         return bg, spline, d_cat, stride
 
 
+def _callable_batches(runner, ctx, fallback4):
+    """The geometry of the reference loops for a model that is a Python callable (csrc/bfg_enum.hpp): yields, batch of halos by
+    batch, (j0, args, counts, base, pix, r_com, halo, D_j) -- host arrays counts / base / r_com / D_j and device tensors pix / halo
+    -- where entry e of halo j0 + j (base[j] <= e < base[j] + counts[j]) is pixel pix[e] of its disc (:463 / :330-334) at
+    r_sep / a_j = r_com[e] (:464-469).  A batch holds at most BFG_CALLABLE_BATCH entries (default 2^24: 320 MB of lists)."""
+    import os
+    from scipy import interpolate
+    NSIDE = runner.LightconeShell.NSIDE
+    bg, spline, d_cat, stride = runner._device_inputs(ctx, [])
+    cat = runner.HaloLightConeCatalog.cat
+    n = int(d_cat.shape[0])
+    md = ctx.massdef_struct(bg, runner.mass_def)
+    z_m = max(float(np.max(cat["z"])) if n else 0.0, getattr(runner, "_spline_z_max", 0.0))
+    z_t = np.linspace(0, z_m + 0.1, 1000)
+    D_a = interpolate.CubicSpline(z_t, bg.angular_diameter_distance(1 / (1 + z_t)))     # :297-299 / :429-431 (the host copy)
+    if n == 0:
+        return
+    counts_all = ctx.disc_count(ctx.shell_args(NSIDE, d_cat, n, stride, 0, runner.epsilon_max, md), spline, fallback4).cpu().numpy()
+    cap = int(os.environ.get("BFG_CALLABLE_BATCH", str(1 << 24)))
+    j0 = 0
+    while j0 < n:
+        csum = np.cumsum(counts_all[j0:])
+        j1 = j0 + max(1, int(np.searchsorted(csum, cap, side="right")))
+        args = ctx.shell_args(NSIDE, d_cat[j0:j1], j1 - j0, stride, 0, runner.epsilon_max, md)
+        counts, base, pix, r_com, halo = ctx.disc_enumerate(args, spline, fallback4)
+        yield j0, args, spline, counts.cpu().numpy(), base.cpu().numpy(), pix, r_com.cpu().numpy(), halo, \
+            D_a(np.asarray(cat["z"][j0:j1], dtype=np.float64))
+        j0 = j1
+
+
 class PaintProfilesShell(DefaultRunner):
     """Paint a tabulated projected profile around every halo onto the shell (HealpixRunner.py:376-483)."""
 
@@ -127,12 +161,43 @@ class PaintProfilesShell(DefaultRunner):
         """the reference's argument checks, before anything touches the GPU"""
         assert self.model is not None, "You must provide a model"         # :446
         keys = self._keys_checked()
+        self._callable_model = False
         if not _is_paint_table(self.model):
             if hasattr(self.model, "setup_interpolator"):
                 raise NameError("No Table created. Run setup_interpolator() method first")
-            raise TypeError(f"PaintProfilesShell on the MI355X path needs a tabulated model (TabulatedProfile / "
-                            f"ParamTabulatedProfile with raw_input_2D); got {type(self.model)}")
+            if not callable(getattr(self.model, "projected", None)):
+                raise TypeError(f"PaintProfilesShell needs a tabulated model (TabulatedProfile / ParamTabulatedProfile with "
+                                f"raw_input_2D) or an object with a .projected(cosmo, r, M, a) method; got {type(self.model)}")
+            self._callable_model = True                                   # (no p_keys here: :436-443 asserted above)
         return keys
+
+    def _paint_callable(self, d_map, fresh):
+        """HealpixRunner.py:449-481 with `Baryons.projected` called per halo on the host (it is a Python callable): the GPU lists
+        every disc's pixels and distances and adds the returned values to the map"""
+        ctx = get_context()
+        NSIDE = self.LightconeShell.NSIDE
+        npix = 12 * NSIDE * NSIDE
+        pixarea = 4.0 * np.pi / npix
+        if d_map is None:
+            d_map = ctx.zeros(npix)                                       # :424
+        elif fresh:
+            d_map.zero_()
+        cat = self.HaloLightConeCatalog.cat
+        total = 0
+        for j0, args, spline, counts, base, pix, r_com, halo, D in _callable_batches(self, ctx, False):
+            vals = np.zeros(r_com.size)
+            for j in range(counts.size):                                  # (an empty disc still gets its call, as in the reference)
+                sl = slice(base[j], base[j] + counts[j])
+                M_j, a_j = cat["M"][j0 + j], 1 / (1 + cat["z"][j0 + j])
+                Paint = np.asarray(self.model.projected(self.cosmo, r_com[sl], M_j, a_j), dtype=np.float64).reshape(-1)   # :472
+                Paint = np.where(np.isfinite(Paint), Paint, 0)            # :473
+                if self.include_pixel_size:
+                    Paint = Paint * (pixarea * D[j] ** 2)                 # :478
+                vals[sl] = Paint
+            ctx.map_add_values(d_map, pix, ctx.to_device(vals))           # :481
+            total += int(r_com.size)
+        self.last_stats = dict(ctx.stats(), pixel_updates=total)
+        return d_map
 
     def process_device(self, d_map=None, overwrite=None, slices=1, on_slice=None, sync_stats=True):
         """Paint into a device map (float64[Npix] torch tensor) and return it.
@@ -145,6 +210,12 @@ class PaintProfilesShell(DefaultRunner):
         sync_stats=False: do not read the counters back (that synchronises the stream); `collect_stats()` does it later --
         what a pipeline over several shells wants."""
         keys = self._validated_keys()
+        if self._callable_model:
+            fresh = d_map is None or bool(overwrite)
+            d_map = self._paint_callable(d_map, fresh)
+            if on_slice is not None:                                      # nothing to cut: the whole map as one slice
+                on_slice(0, 1, 0, int(d_map.numel()))
+            return d_map
         ctx = get_context()
         NSIDE = self.LightconeShell.NSIDE
         bg, spline, d_cat, stride = self._device_inputs(ctx, keys)
@@ -170,6 +241,8 @@ class PaintProfilesShell(DefaultRunner):
 
     def collect_stats(self):
         """read the device counters (synchronises the stream), keep them in `last_stats`, emit the warnings"""
+        if getattr(self, "_callable_model", False) and self.last_stats is not None:
+            return self.last_stats                                        # counted on the host (_paint_callable)
         self.last_stats = get_context().stats()
         emit_fallback_warning(self.last_stats)
         return self.last_stats
@@ -318,18 +391,48 @@ class BaryonifyShell(DefaultRunner):
     def _checked_model_keys(self):
         """the reference's argument checks (:304-311, BaryonCorrection.py:454-455), before anything touches the GPU"""
         keys = self._keys_checked()
+        self._callable_model = False
         if not _is_disp_table(self.model):
-            if self.model is not None and hasattr(self.model, "displacement"):
+            ours = isinstance(self.model, BaryonificationClass) or hasattr(self.model, "setup_interpolator")
+            if self.model is not None and ours:
                 raise NameError("No Table created. Run setup_interpolator() method first")
-            raise TypeError(f"BaryonifyShell needs a BaryonificationClass model with a displacement table; "
-                            f"got {type(self.model)}")
+            if not callable(getattr(self.model, "displacement", None)):
+                raise TypeError(f"BaryonifyShell needs a BaryonificationClass model with a displacement table, or an object "
+                                f"with a .displacement(r, M, a) method; got {type(self.model)}")
+            self._callable_model = True
         return keys
+
+    def _offsets_callable(self):
+        """HealpixRunner.py:313-355 with `model.displacement` called per halo on the host (a Python callable): the GPU lists every
+        disc's pixels and distances (with the < 4 pixel rule) and turns the returned displacements into unit-vector offsets"""
+        ctx = get_context()
+        NSIDE = self.LightconeShell.NSIDE
+        d_off = ctx.zeros(12 * NSIDE * NSIDE, 3)                          # :313
+        cat = self.HaloLightConeCatalog.cat
+        total, fb4 = 0, 0
+        for j0, args, spline, counts, base, pix, r_com, halo, _D in _callable_batches(self, ctx, True):
+            disp = np.zeros(r_com.size)
+            for j in range(counts.size):
+                if counts[j] == 0:                                        # only a NaN record: the reference would have raised in healpy
+                    continue
+                sl = slice(base[j], base[j] + counts[j])
+                M_j, a_j = cat["M"][j0 + j], 1 / (1 + cat["z"][j0 + j])
+                disp[sl] = np.asarray(self.model.displacement(r_com[sl], M_j, a_j), dtype=np.float64).reshape(-1)      # :345
+            ctx.offsets_add_displacements(args, spline, pix, halo, ctx.to_device(disp), d_off)                       # :345-355
+            total += int(r_com.size)
+        self.last_stats = dict(ctx.stats(), pixel_updates=total)
+        return d_off
 
     def offsets_device(self, slices=1, on_slice=None):
         """Accumulate the unit-vector offsets of all halos (:313-355); returns float64[Npix, 3] on the device.
         slices, on_slice: bfg_baryonify_offsets_sliced -- on_slice(k, n, lo, hi) after the k-th band slice of the field has been
         enqueued; lo / hi are ELEMENT indices of the flattened field (3 per pixel)."""
         keys = self._checked_model_keys()
+        if self._callable_model:
+            d_off = self._offsets_callable()
+            if on_slice is not None:                                      # nothing to cut: the whole field as one slice
+                on_slice(0, 1, 0, int(d_off.numel()), d_off.view(-1))
+            return d_off
         ctx = get_context()
         NSIDE = self.LightconeShell.NSIDE
         bg, spline, d_cat, stride = self._device_inputs(ctx, keys)

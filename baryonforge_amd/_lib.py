@@ -42,8 +42,9 @@ SYMBOLS = [
     "bfg_comm_unique_id", "bfg_comm_init", "bfg_comm_destroy", "bfg_comm_info",
     "bfg_allreduce_f64", "bfg_allreduce_f64_begin", "bfg_comm_wait", "bfg_reduce_scatter_f64", "bfg_allgather_f64",
     "bfg_reduce_scatter_f64_begin", "bfg_paint_shell_sliced", "bfg_baryonify_offsets_sliced",
+    "bfg_disc_enumerate_count", "bfg_disc_enumerate", "bfg_map_add_values", "bfg_offsets_add_displacements",
 ]
-ABI_VERSION = 2
+ABI_VERSION = 3
 # bfg_slice_fn: int (*)(void *user, int slice, int n_slices, int64_t elem_begin, int64_t elem_end)
 SLICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64)
 BFG_COMM_ID_BYTES = 128
@@ -162,6 +163,10 @@ def load(build_if_missing=True):
     L.bfg_paint_shell_sliced.argtypes = [_vp, C.POINTER(ShellArgs), _vp, _vp, _vp, C.c_int, SLICE_FN, _vp]
     L.bfg_baryonify_offsets_sliced.argtypes = [_vp, C.POINTER(ShellArgs), _vp, _vp, _vp, C.c_int, SLICE_FN, _vp]
     L.bfg_regrid_shell.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp]
+    L.bfg_disc_enumerate_count.argtypes = [_vp, C.POINTER(ShellArgs), _vp, C.c_int, _vp]
+    L.bfg_disc_enumerate.argtypes = [_vp, C.POINTER(ShellArgs), _vp, C.c_int, _vp, _vp, _vp, _vp]
+    L.bfg_map_add_values.argtypes = [_vp, _vp, _vp, _vp, _i64]
+    L.bfg_offsets_add_displacements.argtypes = [_vp, C.POINTER(ShellArgs), _vp, _vp, _vp, _vp, _i64, _vp]
     L.bfg_reduce_absmax_sum.argtypes = [_vp, _i64, _vp, C.POINTER(_dbl), C.POINTER(_dbl)]
     L.bfg_stats_reset.argtypes = [_vp]
     L.bfg_stats_read.argtypes = [_vp, C.POINTER(Stats)]

@@ -340,6 +340,8 @@ __device__ inline void halo_write_soa(const PrepParams &P, int64_t j, const Halo
     irec[I_FLAGS * cap] = flags;
 }
 
+#include "bfg_enum.hpp"
+
 #ifndef BFG_PREP_WAVES
 #define BFG_PREP_WAVES 1
 #endif
@@ -2043,6 +2045,89 @@ int bfg_baryonify_offsets_sliced(bfg_ctx *c, const bfg_shell_args *a, const bfg_
 {
     if (n_slices < 1 || !fn) return BFG_ERR_INVALID;
     return run_shell(c, a, t, s, d_offsets, MODE_BARYONIFY, n_slices, fn, user);
+}
+
+// ---- models that are not tabulated: the geometry around a host-evaluated .projected / .displacement (bfg_enum.hpp) ----
+static int enum_prep(const bfg_shell_args *a, const bfg_spline *s, PrepParams &pp)
+{
+    if (!a || !s) return BFG_ERR_INVALID;
+    if (a->nside < 1 || a->nside > (1 << 20) || a->n_halo < 0 || (a->n_halo > 0 && !a->d_catalog)) return BFG_ERR_INVALID;
+    if (a->cat_stride < 4 || !(a->epsilon_max >= 0)) return BFG_ERR_INVALID;
+    if (a->n_halo > 0x7fffffffLL) return BFG_ERR_UNSUPPORTED;            // the entry lists carry 32-bit halo indices
+    std::memset(&pp, 0, sizeof(pp));
+    pp.hpx = make_hpx(a->nside);
+    pp.n_halo = a->n_halo; pp.cap = a->n_halo;
+    pp.cat = a->d_catalog; pp.cat_stride = a->cat_stride;
+    pp.eps_run = a->epsilon_max;
+    pp.md_run = a->runner_md; pp.md_model = a->runner_md;
+    pp.spl_n = s->n; pp.spl_knots = s->d_knots; pp.spl_coef = s->d_coef;
+    return BFG_OK;                                                       // tab.nouter = 0: no table, no cell search
+}
+
+int bfg_disc_enumerate_count(bfg_ctx *c, const bfg_shell_args *a, const bfg_spline *s, int fallback4, int64_t *d_counts)
+{
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
+    if (rc) return rc;
+    bfg::EnumParams ep;
+    rc = enum_prep(a, s, ep.prep);
+    if (rc) return rc;
+    if (a->n_halo == 0) return BFG_OK;
+    if (!d_counts) return BFG_ERR_INVALID;
+    ep.fallback4 = fallback4 ? 1 : 0; ep.counts = d_counts; ep.base = nullptr; ep.pix = nullptr; ep.r_com = nullptr; ep.halo = nullptr;
+    const unsigned grid = (unsigned)std::min<int64_t>((a->n_halo + 3) / 4, (int64_t)c->n_cu * 16);
+    hipLaunchKernelGGL((bfg::disc_enum_kernel<true>), dim3(grid), dim3(256), 0, c->stream, ep);
+    HIP_TRY(hipGetLastError());
+    return BFG_OK;
+}
+
+int bfg_disc_enumerate(bfg_ctx *c, const bfg_shell_args *a, const bfg_spline *s, int fallback4, const int64_t *d_base,
+                       int64_t *d_pix, double *d_r_com, int32_t *d_halo)
+{
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
+    if (rc) return rc;
+    bfg::EnumParams ep;
+    rc = enum_prep(a, s, ep.prep);
+    if (rc) return rc;
+    if (a->n_halo == 0) return BFG_OK;
+    if (!d_base || !d_pix || !d_r_com || !d_halo) return BFG_ERR_INVALID;
+    ep.fallback4 = fallback4 ? 1 : 0; ep.counts = nullptr; ep.base = d_base; ep.pix = d_pix; ep.r_com = d_r_com; ep.halo = d_halo;
+    const unsigned grid = (unsigned)std::min<int64_t>((a->n_halo + 3) / 4, (int64_t)c->n_cu * 16);
+    hipLaunchKernelGGL((bfg::disc_enum_kernel<false>), dim3(grid), dim3(256), 0, c->stream, ep);
+    HIP_TRY(hipGetLastError());
+    return BFG_OK;
+}
+
+int bfg_map_add_values(bfg_ctx *c, double *d_map, const int64_t *d_pix, const double *d_val, int64_t n)
+{
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!d_map || !d_pix || !d_val))) return BFG_ERR_INVALID;
+    if (n == 0) return BFG_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)c->n_cu * 16);
+    hipLaunchKernelGGL(bfg::values_add_kernel, dim3(grid), dim3(256), 0, c->stream, d_map, d_pix, d_val, n);
+    HIP_TRY(hipGetLastError());
+    return BFG_OK;
+}
+
+int bfg_offsets_add_displacements(bfg_ctx *c, const bfg_shell_args *a, const bfg_spline *s, const int64_t *d_pix,
+                                  const int32_t *d_halo, const double *d_disp, int64_t n, double *d_offsets)
+{
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
+    if (rc) return rc;
+    bfg::DispParams dp;
+    rc = enum_prep(a, s, dp.prep);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!d_pix || !d_halo || !d_disp || !d_offsets))) return BFG_ERR_INVALID;
+    if (n == 0) return BFG_OK;
+    dp.pix = d_pix; dp.halo = d_halo; dp.disp = d_disp; dp.n = n; dp.out = d_offsets;
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)c->n_cu * 16);
+    hipLaunchKernelGGL(bfg::displacements_add_kernel, dim3(grid), dim3(256), 0, c->stream, dp);
+    HIP_TRY(hipGetLastError());
+    return BFG_OK;
 }
 
 int bfg_regrid_shell(bfg_ctx *c, int64_t nside, const double *d_offsets, const double *d_in_map,

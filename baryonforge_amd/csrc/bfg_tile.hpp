@@ -1753,6 +1753,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         // (the thread index through an opaque asm: otherwise the compiler hoists the per-u row addresses out of the persistent
         // loop, spills some of them, and reloads them here with s_waitcnt vmcnt(0) -- between the stores, i.e. waiting for their
         // acknowledgement after all)
+        BFG_LTICK(9);
         unsigned wt = (unsigned)tid;
         asm volatile("" : "+v"(wt));
         // all LDS reads of the thread's pixels first (ring rows and accumulator values in flight together, one wait), then the
@@ -1769,6 +1770,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
 #pragma unroll
             for (int c = 0; c < NACC; ++c) wv[u][c] = acc[NACC * i + c];
         }
+        BFG_LTICK(10);
 #pragma unroll
         for (int u = 0; u < kPerThread; ++u) {
             const unsigned i = wt + (unsigned)(u * NT);

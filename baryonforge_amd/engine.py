@@ -362,6 +362,49 @@ class Context(object):
         _lib.check(self.lib.bfg_baryonify_offsets(self.handle, C.byref(args), table.handle, spline.handle,
                                                   C.c_void_p(d_offsets.data_ptr())), "bfg_baryonify_offsets")
 
+    # ---- models that are not tabulated: the geometry around a host-evaluated callable (csrc/bfg_enum.hpp) --------------
+    def disc_count(self, args, spline, fallback4=False):
+        """int64[n_halo] device tensor: pixels of every halo's disc (bfg_disc_enumerate_count)"""
+        torch = _torch()
+        self._on_current_stream()
+        counts = torch.zeros(int(args.n_halo), dtype=torch.int64, device=self.device)
+        _lib.check(self.lib.bfg_disc_enumerate_count(self.handle, C.byref(args), spline.handle, int(bool(fallback4)),
+                                                     C.c_void_p(counts.data_ptr())), "bfg_disc_enumerate_count")
+        return counts
+
+    def disc_enumerate(self, args, spline, fallback4=False):
+        """(counts, base, pix, r_com, halo) device tensors for the halos of `args`: entry e of halo j, base[j] <= e <
+        base[j] + counts[j], is RING pixel pix[e] of its disc at comoving distance r_com[e] = r_sep / a_j
+        (HealpixRunner.py:460-469; fallback4: the < 4 pixel rule of :333-334).  Synchronises once (the total)."""
+        torch = _torch()
+        n = int(args.n_halo)
+        counts = self.disc_count(args, spline, fallback4)
+        incl = torch.cumsum(counts, 0)
+        base = incl - counts
+        total = int(incl[-1].item()) if n else 0
+        pix = torch.empty(total, dtype=torch.int64, device=self.device)
+        r_com = torch.empty(total, dtype=torch.float64, device=self.device)
+        halo = torch.empty(total, dtype=torch.int32, device=self.device)
+        if total:
+            _lib.check(self.lib.bfg_disc_enumerate(self.handle, C.byref(args), spline.handle, int(bool(fallback4)),
+                                                   C.c_void_p(base.data_ptr()), C.c_void_p(pix.data_ptr()),
+                                                   C.c_void_p(r_com.data_ptr()), C.c_void_p(halo.data_ptr())),
+                       "bfg_disc_enumerate")
+        return counts, base, pix, r_com, halo
+
+    def map_add_values(self, d_map, d_pix, d_val):
+        self._on_current_stream()
+        _lib.check(self.lib.bfg_map_add_values(self.handle, C.c_void_p(d_map.data_ptr()), C.c_void_p(d_pix.data_ptr()),
+                                               C.c_void_p(d_val.data_ptr()), int(d_pix.numel())), "bfg_map_add_values")
+
+    def offsets_add_displacements(self, args, spline, d_pix, d_halo, d_disp, d_offsets):
+        self._on_current_stream()
+        _lib.check(self.lib.bfg_offsets_add_displacements(self.handle, C.byref(args), spline.handle,
+                                                          C.c_void_p(d_pix.data_ptr()), C.c_void_p(d_halo.data_ptr()),
+                                                          C.c_void_p(d_disp.data_ptr()), int(d_pix.numel()),
+                                                          C.c_void_p(d_offsets.data_ptr())),
+                   "bfg_offsets_add_displacements")
+
     def regrid_shell(self, nside, d_offsets, d_in_map, d_out_map, d_sums=None):
         self._on_current_stream()
         _lib.check(self.lib.bfg_regrid_shell(self.handle, int(nside), C.c_void_p(d_offsets.data_ptr()),

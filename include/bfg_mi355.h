@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BFG_ABI_VERSION 2
+#define BFG_ABI_VERSION 3
 
 typedef enum {
     BFG_OK = 0,
@@ -307,6 +307,28 @@ int bfg_baryonify_offsets_sliced(bfg_ctx *ctx, const bfg_shell_args *args, const
  * for the mass-conservation assert of :368-370.                                       */
 int bfg_regrid_shell(bfg_ctx *ctx, int64_t nside, const double *d_offsets, const double *d_in_map,
                      double *d_out_map, double *d_sums);
+
+/* ---- models that are NOT tabulated (any object with .projected / .displacement) ----------------------------------
+ * The reference hands the distances of a halo's disc pixels to a Python callable, once per halo
+ * (Runners/HealpixRunner.py:472 Baryons.projected(cosmo, r_sep / a_j, M_j, a_j, **o_j); :345 model.displacement(...)).
+ * That call stays on the host; these four entry points are everything around it, for a batch of halos:
+ *   bfg_disc_enumerate_count  d_counts[j] = pixels of halo j's disc (hp.query_disc, :463 / :330; with fallback4 != 0 a disc
+ *                             of fewer than 4 pixels counts as the 4 bilinear neighbours of the centre, :333-334)
+ *   bfg_disc_enumerate        with d_base = exclusive prefix sum of the counts: for entry e of halo j (base[j] <= e <
+ *                             base[j] + counts[j]) d_pix[e] = RING pixel, d_r_com[e] = r_sep / a_j (:464-469, :472),
+ *                             d_halo[e] = j
+ *   bfg_map_add_values        d_map[d_pix[e]] += d_val[e]                                             (:481)
+ *   bfg_offsets_add_displacements  d_offsets[d_pix[e]][0..2] += displaced unit vector - pixel unit vector for the comoving
+ *                             displacement d_disp[e] the host computed for entry e                    (:345-355)
+ * Uses of bfg_shell_args: nside, n_halo, d_catalog, cat_stride, epsilon_max, runner_md; the rest is ignored.          */
+int bfg_disc_enumerate_count(bfg_ctx *ctx, const bfg_shell_args *args, const bfg_spline *da_spline, int fallback4,
+                             int64_t *d_counts);
+int bfg_disc_enumerate(bfg_ctx *ctx, const bfg_shell_args *args, const bfg_spline *da_spline, int fallback4,
+                       const int64_t *d_base, int64_t *d_pix, double *d_r_com, int32_t *d_halo);
+int bfg_map_add_values(bfg_ctx *ctx, double *d_map, const int64_t *d_pix, const double *d_val, int64_t n);
+int bfg_offsets_add_displacements(bfg_ctx *ctx, const bfg_shell_args *args, const bfg_spline *da_spline,
+                                  const int64_t *d_pix, const int32_t *d_halo, const double *d_disp, int64_t n,
+                                  double *d_offsets);
 
 /* ---- multi-GPU: the one exchange step ---------------------------------------------------
  * One process per GPU, one context per process.  Replaces the parent-side join of the reference's joblib wrapper,

@@ -316,6 +316,57 @@ def baryonify_offsets(nside, ra, dec, M, a, D, R, R_model_com, axes, values, eps
     return off, int(ptot)
 
 
+def paint_shell_callable(cosmo, nside, ra, dec, M, z, eps_run, projected, include_pixel_size=False, Delta=200,
+                         rho_type="critical"):
+    """HealpixRunner.py:449-481 line by line for a model that is a Python callable (small cases: a python loop).
+    projected(r_com, M_j, a_j) -> values; returns (map, P_tot)."""
+    a, R, D = halo_scalars(cosmo, M, z, Delta, rho_type)
+    new_map = np.zeros(nside2npix(nside))
+    pixarea = nside2pixarea(nside)
+    ptot = 0
+    for j in range(len(M)):
+        vec_j = ang2vec(ra[j], dec[j], lonlat=True)                         # :460
+        radius = R[j] * eps_run / D[j]                                      # :462
+        pixind = query_disc(nside, vec_j, radius)                           # :463
+        vec = np.stack(pix2vec(nside, pixind), axis=1) if pixind.size else np.zeros((0, 3))
+        diff = vec * D[j] - vec_j * D[j]                                    # :465-467
+        r_sep = np.sqrt(np.sum(diff ** 2, axis=1))
+        Paint = np.asarray(projected(r_sep / a[j], M[j], a[j]), dtype=np.float64).reshape(-1)   # :472
+        Paint = np.where(np.isfinite(Paint), Paint, 0)                      # :473
+        if include_pixel_size:
+            Paint = Paint * (pixarea * D[j] ** 2)                           # :478
+        new_map[pixind] += Paint                                            # :481
+        ptot += pixind.size
+    return new_map, ptot
+
+
+def baryonify_offsets_callable(cosmo, nside, ra, dec, M, z, eps_run, displacement, Delta=200, rho_type="critical"):
+    """HealpixRunner.py:313-355 line by line for a model that is a Python callable.
+    displacement(r_com, M_j, a_j) -> comoving displacement; returns (pix_offsets[Npix, 3], P_tot)."""
+    a, R, D = halo_scalars(cosmo, M, z, Delta, rho_type)
+    pix_offsets = np.zeros((nside2npix(nside), 3))
+    ptot = 0
+    for j in range(len(M)):
+        vec_j = ang2vec(ra[j], dec[j], lonlat=True)
+        radius = R[j] * eps_run / D[j]
+        pixind = query_disc(nside, vec_j, radius)
+        if pixind.size < 4:                                                 # :333-334
+            pixind = get_interp_weights(nside, ra[j], dec[j], lonlat=True)[0]
+        vec = np.stack(pix2vec(nside, pixind), axis=1)
+        pos_j, pos = vec_j * D[j], vec * D[j]
+        diff = pos - pos_j
+        r_sep = np.sqrt(np.sum(diff ** 2, axis=1))
+        with np.errstate(all="ignore"):
+            offset = np.asarray(displacement(r_sep / a[j], M[j], a[j]), dtype=np.float64).reshape(-1) * a[j]      # :345
+            offset = offset[:, None] * (diff / r_sep[:, None])              # :346
+            offset = np.where(np.isfinite(offset), offset, 0)               # :347
+        nw_pos = pos + offset
+        nw_vec = nw_pos / np.sqrt(np.sum(nw_pos ** 2, axis=1))[:, None]
+        np.add.at(pix_offsets, pixind, nw_vec - vec)                        # :355 (fancy += : last write wins for duplicates; none here)
+        ptot += pixind.size
+    return pix_offsets, ptot
+
+
 def regrid_shell(nside, pix_offsets, orig_map):
     """HealpixRunner.py:357-365"""
     out = np.zeros(nside2npix(nside))

@@ -1,0 +1,100 @@
+"""
+GPU tests of the shell runners with a model that is NOT tabulated: any object with .projected(cosmo, r, M, a) /
+.displacement(r, M, a), which the reference calls once per halo (Runners/HealpixRunner.py:472, :345).  The callable
+stays on the host; the disc enumeration, the distances, the scatter-add, the offset geometry and the regrid are HIP
+kernels (csrc/bfg_enum.hpp) -- compared here with the oracle's line-by-line restatement of the reference loops.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import baryonforge_amd as bfg
+from baryonforge_amd import synthetic as syn
+from oracle import oracle as orc
+from util import assert_maps_close
+
+
+class AnalyticPressure(object):
+    """a projected profile in closed form, with the awkward values a real model produces: inf at r = 0 is impossible here
+    (pixel centres never coincide with a halo centre) but NaN beyond a cut and negative values are"""
+
+    def __init__(self, nan_beyond=None):
+        self.nan_beyond = nan_beyond
+        self.calls = 0
+
+    def projected(self, cosmo, r, M, a):
+        self.calls += 1
+        r = np.asarray(r, dtype=np.float64)
+        rc = 0.3 * (M / 1e14) ** (1 / 3)
+        out = 1e-6 * (M / 1e14) ** (5 / 3) / a ** 2 * (1 + (r / rc) ** 2) ** -1.5 * np.cos(r / (4 * rc))
+        if self.nan_beyond is not None:
+            out = np.where(r > self.nan_beyond * rc, np.nan, out)
+        return out
+
+
+class AnalyticDisplacement(object):
+    def displacement(self, r, M, a):
+        r = np.asarray(r, dtype=np.float64)
+        x = r / (0.8 * (M / 1e14) ** (1 / 3) / a)
+        return 0.1 * (M / 1e14) ** (1 / 3) * x * (1 - x / 4) * np.exp(-x)
+
+
+@pytest.mark.parametrize("include_pixel_size", [False, True])
+@pytest.mark.parametrize("batch", [None, 3000])
+def test_paint_callable_model_vs_oracle(cosmo, include_pixel_size, batch, monkeypatch):
+    nside, n, eps = 128, 400, 6.0
+    if batch:
+        monkeypatch.setenv("BFG_CALLABLE_BATCH", str(batch))               # several batches of halos
+    ra, dec, M, z = syn.catalog(n, seed=5, logM=(13.0, 15.5))
+    ra[0], dec[0] = 10.0, 89.9                                             # one disc over the north pole
+    ra[1], dec[1] = 359.99, -0.01                                          # one across phi = 0
+    model = AnalyticPressure(nan_beyond=8.0)
+    ref, ptot = orc.paint_shell_callable(cosmo, nside, ra, dec, M, z, eps,
+                                         lambda r, Mj, aj: model.projected(None, r, Mj, aj), include_pixel_size)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), eps, model,
+                               include_pixel_size=include_pixel_size, verbose=False)
+    model.calls = 0
+    got = R.process()
+    assert model.calls == n                                                # once per halo, as the reference
+    assert R.last_stats["pixel_updates"] == ptot
+    assert np.array_equal(got != 0, ref != 0)
+    assert_maps_close(got, ref, 1e-10, what="paint with a callable model")
+    # the device-map entry point accumulates INTO a given map
+    d = R.process_device()
+    d2 = R.process_device(d_map=d)
+    assert_maps_close(d2.cpu().numpy(), 2 * ref, 1e-10, what="accumulate into a given map")
+
+
+def test_baryonify_callable_model_vs_oracle(cosmo):
+    nside, n, eps = 128, 300, 4.0
+    ra, dec, M, z = syn.catalog(n, seed=6, logM=(12.0, 15.3))              # the small halos have < 4 pixels at NSIDE 128
+    model = AnalyticDisplacement()
+    off, ptot = orc.baryonify_offsets_callable(cosmo, nside, ra, dec, M, z, eps, model.displacement)
+    m_in = syn.mass_map(nside)
+    ref = orc.regrid_shell(nside, off, m_in)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    R = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo), eps, model, verbose=False)
+    d_off = R.offsets_device()
+    assert R.last_stats["pixel_updates"] == ptot
+    got_off = d_off.cpu().numpy()
+    # (unit-vector differences: a far pixel's offset of ~1e-17 may round to exactly 0 on one side and not on the other)
+    touched, touched_ref = np.any(np.abs(got_off) > 1e-14, axis=1), np.any(np.abs(off) > 1e-14, axis=1)
+    assert touched_ref.sum() > 500 and np.sum(touched != touched_ref) <= 2
+    np.testing.assert_allclose(got_off, off, rtol=1e-7, atol=1e-15 + 1e-9 * np.abs(off).max())
+    got = R.process()
+    assert np.isclose(got.sum(), m_in.sum())
+    assert_maps_close(got, ref, 1e-5, floor=1e-9, what="baryonify with a callable model")
+
+
+def test_callable_model_argument_checks(cosmo):
+    ra, dec, M, z = syn.catalog(10, seed=1)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    Shell = bfg.LightconeShell(map=np.ones(12 * 16 * 16), cosmo=cosmo)
+    with pytest.raises(TypeError):
+        bfg.PaintProfilesShell(Cat, Shell, 5, object(), verbose=False).process()
+    with pytest.raises(TypeError):
+        bfg.BaryonifyShell(Cat, Shell, 5, AnalyticPressure(), verbose=False).process()
+    with pytest.raises(AssertionError):
+        bfg.PaintProfilesShell(Cat, Shell, 5, None, verbose=False).process()

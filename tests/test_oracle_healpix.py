@@ -189,3 +189,38 @@ def test_query_disc_equals_brute_force_at_workload_resolution(nside):
         rim = band[margin < 1e-12]
         assert np.array_equal(np.setdiff1d(got, rim), np.setdiff1d(inside, rim)), (th, ph, rad)
         assert np.all(np.diff(got) > 0)
+
+
+def test_callable_model_loops_equal_the_table_loops(cosmo):
+    """the python restatement of the reference loops for models that are callables (oracle.paint_shell_callable /
+    baryonify_offsets_callable -- what tests/test_gpu_callable.py checks the GPU against) run with a callable that IS the
+    tabulated read-out must reproduce the C oracle's table loops, which the reference's golden vectors pin"""
+    from baryonforge_amd import synthetic as syn
+    from oracle import oracle as orc
+    from util import oracle_baryonify, oracle_paint
+    nside, n, eps = 64, 150, 8.0
+    ra, dec, M, z = syn.catalog(n, seed=12, logM=(12.5, 15.3))
+    zax, Max, rax, T = syn.pressure_table()
+    ref, ptot = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax), T, nside, eps, include_pixel_size=True)
+
+    def projected(r, Mj, aj):                               # Tabulate.py:305-316: exp of the read-out on (ln(1+z), ln M, ln r)
+        with np.errstate(all="ignore"):
+            pts = np.stack([np.full(r.size, np.log(1 / aj)), np.full(r.size, np.log(Mj)), np.log(r)], axis=1)
+            return np.exp(orc.interp_linear((zax, Max, rax), np.log(T), pts))
+    got, p2 = orc.paint_shell_callable(cosmo, nside, ra, dec, M, z, eps, projected, include_pixel_size=True)
+    assert p2 == ptot and np.array_equal(got != 0, ref != 0)
+    np.testing.assert_allclose(got, ref, rtol=1e-10, atol=0)
+
+    zd, Md, rd, d = syn.displacement_table()
+    a_all, R_all, _ = orc.halo_scalars(cosmo, M, z)
+
+    def displacement(r, Mj, aj):                            # BaryonCorrection.py:396-411: linear table, zero beyond eps_model R
+        Rm = float(orc.get_radius(cosmo, Mj, aj)) / aj
+        pts = np.stack([np.full(r.size, np.log(1 / aj)), np.full(r.size, np.log(Mj)), np.log(r)], axis=1)
+        with np.errstate(all="ignore"):
+            out = orc.interp_linear((zd, Md, rd), d, pts)
+        return np.where(r < 20.0 * Rm, out, 0.0)
+    refo, ptot_b = oracle_baryonify(cosmo, ra, dec, M, z, (zd, Md, rd), d, nside, eps, 20, None, offsets_only=True)
+    goto, p3 = orc.baryonify_offsets_callable(cosmo, nside, ra, dec, M, z, eps, displacement)
+    assert p3 == ptot_b
+    np.testing.assert_allclose(goto, np.asarray(refo).reshape(-1, 3), rtol=1e-9, atol=1e-18)

@@ -61,10 +61,10 @@ if os.environ.get("BFG_ST_MODE") == "4":
            "t1: accumulator clear, ring rows (wave 1), first records (wave 0)", "t2: stage a + its barrier (first chunk incl. wait for the records)",
            "t3: stage b: blend / window DMA issue, halo records, ring windows, segments", "t4: barrier after stage b (vmcnt(0): loads, DMA, earlier stores)",
            "t5: next records issued, pixel loop", "t6: end-of-chunk barrier (+ queue drain check)", "t7: write-back: addresses, deferred pixels, stores issued",
-           "t8: end-of-item barrier"]
-    tot = allv[:9].sum()
+           "t8: end-of-item barrier", "t7a: (of the write-back) look-ahead parked, deferred pixels", "t7b: (of the write-back) LDS reads of the thread's pixels"]
+    tot = allv[:11].sum()
     print(f"workload {workload} n={n} nside={nside}: thread {os.environ.get('BFG_ST_TID', '64')}: {tot:.4g} cycles per launch summed over workgroups")
-    for nm, x in zip(lab, allv[:9]):
+    for nm, x in zip(lab, allv[:11]):
         print(f"    {nm:100s} {x:12.4g}  {100 * x / tot:5.1f} %")
     sys.exit(0)
 if sub.sum() and os.environ.get("BFG_ST_MODE") == "3":
