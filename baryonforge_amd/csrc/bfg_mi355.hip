@@ -1748,8 +1748,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         // L2-resident table (the BLEND instantiation of shell_tile_kernel; BFG_BLEND=0: the windows of round 2, built by the prep
         // kernel and fetched by LDS-DMA).  Measured (profiles/r03_blend_ab.txt): 1e6 halos step 1.27 -> 1.14 ms (prep 0.223 ->
         // 0.156, tile kernel 1.01 -> 0.95), 1e5 halos 0.242 -> 0.235, steep mass function 0.533 -> 0.446.
-        const bool can_blend = mode == MODE_PAINT && !win_table && win_nodes == kWinLds && t->dev.nouter == 2 && !use_wave &&
-                               !(std::getenv("BFG_TILE_LIGHT") && std::atoi(std::getenv("BFG_TILE_LIGHT")) != 0);
+        const bool can_blend = mode == MODE_PAINT && !win_table && win_nodes == kWinLds && t->dev.nouter == 2 && !use_wave;
         blend = can_blend;
         if (const char *e = std::getenv("BFG_BLEND")) blend = can_blend && std::atoi(e) != 0;
         const int64_t want = (win_table || blend) ? 0 : a->n_halo * (int64_t)win_nodes;
@@ -1856,12 +1855,15 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         const bfg_ctx::TileSet &ts = c->tiles[mode];
         // grid of the tile kernel: persistent (a few workgroups per CU looping over the work list) unless BFG_TILE_PERSIST=0
         const bool win_lds_path = win_nodes <= kWinLds;
-        // BFG_TILE_LIGHT=1: the 256-thread instantiation with three workgroups per CU (TileCfg<., 1>); measured no faster than
-        // the 512-thread one at any density (profiles/r02_tile_variants.txt), kept as an A/B switch
-        bool light = false;
+        // Sparse catalogs take the 256-thread instantiation with four (paint) / three (offsets) workgroups per CU (TileCfg<., 1>):
+        // below ~6 (paint) / ~10 (offsets) halos per sky tile an item is a chain of latencies, and more items in flight beat larger
+        // chunks (profiles/r03_light_ab.txt: paint 1e4 halos at NSIDE 1024 0.072 -> 0.057 ms, offsets 1e4 halos 0.170 -> 0.115,
+        // offsets 1e5 halos 0.292 -> 0.283; paint 1e5 halos 0.140 -> 0.160, so not there).  BFG_TILE_LIGHT=0 / 1 forces either.
+        const double halos_per_tile = (double)a->n_halo / (double)std::max(1, ts.geo.ntiles);
+        bool light = win_lds_path && halos_per_tile < (mode == MODE_PAINT ? 6.0 : 10.0);
         if (const char *e = std::getenv("BFG_TILE_LIGHT")) light = win_lds_path && std::atoi(e) != 0;
         const int items_max = 2 * ts.geo.ntiles + kWorkExtra;
-        int persist = c->n_cu * (light ? 3 : 2);
+        int persist = c->n_cu * (light ? (mode == MODE_PAINT ? 4 : 3) : 2);
         if (const char *e = std::getenv("BFG_TILE_PERSIST")) persist = std::atoi(e) > 1 ? std::atoi(e) : (std::atoi(e) ? persist : 0);
         const int tile_grid = persist > 0 ? std::min(persist, items_max) : items_max;
         // item counters of the persistent grid (bfg_tile.hpp: one address serialises the hand-out); BFG_ITEM_COUNTERS=1: the A/B
@@ -1988,7 +1990,9 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         } else if (light && wl) {
             constexpr int ntp = TileCfg<MODE_PAINT, 1>::NT, ntb = TileCfg<MODE_BARYONIFY, 1>::NT;
             constexpr size_t ldp = tile_lds_bytes<MODE_PAINT, 1>(), ldb = tile_lds_bytes<MODE_BARYONIFY, 1>();
-            if (mode == MODE_PAINT)
+            if (mode == MODE_PAINT && blend)
+                hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, true, 1, true>), tgrid, dim3(ntp), ldp, c->stream, tp);
+            else if (mode == MODE_PAINT)
                 hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, true, 1>), tgrid, dim3(ntp), ldp, c->stream, tp);
             else
                 hipLaunchKernelGGL((shell_tile_kernel<MODE_BARYONIFY, true, 1>), tgrid, dim3(ntb), ldb, c->stream, tp);

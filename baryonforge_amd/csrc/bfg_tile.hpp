@@ -802,10 +802,10 @@ constexpr int kPrOff = 64;           // slot offsets of the chunk's pairs (one p
 constexpr int kSegExtra = 32;
 
 // per-mode shape of a tile workgroup: threads, rings per tile, accumulators per pixel, LDS capacities of a chunk.
-// LIGHT = 1: the instantiation for sparse catalogs (a few dozen pairs per tile, BASELINE configs 1-2).  There a tile is one
-// or two chunks and the workgroup's time is its chain of latencies (pair list -> halo records -> row windows -> write-back),
-// not its arithmetic: 256 threads and half-size chunks need ~52 KB of LDS, so THREE workgroups share a CU instead of two and
-// half again as many tiles are in flight.
+// LIGHT = 1: the instantiation for sparse catalogs (up to ~a dozen pairs per tile).  There a tile is one chunk and the
+// workgroup's time is its chain of latencies (pair list -> halo records -> table rows -> write-back), not its arithmetic:
+// 256 threads and smaller chunks need 40 KB (paint) / 52 KB (offsets) of LDS, so FOUR / THREE workgroups share a CU instead of
+// two and twice / half again as many tiles are in flight.  The host picks it by halos per tile (run_shell).
 template <int MODE, int LIGHT = 0> struct TileCfg;
 template <> struct TileCfg<MODE_PAINT, 0> {
     // rings per tile, accumulators per pixel, (pair, ring) slots / pairs per chunk, pixel -> segment table entries per round
@@ -821,8 +821,11 @@ template <> struct TileCfg<MODE_BARYONIFY, 0> {
     using Pair = PairInfoDisp;
 };
 template <> struct TileCfg<MODE_PAINT, 1> {
-    static constexpr int NT = 256, WPS = 3, LDS_MAX = 54608;
-    static constexpr int TR = BFG_PAINT_TR, TW = BFG_PAINT_TW, NACC = 1, SLOTMAX = 256, PAIRMAX = 32, PIXMAX = 3072, QCAP = 16;
+    // FOUR workgroups per CU (40 KB of LDS each): the same 16 wavefronts per CU as two 512-thread workgroups, twice as many items
+    // in flight.  Measured (profiles/r03_light_ab.txt): 1e4 halos 0.072 -> 0.057 ms (three per CU with the larger chunks: 0.062),
+    // 3e4 halos 0.085 -> 0.079, 1e5 halos 0.140 -> 0.160 (three chunks of 160 slots per item instead of one of 512).
+    static constexpr int NT = 256, WPS = 4, LDS_MAX = 40960;
+    static constexpr int TR = BFG_PAINT_TR, TW = BFG_PAINT_TW, NACC = 1, SLOTMAX = 160, PAIRMAX = 20, PIXMAX = 2048, QCAP = 8;
     static constexpr int SEGMAX = SLOTMAX + kSegExtra / 2;
     using Pair = PairInfo;
 };
@@ -846,7 +849,7 @@ __host__ __device__ constexpr size_t tile_lds_bytes()
 
 // two (LIGHT: three) tile workgroups share a CU's 160 KB of LDS
 static_assert(tile_lds_bytes<MODE_PAINT>() <= 81920 && tile_lds_bytes<MODE_BARYONIFY>() <= 81920, "two workgroups per CU");
-static_assert(tile_lds_bytes<MODE_PAINT, 1>() <= 54608 && tile_lds_bytes<MODE_BARYONIFY, 1>() <= 54608, "three workgroups per CU");
+static_assert(tile_lds_bytes<MODE_PAINT, 1>() <= 40960 && tile_lds_bytes<MODE_BARYONIFY, 1>() <= 54608, "four / three workgroups per CU");
 
 // sin(h) for h^2 <= kSinSmall: odd series to h^7 (rel err < 3e-12)
 __device__ inline double sin_small(double h, double h2)
@@ -984,7 +987,7 @@ __device__ __forceinline__ void lds_barrier()
 template <int MODE, bool WIN_LDS, int LIGHT = 0, bool BLEND = false>
 __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::WPS)) void shell_tile_kernel(const TileParams P)
 {
-    static_assert(!BLEND || (MODE == MODE_PAINT && WIN_LDS && LIGHT == 0), "the blend instantiation is paint with LDS windows");
+    static_assert(!BLEND || (MODE == MODE_PAINT && WIN_LDS), "the blend instantiation is paint with LDS windows");
     using Cfg = TileCfg<MODE, LIGHT>;
     using Pair = typename Cfg::Pair;
     constexpr int TR = Cfg::TR, TW = Cfg::TW, NT = Cfg::NT, NACC = Cfg::NACC;
@@ -1727,8 +1730,6 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     // the look-ahead of the persistent loop goes to LDS BEFORE the write-back stores (see the hand-over above)
     if (tid == 0) ctl[6] = P.work_counter ? item_first + item3 * n_counters + my_c : kNoItem;
     constexpr int kPerThread = (TR * TW + NT - 1) / NT;
-    int64_t wpix[kPerThread];
-    double wold[kPerThread][NACC];
     const bool shared = wk.w && !degraded;
     const bool rmw = !shared && !p_out_zero && !p_overwrite;
     // Overwrite mode, tile not shared (the runners' and the bench's case): plain stores of every pixel and NOT ONE vector load in
@@ -1759,12 +1760,17 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         // all LDS reads of the thread's pixels first (ring rows and accumulator values in flight together, one wait), then the
         // stores: read -> wait -> read -> wait per pixel cost ~3 LDS round trips x 4 pixels on the critical path of every item.
         // (Tried: wave 0, whose loads pace the next item, issuing no stores at all -- no change: profiles/r03_writeback_ab.txt.)
-        int wk0[kPerThread], wk1[kPerThread];
-        int64_t wst[kPerThread];
-        double wv[kPerThread][NACC];
+        // (four pixels per thread at a time: the 256-thread instantiations own eight, and eight sets of these spill)
+        constexpr int kGrp = kPerThread < 4 ? kPerThread : 4;
+        static_assert(kPerThread % kGrp == 0, "write-back groups");
+#pragma unroll 1
+        for (int u0 = 0; u0 < kPerThread; u0 += kGrp) {
+        int wk0[kGrp], wk1[kGrp];
+        int64_t wst[kGrp];
+        double wv[kGrp][NACC];
 #pragma unroll
-        for (int u = 0; u < kPerThread; ++u) {
-            const unsigned i = min(wt + (unsigned)(u * NT), (unsigned)(TR * TW - 1));
+        for (int u = 0; u < kGrp; ++u) {
+            const unsigned i = min(wt + (unsigned)((u0 + u) * NT), (unsigned)(TR * TW - 1));
             const RingRow &rr = rows[i / TW];
             wk0[u] = rr.k0; wk1[u] = rr.k1; wst[u] = rr.start;
 #pragma unroll
@@ -1772,8 +1778,8 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         }
         BFG_LTICK(10);
 #pragma unroll
-        for (int u = 0; u < kPerThread; ++u) {
-            const unsigned i = wt + (unsigned)(u * NT);
+        for (int u = 0; u < kGrp; ++u) {
+            const unsigned i = wt + (unsigned)((u0 + u) * NT);
             const int row = (int)(i / TW), col = (int)(i % TW);
             if (i < (unsigned)(TR * TW) && ring_lo + row <= ring_hi && wk0[u] + col < wk1[u]) {
                 double *dst = P.out + NACC * (wst[u] + wk0[u] + col);
@@ -1781,19 +1787,8 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                 for (int c = 0; c < NACC; ++c) dst[c] = wv[u][c];
             }
         }
-    } else if (!(P.debug & 128)) {                     // profiling: bit 128 skips the write-back (wrong results)
-#pragma unroll
-    for (int u = 0; u < kPerThread; ++u) {
-        const int i = tid + u * NT;
-        wpix[u] = -1;
-        if (i < TR * TW) {
-            const int row = i / TW, col = i % TW;
-            const int ring = ring_lo + row;
-            if (ring <= ring_hi && rows[row].k0 + col < rows[row].k1) wpix[u] = rows[row].start + rows[row].k0 + col;
         }
-#pragma unroll
-        for (int c = 0; c < NACC; ++c) wold[u][c] = (wpix[u] >= 0 && rmw) ? P.out[NACC * wpix[u] + c] : 0.0;
-    }
+    } else if (!(P.debug & 128)) {                     // profiling: bit 128 skips the write-back (wrong results)
     if constexpr (kQCap > 0) {
         const int n = min(ctl[5], qcap);
         if (P.defer && dfill + n <= P.defer_cap_wg) {
@@ -1809,16 +1804,36 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         } else if (n > 0) drain();                                         // no list, or this workgroup's slice is full
     }
     BFG_ITICK(13);
+    // four pixels per thread at a time (their old map values are fetched in one burst); the 256-thread instantiations own eight
+    constexpr int kGrp = kPerThread < 4 ? kPerThread : 4;
+    static_assert(kPerThread % kGrp == 0, "write-back groups");
+#pragma unroll 1
+    for (int u0 = 0; u0 < kPerThread; u0 += kGrp) {
+        int64_t wpix[kGrp];
+        double wold[kGrp][NACC];
 #pragma unroll
-    for (int u = 0; u < kPerThread; ++u) {
-        if (wpix[u] < 0) continue;
-        const int i = tid + u * NT;
+        for (int u = 0; u < kGrp; ++u) {
+            const int i = tid + (u0 + u) * NT;
+            wpix[u] = -1;
+            if (i < TR * TW) {
+                const int row = i / TW, col = i % TW;
+                const int ring = ring_lo + row;
+                if (ring <= ring_hi && rows[row].k0 + col < rows[row].k1) wpix[u] = rows[row].start + rows[row].k0 + col;
+            }
 #pragma unroll
-        for (int c = 0; c < NACC; ++c) {
-            const double v = acc[NACC * i + c];
-            if (shared) { if (v != 0.0) unsafeAtomicAdd(P.out + NACC * wpix[u] + c, v); }   // the tile is shared with other workgroups
-            else if (p_overwrite) P.out[NACC * wpix[u] + c] = v;             // every pixel, zeros included: the map was not cleared
-            else if (v != 0.0) P.out[NACC * wpix[u] + c] = wold[u][c] + v;
+            for (int c = 0; c < NACC; ++c) wold[u][c] = (wpix[u] >= 0 && rmw) ? P.out[NACC * wpix[u] + c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kGrp; ++u) {
+            if (wpix[u] < 0) continue;
+            const int i = tid + (u0 + u) * NT;
+#pragma unroll
+            for (int c = 0; c < NACC; ++c) {
+                const double v = acc[NACC * i + c];
+                if (shared) { if (v != 0.0) unsafeAtomicAdd(P.out + NACC * wpix[u] + c, v); }   // the tile is shared with other workgroups
+                else if (p_overwrite) P.out[NACC * wpix[u] + c] = v;             // every pixel, zeros included: the map was not cleared
+                else if (v != 0.0) P.out[NACC * wpix[u] + c] = wold[u][c] + v;
+            }
         }
     }
     }

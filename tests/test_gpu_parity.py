@@ -1046,7 +1046,7 @@ def test_paint_and_baryonify_any_nside(cosmo, nside, variant):
     assert_maps_close(gotb, refb, RTOL, floor=BFLOOR, what=f"baryonify nside {nside}")
 
 
-@pytest.mark.parametrize("switch", ["BFG_TILE_KERNEL=wave", "BFG_TILE_LIGHT=1", "BFG_TILE_PERSIST=0", "BFG_TILE_PERSIST=7",
+@pytest.mark.parametrize("switch", ["BFG_TILE_KERNEL=wave", "BFG_TILE_LIGHT=1", "BFG_TILE_LIGHT=0", "BFG_TILE_PERSIST=0", "BFG_TILE_PERSIST=7",
                                     "BFG_FINAL_DRAIN=inline", "BFG_FINAL_DRAIN=kernel", "BFG_TILE_SCAN=1", "BFG_OUT_OVERWRITE=0",
                                     "BFG_ROWS=separate", "BFG_BLEND=0", "BFG_BLEND=0 BFG_ROWS=separate", "BFG_EAGER_SOA=1",
                                     "BFG_ITEM_COUNTERS=1", "BFG_ITEM_COUNTERS=3", "BFG_ITEM_COUNTERS=16 BFG_TILE_PERSIST=40"])

@@ -29,6 +29,10 @@ WORK = {
     "n2048": dict(kind="paint", n=1_250_000, nside=2048, eps=10.0),
     "stress": dict(kind="paint", n=1_000_000, nside=1024, eps=10.0, shape=(2, 30, 2000)),
     "paint1e4": dict(kind="paint", n=10_000, nside=1024, eps=10.0),
+    "paint3e4": dict(kind="paint", n=30_000, nside=1024, eps=10.0),
+    "paint3e5": dict(kind="paint", n=300_000, nside=1024, eps=10.0),
+    "bary1e4": dict(kind="bary", n=10_000, nside=1024, eps=10.0),
+    "bary3e5": dict(kind="bary", n=300_000, nside=1024, eps=10.0),
 }
 
 
