@@ -1121,7 +1121,9 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                                          (__attribute__((address_space(3))) void *)(ctl + 8 + 8 * par), 16, 0, 0);
     if (wave == 0 && have_next) {                     // first pair-list windows of the next item
         const int32_t *plist1 = P.pairs + wk1.y;
-        const int n1 = wk1.z - wk1.y;
+        // (the binning gave up: the work records point past the end of the pair buffer -- found by the soak as a memory fault
+        // once the buffer happened to be the last allocation of its region)
+        const int n1 = degraded ? 0 : wk1.z - wk1.y;
         pjA1 = (lane < n1) ? plist1[lane] : -1;
         pjB1 = (64 + lane < n1) ? plist1[64 + lane] : -1;
     }

@@ -11,6 +11,11 @@ run "BFG_TILE_CAP=3 BFG_TILE_SCAN=1" 90 3003
 run "BFG_D2H_SLICES=1 BFG_EAGER_SOA=1" 60 3004
 run "BFG_TILE_CAP=2 BFG_PAIR_CAP=100" 45 3005
 run "BFG_TILE_KERNEL=wave" 45 3006
+run "BFG_TILE_LIGHT=1" 90 3008
+run "BFG_TILE_LIGHT=0 BFG_ITEM_COUNTERS=1" 60 3009
+run "BFG_ITEM_COUNTERS=16 BFG_REGRID=full" 45 3010
 echo "== aux (snapshot / deposit / grid)" >> $O
 timeout -k 10 200 python3 tests/soak/soak_aux.py 60 3007 2>&1 | grep -v "^ok\|amdgpu.ids" | tail -3 >> $O
 cat $O
+# a GPU memory fault or a failed case anywhere fails the whole soak
+if grep -q "Memory access fault\|Error\|error\|dumped core" $O; then exit 1; fi
