@@ -16,7 +16,7 @@ stats() {  # name, bench args...
 pmc() {  # name, bench args...
   name=$1; shift
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/${tag}_pmc_${name}_$ctr -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e "$@" > /dev/null 2>&1 )
+    ( cd /tmp && export TMPDIR=/tmp BFG_BENCH_RAMP_S=0 && rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/${tag}_pmc_${name}_$ctr -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e "$@" > /dev/null 2>&1 )
     python3 $R/tools/pmc_summary.py $O/${tag}_pmc_${name}_$ctr > $O/${tag}_pmc_${name}_$ctr.txt 2>&1
     grep -A2 "shell_tile_kernel\|halo_prep" $O/${tag}_pmc_${name}_$ctr.txt | head -8
   done
