@@ -301,3 +301,79 @@ def test_cabi_sliced_paint_through_ctypes(cosmo):
     _lib.check(L.bfg_table_destroy(ctx, tab))
     _lib.check(L.bfg_spline_destroy(ctx, spl))
     _lib.check(L.bfg_ctx_destroy(ctx))
+
+
+def test_cabi_disc_enumeration_and_value_scatter(cosmo):
+    """the four entry points around a host-evaluated model (bfg_disc_enumerate_count / _enumerate / bfg_map_add_values /
+    bfg_offsets_add_displacements) through ctypes with plain pointers: the pixel lists equal hp.query_disc + the < 4 pixel rule as
+    the oracle restates them, the distances equal |vec D - vec_j D| / a_j, and the two scatter kernels reproduce the oracle's
+    loops for a closed-form model"""
+    from scipy import interpolate
+    L = _lib.load()
+    ctx = C.c_void_p()
+    _lib.check(L.bfg_ctx_create(0, C.c_void_p(-1), C.byref(ctx)), "ctx")
+    nside, npix, eps, n = 64, 12 * 64 * 64, 6.0, 300
+    ra, dec, M, z = syn.catalog(n, seed=33, z=(0.1, 0.4), logM=(12.0, 15.3))
+    ra[0], dec[0] = 123.0, -89.95                                          # a disc over the south pole
+    bg = Background(cosmo)
+    z_t = np.linspace(0, z.max() + 0.1, 1000)
+    cs = interpolate.CubicSpline(z_t, bg.angular_diameter_distance(1 / (1 + z_t)))
+    spl = C.c_void_p()
+    knots, coef = np.ascontiguousarray(cs.x), np.ascontiguousarray(cs.c)
+    _lib.check(L.bfg_spline_create(ctx, knots.size, _dp(knots), _dp(coef), C.byref(spl)), "spline")
+    d_cat = Dev(L, ctx, n * 32).up(np.stack([M, z, ra, dec], 1))
+    args = _lib.ShellArgs()
+    args.nside, args.n_halo, args.d_catalog, args.cat_stride, args.n_extra = nside, n, d_cat.p.value, 4, 0
+    args.epsilon_max, args.runner_md, args.model_md = eps, _massdef(bg), _massdef(bg)
+    a, R, D = orc.halo_scalars(cosmo, M, z)
+
+    for fallback4 in (0, 1):
+        d_counts = Dev(L, ctx, n * 8)
+        _lib.check(L.bfg_disc_enumerate_count(ctx, C.byref(args), spl, fallback4, d_counts.p), "count")
+        counts = np.empty(n, dtype=np.int64)
+        _lib.check(L.bfg_memcpy_d2h(ctx, counts.ctypes.data, d_counts.p, counts.nbytes))
+        base = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)
+        total = int(counts.sum())
+        d_base = Dev(L, ctx, n * 8)
+        _lib.check(L.bfg_memcpy_h2d(ctx, d_base.p, base.ctypes.data, base.nbytes))
+        d_pix, d_r, d_halo = Dev(L, ctx, total * 8), Dev(L, ctx, total * 8), Dev(L, ctx, total * 4)
+        _lib.check(L.bfg_disc_enumerate(ctx, C.byref(args), spl, fallback4, d_base.p, d_pix.p, d_r.p, d_halo.p), "enumerate")
+        pix, halo = np.empty(total, dtype=np.int64), np.empty(total, dtype=np.int32)
+        _lib.check(L.bfg_memcpy_d2h(ctx, pix.ctypes.data, d_pix.p, pix.nbytes))
+        _lib.check(L.bfg_memcpy_d2h(ctx, halo.ctypes.data, d_halo.p, halo.nbytes))
+        r_com = d_r.down(total)
+        for j in range(n):
+            vec_j = orc.ang2vec(ra[j], dec[j], lonlat=True)
+            ref_pix = orc.query_disc(nside, vec_j, R[j] * eps / D[j])
+            if fallback4 and ref_pix.size < 4:
+                ref_pix = orc.get_interp_weights(nside, ra[j], dec[j], lonlat=True)[0]
+            sl = slice(base[j], base[j] + counts[j])
+            assert counts[j] == ref_pix.size, (j, fallback4)
+            assert np.array_equal(np.sort(pix[sl]), np.sort(ref_pix)) and np.all(halo[sl] == j)
+            vec = np.stack(orc.pix2vec(nside, pix[sl]), axis=1)
+            np.testing.assert_allclose(r_com[sl], np.sqrt(np.sum((vec * D[j] - vec_j * D[j]) ** 2, axis=1)) / a[j], rtol=1e-11)
+        if not fallback4:
+            # paint: values = a closed form of (r, M)
+            vals = 1e-3 * (M[halo] / 1e14) / (1 + r_com ** 2)
+            d_val, d_map = Dev(L, ctx, total * 8).up(vals), Dev(L, ctx, npix * 8).zero()
+            _lib.check(L.bfg_map_add_values(ctx, d_map.p, d_pix.p, d_val.p, total), "add values")
+            ref = np.zeros(npix)
+            np.add.at(ref, pix, vals)
+            assert_maps_close(d_map.down(npix), ref, 1e-12, what="bfg_map_add_values")
+            d_val.free(); d_map.free()
+        else:
+            disp = 0.05 * (M[halo] / 1e14) ** (1 / 3) * r_com * np.exp(-r_com)
+            d_disp, d_off = Dev(L, ctx, total * 8).up(disp), Dev(L, ctx, npix * 24).zero()
+            _lib.check(L.bfg_offsets_add_displacements(ctx, C.byref(args), spl, d_pix.p, d_halo.p, d_disp.p, total, d_off.p), "disp")
+            ref, _ = orc.baryonify_offsets_callable(cosmo, nside, ra, dec, M, z, eps,
+                                                    lambda r, Mj, aj: 0.05 * (Mj / 1e14) ** (1 / 3) * r * np.exp(-r))
+            np.testing.assert_allclose(d_off.down((npix, 3)), ref, rtol=1e-7, atol=1e-15 + 1e-9 * np.abs(ref).max())
+            d_disp.free(); d_off.free()
+        for b in (d_counts, d_base, d_pix, d_r, d_halo):
+            b.free()
+    # bad arguments are refused
+    assert L.bfg_disc_enumerate_count(ctx, C.byref(args), spl, 0, None) == -1
+    assert L.bfg_map_add_values(ctx, None, None, None, 5) == -1
+    d_cat.free()
+    _lib.check(L.bfg_spline_destroy(ctx, spl))
+    _lib.check(L.bfg_ctx_destroy(ctx))
