@@ -171,7 +171,12 @@ static int comm_side_begin(bfg_ctx *c, const bfg_rccl::Api *A, int64_t *ticket, 
     (void)A;
     bfg_comm_state *m = c->comm;
     if (!m->side) {
-        HIP_TRY(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+        // the highest priority the device offers: the persistent tile kernel fills every CU, and a collective enqueued behind it should
+        // take the workgroup slots the next slice's launch frees before that launch's own workgroups do (what DDP does with its
+        // NCCL streams); on a device without stream priorities the range is (0, 0) and this is a plain stream
+        int prio_least = 0, prio_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        HIP_TRY(hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, prio_greatest));
         HIP_TRY(hipEventCreateWithFlags(&m->ev_ready, hipEventDisableTiming));
     }
     const int64_t tk = m->issued + 1;

@@ -239,7 +239,17 @@ def main():
         tmo = datetime.timedelta(seconds=int(os.environ.get("BFG_BENCH_TIMEOUT_S", "180")))
         try:
             if backend == "nccl":
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
+                # RCCL's kernels on a high-priority stream (as DDP runs them): they take the workgroup slots a finishing slice of the
+                # persistent tile kernel frees before the next slice's own workgroups do
+                opts = None
+                try:
+                    opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+                except Exception:
+                    pass
+                try:
+                    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo, pg_options=opts)
+                except TypeError:                                  # a torch without pg_options / this option
+                    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
             else:
                 dist.init_process_group(backend, timeout=tmo)
         except Exception as exc:
