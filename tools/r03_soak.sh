@@ -4,7 +4,8 @@
 cd ${GRAFT_REPO_ROOT:-.}
 O=gpurun_out/r03_soak.txt
 : > $O
-run() { echo "== $1 ($2 s, seed $3)" >> $O; env $1 timeout -k 10 $(( $2 + 120 )) python3 tests/soak/soak.py $2 $3 2>&1 | grep -v "^ok\|amdgpu.ids" | tail -3 >> $O; }
+# SOAK_SEED (added to every seed) and SOAK_SCALE (multiplies every duration) give a second, different, longer soak
+run() { d=$(( $2 * ${SOAK_SCALE:-1} )); sd=$(( $3 + ${SOAK_SEED:-0} )); echo "== $1 ($d s, seed $sd)" >> $O; env $1 timeout -k 10 $(( d + 120 )) python3 tests/soak/soak.py $d $sd 2>&1 | grep -v "^ok\|amdgpu.ids" | tail -3 >> $O; }
 run "BFG_X=0" 240 3001
 run "BFG_BLEND=0" 90 3002
 run "BFG_TILE_CAP=3 BFG_TILE_SCAN=1" 90 3003
