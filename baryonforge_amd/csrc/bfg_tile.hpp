@@ -295,7 +295,9 @@ __device__ inline int wave_merged_inc(int32_t *counter, int idx)
         if (round == 1 && !merged) break;          // two singleton groups in a row: an unsorted catalog, stop looking
     }
     int base = 0;
+#ifndef BFG_ABLATE_BIN_ATOMIC          // (profiling build: what the binning costs without its returning atomics; wrong results)
     if (lane == leader) base = atomicAdd(&counter[idx], __popcll(mine));
+#endif
     base = __shfl(base, leader, 64);
     return base + __popcll(mine & ((1ull << lane) - 1ull));
 }
