@@ -423,8 +423,9 @@ class BaryonifyShell(DefaultRunner):
         self.last_stats = dict(ctx.stats(), pixel_updates=total)
         return d_off
 
-    def offsets_device(self, slices=1, on_slice=None):
+    def offsets_device(self, slices=1, on_slice=None, sync_stats=True):
         """Accumulate the unit-vector offsets of all halos (:313-355); returns float64[Npix, 3] on the device.
+        sync_stats=False: the counters are not read back (that synchronises the stream); `collect_stats()` does it later.
         slices, on_slice: bfg_baryonify_offsets_sliced -- on_slice(k, n, lo, hi) after the k-th band slice of the field has been
         enqueued; lo / hi are ELEMENT indices of the flattened field (3 per pixel)."""
         keys = self._checked_model_keys()
@@ -447,17 +448,27 @@ class BaryonifyShell(DefaultRunner):
                               rdelta_sampling=getattr(model, "Rdelta_sampling", False), variant=self.variant,
                               out_overwrite=True)
         d_off = ctx.empty(12 * NSIDE * NSIDE, 3)                          # :313 -- the zeros come from the kernels
-        ctx.stats_reset()
+        if sync_stats:
+            ctx.stats_reset()
         if on_slice is not None:
             flat = d_off.view(-1)
             ctx.baryonify_offsets(args, table, spline, d_off, slices=slices,
                                   on_slice=lambda k, n, lo, hi: on_slice(k, n, lo, hi, flat))
         else:
             ctx.baryonify_offsets(args, table, spline, d_off)             # :315-355
-        self.last_stats = ctx.stats()
+        self.last_stats = None
+        if sync_stats:
+            self.collect_stats()
+        return d_off
+
+    def collect_stats(self):
+        """read the device counters (synchronises the stream), keep them in `last_stats`, emit the warnings"""
+        if getattr(self, "_callable_model", False) and self.last_stats is not None:
+            return self.last_stats
+        self.last_stats = get_context().stats()
         emit_range_warnings(self.last_stats, "table")                     # BaryonCorrection.py:382-394
         emit_fallback_warning(self.last_stats)
-        return d_off
+        return self.last_stats
 
     def process(self, distributed=None):
         """returns new_map : float64[Npix]; the input array itself if the map is all zeros (:293-294).
@@ -467,6 +478,8 @@ class BaryonifyShell(DefaultRunner):
         in halos (:355), so it is summed across the ranks -- by a reduce-scatter, because every rank regrids only the
         sources of the pixel range it owns (:357-365 on that range) --, and the regridded maps, whose deposits can cross
         the range borders, are all-reduced."""
+        if distributed is None:
+            return _baryonify_pipelined([self])[0]
         return _baryonify_process(self, _BaryonifyDeviceOps(self), distributed)
 
 
@@ -493,6 +506,92 @@ class _BaryonifyDeviceOps(object):
 
     def to_host(self, t):
         return get_context().to_host(t)
+
+
+def _baryonify_pipelined(runners, in_flight=2):
+    """BaryonifyShell.process (HealpixRunner.py:252-373) for one or several shells on ONE GPU with the host transfers off the
+    critical path.  Per shell the reference does: map to the device, offsets, regrid, map back -- 1.8 + 0.6 + 0.3 + 1.8 ms at
+    BASELINE configs[2], the two PCIe legs being three quarters of it.  Here the offset kernels are enqueued BEFORE the upload
+    (they do not need the map; the pageable copy blocks the host thread, not the GPU, and runs on a stream of its own), nothing
+    is read back in between (the mass sums come out of the regrid kernel, the all-zero test out of a device reduction, the
+    counters once at the end), and the copy of shell k's result to page-locked memory overlaps the upload and the kernels of
+    shell k + 1 (PCIe is full duplex -- with a copy kernel for one of the two directions): 4.7 -> 2.8 ms per shell of a list,
+    4.7 -> 4.4 ms for a single shell (tools/bary_api_probe.py, tools/bary_pipe_probe.py).  Returns the list of new maps (the input array itself where it is all zeros, :293-294)."""
+    n = len(runners)
+    results, pend = [None] * n, []
+    todo = []
+    for k, R in enumerate(runners):                                       # the reference's checks first, before anything touches the GPU
+        orig = R.LightconeShell.map
+        if orig.size < (1 << 16) and np.allclose(orig, 0):                # small maps: decided on the host, as the reference (:293-294)
+            results[k] = orig
+            continue
+        R._checked_model_keys()
+        todo.append(k)
+    if not todo:
+        return results
+    import torch
+    ctx = get_context()
+    dev = ctx.device
+    up, down = ctx.upload_stream(), ctx.copy_stream()
+
+    def finish(item):
+        k, orig, h, h_small, ev = item
+        ev.synchronize()
+        absmax, old_sum, new_sum = (float(x) for x in h_small.tolist())
+        if not (absmax > 1e-8) and np.allclose(orig, 0):                  # :293-294 (False for NaN maps)
+            results[k] = orig
+            return
+        assert np.isclose(new_sum, old_sum), \
+            "ERROR in pixel regridding, sum(new_map) [%0.14e] != sum(oldmap) [%0.14e]" % (new_sum, old_sum)  # :368-370
+        results[k] = h.numpy().reshape(np.shape(orig))
+
+    ctx.stats_reset()
+    ran = []
+    for k in todo:
+        R = runners[k]
+        orig = R.LightconeShell.map
+        NSIDE = R.LightconeShell.NSIDE
+        npix = 12 * NSIDE * NSIDE
+        while len(pend) >= in_flight:                                     # bounds the HBM in flight (~0.5 GB per shell at NSIDE 1024)
+            finish(pend.pop(0))
+        main = torch.cuda.current_stream(dev)
+        d_off = R.offsets_device(sync_stats=False)                        # :313-355, enqueued; the GPU works while the host copies
+        ran.append(R)
+        flat = np.ascontiguousarray(orig, dtype=np.float64).ravel()
+        with torch.cuda.stream(up):
+            d_orig = torch.from_numpy(flat).to(dev)
+        main.wait_stream(up)
+        d_orig.record_stream(main)
+        d_out, d_small = ctx.zeros(npix), ctx.zeros(3)
+        d_small[0] = d_orig.abs().max()                                   # np.allclose(orig_map, 0) <=> max |map| <= 1e-8
+        ctx.regrid_shell(NSIDE, d_off, d_orig, d_out, d_small[1:])        # :357-365; {sum(in), sum(deposits)} from the kernel
+        try:
+            h = torch.empty(npix, dtype=torch.float64, pin_memory=True)
+            h_small = torch.empty(3, dtype=torch.float64, pin_memory=True)
+        except RuntimeError:                                              # no page-locked memory to be had
+            h, h_small = torch.empty(npix, dtype=torch.float64), torch.empty(3, dtype=torch.float64)
+        down.wait_stream(main)
+        with torch.cuda.stream(down):
+            if h.is_pinned() and n > 1:
+                # a copy KERNEL, not the DMA engine: the next shell's upload is a DMA copy, and two DMA copies in opposite directions
+                # take turns on this platform (tools/copy_probe.py: 3.7 ms for the pair, 2.3 ms with the kernel)
+                ctx.copy_to_pinned(h, d_out)
+            else:
+                h.copy_(d_out, non_blocking=True)
+            h_small.copy_(d_small, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(down)
+        d_out.record_stream(down)
+        d_small.record_stream(down)
+        pend.append((k, orig, h, h_small, ev))
+    for item in pend:
+        finish(item)
+    if ran:
+        stats = ran[0].collect_stats()                                    # one read-back for the whole list
+        for R in ran[1:]:
+            if not getattr(R, "_callable_model", False):
+                R.last_stats = stats
+    return results
 
 
 def _baryonify_process(runner, ops, exchange, slices=1):

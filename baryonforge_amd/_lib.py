@@ -43,6 +43,7 @@ SYMBOLS = [
     "bfg_allreduce_f64", "bfg_allreduce_f64_begin", "bfg_comm_wait", "bfg_reduce_scatter_f64", "bfg_allgather_f64",
     "bfg_reduce_scatter_f64_begin", "bfg_paint_shell_sliced", "bfg_baryonify_offsets_sliced",
     "bfg_disc_enumerate_count", "bfg_disc_enumerate", "bfg_map_add_values", "bfg_offsets_add_displacements",
+    "bfg_copy_to_mapped_host",
 ]
 ABI_VERSION = 3
 # bfg_slice_fn: int (*)(void *user, int slice, int n_slices, int64_t elem_begin, int64_t elem_end)
@@ -163,6 +164,7 @@ def load(build_if_missing=True):
     L.bfg_paint_shell_sliced.argtypes = [_vp, C.POINTER(ShellArgs), _vp, _vp, _vp, C.c_int, SLICE_FN, _vp]
     L.bfg_baryonify_offsets_sliced.argtypes = [_vp, C.POINTER(ShellArgs), _vp, _vp, _vp, C.c_int, SLICE_FN, _vp]
     L.bfg_regrid_shell.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp]
+    L.bfg_copy_to_mapped_host.argtypes = [_vp, _vp, _vp, _vp, C.c_size_t]
     L.bfg_disc_enumerate_count.argtypes = [_vp, C.POINTER(ShellArgs), _vp, C.c_int, _vp]
     L.bfg_disc_enumerate.argtypes = [_vp, C.POINTER(ShellArgs), _vp, C.c_int, _vp, _vp, _vp, _vp]
     L.bfg_map_add_values.argtypes = [_vp, _vp, _vp, _vp, _i64]

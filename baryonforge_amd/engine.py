@@ -246,6 +246,23 @@ class Context(object):
             self._copy_stream = _torch().cuda.Stream(device=self.device)
         return self._copy_stream
 
+    def upload_stream(self):
+        """a second copy stream, for host -> device copies that overlap kernels AND device -> host copies (PCIe is full duplex)"""
+        if getattr(self, "_upload_stream", None) is None:
+            self._upload_stream = _torch().cuda.Stream(device=self.device)
+        return self._upload_stream
+
+    def copy_to_pinned(self, h_pinned, d_tensor):
+        """d_tensor -> h_pinned (a page-locked torch CPU tensor) by a copy kernel on torch's CURRENT stream
+        (bfg_copy_to_mapped_host; the context stays bound to the stream its kernels run on): unlike a second DMA copy it
+        overlaps a host -> device copy running on another stream"""
+        assert h_pinned.is_pinned() and h_pinned.is_contiguous() and d_tensor.is_contiguous()
+        assert h_pinned.numel() * h_pinned.element_size() == d_tensor.numel() * d_tensor.element_size()
+        stream = int(_torch().cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self.lib.bfg_copy_to_mapped_host(self.handle, C.c_void_p(stream), C.c_void_p(h_pinned.data_ptr()),
+                                                    C.c_void_p(d_tensor.data_ptr()),
+                                                    d_tensor.numel() * d_tensor.element_size()), "bfg_copy_to_mapped_host")
+
     def to_host(self, d_tensor):
         """device tensor -> numpy array.  Up to 1 GiB the copy lands in page-locked memory from torch's caching host
         allocator and the array is a view of it: 1.8 ms instead of 11 ms for a 101 MB map once a block is being

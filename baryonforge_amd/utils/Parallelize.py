@@ -280,6 +280,11 @@ class _DeviceOps(object):
         return h.numpy()
 
 
+def _plain_baryonify_process():
+    from ..Runners.HealpixRunner import BaryonifyShell
+    return BaryonifyShell.process
+
+
 class SimpleParallel(object):
     """Run several independent Runners (Parallelize.py:8-113).
 
@@ -304,6 +309,11 @@ class SimpleParallel(object):
         if self.split:
             return SplitJoinParallel(self.Runner_list, self.njobs, self.seed, **self.splitjoin_args).process()
         if dist is None or dist.get_world_size() == 1:
+            if len(self.Runner_list) > 1 and all(hasattr(R, "offsets_device") and type(R).process is _plain_baryonify_process()
+                                                 for R in self.Runner_list):
+                # a list of BaryonifyShell runners on one GPU: uploads, kernels and downloads of consecutive shells overlap
+                from ..Runners.HealpixRunner import _baryonify_pipelined
+                return _baryonify_pipelined(self.Runner_list)
             return [self.single_run(R) for R in self.Runner_list]
         rank, world = dist.get_rank(), dist.get_world_size()
         mine = {i: self.single_run(R) for i, R in enumerate(self.Runner_list) if i % world == rank}
@@ -462,7 +472,11 @@ class SplitJoinParallel(object):
         """The summed map(s) on the host: float64[Npix] for one Runner, a list for a list of Runners."""
         first = self.Runner_list[0] if self.Runner_list else None
         if first is not None and hasattr(first, "offsets_device"):
-            outs = [self._baryonify(R, ops) for R in self.Runner_list]
+            if ops is None and self.world == 1:                        # one GPU: the transfers of consecutive shells overlap
+                from ..Runners.HealpixRunner import _baryonify_pipelined
+                outs = _baryonify_pipelined(self.Runner_list)
+            else:
+                outs = [self._baryonify(R, ops) for R in self.Runner_list]
             return outs if self.is_list else outs[0]
         ops = ops or _DeviceOps()
         n = len(self.Runner_list)

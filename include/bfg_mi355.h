@@ -308,6 +308,11 @@ int bfg_baryonify_offsets_sliced(bfg_ctx *ctx, const bfg_shell_args *args, const
 int bfg_regrid_shell(bfg_ctx *ctx, int64_t nside, const double *d_offsets, const double *d_in_map,
                      double *d_out_map, double *d_sums);
 
+/* Device -> page-locked host memory by a copy kernel on `stream` (a hipStream_t; NULL: the context's stream; the context's own
+ * stream binding is left alone) (host_dst: hipHostMalloc'd / registered memory, 16-byte aligned; bytes a multiple of 8): it overlaps a host -> device DMA copy running on another stream, which a second DMA
+ * copy in the opposite direction does not on every platform (the map of shell k leaves while the map of shell k + 1 arrives).  */
+int bfg_copy_to_mapped_host(bfg_ctx *ctx, void *stream, void *host_dst, const void *d_src, size_t bytes);
+
 /* ---- models that are NOT tabulated (any object with .projected / .displacement) ----------------------------------
  * The reference hands the distances of a halo's disc pixels to a Python callable, once per halo
  * (Runners/HealpixRunner.py:472 Baryons.projected(cosmo, r_sep / a_j, M_j, a_j, **o_j); :345 model.displacement(...)).

@@ -1725,3 +1725,36 @@ def test_list_of_shells_on_one_gpu_pipelined(cosmo):
     assert all(np.allclose(m, o, rtol=1e-12, atol=0) for (_, m), o in zip(seen, outs))
     devs = SJ.process_device()
     assert len(devs) == 5 and all(np.allclose(d.cpu().numpy(), o, rtol=1e-12, atol=0) for d, o in zip(devs, outs))
+
+
+def test_baryonify_list_on_one_gpu_overlaps_transfers_and_equals_the_plain_path(cosmo):
+    """SimpleParallel / SplitJoinParallel over a list of BaryonifyShell runners on one GPU run the shells through
+    _baryonify_pipelined (uploads, kernels and downloads of consecutive shells overlap; nothing is read back in between): the
+    maps equal those of the step-by-step path (_baryonify_process) and the oracle, an all-zero shell comes back as the input
+    array itself (HealpixRunner.py:293-294), the mass sums are checked, the counters are those of the whole list"""
+    import warnings
+    from baryonforge_amd.Runners.HealpixRunner import _BaryonifyDeviceOps, _baryonify_process
+    nside, eps = 256, 10.0
+    zd, Md, rd, d = syn.displacement_table()
+    bm = bfg.Baryonification2D.from_arrays(zd, Md, rd, d, cosmo, epsilon_max=20)
+    runners, refs, ptots = [], [], 0
+    for k, n in enumerate([3000, 0, 5000, 800, 2500]):
+        ra, dec, M, z = syn.catalog(max(n, 1), seed=300 + k)
+        m_in = syn.mass_map(nside) * (1.0 + 0.1 * k) if n else np.zeros(12 * nside * nside)
+        Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+        runners.append(bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo), eps, bm, verbose=False))
+        refs.append(oracle_baryonify(cosmo, ra, dec, M, z, (zd, Md, rd), d, nside, eps, 20, m_in) if n else None)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        outs = bfg.SimpleParallel(runners).process()
+        outs2 = bfg.SplitJoinParallel(runners).process()
+        plain = [_baryonify_process(R, _BaryonifyDeviceOps(R), None) for R in runners]
+        single = runners[2].process()
+    assert outs[1] is runners[1].LightconeShell.map and outs2[1] is runners[1].LightconeShell.map      # the all-zero shell
+    for k in (0, 2, 3, 4):
+        assert_maps_close(outs[k], refs[k], RTOL, floor=BFLOOR, what=f"pipelined list, shell {k}")
+        assert_maps_close(outs[k], plain[k], 1e-9, floor=BFLOOR, what=f"pipelined vs step by step, shell {k}")
+        assert_maps_close(outs2[k], plain[k], 1e-9, floor=BFLOOR, what=f"SplitJoinParallel list, shell {k}")
+        assert np.isclose(outs[k].sum(), runners[k].LightconeShell.map.sum(), rtol=1e-12)
+    assert_maps_close(single, plain[2], 1e-9, floor=BFLOOR, what="single process()")
+    assert runners[0].last_stats["pixel_updates"] > 0
