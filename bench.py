@@ -63,10 +63,12 @@ def parse():
     p.add_argument("--collective", choices=["torch", "bfg"], default="torch")
     p.add_argument("--slices", type=int, default=4, help="N > 1: pieces in which a painted map is handed to the all-reduce")
     p.add_argument("--layout", choices=["interleaved", "contiguous"], default="interleaved", help="sky-patch sharding layout")
-    p.add_argument("--exchange", choices=["auto", "allreduce", "owner"], default="auto",
-                   help="N > 1, paint: all-reduce of the replicated maps (sliced, behind the painting) or the owner-computes join "
-                        "(declination stripes, border exchange + all-gather: half the bytes); auto = both are tried in the warm-up: the "
-                        "owner-computes join is used if its map equals the all-reduce's on every rank AND it is the faster of the two")
+    p.add_argument("--exchange", choices=["auto", "allreduce", "owner"], default="allreduce",
+                   help="N > 1, paint: all-reduce of the replicated maps (sliced, behind the painting; the default: in the weak-scaling "
+                        "run it hides behind the painting and it is the one collective every RCCL installation runs daily) or the "
+                        "owner-computes join (declination stripes, point-to-point border exchange + all-gather: half the bytes, what an "
+                        "exchange-bound strong-scaling run wants); auto = both are tried in the warm-up: the owner-computes join is "
+                        "used if its map equals the all-reduce's on every rank AND it is the faster of the two")
     p.add_argument("--nside", type=int, default=1024)
     p.add_argument("--eps", type=float, default=10.0)
     p.add_argument("--workload", choices=["paint", "baryonify"], default="paint")
