@@ -6,6 +6,7 @@ halos/s + achieved HBM GB/s, NSIDE = 1024 shell, 1e6 halos, at 1/2/4/8 GPUs).
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--collective torch|bfg]
+         [--exchange allreduce|owner|auto]
 
 One "step" = one full pass of the hot path over one synthetic catalog that is already
 resident in HBM as float64 (M, z, ra, dec) records: halo preparation + binning kernels, row windows,
@@ -22,6 +23,8 @@ baryonforge_amd.SplitJoinParallel (utils/Parallelize.py), which paints shell k +
 flight (two rotating map buffers) and hands every map to the all-reduce in --slices pieces as the tile kernel finishes them
 (bfg_paint_shell_sliced).  `api_single_call_ms` = one SplitJoinParallel(runner).process_device() on its own (nothing to
 overlap with but its own slices; `api_single_call_unsliced_ms`: one all-reduce after the call).
+Before the W warm-up steps the run executes BFG_BENCH_RAMP_S (default 0.25 s) of the very same steps (`ramp_steps` in the line):
+an idle MI355X needs ~50 ms of load to reach its sustained clocks, W = 5 steps are 6 ms of it.
 The run exits non-zero with a one-line reason -- it never hangs -- when fewer than N GPUs are visible, when RCCL cannot be
 loaded, when a rank fails (collective timeout BFG_BENCH_TIMEOUT_S, default 180 s) or when the whole run exceeds
 BFG_BENCH_DEADLINE_S (default 1500 s).
