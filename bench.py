@@ -610,6 +610,11 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
                 "bytes_per_halo": kernel_bytes / max(idx.size, 1),
                 "pixel_updates_per_launch": ptot_step,
                 "pixel_updates_per_s": ptot_step / kernel_s if kernel_s > 0 else 0.0,
+                # the other yardstick SURVEY.md 8d asks for: the updates are ds_add_f64 in LDS, whose measured ceiling on this part
+                # is 2.0e12 adds/s (tools/atomic_microbench.hip, profiles/r01_atomic_microbench.txt; global f64 atomics: 1.0-1.7e11/s)
+                "lds_atomic_ceiling_per_s": 2.0e12,
+                "pixel_updates_frac_of_lds_atomic_ceiling": (ptot_step * (1 if args.workload == "paint" else 3) / kernel_s / 2.0e12)
+                if kernel_s > 0 else 0.0,
                 "other_kernels_timed_in": f"an extra untimed leg of {n_extra} steps with every kernel class timed (the timed "
                                           "region carries events for the dominant kernel only)",
                 "prep_kernel_ms": p_ms / max(p_n, 1),
