@@ -11,7 +11,7 @@ python3 $R/bench.py --workload baryonify --nside 2048 --halos 10000000 --steps 3
 echo "whole rc=$?"
 python3 $R/bench.py --workload paint --nside 2048 --halos 10000000 --steps 3 --warmup 1 --no-cpu-baseline --no-e2e > $O/r03_bench_paint2048_whole.json 2> $O/r03_bench_paint2048_whole.err
 echo "paint whole rc=$?"
-rm -rf $O/prof_c4 && rocprofv3 --kernel-trace --stats -d $O/prof_c4 -o c4 -- python3 $R/bench.py --workload baryonify --nside 2048 --halos 10000000 --steps 3 --warmup 1 --no-cpu-baseline > $O/r03_c4_prof.log 2>&1
+rm -rf $O/prof_c4 && rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c4 -o c4 -- python3 $R/bench.py --workload baryonify --nside 2048 --halos 10000000 --steps 3 --warmup 1 --no-cpu-baseline > $O/r03_c4_prof.log 2>&1
 echo "rocprof rc=$?"
 find $O/prof_c4 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/r03_bary2048_whole_kernel_stats.csv
 head -8 $O/r03_bary2048_whole_kernel_stats.csv | cut -c1-200
