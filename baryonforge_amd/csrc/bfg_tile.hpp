@@ -1764,6 +1764,33 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         // all LDS reads of the thread's pixels first (ring rows and accumulator values in flight together, one wait), then the
         // stores: read -> wait -> read -> wait per pixel cost ~3 LDS round trips x 4 pixels on the critical path of every item.
         // (Tried: wave 0, whose loads pace the next item, issuing no stores at all -- no change: profiles/r03_writeback_ab.txt.)
+        if constexpr (NACC == 1 && TW % 2 == 0 && (TR * TW / 2) % NT == 0) {
+        // paint: two neighbouring pixels of a ring per thread -- one 16-byte LDS read and one 16-byte store (8-byte aligned: the
+        // row's first pixel may be odd) instead of two of each: half the store and LDS-read instructions of the write-back
+        typedef double wb_v2d __attribute__((ext_vector_type(2), aligned(8)));
+        constexpr int kPP = TR * TW / 2 / NT;
+        int pk0[kPP], pk1[kPP];
+        int64_t pst[kPP];
+        double2 pv[kPP];
+#pragma unroll
+        for (int u = 0; u < kPP; ++u) {
+            const unsigned i = 2u * (wt + (unsigned)(u * NT));
+            const RingRow &rr = rows[i / TW];
+            pk0[u] = rr.k0; pk1[u] = rr.k1; pst[u] = rr.start;
+            pv[u] = *reinterpret_cast<const double2 *>(acc + i);
+        }
+        BFG_LTICK(10);
+#pragma unroll
+        for (int u = 0; u < kPP; ++u) {
+            const unsigned i = 2u * (wt + (unsigned)(u * NT));
+            const int row = (int)(i / TW), col = (int)(i % TW);
+            if (ring_lo + row <= ring_hi && pk0[u] + col < pk1[u]) {
+                double *dst = P.out + (pst[u] + pk0[u] + col);
+                if (pk0[u] + col + 1 < pk1[u]) { wb_v2d v; v.x = pv[u].x; v.y = pv[u].y; *reinterpret_cast<wb_v2d *>(dst) = v; }
+                else dst[0] = pv[u].x;
+            }
+        }
+        } else {
         // (four pixels per thread at a time: the 256-thread instantiations own eight, and eight sets of these spill)
         constexpr int kGrp = kPerThread < 4 ? kPerThread : 4;
         static_assert(kPerThread % kGrp == 0, "write-back groups");
@@ -1790,6 +1817,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
 #pragma unroll
                 for (int c = 0; c < NACC; ++c) dst[c] = wv[u][c];
             }
+        }
         }
         }
     } else if (!(P.debug & 128)) {                     // profiling: bit 128 skips the write-back (wrong results)
