@@ -212,9 +212,26 @@ class BaryonificationClass(object):
 
     def _readout(self, r, M, a, **kwargs):
         """BaryonCorrection.py:331-419, the table lookup itself on the GPU"""
-        from ..engine import get_context
-        ctx = get_context()
-        table = self.device_table(ctx)
+        from .. import _lib
+        n_axes = 3 + len(self.p_keys)
+        if n_axes > _lib.BFG_MAX_DIM:
+            # more p_keys axes than the device read-out takes: scipy's N-linear interpolation on the host, literally the reference's
+            # (:312-328); such a model runs through the runners' callable-model path, per halo
+            from scipy import interpolate
+            hit = getattr(self, "_host_interp", None)
+            if hit is None or hit[0] is not self.raw_input_d:
+                axes = [self.raw_input_z_range, self.raw_input_M_range, self.raw_input_r_range] + \
+                       [getattr(self, "raw_input_%s_range" % k) for k in self.p_keys]
+                hit = self._host_interp = (self.raw_input_d, interpolate.RegularGridInterpolator(
+                    tuple(axes), self.raw_input_d, bounds_error=False, fill_value=np.nan))
+
+            class _HostTable(object):
+                eval = staticmethod(hit[1])
+            table = _HostTable()
+        else:
+            from ..engine import get_context
+            ctx = get_context()
+            table = self.device_table(ctx)
         r_use, M_use = np.atleast_1d(r).astype(np.float64), np.atleast_1d(M).astype(np.float64)
         a_use = np.atleast_1d(a)
         z_use = 1 / a_use - 1

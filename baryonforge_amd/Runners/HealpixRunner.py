@@ -23,6 +23,7 @@ geometry, the regrid): `_callable_batches`.
 import numpy as np
 
 from ..background import Background, MassDef
+from .._lib import BFG_MAX_EXTRA
 from ..engine import emit_fallback_warning, emit_range_warnings, get_context
 from ..utils.Tabulate import ParamTabulatedProfile, _get_parameter
 from ..Profiles.BaryonCorrection import BaryonificationClass
@@ -169,9 +170,13 @@ class PaintProfilesShell(DefaultRunner):
                 raise TypeError(f"PaintProfilesShell needs a tabulated model (TabulatedProfile / ParamTabulatedProfile with "
                                 f"raw_input_2D) or an object with a .projected(cosmo, r, M, a) method; got {type(self.model)}")
             self._callable_model = True                                   # (no p_keys here: :436-443 asserted above)
+        elif len(keys) > BFG_MAX_EXTRA and callable(getattr(self.model, "projected", None)):
+            # a table with more p_keys axes than the kernels read (Tabulate.py:497-650 is N-dimensional): its .projected -- scipy's
+            # N-linear interpolation on the host, as in the reference -- is evaluated per halo like any other callable
+            self._callable_model = True
         return keys
 
-    def _paint_callable(self, d_map, fresh):
+    def _paint_callable(self, d_map, fresh, keys=()):
         """HealpixRunner.py:449-481 with `Baryons.projected` called per halo on the host (it is a Python callable): the GPU lists
         every disc's pixels and distances and adds the returned values to the map"""
         ctx = get_context()
@@ -189,7 +194,8 @@ class PaintProfilesShell(DefaultRunner):
             for j in range(counts.size):                                  # (an empty disc still gets its call, as in the reference)
                 sl = slice(base[j], base[j] + counts[j])
                 M_j, a_j = cat["M"][j0 + j], 1 / (1 + cat["z"][j0 + j])
-                Paint = np.asarray(self.model.projected(self.cosmo, r_com[sl], M_j, a_j), dtype=np.float64).reshape(-1)   # :472
+                o_j = {key: cat[key][j0 + j] for key in keys}             # :456
+                Paint = np.asarray(self.model.projected(self.cosmo, r_com[sl], M_j, a_j, **o_j), dtype=np.float64).reshape(-1)   # :472
                 Paint = np.where(np.isfinite(Paint), Paint, 0)            # :473
                 if self.include_pixel_size:
                     Paint = Paint * (pixarea * D[j] ** 2)                 # :478
@@ -212,7 +218,7 @@ class PaintProfilesShell(DefaultRunner):
         keys = self._validated_keys()
         if self._callable_model:
             fresh = d_map is None or bool(overwrite)
-            d_map = self._paint_callable(d_map, fresh)
+            d_map = self._paint_callable(d_map, fresh, keys)
             if on_slice is not None:                                      # nothing to cut: the whole map as one slice
                 on_slice(0, 1, 0, int(d_map.numel()))
             return d_map
@@ -400,9 +406,11 @@ class BaryonifyShell(DefaultRunner):
                 raise TypeError(f"BaryonifyShell needs a BaryonificationClass model with a displacement table, or an object "
                                 f"with a .displacement(r, M, a) method; got {type(self.model)}")
             self._callable_model = True
+        elif len(keys) > BFG_MAX_EXTRA and callable(getattr(self.model, "displacement", None)):
+            self._callable_model = True                                   # more p_keys axes than the kernels read: per halo on the host
         return keys
 
-    def _offsets_callable(self):
+    def _offsets_callable(self, keys=()):
         """HealpixRunner.py:313-355 with `model.displacement` called per halo on the host (a Python callable): the GPU lists every
         disc's pixels and distances (with the < 4 pixel rule) and turns the returned displacements into unit-vector offsets"""
         ctx = get_context()
@@ -417,7 +425,8 @@ class BaryonifyShell(DefaultRunner):
                     continue
                 sl = slice(base[j], base[j] + counts[j])
                 M_j, a_j = cat["M"][j0 + j], 1 / (1 + cat["z"][j0 + j])
-                disp[sl] = np.asarray(self.model.displacement(r_com[sl], M_j, a_j), dtype=np.float64).reshape(-1)      # :345
+                o_j = {key: cat[key][j0 + j] for key in keys}             # :322
+                disp[sl] = np.asarray(self.model.displacement(r_com[sl], M_j, a_j, **o_j), dtype=np.float64).reshape(-1)   # :345
             ctx.offsets_add_displacements(args, spline, pix, halo, ctx.to_device(disp), d_off)                       # :345-355
             total += int(r_com.size)
         self.last_stats = dict(ctx.stats(), pixel_updates=total)
@@ -430,7 +439,7 @@ class BaryonifyShell(DefaultRunner):
         enqueued; lo / hi are ELEMENT indices of the flattened field (3 per pixel)."""
         keys = self._checked_model_keys()
         if self._callable_model:
-            d_off = self._offsets_callable()
+            d_off = self._offsets_callable(keys)
             if on_slice is not None:                                      # nothing to cut: the whole field as one slice
                 on_slice(0, 1, 0, int(d_off.numel()), d_off.view(-1))
             return d_off

@@ -85,12 +85,40 @@ class _TabulatedBase(object):
                 return np.log(raw)
         return ctx.table(self._axes(), log_table, log_values=True, cache_key=key)
 
+    def _host_interpolator(self, which):
+        """scipy RegularGridInterpolator over ln(raw_input_<which>) -- literally what the reference builds (Tabulate.py:270-271,
+        :585-590).  Only for tables with more axes than the device read-out takes (BFG_MAX_DIM = 6, i.e. more than three p_keys):
+        such a model runs through the runners' callable-model path, evaluated per halo on the host like any other callable."""
+        from scipy import interpolate
+        raw = self.raw_input_2D if which == "2D" else self.raw_input_3D
+        hit = getattr(self, "_host_interp_cache", {}).get(which)
+        if hit is None or hit[0] is not raw:
+            with np.errstate(all="ignore"):
+                f = interpolate.RegularGridInterpolator(tuple(self._axes()), np.log(raw), bounds_error=False, fill_value=np.nan)
+            self._host_interp_cache = dict(getattr(self, "_host_interp_cache", {}), **{which: (raw, f)})
+            hit = (raw, f)
+        return hit[1]
+
     def _readout(self, r, M, a, which, **kwargs):
         """Tabulate.py:279-327 / :598-650 on the GPU."""
+        from .. import _lib
+        r_use, M_use = np.atleast_1d(r).astype(np.float64), np.atleast_1d(M).astype(np.float64)
+        if len(self._axes()) > _lib.BFG_MAX_DIM:
+            f = self._host_interpolator(which)
+            prof = np.zeros([M_use.size, r_use.size])
+            with np.errstate(all="ignore"):
+                cols = [np.log(1 / a) * np.ones_like(r_use), None, np.log(r_use)] + [kwargs[k] * np.ones_like(r_use) for k in self.p_keys]
+                for i in range(M_use.size):
+                    cols[1] = np.log(M_use[i]) * np.ones_like(r_use)
+                    prof[i] = np.exp(f(np.stack(cols, axis=1)))
+            if np.ndim(r) == 0:
+                prof = np.squeeze(prof, axis=-1)
+            if np.ndim(M) == 0:
+                prof = np.squeeze(prof, axis=0)
+            return prof
         from ..engine import get_context
         ctx = get_context()
         table = self.device_table(ctx, which)
-        r_use, M_use = np.atleast_1d(r).astype(np.float64), np.atleast_1d(M).astype(np.float64)
         prof = np.zeros([M_use.size, r_use.size])
         with np.errstate(all="ignore"):
             z_in = np.log(1 / a) * np.ones_like(r_use)

@@ -43,7 +43,8 @@ typedef enum {
     BFG_ERR_COMM = -6          /* RCCL missing or a collective failed; see bfg_last_error() */
 } bfg_status;
 
-#define BFG_MAX_DIM 6          /* (ln(1+z), ln M, ln r) + up to 3 extra p_keys axes    */
+#define BFG_MAX_DIM 6          /* (ln(1+z), ln M, ln r) + up to 3 extra p_keys axes: what the kernels read; wider tables
+                                * are read out per halo on the host and enter through bfg_disc_enumerate / bfg_map_add_values */
 #define BFG_MAX_EXTRA (BFG_MAX_DIM - 3)
 
 typedef struct bfg_ctx bfg_ctx;        /* one per GPU / stream                         */

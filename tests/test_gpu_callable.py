@@ -98,3 +98,40 @@ def test_callable_model_argument_checks(cosmo):
         bfg.BaryonifyShell(Cat, Shell, 5, AnalyticPressure(), verbose=False).process()
     with pytest.raises(AssertionError):
         bfg.PaintProfilesShell(Cat, Shell, 5, None, verbose=False).process()
+
+
+def test_tables_with_more_than_three_extra_axes_run_per_halo_on_the_host(cosmo):
+    """ParamTabulatedProfile / BaryonificationClass are N-dimensional in the reference (utils/Tabulate.py:497-650,
+    BaryonCorrection.py:211-227); the kernels read at most three p_keys axes (BFG_MAX_EXTRA).  A table with four goes through the
+    callable-model path: its .projected / .displacement -- scipy's N-linear interpolation on the host, as in the reference -- is
+    evaluated per halo, the geometry and the scatter-add stay on the GPU.  Against the oracle's own N-linear loops."""
+    from util import oracle_baryonify, oracle_paint
+    nside, n, eps = 128, 300, 6.0
+    ra, dec, M, z = syn.catalog(n, seed=77, logM=(13.0, 15.3))
+    rng = np.random.default_rng(8)
+    p = [rng.uniform(0.7, 1.4, n), rng.uniform(-1.0, 2.0, n), rng.uniform(10.0, 20.0, n), rng.uniform(0.0, 1.0, n)]
+    ax = [np.array([0.6, 1.0, 1.5]), np.array([-1.5, 0.0, 2.5]), np.array([5.0, 25.0]), np.array([-0.5, 0.5, 1.5])]
+    f4 = ((1.0 + 0.3 * (ax[0] - 1.0))[:, None, None, None] * (1.0 + 0.05 * ax[1] ** 2)[None, :, None, None]
+          * (ax[2] / 10.0)[None, None, :, None] * (1.0 + 0.2 * ax[3])[None, None, None, :])
+    zax, Max, rax, T = syn.pressure_table(3, 8, 60)
+    T7 = T[..., None, None, None, None] * f4[None, None, None]
+    keys = ["pa", "pb", "pc", "pd"]
+    extra = np.stack(p, 1)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo, **dict(zip(keys, p)))
+    ref, ptot = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax, *ax), T7, nside, eps, extra=extra)
+    model = bfg.ParamTabulatedProfile.from_arrays(zax, Max, rax, T7, other_params=dict(zip(keys, ax)))
+    R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), eps, model, verbose=False)
+    got = R.process()
+    assert R.last_stats["pixel_updates"] == ptot and np.array_equal(got != 0, ref != 0)
+    assert_maps_close(got, ref, 1e-9, what="paint, four extra table axes")
+
+    zd, Md, rd, d = syn.displacement_table(3, 8, 60)
+    d7 = d[..., None, None, None, None] * f4[None, None, None]
+    m_in = syn.mass_map(nside)
+    refb = oracle_baryonify(cosmo, ra, dec, M, z, (zd, Md, rd, *ax), d7, nside, eps, 20, m_in, extra=extra)
+    bm = bfg.Baryonification2D.from_arrays(zd, Md, rd, d7, cosmo, epsilon_max=20, other_params=dict(zip(keys, ax)))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gotb = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo), eps, bm, verbose=False).process()
+    assert_maps_close(gotb, refb, 1e-5, floor=1e-9, what="baryonify, four extra table axes")
