@@ -15,6 +15,8 @@ run "BFG_TILE_KERNEL=wave" 45 3006
 run "BFG_TILE_LIGHT=1" 90 3008
 run "BFG_TILE_LIGHT=0 BFG_ITEM_COUNTERS=1" 60 3009
 run "BFG_ITEM_COUNTERS=16 BFG_REGRID=full" 45 3010
+echo "== callable models" >> $O
+timeout -k 10 200 python3 tests/soak/soak_callable.py 60 $(( 3011 + ${SOAK_SEED:-0} )) 2>&1 | grep -v "^ok\|amdgpu.ids" | tail -3 >> $O
 echo "== aux (snapshot / deposit / grid)" >> $O
 timeout -k 10 200 python3 tests/soak/soak_aux.py 60 3007 2>&1 | grep -v "^ok\|amdgpu.ids" | tail -3 >> $O
 cat $O
