@@ -1708,9 +1708,20 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     bool overwrite = (a->flags & BFG_SHELL_OUT_OVERWRITE) != 0;
     bool out_zero = (a->flags & BFG_SHELL_OUT_IS_ZERO) != 0;
     const int64_t out_elems = (int64_t)(out_bytes / sizeof(double));
-    // a call that is not cut into slices (no halos, scatter variants, the wave kernel) reports the whole output as one slice
+    // The slices of a sliced call are a function of (nside, mode, n_slices) ONLY -- never of the catalog: the ranks of a process group
+    // issue one collective per callback, so a rank with an empty shard (or one whose call takes a scatter variant) must report the
+    // same K ranges as its peers.  The cuts are runs of whole bands of the tile geometry (contiguous RING pixel ranges).
+    const int slice_tr = (mode == MODE_PAINT) ? TileCfg<MODE_PAINT>::TR : TileCfg<MODE_BARYONIFY>::TR;
+    const int slice_nbands = (int)((4 * a->nside - 1 + slice_tr - 1) / slice_tr);
+    const int slice_K = slice_fn ? std::max(1, std::min(std::min(n_slices, kMaxSlices), slice_nbands)) : 0;
+    int64_t slice_elem[kMaxSlices + 1];
+    for (int k = 0; slice_K > 0 && k <= slice_K; ++k)
+        slice_elem[k] = (mode == MODE_PAINT ? 1 : 3) * ring_first_pixel(a->nside, 1 + ((int64_t)slice_nbands * k / slice_K) * slice_tr);
+    // a call whose kernels are not launched per slice (no halos, scatter variants, the wave kernel) reports the same K ranges, all
+    // of them final once the stream gets there
     auto whole_output = [&]() -> int {
-        if (slice_fn && slice_fn(slice_user, 0, 1, 0, out_elems) != 0) { g_last_error = "the slice callback failed"; return BFG_ERR_INVALID; }
+        for (int k = 0; k < slice_K; ++k)
+            if (slice_fn(slice_user, k, slice_K, slice_elem[k], slice_elem[k + 1]) != 0) { g_last_error = "the slice callback failed"; return BFG_ERR_INVALID; }
         return BFG_OK;
     };
     if (a->n_halo == 0) {
@@ -1884,17 +1895,15 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         // sliced call: cut the tiles into n_slices runs of whole bands (contiguous ring ranges = contiguous RING pixel ranges)
         SliceCuts cuts;
         std::memset(&cuts, 0, sizeof(cuts));
-        int64_t slice_elem[kMaxSlices + 1];
         const bool wave_requested = use_wave && win_nodes == kWinLds && !win_table;
-        if (slice_fn && n_slices > 1 && persist > 0 && !wave_requested) {
-            const int K = std::min(std::min(n_slices, kMaxSlices), ts.geo.nbands);
-            const int per = (mode == MODE_PAINT) ? 1 : 3;
+        if (slice_fn && slice_K > 1 && persist > 0 && !wave_requested) {
+            const int K = slice_K;
+            if (ts.geo.nbands != slice_nbands || ts.geo.tr != slice_tr) { g_last_error = "slice cuts: tile geometry mismatch"; return BFG_ERR_INVALID; }
             int b = 0, tile0 = 0;
             for (int k = 0; k <= K; ++k) {
                 const int bk = (int)((int64_t)ts.geo.nbands * k / K);
                 for (; b < bk; ++b) tile0 += band_sectors_host(a->nside, ts.geo.tr, ts.geo.tw, b);
                 cuts.tile[k] = tile0;
-                slice_elem[k] = per * ring_first_pixel(a->nside, 1 + (int64_t)bk * ts.geo.tr);
             }
             if (cuts.tile[K] != ts.geo.ntiles) { g_last_error = "slice cuts do not cover the tiles"; return BFG_ERR_INVALID; }
             cuts.n = K; cuts.range = ts.d_slices;
@@ -1981,9 +1990,13 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         if (cuts.n > 0) {
             // sliced: left-overs first (into a cleared output, if there are any), then one tile launch per slice, each followed by
             // the caller's callback -- which typically starts the exchange of that part of the output on another stream
-            hipLaunchKernelGGL(out_clear_if_left_kernel, dim3((unsigned)(4 * c->n_cu)), dim3(256), 0, c->stream, d_out, out_elems,
-                               pp.left_n, ts.d_tile_start + ts.geo.ntiles, (long long)c->pair_cap);
-            HIP_TRY(hipGetLastError());
+            // (only an output the call DEFINES is cleared: without BFG_SHELL_OUT_OVERWRITE the scatter kernel and the tiles add to what
+            // the caller's buffer holds -- accumulate INTO -- or to the zeros the caller vouched for)
+            if (overwrite) {
+                hipLaunchKernelGGL(out_clear_if_left_kernel, dim3((unsigned)(4 * c->n_cu)), dim3(256), 0, c->stream, d_out, out_elems,
+                                   pp.left_n, ts.d_tile_start + ts.geo.ntiles, (long long)c->pair_cap);
+                HIP_TRY(hipGetLastError());
+            }
             rc = launch_scatter();
             if (rc) return rc;
             tp.accum_left = pp.left_n;

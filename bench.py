@@ -3,19 +3,24 @@
 bench.py -- headline benchmark of the MI355X shell-paint hot path (BASELINE.json metric:
 halos/s + achieved HBM GB/s, NSIDE = 1024 shell, 1e6 halos, at 1/2/4/8 GPUs).
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          # any N: for N > 1 the process spawns its own N ranks (below)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--collective torch|bfg]
-         [--exchange allreduce|owner|auto]
+         --master-port P bench.py --gpus N --steps K --warmup W [--scaling strong|weak] [--collective torch|bfg]
+         [--exchange allreduce|owner|auto] [--legs auto|none|weak,owner,configs3]
+
+Launch.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) every process is one rank.  Started as plain
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE, the process becomes a LAUNCHER: before anything touches the GPU (it
+imports neither torch nor the library) it starts N fresh child processes of this file with RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_ADDR=127.0.0.1 / MASTER_PORT set, relays rank 0's JSON line, and exits non-zero with one line if a child does (the
+survivors are killed by PID).  Nothing is ever exec'd, and no process that has initialised the GPU starts another.
 
 One "step" = one full pass of the hot path over one synthetic catalog that is already
 resident in HBM as float64 (M, z, ra, dec) records: halo preparation + binning kernels, row windows,
 shell paint kernel (which also defines the pixels no halo touches: the map buffer is not cleared beforehand),
-and -- for N > 1 -- the RCCL all-reduce of the per-rank maps.
---scaling weak (default): every rank paints its own sky-patch shard (sharding.shard_by_sky_patch) of a catalog of
-`--halos` halos PER GPU (N x halos in total); --scaling strong: `--halos` halos IN TOTAL, cut into N shards (how
-BASELINE.json's metric reads: one 1e6-halo catalog at 1/2/4/8 GPUs).  Either way value = all halos painted by all ranks
-/ max-over-ranks time, and the N = 1 run is the same workload.
+and -- for N > 1 -- the exchange that joins the per-rank maps (RCCL all-reduce by default).
+--scaling strong (default: how BASELINE.json's metric reads -- ONE 1e6-halo catalog at 1/2/4/8 GPUs): `--halos` halos IN
+TOTAL, cut into N sky-patch shards (sharding.shard_by_sky_patch); --scaling weak: `--halos` halos PER GPU (N x halos in
+total).  Either way value = all halos painted by all ranks / max-over-ranks time, and the N = 1 run is the same workload.
 --collective torch (default): torch.distributed's all_reduce (backend nccl = RCCL), asynchronous on RCCL's stream;
 --collective bfg: the library's own RCCL communicator (bfg_allreduce_f64_begin / bfg_comm_wait(ticket) of include/bfg_mi355.h).
 For N > 1 the paint workload runs through the PRODUCT API: the K timed steps are K shell runners handed as a list to
@@ -23,19 +28,26 @@ baryonforge_amd.SplitJoinParallel (utils/Parallelize.py), which paints shell k +
 flight (two rotating map buffers) and hands every map to the all-reduce in --slices pieces as the tile kernel finishes them
 (bfg_paint_shell_sliced).  `api_single_call_ms` = one SplitJoinParallel(runner).process_device() on its own (nothing to
 overlap with but its own slices; `api_single_call_unsliced_ms`: one all-reduce after the call).
+The main number is the robust one (strong scaling, all-reduce).  After it has been measured the run adds EXTRA LEGS
+(`legs` in the line; --legs) -- the weak-scaling run, the owner-computes join (half the bytes), and BASELINE configs[3]
+(BaryonifyShell, NSIDE 2048, 1.25e6 halos per GPU) -- each guarded: a leg that fails, or hangs past
+BFG_BENCH_LEGS_DEADLINE_S (default 240 s), is recorded as an error and the main line is printed all the same, exit 0.
 Before the W warm-up steps the run executes BFG_BENCH_RAMP_S (default 0.25 s) of the very same steps (`ramp_steps` in the line):
 an idle MI355X needs ~50 ms of load to reach its sustained clocks, W = 5 steps are 6 ms of it.
 The run exits non-zero with a one-line reason -- it never hangs -- when fewer than N GPUs are visible, when RCCL cannot be
 loaded, when a rank fails (collective timeout BFG_BENCH_TIMEOUT_S, default 180 s) or when the whole run exceeds
-BFG_BENCH_DEADLINE_S (default 1500 s).
+BFG_BENCH_DEADLINE_S (default 1500 s; a watchdog THREAD, so it also fires while the main thread sits in a HIP / RCCL call).
 
 Rank 0 prints ONE JSON line (see the contract in the task statement) with these extra objects:
   "roofline":     algorithmic bytes of the dominant kernel / its mean duration (HIP events on the
                   kernel's own stream, live in this process) against the 8 TB/s HBM peak
   "cpu_baseline": the CPU oracle (a C port of the reference loop; kind "port") timed on this
                   box's host cores on a bounded sample of the same workload (N = 1 only)
-  "ranks":        N > 1: per-rank shard size, compute-only ms, collective-only ms and how much of the collective
-                  the overlap hid (measured in two extra untimed legs after the timed region)
+  "ranks":        N > 1: per-rank shard size, compute-only ms, collective-only ms, how much of the collective
+                  the overlap hid (measured in two extra untimed legs after the timed region) and the rank's own roofline
+  "rccl_ranks":   N > 1: the number of ranks that took part in an RCCL all-reduce of ones on the GPUs (0 in a gloo rehearsal)
+  "vs_n1":        N > 1: value / the N = 1 value of the same `--halos` catalog, measured on rank 0's GPU in this run
+  "legs":         the guarded extra legs
 """
 import argparse
 import json
@@ -61,8 +73,13 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--halos", type=int, default=1_000_000, help="halos per GPU (weak scaling) / in total (strong scaling)")
-    p.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    p.add_argument("--halos", type=int, default=1_000_000, help="halos in total (strong scaling, the default) / per GPU (weak scaling)")
+    p.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                   help="strong (default; BASELINE's metric): --halos halos in total at every N; weak: --halos per GPU")
+    p.add_argument("--legs", default="auto",
+                   help="guarded extra legs after the main measurement, comma separated: weak (weak-scaling run), owner (owner-computes "
+                        "join), configs3 (BaryonifyShell NSIDE 2048, 1.25e6 halos per GPU); auto = all three for N > 1 on the default "
+                        "paint workload, configs3 alone at N = 1; none = no legs")
     p.add_argument("--collective", choices=["torch", "bfg"], default="torch")
     p.add_argument("--slices", type=int, default=4, help="N > 1: pieces in which a painted map is handed to the all-reduce")
     p.add_argument("--layout", choices=["interleaved", "contiguous"], default="interleaved", help="sky-patch sharding layout")
@@ -210,14 +227,120 @@ def agree(dist, ok, reason, backend):
         die(reason if not ok else "another rank failed during set-up (see its message)")
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# Launcher: `python bench.py --gpus N` (N > 1) without WORLD_SIZE.  Standard library only -- this process never imports torch
+# or the HIP library, so it never initialises the GPU; the ranks are fresh children, nothing is exec'd.
+def spawn_ranks(n, argv, script=None, python=None, extra_env=None, deadline=None, grace=8.0, out=None, err=None):
+    """start n children `python script argv...` with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relay rank 0's stdout to
+    `out` (the other ranks' stdout goes to `err`: only rank 0 prints the line), wait.  Returns the exit code: 0 if every child
+    exited 0; otherwise the first failing child's code -- after one line on `err` -- with the survivors given `grace` seconds to
+    fail by themselves (they learn of a failed peer through the group) and then killed by PID."""
+    import socket
+    import subprocess
+    import threading
+    out, err = out or sys.stdout, err or sys.stderr
+    script, python = script or os.path.abspath(__file__), python or sys.executable
+    deadline = deadline if deadline is not None else float(os.environ.get("BFG_BENCH_DEADLINE_S", "1500")) + 60.0
+    with socket.socket() as sk:                                   # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs, relays = [], []
+
+    def relay(src, dst):
+        for line in iter(src.readline, b""):
+            dst.write(line.decode(errors="replace"))
+            dst.flush()
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BFG_BENCH_SPAWNED="1", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1"))
+        env.update(extra_env or {})
+        pr = subprocess.Popen([python, script] + list(argv), env=env, stdout=subprocess.PIPE, stderr=None)
+        procs.append(pr)
+        t = threading.Thread(target=relay, args=(pr.stdout, out if r == 0 else err), daemon=True)
+        t.start()
+        relays.append(t)
+    t0, failed, t_fail = time.monotonic(), None, None
+    while True:
+        codes = [pr.poll() for pr in procs]
+        if failed is None:
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed, t_fail = bad[0], time.monotonic()
+        if all(c is not None for c in codes):
+            break
+        if failed is not None and time.monotonic() - t_fail > grace:
+            break
+        if time.monotonic() - t0 > deadline:
+            failed = failed or (-1, 3)
+            break
+        time.sleep(0.05)
+    for pr in procs:                                              # exact PIDs of our own children, never a pattern
+        if pr.poll() is None:
+            pr.kill()
+    for pr in procs:
+        pr.wait()
+    for t in relays:
+        t.join(timeout=5.0)
+    if failed is None:
+        return 0
+    r, c = failed
+    what = f"deadline of {deadline:.0f} s exceeded" if r < 0 else f"rank {r} exited with code {c}"
+    print(f"bench.py: FAILED (launcher, {n} ranks): {what}", file=err, flush=True)
+    return c if isinstance(c, int) and 0 < c < 256 else 1
+
+
+class Watchdog(object):
+    """The run's deadline as a daemon THREAD.  A Python-level SIGALRM handler only runs when the main thread returns to the
+    interpreter -- never while it is blocked in hipStreamSynchronize / an RCCL call, which is exactly where a wedged peer leaves it --;
+    a timer thread gets the GIL (those calls release it), writes one line and ends the process with os._exit.  `arm(seconds, fn)`
+    replaces the pending deadline; fn() decides what to print and returns the exit code."""
+
+    def __init__(self):
+        import threading
+        self._threading = threading
+        self._timer = None
+
+    def arm(self, seconds, fn):
+        self.disarm()
+
+        def fire():
+            try:
+                code = fn()
+            except BaseException:
+                code = 3
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(code)
+        self._timer = self._threading.Timer(seconds, fire)
+        self._timer.daemon = True
+        self._timer.start()
+
+    def disarm(self):
+        if self._timer is not None:
+            self._timer.cancel()
+            self._timer = None
+
+
+WATCHDOG = Watchdog()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (no GPU call has happened or will happen in this process)
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     import datetime
-    import signal
     # the whole run has a deadline: a wedged collective or GPU ends as an error line, not as a hang
     deadline = int(os.environ.get("BFG_BENCH_DEADLINE_S", "1500"))
-    signal.signal(signal.SIGALRM, lambda *_: die(f"deadline of {deadline} s exceeded", 3))
-    signal.alarm(deadline)
+
+    def overdue():
+        print(f"bench.py: FAILED (rank {os.environ.get('RANK', '0')}): deadline of {deadline} s exceeded", file=sys.stderr, flush=True)
+        return 3
+    WATCHDOG.arm(deadline, overdue)
+    if os.environ.get("BFG_BENCH_TEST_STALL"):                   # rehearsal of the deadline (profiles/r04_bench_failure_modes.txt):
+        if int(os.environ.get("RANK", "0")) == int(os.environ["BFG_BENCH_TEST_STALL"]):   # this rank blocks in a C call, GIL released
+            import ctypes
+            ctypes.CDLL(None).sleep(10 ** 6)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -227,8 +350,8 @@ def main():
     backend = os.environ.get("BFG_BENCH_BACKEND", "nccl")
     one_device = bool(os.environ.get("BFG_BENCH_ONE_DEVICE"))
     if world != args.gpus:
-        die(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with python -m torch.distributed.run --nproc-per-node "
-            f"{args.gpus} (N > 1) or plain python (N = 1)")
+        die(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with plain python (any N: bench.py spawns its ranks) or with "
+            f"python -m torch.distributed.run --nproc-per-node {args.gpus}")
     n_dev = torch.cuda.device_count()            # counts devices without initialising the runtime
     if n_dev < (1 if one_device else world):
         die(f"{n_dev} GPU(s) visible, {world} needed (one process per GPU)")
@@ -267,11 +390,112 @@ def main():
         import traceback
         traceback.print_exc()
         die(f"{type(exc).__name__}: {str(exc).splitlines()[0] if str(exc) else ''}")
+    WATCHDOG.disarm()
+
+
+LEG_ARGS = {
+    # name: overrides of the parsed arguments (the main run is strong scaling, all-reduce, the headline paint workload)
+    "weak": dict(scaling="weak", exchange="allreduce"),                       # --halos per GPU: the all-reduce hides behind the painting
+    "owner": dict(exchange="owner"),                                          # the owner-computes join: half the bytes of the all-reduce
+    "configs3": dict(workload="baryonify", nside=2048, halos=1_250_000, scaling="weak", exchange="allreduce",   # BASELINE configs[3]:
+                     table="default", steep=False, eps=10.0),                 # 1e7 halos over 8 GPUs = 1.25e6 per GPU
+}
 
 
 def _main(args, torch, dist, rank, local_rank, world, backend):
-
+    """the main measurement (-> the line's top-level fields), then the guarded extra legs, then rank 0 prints the ONE line"""
+    import copy
     _mark("process group up")
+    # how many ranks RCCL itself connects: an all-reduce of ones on the GPUs through the nccl (= RCCL) backend
+    rccl = {"rccl_ranks": 0 if world > 1 else None, "backend": backend if world > 1 else None, "rccl_version": None}
+    if dist is not None and backend == "nccl":
+        one = torch.ones(1, dtype=torch.float64, device="cuda")
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        rccl["rccl_ranks"] = int(round(float(one.item())))
+        try:
+            rccl["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            pass
+    out = run_config(args, torch, dist, rank, local_rank, world, backend, main=True)
+    if rank == 0:
+        out.update(rccl)
+    # ---- guarded extra legs: whatever happens from here on, the main line above is printed and the run exits 0 -----------
+    if args.legs == "auto":
+        default_paint = args.workload == "paint" and args.nside == 1024 and args.table == "default" and not args.steep
+        legs = (["weak", "owner", "configs3"] if world > 1 else ["configs3"]) if default_paint else []
+    else:
+        legs = [x for x in args.legs.split(",") if x and x != "none"]
+    unknown = [x for x in legs if x not in LEG_ARGS]
+    if unknown:
+        die(f"unknown --legs entries {unknown}; known: {sorted(LEG_ARGS)}")
+    if world == 1:
+        legs = [x for x in legs if x == "configs3"]                # the other two are the main run itself at N = 1
+    done = {}
+
+    def emit(note=None):
+        if rank == 0:
+            out["legs"] = dict(done)
+            if note:
+                out["legs"]["_aborted"] = note
+            print(json.dumps(out), flush=True)
+
+    def legs_overdue():
+        emit(f"the extra legs exceeded BFG_BENCH_LEGS_DEADLINE_S = {legs_deadline:g} s; the main measurement above is complete")
+        return 0
+    legs_deadline = float(os.environ.get("BFG_BENCH_LEGS_DEADLINE_S", "240"))
+    if legs:
+        WATCHDOG.arm(legs_deadline, legs_overdue)
+    try:
+        for name in legs:
+            largs = copy.copy(args)
+            for k, v in LEG_ARGS[name].items():
+                setattr(largs, k, v)
+            if name == "owner" and (12 * largs.nside ** 2) % world:
+                done[name] = {"error": "12 NSIDE^2 does not divide by the number of ranks"}
+                continue
+            t0 = time.perf_counter()
+            try:
+                res = run_config(largs, torch, dist, rank, local_rank, world, backend, main=False)
+                if rank == 0:
+                    done[name] = leg_summary(res, time.perf_counter() - t0)
+                del res
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
+            except BaseException as exc:       # a failing leg is recorded; the peers of a rank that failed alone end at the legs' deadline
+                if isinstance(exc, (SystemExit, KeyboardInterrupt)):
+                    raise
+                done[name] = {"error": f"{type(exc).__name__}: {str(exc).splitlines()[0] if str(exc) else ''}"}
+                break                          # the ranks may be out of step now: no further collective
+    finally:
+        WATCHDOG.disarm()
+    emit()
+    if dist is not None:
+        WATCHDOG.arm(30.0, lambda: 0)                              # a destructor stuck on a dead peer does not keep the job alive
+        dist.destroy_process_group()
+        WATCHDOG.disarm()
+
+
+def leg_summary(res, wall_s):
+    """the compact record of one extra leg (the same measurement as the main line, fewer fields)"""
+    keep = ("value", "unit", "ms_per_step", "scaling", "steps", "ramp_steps")
+    o = {k: res[k] for k in keep}
+    o["workload"] = res["config"]["workload"]
+    o["halos_total"] = res["config"]["halos_total"]
+    o["sharding"] = res["config"]["sharding"]
+    rf = res["roofline"]
+    o["roofline"] = {k: rf[k] for k in ("kernel", "frac", "achieved", "kernel_ms", "algorithmic_bytes_per_launch", "regrid_kernel_ms",
+                                       "prep_kernel_ms", "step_frac")}
+    if res.get("ranks"):
+        o["ranks"] = [{k: r.get(k) for k in ("rank", "shard_halos", "compute_ms", "allreduce_ms", "overlap_ms", "kernel_ms",
+                                              "roofline_frac")} for r in res["ranks"]]
+        o["exchange"] = res.get("exchange")
+    o["leg_wall_s"] = wall_s
+    return o
+
+
+def run_config(args, torch, dist, rank, local_rank, world, backend, main=True):
+    """one measured configuration: returns the line's dictionary on rank 0, None on the other ranks"""
     from baryonforge_amd import sharding, synthetic as syn
     from baryonforge_amd.background import Background
     from baryonforge_amd.engine import get_context
@@ -292,7 +516,8 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
         probe = ctypes.create_string_buffer(_lib.BFG_COMM_ID_BYTES)
         st = ctx.lib.bfg_comm_unique_id(probe, _lib.BFG_COMM_ID_BYTES)
         agree(dist, st == 0, f"RCCL unavailable: {ctx.lib.bfg_last_error().decode()} (status {st})", backend)
-        ctx.comm_init(dist)
+        if ctx.comm_world != world:
+            ctx.comm_init(dist)
 
     # this rank's sky-patch shard (the whole catalog at N = 1), resident in HBM before timing starts
     if world > 1:
@@ -544,10 +769,16 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
     if dist is not None:
         t_comp = timed(args.steps, collective=False) / args.steps * 1e3
         t_coll = timed(args.steps, do_compute=False) / args.steps * 1e3
+        rk_ms = k_ms / max(k_n, 1)
+        rk_bytes = 32.0 * idx.size + (16.0 if args.workload == "paint" else 48.0) * ptot_step
         mine = {"rank": rank, "shard_halos": int(idx.size), "pixel_updates_per_step": ptot_step,
-                "compute_ms": t_comp, "allreduce_ms": t_coll, "kernel_ms": k_ms / max(k_n, 1),
-                "prep_kernel_ms": p_ms / max(p_n, 1), "tile_binning_ms": (b_ms / b_n) if b_n else None}
-        if api is not None:
+                "compute_ms": t_comp, "allreduce_ms": t_coll, "kernel_ms": rk_ms,
+                "prep_kernel_ms": p_ms / max(p_n, 1), "tile_binning_ms": (b_ms / b_n) if b_n else None,
+                # this rank's own roofline: the algorithmic bytes of ITS shard / ITS dominant-kernel time
+                "roofline_bytes": rk_bytes, "roofline_GBps": rk_bytes / max(rk_ms * 1e-3, 1e-12) / 1e9,
+                "roofline_frac": rk_bytes / max(rk_ms * 1e-3, 1e-12) / HBM_PEAK,
+                "device": torch.cuda.get_device_name(), "device_index": torch.cuda.current_device()}
+        if api is not None and main:
             # one product call on its own: SplitJoinParallel(runner).process_device() -- painting + exchange of ONE shell, with
             # the map handed to the all-reduce in --slices pieces, and with a single all-reduce after the call
             def single(slices, reps=5):
@@ -569,10 +800,14 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
     else:
         ptot_all = ptot_step
 
+    # ---- N > 1, main run: the N = 1 value of the same `--halos` catalog, on this GPU, in this run (-> vs_n1) -------------
+    n1 = None
+    if main and dist is not None and args.workload == "paint":
+        if rank == 0:                            # (the other ranks' GPUs idle at the barrier: nothing shares rank 0's host thread or GPU)
+            n1 = n1_anchor(args, torch, ctx, syn, bg, cosmo, shape, md, (ra, dec, M, z) if args.scaling == "strong" else None)
+        barrier()
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
+        return None
 
     ms_per_step = dt / args.steps * 1e3
     value = n_total / (dt / args.steps)
@@ -627,8 +862,10 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
                 "step_frac": step_bytes / (dt / args.steps) / HBM_PEAK if world == 1 else None}
     sharding_txt = "none"
     if world > 1:
-        sharding_txt = (f"sky patch, layout {args.layout} (interleaved: nside-64 patches dealt round-robin in NEST order, every rank's "
-                        "shard covers the sky; contiguous: one compact region per rank; sorted by position) + "
+        owner_join = api is not None and mode["exchange"] == "owner"
+        sharding_txt = (("declination stripes of equal area (the RING-ordered form of a sky patch; sharding.shard_by_stripes) + " if owner_join else
+                         f"sky patch, layout {args.layout} (interleaved: nside-64 patches dealt round-robin in NEST order, every rank's "
+                         "shard covers the sky; contiguous: one compact region per rank; sorted by position) + ")
                         + (f"product API SplitJoinParallel over the list of {args.steps} shell runners: "
                            + ("declination-stripe shards, owner-computes join (border exchange + all-gather), overlapped with the next "
                               "shell (two map buffers)" if mode["exchange"] == "owner" else
@@ -659,7 +896,7 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
         for r in ranks:
             r["overlap_ms"] = max(0.0, r["compute_ms"] + r["allreduce_ms"] - ms_per_step)   # collective time hidden behind compute
         out["ranks"] = ranks
-        if api is not None:
+        if api is not None and main:
             out["api_single_call_ms"] = max(r["api_single_call_ms"] for r in ranks)
             out["api_single_call_unsliced_ms"] = max(r["api_single_call_unsliced_ms"] for r in ranks)
             out["slices"] = args.slices
@@ -667,13 +904,17 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
         sent = ((world - 1) / world * exchange_bytes + max(r.get("border_bytes_sent", 0) for r in ranks)) if owner_mode else \
             2.0 * (world - 1) / world * exchange_bytes
         out["exchange"] = {"mode": ("owner-computes: border exchange (point to point) + all-gather of the owned parts" if owner_mode
-                                    else "all-reduce of the replicated maps"),
+                                    else "all-reduce of the replicated maps" if args.workload == "paint" else
+                                    "reduce-scatter of the offset field (3 doubles per pixel) + all-reduce of the regridded map"),
                            "selfcheck": mode["selfcheck"] if api is not None else None,
                            "auto_trial_ms_per_shell": mode.get("trial_ms_per_shell"),
                            "bytes_per_rank_per_step": exchange_bytes, "bytes_sent_per_rank_per_step": sent, "backend": backend,
                            "collective": "bfg" if use_bfg else "torch",
                            "busbw_GBps": sent / max(max(r["allreduce_ms"] for r in ranks) * 1e-3, 1e-9) / 1e9}
-    if world == 1 and not args.no_e2e and args.workload == "paint":
+    if n1 is not None:
+        out["n1"] = n1
+        out["vs_n1"] = value / n1["value"] if n1.get("value") else None
+    if main and world == 1 and not args.no_e2e and args.workload == "paint":
         try:
             # the product API with everything left on the device: SplitJoinParallel over a list of shell runners (the call the
             # N > 1 runs time), here with a world of one -- what the Python layer adds to a resident-input step
@@ -701,14 +942,42 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
         except Exception as exc:                       # never lose the line to the side measurement
             out["e2e_ms_python_api"] = None
             out["e2e_error"] = repr(exc)
-    if world == 1 and not args.no_cpu_baseline and args.workload == "paint":
+    if main and world == 1 and not args.no_cpu_baseline and args.workload == "paint":
         out["cpu_baseline"] = cpu_baseline(args, cosmo, ra, dec, M, z, (zax, Max, rax), T)
         out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    return out
+
+
+def n1_anchor(args, torch, ctx, syn, bg, cosmo, shape, md, cat=None):
+    """what ONE GPU does with the whole `--halos` catalog (the N = 1 workload of this run), measured on this rank's GPU outside the
+    timed region: bfg_paint_shell on resident records, a clock ramp, then max(--steps, 5) steps between synchronisations"""
+    ra, dec, M, z = cat if cat is not None else syn.catalog(args.halos, seed=42, steep=args.steep)
+    nside, npix = args.nside, 12 * args.nside * args.nside
+    zax, Max, rax, T = syn.pressure_table(*shape)
+    with np.errstate(all="ignore"):
+        table = ctx.table([zax, Max, rax], np.log(T), log_values=True)
+    d_cat = ctx.to_device(np.stack([M, z, ra, dec], axis=1))
+    spline = ctx.da_spline(bg, float(np.max(z)))
+    sargs = ctx.shell_args(nside, d_cat, M.size, 4, 0, args.eps, md, variant=args.variant, out_overwrite=True)
+    d_map = ctx.empty(npix)
+    n = max(args.steps, 5)
+
+    def run(k):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            ctx.paint_shell(sargs, table, spline, d_map)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    t = run(n)
+    for _ in range(min(200, int(float(os.environ.get("BFG_BENCH_RAMP_S", "0.25")) / max(t, 1e-4)))):
+        run(n)
+    t = min(run(n), run(n))
+    del d_map, d_cat
+    return {"value": M.size / (t / n), "unit": "halos/s", "ms_per_step": t / n * 1e3, "halos": int(M.size),
+            "what": "the whole --halos catalog painted by rank 0's GPU alone (bfg_paint_shell, inputs resident), same run"}
 
 
 if __name__ == "__main__":

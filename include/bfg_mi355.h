@@ -291,10 +291,14 @@ int bfg_baryonify_offsets(bfg_ctx *ctx, const bfg_shell_args *args, const bfg_ta
  * contiguous RING pixel ranges, x 3 for the offset field) holds its final values, so the callback can start that part of the
  * exchange on another stream -- e.g. bfg_allreduce_f64_begin(ctx, d_out + elem_begin, elem_end - elem_begin, &ticket), which
  * replaces, slice by slice, the parent-side np.sum(outputs, axis=0) of utils/Parallelize.py:318 -- while the next slice is
- * painted.  The slices cover the output exactly once, in ascending order.  Calls that cannot be cut (no halos, the scatter
- * variants) report the whole output as one slice (slice 0 of 1) after their last launch.  A non-zero return of fn aborts the
- * call with BFG_ERR_INVALID.  Halos the tile path leaves to the scatter kernel are handled BEFORE the first slice (into a
- * cleared output, to which the tiles are then added), so every slice is final when it is reported.                    */
+ * painted.  The slices cover the output exactly once, in ascending order, and their number and ranges depend on (nside,
+ * which of the two loops, n_slices) ONLY -- never on the catalog: the ranks of a process group issue one collective per
+ * callback, so a rank whose shard is empty, or whose call cannot be cut (the scatter variants), reports the same ranges as
+ * its peers (all of them after its last launch).  A non-zero return of fn aborts the call with BFG_ERR_INVALID.  Halos the
+ * tile path leaves to the scatter kernel are handled BEFORE the first slice, so every slice is final when it is reported:
+ * with BFG_SHELL_OUT_OVERWRITE into an output the library clears first (the tiles are then added to it); without the flag
+ * they -- like the tiles -- are added to what the buffer holds (accumulate INTO; BFG_SHELL_OUT_IS_ZERO: to the zeros the
+ * caller vouched for).                                                                                                 */
 typedef int (*bfg_slice_fn)(void *user, int slice, int n_slices, int64_t elem_begin, int64_t elem_end);
 int bfg_paint_shell_sliced(bfg_ctx *ctx, const bfg_shell_args *args, const bfg_table *table,
                            const bfg_spline *da_spline, double *d_map, int n_slices, bfg_slice_fn fn, void *user);

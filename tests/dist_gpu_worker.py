@@ -29,6 +29,11 @@ def inputs():
     return dict(cosmo=dict(syn.COSMO), ra=ra, dec=dec, M=M, z=z, paint=(zax, Max, rax, T), disp=(dz, dM, dr, dtab), m_in=m_in)
 
 
+def north_mask(I, n=1200):
+    """the first n halos north of dec = +10 deg"""
+    return np.flatnonzero(I["dec"] > 10.0)[:n]
+
+
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--rank", type=int, required=True)
@@ -98,6 +103,24 @@ def main():
             warnings.simplefilter("ignore")
             bout = bfg.SplitJoinParallel(BR, collective=coll).process()
         np.save(os.path.join(a.out, f"bary_{coll}_{a.rank}.npy"), bout)
+    # one rank's shard EMPTY (a partial-sky catalog cut into declination stripes: every halo north of dec = +10 deg, so rank 1 of 2
+    # gets none): the sliced exchange must still issue the same collectives on both ranks (bfg_*_sliced reports slices that do
+    # not depend on the catalog)
+    nn = north_mask(I)
+    ncat = bfg.HaloLightConeCatalog(I["ra"][nn], I["dec"][nn], I["M"][nn], I["z"][nn], cosmo)
+    for coll in collectives:
+        R = bfg.PaintProfilesShell(ncat, bfg.LightconeShell(map=np.zeros(npix), cosmo=cosmo), EPS,
+                                   bfg.TabulatedProfile.from_arrays(zax, Max, rax, T), verbose=False)
+        SJ = bfg.SplitJoinParallel(R, collective=coll, layout="stripes", slices=4)
+        info[f"north_{coll}_shard"] = int(SJ.shard_indices.size)
+        np.save(os.path.join(a.out, f"north_paint_{coll}_{a.rank}.npy"), SJ.process())
+        dz, dM, dr, dtab = I["disp"]
+        BR = bfg.BaryonifyShell(ncat, bfg.LightconeShell(map=I["m_in"].copy(), cosmo=cosmo), EPS,
+                                bfg.Baryonification2D.from_arrays(dz, dM, dr, dtab, cosmo, epsilon_max=20), verbose=False)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            bout = bfg.SplitJoinParallel(BR, collective=coll, layout="stripes", slices=4).process()
+        np.save(os.path.join(a.out, f"north_bary_{coll}_{a.rank}.npy"), bout)
     from baryonforge_amd import _lib
     info["so"] = _lib.so_path()
     info["maps"] = [m.split()[-1] for m in open("/proc/self/maps") if "libbfg_mi355" in m][:1]

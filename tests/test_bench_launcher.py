@@ -1,0 +1,109 @@
+"""
+bench.py as its own launcher (`python bench.py --gpus N`, N > 1, no WORLD_SIZE): the parent spawns N fresh ranks before any GPU
+call, relays rank 0's line and fails with one line when a rank does -- plus the deadline watchdog, which must fire while the
+main thread is blocked in a C call.  CPU only: the ranks here are stub scripts (or bench.py itself refusing to run without GPUs).
+"""
+import io
+import json
+import os
+import subprocess
+import sys
+import textwrap
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def _stub(tmp_path, body):
+    path = tmp_path / "rank_stub.py"
+    path.write_text(textwrap.dedent(body))
+    return str(path)
+
+
+def test_launcher_sets_the_rank_environment_and_relays_rank0_only(tmp_path):
+    import bench
+    stub = _stub(tmp_path, """
+        import json, os, sys
+        r = int(os.environ["RANK"])
+        env = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "BFG_BENCH_SPAWNED")}
+        json.dump(env, open(os.path.join(sys.argv[1], f"env_{r}.json"), "w"))
+        print(json.dumps({"rank": r, "argv": sys.argv[2:]}))          # every rank prints: only rank 0's line may reach stdout
+    """)
+    out, err = io.StringIO(), io.StringIO()
+    rc = bench.spawn_ranks(3, [str(tmp_path), "--gpus", "3", "--steps", "7"], script=stub, out=out, err=err)
+    assert rc == 0
+    lines = [l for l in out.getvalue().splitlines() if l.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"rank": 0, "argv": ["--gpus", "3", "--steps", "7"]}
+    assert sorted(json.loads(l)["rank"] for l in err.getvalue().splitlines() if l.strip()) == [1, 2]
+    envs = [json.load(open(tmp_path / f"env_{r}.json")) for r in range(3)]
+    assert [e["RANK"] for e in envs] == ["0", "1", "2"] and [e["LOCAL_RANK"] for e in envs] == ["0", "1", "2"]
+    assert all(e["WORLD_SIZE"] == "3" and e["MASTER_ADDR"] == "127.0.0.1" and e["BFG_BENCH_SPAWNED"] == "1" for e in envs)
+    assert len({e["MASTER_PORT"] for e in envs}) == 1 and int(envs[0]["MASTER_PORT"]) > 0
+
+
+def test_launcher_fails_with_the_first_failing_rank_and_kills_the_survivors(tmp_path):
+    import bench
+    stub = _stub(tmp_path, """
+        import os, sys, time
+        r = int(os.environ["RANK"])
+        open(os.path.join(sys.argv[1], f"pid_{r}"), "w").write(str(os.getpid()))
+        if r == 1:
+            time.sleep(0.3)
+            sys.exit(7)
+        time.sleep(600)                                               # a peer stuck in a collective
+    """)
+    out, err = io.StringIO(), io.StringIO()
+    t0 = time.monotonic()
+    rc = bench.spawn_ranks(3, [str(tmp_path)], script=stub, grace=0.5, out=out, err=err)
+    assert rc == 7 and time.monotonic() - t0 < 30
+    assert out.getvalue() == ""
+    assert "FAILED (launcher, 3 ranks): rank 1 exited with code 7" in err.getvalue()
+    for r in (0, 2):                                                  # the stuck ranks are gone
+        pid = int(open(tmp_path / f"pid_{r}").read())
+        try:
+            os.kill(pid, 0)
+            alive = open(f"/proc/{pid}/stat").read().split()[2] != "Z"
+        except (ProcessLookupError, FileNotFoundError):
+            alive = False
+        assert not alive
+
+
+def test_launcher_deadline(tmp_path):
+    import bench
+    stub = _stub(tmp_path, "import time; time.sleep(600)")
+    err = io.StringIO()
+    t0 = time.monotonic()
+    rc = bench.spawn_ranks(2, [], script=stub, deadline=1.0, out=io.StringIO(), err=err)
+    assert rc == 3 and time.monotonic() - t0 < 30 and "deadline" in err.getvalue()
+
+
+def test_plain_python_gpus2_spawns_ranks_that_refuse_without_gpus():
+    """the review's case: `python3 bench.py --gpus 2` as plain python.  On this box (no GPU) both ranks must come up as ranks of a
+    world of two (not die on WORLD_SIZE) and refuse with the device count; the launcher reports the failure and exits non-zero."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = ""                                   # (also without GPUs on a GPU box)
+    env["ROCR_VISIBLE_DEVICES"] = ""
+    pr = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                        capture_output=True, text=True, timeout=300)
+    assert pr.returncode != 0 and pr.stdout.strip() == ""
+    assert "0 GPU(s) visible, 2 needed" in pr.stderr and "WORLD_SIZE is" not in pr.stderr
+    assert "FAILED (launcher, 2 ranks)" in pr.stderr
+
+
+def test_watchdog_fires_while_the_main_thread_is_blocked_in_a_c_call(tmp_path):
+    """a SIGALRM handler would wait for the interpreter; the watchdog thread does not"""
+    stub = _stub(tmp_path, f"""
+        import ctypes, sys
+        sys.path.insert(0, {REPO!r})
+        import bench
+
+        def overdue():
+            print("deadline line", file=sys.stderr, flush=True)
+            return 5
+        bench.WATCHDOG.arm(0.5, overdue)
+        ctypes.CDLL(None).sleep(600)                                  # blocked outside the interpreter, GIL released
+    """)
+    t0 = time.monotonic()
+    pr = subprocess.run([sys.executable, stub], capture_output=True, text=True, timeout=120)
+    assert pr.returncode == 5 and "deadline line" in pr.stderr and time.monotonic() - t0 < 60

@@ -91,6 +91,19 @@ def test_two_ranks_real_kernels_paint_and_baryonify(tmp_path):
                 assert np.array_equal(lgot != 0, lref != 0)
                 assert_maps_close(lgot, lref, 1e-5, what=f"2-rank list shell {k} ({backend}/{coll}), rank {r}")
         assert sum(info[f"list_{coll}_pixel_updates"] for info in infos) == ptot_list
+    # one rank's shard empty (all halos in rank 0's declination stripe): same collectives on both ranks, right answers
+    nn = W.north_mask(I)
+    nref, _ = oracle_paint(I["cosmo"], I["ra"][nn], I["dec"][nn], I["M"][nn], I["z"][nn], (zax, Max, rax), T, W.NSIDE, W.EPS)
+    nbref = oracle_baryonify(I["cosmo"], I["ra"][nn], I["dec"][nn], I["M"][nn], I["z"][nn], (dz, dM, dr), dtab, W.NSIDE,
+                             W.EPS, 20.0, I["m_in"])
+    for coll in collectives:
+        assert sorted(info[f"north_{coll}_shard"] for info in infos) == [0, nn.size]
+        for r in range(world):
+            got = np.load(tmp_path / f"north_paint_{coll}_{r}.npy")
+            assert np.array_equal(got != 0, nref != 0)
+            assert_maps_close(got, nref, 1e-5, what=f"2-rank paint, one shard empty ({backend}/{coll}), rank {r}")
+            bgot = np.load(tmp_path / f"north_bary_{coll}_{r}.npy")
+            assert_maps_close(bgot, nbref, 1e-5, floor=1e-9, what=f"2-rank baryonify, one shard empty ({backend}/{coll}), rank {r}")
     # the owner-computes join painted every (halo, pixel) pair once as well, and only a border travelled point to point
     assert sum(info["owner_pixel_updates"] for info in infos) == ptot_list
     assert all(0 < info["owner_border_fraction"] < 0.2 for info in infos)

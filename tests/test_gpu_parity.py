@@ -1533,6 +1533,12 @@ def test_sliced_paint_equals_the_plain_call(cosmo, case, monkeypatch):
         warnings.simplefilter("ignore")
         plain = R.process()
         assert R.last_stats["pixel_updates"] == ptot
+        # the reference ranges: an EMPTY catalog on the same shell (what a rank whose sky-patch shard holds no halo reports)
+        ranges = {}
+        R0 = bfg.PaintProfilesShell(Cat[np.arange(0)], Shell, 10, _paint_model(zax, Max, rax, T), verbose=False)
+        for slices in (1, 3, 7, 64):
+            got0, ranges[slices] = _sliced_paint(R0, slices)
+            assert not got0.any()
         for slices in (1, 3, 7, 64):
             got, seen = _sliced_paint(R, slices)
             assert R.last_stats["pixel_updates"] == ptot
@@ -1540,14 +1546,41 @@ def test_sliced_paint_equals_the_plain_call(cosmo, case, monkeypatch):
             assert [s[0] for s in seen] == list(range(nrep)) and all(s[1] == nrep for s in seen)
             assert seen[0][2] == 0 and seen[-1][3] == got.size
             assert all(a[3] == b[2] and a[2] < a[3] for a, b in zip(seen, seen[1:]))      # contiguous, ascending, non-empty
-            if case == "scatter_variant":
-                assert nrep == 1
-            else:
-                assert nrep == min(slices, 16, (4 * nside - 1 + 31) // 32)
+            # the number of slices and their ranges are a function of (nside, loop, slices) only: a scatter variant -- or a rank
+            # with an empty shard, below -- reports the ranges its peers report (one collective per callback on every rank)
+            assert nrep == min(slices, 16, (4 * nside - 1 + 31) // 32)
+            ranges.setdefault(slices, seen)
+            assert [s[2:] for s in seen] == [s[2:] for s in ranges[slices]]
             # equal up to the order in which atomics add (deferred pixels, shared tiles, the scatter kernel): rounding only
             assert np.array_equal(got != 0, plain != 0)
             np.testing.assert_allclose(got, plain, rtol=1e-12, atol=0, err_msg=f"{case}: {slices} slices vs the plain call")
     assert_maps_close(plain, ref, RTOL, what=f"sliced paint ({case})")
+
+
+@pytest.mark.parametrize("case", ["plain", "leftover", "degraded"])
+def test_sliced_paint_accumulates_into_a_given_map(cosmo, case, monkeypatch):
+    """process_device(d_map=existing, slices > 1) without overwrite adds INTO the map -- also when left-over halos exist or the
+    binning degrades (the sliced call used to clear the output in exactly those cases)"""
+    import warnings
+    nside, n = 128, 1500
+    ra, dec, M, z = syn.catalog(n, seed=79)
+    if case == "leftover":
+        ra, dec, M, z = np.append(ra, 10.0), np.append(dec, 5.0), np.append(M, 5e15), np.append(z, 0.012)
+    if case == "degraded":
+        monkeypatch.setenv("BFG_TILE_CAP", "2")
+        monkeypatch.setenv("BFG_PAIR_CAP", "100")
+    zax, Max, rax, T = syn.pressure_table()
+    ctx = bfg.engine.get_context()
+    R = bfg.PaintProfilesShell(bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo),
+                               bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), 10,
+                               _paint_model(zax, Max, rax, T), verbose=False)
+    before = np.random.default_rng(3).uniform(1.0, 2.0, 12 * nside * nside)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        plain = R.process()
+        d_map = ctx.to_device(before)
+        R.process_device(d_map=d_map, slices=4, on_slice=lambda k, n, lo, hi: None)
+    np.testing.assert_allclose(ctx.to_host(d_map), before + plain, rtol=1e-12, atol=0)
 
 
 def test_sliced_offsets_equal_the_plain_call(cosmo):
