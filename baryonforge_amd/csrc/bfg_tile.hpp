@@ -862,6 +862,25 @@ __device__ inline double sin_small(double h, double h2)
     return h * p;
 }
 
+// cos(h) for h^2 <= kSinSmall: even series to h^10 (next term h^12 / 12! < 1e-25; rel err < 1e-16 of a value >= 0.98)
+__device__ inline double cos_small(double h2)
+{
+    double p = fma(h2, -1.0 / 3628800.0, 1.0 / 40320.0);
+    p = fma(h2, p, -1.0 / 720.0);
+    p = fma(h2, p, 1.0 / 24.0);
+    p = fma(h2, p, -0.5);
+    return fma(h2, p, 1.0);
+}
+
+// 1 / x for a normal x away from the ends of the exponent range: v_rcp_f64 + two Newton steps (<= 1 ulp); no scaling, no
+// special cases, unlike the IEEE division sequence (div_scale x 2, div_fmas, div_fixup: twice the instructions)
+__device__ inline double rcp_newton(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+
 // (sin h, cos h) for |h| <= 3.2 without libm: series on h/16, then four angle doublings
 __device__ inline void sincos_wide(double h, double &sh, double &ch)
 {
@@ -1371,17 +1390,14 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
             // HealpixRunner.py:336-355 for one pixel
+            // (the read-out first, the pixel's geometry only where the displacement is non-zero: what is live across the read-out --
+            // and across its rare direct path, a function of its own -- is the chord, not six vector components)
             const int pidx = sg.pk & 63, wl1 = sg.pk >> 12;
             const Pair &pi = pinfo[pidx];
-            const RingRow &rr = rows[(sg.pk >> 6) & 63];
-            double sh = sin_small(h, h2), ch = sqrt_unit(1.0 - sh * sh);   // sin, cos of dphi/2 (cos >= 0; 1 - sh^2 > 0.9 here)
+            double sh = sin_small(h, h2), ch = cos_small(h2);              // sin, cos of dphi/2: series (h^2 <= 0.04), no square root
             if (__any(h2 > kSinSmall)) { if (h2 > kSinSmall) sincos_wide(h, sh, ch); }
             const double s2 = sh * sh;
             const double x = fma(sg.Bq, s2, sg.Aq);                        // r_com^2
-            const double sd = 2.0 * sh * ch, cd = 1.0 - 2.0 * s2;          // sin, cos of dphi
-            const double cphi = pi.cp0 * cd - pi.sp0 * sd, sphi = pi.sp0 * cd + pi.cp0 * sd;
-            const double vx = rr.sth * cphi, vy = rr.sth * sphi, vz = rr.z;                 // pixel unit vector
-            const double dx = vx - pi.st * pi.cp0, dy = vy - pi.st * pi.sp0, dz = vz - pi.ct;   // vec - vec_j
             const double t1 = fma(fast_log_biased(x, logtab), t_m, t_c1 + pi.tshift);
             bool in;
             double d = window_row(sg, wl1, pidx, t1, in);                  // comoving displacement; table holds d
@@ -1393,19 +1409,43 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
             // zero outside the hull (NaN fill), beyond the model's epsilon_max R (BaryonCorrection.py:410-411),
             // for non-finite table values and at r = 0 (HealpixRunner.py:347)
             const bool use = in && (x < pi.xcut) && (x > 0.0) && (fabs(d) < 1.0e300);
-            d = use ? d * pi.a : 0.0;                                      // physical (HealpixRunner.py:345)
-            if (d != 0.0) {
-                // (the offsets are continuous in all of this: the lean sqrt, a / D formed once per pair and one division
-                // shared by g and kk move them by rounding errors)
-                const double rc = (x > 1e-280 && x < 1e280) ? sqrt_unit(x) : sqrt(x);   // r_com; chord = rc a / D
-                const double chord = rc * pi.a_over_D;
-                const double qq = pi.D * d * chord + d * d;                // |pos + off|^2 - D^2
-                const double n2 = fma(pi.D, pi.D, qq);
-                const double nwn = (n2 > 1e-280 && n2 < 1e280) ? sqrt_unit(n2) : sqrt(n2);
-                const double ga = nwn * (nwn + pi.D), kb = chord * nwn;
-                const double inv = 1.0 / (ga * kb);
-                const double g = -qq * kb * inv;                           // D / |nw| - 1 without cancellation: -qq / (nwn (nwn + D))
-                const double kk = d * ga * inv;                            // offset along (vec - vec_j) / chord, / |nw|: d / (chord nwn)
+            const double dcom = use ? d : 0.0;                             // comoving; physical d = dcom a (HealpixRunner.py:345)
+            if (dcom != 0.0) {
+                const RingRow &rr = rows[(sg.pk >> 6) & 63];
+                const double sd = 2.0 * sh * ch, cd = 1.0 - 2.0 * s2;      // sin, cos of dphi
+                const double cphi = pi.cp0 * cd - pi.sp0 * sd, sphi = pi.sp0 * cd + pi.cp0 * sd;
+                const double vx = rr.sth * cphi, vy = rr.sth * sphi, vz = rr.z;                 // pixel unit vector
+                const double dx = vx - pi.st * pi.cp0, dy = vy - pi.st * pi.sp0, dz = vz - pi.ct;   // vec - vec_j
+                // new direction = (D vec + d u) / |D vec + d u|, u = (vec - vec_j) / chord (unit-sphere chord = r_com a / D); the offset
+                // is vec g + (vec - vec_j) kk with g = D / |.| - 1, kk = d / (chord |.|).  With delta = d / D (~1e-3 at most) and
+                // e = |.|^2 / D^2 - 1 = delta (chord + delta): g = (1 + e)^(-1/2) - 1 by its series (no cancellation, no second square
+                // root, no division) and kk = dcom (1 + g) / r_com; 1 / r_com and r_com come out of ONE v_rsq_f64 + a coupled Newton
+                // step.  The offsets are continuous in all of this: rounding-level differences.  Anything outside the series' range
+                // (|e| >= 2^-10: d / D of a few per cent) or the lean square root's takes the plain formulas.
+                double g, kk;
+                const double y0 = __builtin_amdgcn_rsq(x);
+                double sq = x * y0, hq = 0.5 * y0;                         // -> sqrt(x), 0.5 / sqrt(x)
+                const double rq = fma(-hq, sq, 0.5);
+                sq = fma(sq, rq, sq); hq = fma(hq, rq, hq);
+                hq = fma(hq, fma(-hq, sq, 0.5), hq);
+                const double delta = dcom * pi.a_over_D, chord = sq * pi.a_over_D;
+                const double e = delta * (chord + delta);
+                if ((x > 1e-280) && (x < 1e280) && (fabs(e) < 0.0009765625)) {
+                    double ps = fma(e, -63.0 / 256.0, 35.0 / 128.0);
+                    ps = fma(e, ps, -5.0 / 16.0);
+                    ps = fma(e, ps, 3.0 / 8.0);
+                    ps = fma(e, ps, -0.5);
+                    g = e * ps;                                            // (1 + e)^(-1/2) - 1; next term 231/1024 e^6 < 2e-19
+                    const double tq = dcom * hq;
+                    kk = 2.0 * fma(tq, g, tq);
+                } else {
+                    const double dp = dcom * pi.a;
+                    const double ch2 = sqrt(x) * pi.a_over_D;
+                    const double qq = pi.D * dp * ch2 + dp * dp;           // |pos + off|^2 - D^2
+                    const double nwn = sqrt(fma(pi.D, pi.D, qq));
+                    g = -qq / (nwn * (nwn + pi.D));                        // D / |nw| - 1 without cancellation
+                    kk = dp / (ch2 * nwn);
+                }
                 lds_double *ap = lds_ptr<double>(lds_base + sg.abyte + 24 * k);
                 __hip_atomic_fetch_add(ap + 0, fma(vx, g, dx * kk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(ap + 1, fma(vy, g, dy * kk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

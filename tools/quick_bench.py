@@ -33,6 +33,7 @@ WORK = {
     "paint3e5": dict(kind="paint", n=300_000, nside=1024, eps=10.0),
     "bary1e4": dict(kind="bary", n=10_000, nside=1024, eps=10.0),
     "bary3e5": dict(kind="bary", n=300_000, nside=1024, eps=10.0),
+    "bary2048": dict(kind="bary", n=1_250_000, nside=2048, eps=10.0),
 }
 
 

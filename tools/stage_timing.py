@@ -15,7 +15,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 nside = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 workload = sys.argv[3] if len(sys.argv) > 3 else "paint"
 cosmo = dict(syn.COSMO)
-ra, dec, M, z = syn.catalog(n, seed=42)
+ra, dec, M, z = syn.catalog(n, seed=42, steep=bool(os.environ.get("BFG_ST_STEEP")))
 ctx = get_context(0)
 bg = Background(cosmo)
 d_cat = ctx.to_device(np.stack([M, z, ra, dec], axis=1))
