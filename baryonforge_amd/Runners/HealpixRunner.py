@@ -497,24 +497,62 @@ class _BaryonifyDeviceOps(object):
 
     def __init__(self, runner):
         self.runner = runner
+        self.h2d_bytes = 0                                                # of the input map, for tools/bary_api_probe.py and the tests
 
-    def upload(self, flat):
-        return get_context().to_device(flat)
+    def slice_cuts(self, nside, slices):
+        """ELEMENT cuts (3 per pixel) of the slices offsets() will report: known before the call (bfg_shell_slice_cuts), so the pixels
+        this rank will own can be uploaded while the offsets are still being accumulated"""
+        from .._lib import shell_slice_cuts
+        if getattr(self.runner, "_callable_model", False) or slices <= 1:
+            return [0, 3 * 12 * nside * nside]                            # (a host-evaluated model reports its field in one piece)
+        return shell_slice_cuts(nside, True, slices)
+
+    def upload_ranges(self, flat, ranges, npix):
+        """float64[npix] on the device: flat[lo:hi] inside the given pixel ranges, zeros elsewhere -- only those bytes cross PCIe"""
+        import torch
+        ctx = get_context()
+        d = ctx.zeros(npix)
+        for lo, hi in ranges:
+            if hi > lo:
+                d[lo:hi].copy_(torch.from_numpy(flat[lo:hi]))
+                self.h2d_bytes += 8 * (hi - lo)
+        return d
 
     def zeros(self, *shape):
         return get_context().zeros(*shape)
 
-    def absmax_sum(self, t):
-        return get_context().absmax_sum(t)
-
     def offsets(self, slices=1, on_slice=None):
         return self.runner.offsets_device(slices=slices, on_slice=on_slice)
 
-    def regrid(self, nside, d_off, d_in, d_out):
-        get_context().regrid_shell(nside, d_off, d_in, d_out, None)
+    def regrid(self, nside, d_off, d_in, d_out, d_sums=None):
+        get_context().regrid_shell(nside, d_off, d_in, d_out, d_sums)
+
+    def count_above(self, d_in, ranges, threshold, d_dst):
+        """d_dst[0] = number of pixels of the ranges with |value| > threshold (NaN counts as not above), left on the device"""
+        total = None
+        for lo, hi in ranges:
+            if hi > lo:
+                c = (d_in[lo:hi].abs() > threshold).sum()
+                total = c if total is None else total + c
+        if total is not None:
+            d_dst[0] = total
 
     def to_host(self, t):
         return get_context().to_host(t)
+
+
+def _checks_or_zero_map(runner, orig_map):
+    """The reference returns an all-zero input map BEFORE it looks at the model (HealpixRunner.py:293-294 precede :304-311 and the
+    table lookup).  Here the argument checks come first because they are free and the zero test of a large map is a device
+    reduction; so when they fail, the (host) zero test decides whether the reference would have raised at all.
+    Returns True if the input map is to be handed back unchanged."""
+    try:
+        runner._checked_model_keys()
+    except Exception:
+        if np.allclose(runner.LightconeShell.map, 0):
+            return True
+        raise
+    return False
 
 
 def _baryonify_pipelined(runners, in_flight=2):
@@ -534,7 +572,9 @@ def _baryonify_pipelined(runners, in_flight=2):
         if orig.size < (1 << 16) and np.allclose(orig, 0):                # small maps: decided on the host, as the reference (:293-294)
             results[k] = orig
             continue
-        R._checked_model_keys()
+        if _checks_or_zero_map(R, orig):
+            results[k] = orig
+            continue
         todo.append(k)
     if not todo:
         return results
@@ -605,65 +645,66 @@ def _baryonify_pipelined(runners, in_flight=2):
 
 def _baryonify_process(runner, ops, exchange, slices=1):
     """BaryonifyShell.process (HealpixRunner.py:252-373) over an `ops` object (the device side: _BaryonifyDeviceOps) and an
-    optional Exchange between ranks.  slices > 1: the offset field is exchanged in band slices while the rest is still being
-    accumulated -- every slice is reduce-scattered (rank r ends up owning the r-th part of EVERY slice; all-reduced instead if
-    its length does not divide by the world size), and a rank regrids the sources of the pixels it owns."""
+    optional Exchange between ranks.
+
+    Several ranks: every rank holds a shard of the halos and accumulates their offsets over the whole sky (:313-355); the field is
+    summed by reduce-scatter -- in `slices` band slices while the rest is still being accumulated: rank r ends up owning the r-th
+    part of EVERY slice (a slice whose length does not divide by the world size is all-reduced instead) -- and a rank regrids the
+    sources of the pixels it owns (:357-365 on that range).  Which pixels those are is known before the call (the slices depend
+    on NSIDE and the slice count only: bfg_shell_slice_cuts), so ONLY THEY are uploaded: 8 Npix / N bytes of input map per rank.
+    The regridded maps, whose deposits cross the range borders, are all-reduced together with three scalars -- sum(in),
+    sum(deposits), count(|in| > 1e-8) of the rank's sources -- so the mass assertion (:368-370) and the all-zero test (:293-294)
+    need no collective or read-back of their own: nothing comes back from the device before the final map."""
     orig_map = runner.LightconeShell.map
     NSIDE = runner.LightconeShell.NSIDE
     if orig_map.size < (1 << 16) and np.allclose(orig_map, 0):         # small maps: decided on the host, as the reference
         return orig_map
-    runner._checked_model_keys()
+    if _checks_or_zero_map(runner, orig_map):
+        return orig_map
     npix = 12 * NSIDE * NSIDE
     flat = np.ascontiguousarray(orig_map, dtype=np.float64).ravel()
-    d_orig = ops.upload(flat)
-    absmax, old_sum = ops.absmax_sum(d_orig)                          # on the device: one pass instead of three host ones
-    if not (absmax > 1e-8):                                           # np.allclose(orig_map, 0) (:293); False for NaN maps
-        if np.allclose(orig_map, 0):
-            return orig_map
     if exchange is not None and not hasattr(exchange, "reduce_scatter"):
         from ..utils.Parallelize import Exchange
         exchange = Exchange(exchange)
-    if exchange is not None and exchange.world > 1 and slices > 1:
-        rank, world = exchange.rank, exchange.world
-        owned, handles = [], []
+    multi = exchange is not None and exchange.world > 1
+    rank, world = (exchange.rank, exchange.world) if multi else (0, 1)
+    # the slices of the offset field and, in each, the pixels this rank owns after its exchange
+    cuts = [int(c) for c in ops.slice_cuts(NSIDE, slices)] if multi else [0, 3 * npix]
+    assert cuts[0] == 0 and cuts[-1] == 3 * npix and all(c % 3 == 0 for c in cuts)
+    plan, owned = [], []
+    for lo, hi in zip(cuts, cuts[1:]):
+        plo, npx = lo // 3, (hi - lo) // 3
+        scatter = multi and npx % world == 0                          # reduce-scatter if the slice splits evenly, else all-reduce
+        plan.append((lo, hi, scatter))
+        owned.append((plo + npx * rank // world, plo + npx * (rank + 1) // world))
+    assert sum(hi - lo for lo, hi in owned) > 0 or npix < world
+    d_in = ops.upload_ranges(flat, owned, npix)                        # sources this rank does not own have no mass here
+    d_out = ops.zeros(npix + 3)
+    ops.count_above(d_in, owned, 1e-8, d_out[npix + 2:])              # np.allclose(orig_map, 0) <=> no |value| > 1e-8 (NaN: see below)
+    handles, seen = [], []
 
-        def on_slice(k, n, lo, hi, flat):                             # element range [lo, hi) of the flattened field: final
-            plo, phi = lo // 3, hi // 3
-            npx = phi - plo
-            if npx % world == 0:
-                handles.append(exchange.reduce_scatter_begin(flat[lo:hi]))
-            else:
-                handles.append(exchange.allreduce_begin(flat[lo:hi]))
-            owned.append((plo + npx * rank // world, plo + npx * (rank + 1) // world))
-        d_off = ops.offsets(slices=slices, on_slice=on_slice)          # :313-355, this rank's halos
+    def on_slice(k, n, lo, hi, field):                                # element range [lo, hi) of the flattened field: final
+        seen.append((lo, hi))
+        if (lo, hi) != plan[k][:2] or n != len(plan):
+            raise RuntimeError(f"slice {k} of {n} is [{lo}, {hi}), planned {plan[k][:2]} of {len(plan)}")
+        if plan[k][2]:
+            handles.append(exchange.reduce_scatter_begin(field[lo:hi]))
+        else:
+            handles.append(exchange.allreduce_begin(field[lo:hi]))
+    if multi:
+        d_off = ops.offsets(slices=len(plan) if len(plan) > 1 else 1, on_slice=on_slice)   # :313-355, this rank's halos
+        assert len(seen) == len(plan), "the offsets call reported fewer slices than planned"
         for h in handles:
             exchange.wait(h)
-        d_in = ops.zeros(npix)
-        for lo, hi in owned:
-            d_in[lo:hi] = d_orig[lo:hi]                               # sources this rank does not own have no mass here
-        assert sum(hi - lo for lo, hi in owned) > 0 or npix < world
     else:
-        d_off = ops.offsets()                                         # :313-355, this rank's halos
-    if exchange is not None and exchange.world > 1 and slices > 1:
-        pass
-    elif exchange is not None and exchange.world > 1:
-        rank, world = exchange.rank, exchange.world
-        if npix % world == 0:
-            exchange.reduce_scatter(d_off)                            # summed offsets of the pixels this rank owns
-            lo, hi = (x // 3 for x in exchange.own_range(3 * npix))
-        else:                                                         # a world size that does not divide 12 NSIDE^2
-            exchange.allreduce(d_off)
-            lo, hi = npix * rank // world, npix * (rank + 1) // world
-        d_in = ops.zeros(npix)
-        d_in[lo:hi] = d_orig[lo:hi]                                   # sources outside the range have no mass here
-    else:
-        d_in = d_orig
-    d_out = ops.zeros(npix)
-    ops.regrid(NSIDE, d_off, d_in, d_out)                             # :357-365
-    if exchange is not None and exchange.world > 1:
-        exchange.allreduce(d_out)
-    _, new_sum = ops.absmax_sum(d_out)
-    new_map = ops.to_host(d_out)
+        d_off = ops.offsets()
+    ops.regrid(NSIDE, d_off, d_in, d_out[:npix], d_out[npix:npix + 2])  # :357-365; {sum(in), sum(deposits)} of this rank's sources
+    if multi:
+        exchange.allreduce(d_out)                                     # the map and the three scalars in one collective
+    host = ops.to_host(d_out)                                          # the one read-back
+    old_sum, new_sum, n_above = (float(x) for x in host[npix:])
+    if n_above == 0 and np.allclose(orig_map, 0):                      # :293-294 (a NaN map counts nothing but is not all-zero)
+        return orig_map
     assert np.isclose(new_sum, old_sum), \
         "ERROR in pixel regridding, sum(new_map) [%0.14e] != sum(oldmap) [%0.14e]" % (new_sum, old_sum)  # :368-370
-    return new_map
+    return host[:npix]

@@ -43,9 +43,9 @@ SYMBOLS = [
     "bfg_allreduce_f64", "bfg_allreduce_f64_begin", "bfg_comm_wait", "bfg_reduce_scatter_f64", "bfg_allgather_f64",
     "bfg_reduce_scatter_f64_begin", "bfg_paint_shell_sliced", "bfg_baryonify_offsets_sliced",
     "bfg_disc_enumerate_count", "bfg_disc_enumerate", "bfg_map_add_values", "bfg_offsets_add_displacements",
-    "bfg_copy_to_mapped_host",
+    "bfg_copy_to_mapped_host", "bfg_shell_slice_cuts",
 ]
-ABI_VERSION = 3
+ABI_VERSION = 4
 # bfg_slice_fn: int (*)(void *user, int slice, int n_slices, int64_t elem_begin, int64_t elem_end)
 SLICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64)
 BFG_COMM_ID_BYTES = 128
@@ -165,6 +165,7 @@ def load(build_if_missing=True):
     L.bfg_baryonify_offsets_sliced.argtypes = [_vp, C.POINTER(ShellArgs), _vp, _vp, _vp, C.c_int, SLICE_FN, _vp]
     L.bfg_regrid_shell.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp]
     L.bfg_copy_to_mapped_host.argtypes = [_vp, _vp, _vp, _vp, C.c_size_t]
+    L.bfg_shell_slice_cuts.argtypes = [_i64, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(C.c_int)]
     L.bfg_disc_enumerate_count.argtypes = [_vp, C.POINTER(ShellArgs), _vp, C.c_int, _vp]
     L.bfg_disc_enumerate.argtypes = [_vp, C.POINTER(ShellArgs), _vp, C.c_int, _vp, _vp, _vp, _vp]
     L.bfg_map_add_values.argtypes = [_vp, _vp, _vp, _vp, _i64]
@@ -196,3 +197,12 @@ def dptr(arr):
     """ctypes double* view of a C-contiguous float64 numpy array"""
     assert arr.dtype == np.float64 and arr.flags["C_CONTIGUOUS"]
     return arr.ctypes.data_as(C.POINTER(_dbl))
+
+
+def shell_slice_cuts(nside, offsets, n_slices):
+    """element cuts [0, ..., all] of the slices bfg_paint_shell_sliced (offsets=False) / bfg_baryonify_offsets_sliced (True) report
+    for this NSIDE and slice count (bfg_shell_slice_cuts; no GPU needed)"""
+    cuts = (_i64 * 17)()
+    n = C.c_int(0)
+    check(load().bfg_shell_slice_cuts(int(nside), 1 if offsets else 0, int(n_slices), cuts, C.byref(n)), "bfg_shell_slice_cuts")
+    return [int(cuts[k]) for k in range(n.value + 1)]

@@ -69,7 +69,19 @@ def lcdm(cosmo):
 class Background(object):
     """E(a), chi(a), D_A(a), rho_x(a) of a flat wCDM cosmology with radiation."""
 
-    def __init__(self, cosmo, T_CMB=T_CMB_DEFAULT, N_eff=N_EFF_DEFAULT, T_ncdm=T_NCDM_DEFAULT):
+    def __init__(self, cosmo, T_CMB=T_CMB_DEFAULT, N_eff=N_EFF_DEFAULT, T_ncdm=T_NCDM_DEFAULT, nu_rel="T_ncdm"):
+        """nu_rel: the density of the massless neutrinos, Omega_nu,rel = N_eff 7/8 x^4 Omega_gamma with
+        "T_ncdm"   x = T_ncdm = 0.71611 (the default: what pyccl >= 2.1 does for ccl.Cosmology's defaults, as recalled from its
+                   source -- T_nu = T_CMB T_ncdm; pyccl is not installed here and the reference's tests hold no distances);
+        "4/11"     x = (4/11)^(1/3) = 0.71377, the instantaneous-decoupling textbook value.
+        The two differ by 1.3 % in Omega_nu,rel, i.e. 2.5e-7 relative in D_A at z = 0.5 and 1.2e-6 at z = 3 (tests/test_oracle_healpix.py):
+        40x inside the 1e-5 map tolerance, but it is the one constant of this module a run against live pyccl
+        (tests/golden/make_golden.py --real-deps) has to decide."""
+        if nu_rel not in ("T_ncdm", "4/11"):
+            raise ValueError("nu_rel must be 'T_ncdm' or '4/11'")
+        if nu_rel == "4/11":
+            T_ncdm = (4.0 / 11.0) ** (1.0 / 3.0)
+        self.nu_rel = nu_rel
         p = as_cosmo_dict(cosmo)
         self.params = dict(p)
         self.h = float(p["h"])

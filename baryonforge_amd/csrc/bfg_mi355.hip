@@ -1692,6 +1692,25 @@ static int64_t ring_first_pixel(int64_t nside, int64_t ring)
     return npix - 2 * nr * (nr + 1);
 }
 
+// The element ranges of a sliced call's K slices: cuts[0] = 0 < ... < cuts[K] = all elements; K = min(n_slices, 16, bands of the
+// loop's tile geometry), every slice a run of whole bands.  A function of (nside, mode, n_slices) only.
+static int shell_slice_cuts(int64_t nside, int mode, int n_slices, int64_t *cuts)
+{
+    const int tr = (mode == MODE_PAINT) ? TileCfg<MODE_PAINT>::TR : TileCfg<MODE_BARYONIFY>::TR;
+    const int nbands = (int)((4 * nside - 1 + tr - 1) / tr);
+    const int K = std::max(1, std::min(std::min(n_slices, kMaxSlices), nbands));
+    for (int k = 0; k <= K; ++k)
+        cuts[k] = (mode == MODE_PAINT ? 1 : 3) * ring_first_pixel(nside, 1 + ((int64_t)nbands * k / K) * tr);
+    return K;
+}
+
+int bfg_shell_slice_cuts(int64_t nside, int offsets, int n_slices, int64_t *elem_cuts, int *n_out)
+{
+    if (nside < 1 || nside > (1 << 20) || n_slices < 1 || !elem_cuts || !n_out) return BFG_ERR_INVALID;
+    *n_out = shell_slice_cuts(nside, offsets ? MODE_BARYONIFY : MODE_PAINT, n_slices, elem_cuts);
+    return BFG_OK;
+}
+
 static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, const bfg_spline *s,
                      double *d_out, int mode, int n_slices = 1, bfg_slice_fn slice_fn = nullptr, void *slice_user = nullptr)
 {
@@ -1713,10 +1732,8 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     // same K ranges as its peers.  The cuts are runs of whole bands of the tile geometry (contiguous RING pixel ranges).
     const int slice_tr = (mode == MODE_PAINT) ? TileCfg<MODE_PAINT>::TR : TileCfg<MODE_BARYONIFY>::TR;
     const int slice_nbands = (int)((4 * a->nside - 1 + slice_tr - 1) / slice_tr);
-    const int slice_K = slice_fn ? std::max(1, std::min(std::min(n_slices, kMaxSlices), slice_nbands)) : 0;
     int64_t slice_elem[kMaxSlices + 1];
-    for (int k = 0; slice_K > 0 && k <= slice_K; ++k)
-        slice_elem[k] = (mode == MODE_PAINT ? 1 : 3) * ring_first_pixel(a->nside, 1 + ((int64_t)slice_nbands * k / slice_K) * slice_tr);
+    const int slice_K = slice_fn ? shell_slice_cuts(a->nside, mode, n_slices, slice_elem) : 0;
     // a call whose kernels are not launched per slice (no halos, scatter variants, the wave kernel) reports the same K ranges, all
     // of them final once the stream gets there
     auto whole_output = [&]() -> int {

@@ -309,8 +309,8 @@ class SimpleParallel(object):
         if self.split:
             return SplitJoinParallel(self.Runner_list, self.njobs, self.seed, **self.splitjoin_args).process()
         if dist is None or dist.get_world_size() == 1:
-            if len(self.Runner_list) > 1 and all(hasattr(R, "offsets_device") and type(R).process is _plain_baryonify_process()
-                                                 for R in self.Runner_list):
+            if len(self.Runner_list) > 1 and type(self).single_run is SimpleParallel.single_run and \
+                    all(hasattr(R, "offsets_device") and type(R).process is _plain_baryonify_process() for R in self.Runner_list):
                 # a list of BaryonifyShell runners on one GPU: uploads, kernels and downloads of consecutive shells overlap
                 from ..Runners.HealpixRunner import _baryonify_pipelined
                 return _baryonify_pipelined(self.Runner_list)
@@ -511,4 +511,5 @@ class SplitJoinParallel(object):
 
     def _baryonify(self, local, ops):
         from ..Runners.HealpixRunner import _baryonify_process, _BaryonifyDeviceOps
-        return _baryonify_process(local, ops or _BaryonifyDeviceOps(local), self._exchange(), slices=self.slices)
+        self.last_ops = ops = ops or _BaryonifyDeviceOps(local)           # (its h2d_bytes: what this rank uploaded of the input map)
+        return _baryonify_process(local, ops, self._exchange(), slices=self.slices)

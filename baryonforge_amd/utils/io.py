@@ -149,16 +149,20 @@ class HaloLightConeCatalog(object):
 class LightconeShell(object):
     """
     Full-sky HEALPix (RING) shell: `map`, `NSIDE`, `redshift`, `cosmo`.
-    Mirrors utils/io.py:290-379.  `path` accepts a .npy file (FITS needs healpy and is out of scope).
+    Mirrors utils/io.py:290-379.  `path`: a HEALPix FITS file, read as `hp.read_map(path)` reads it (:346-347: first map column,
+    RING order -- a NESTED file is reordered --, the file's dtype) by utils/fits.py on numpy alone, or by healpy itself where it is
+    installed; a .npy file is accepted as well.
     """
 
     def __init__(self, map=None, path=None, cosmo=None, redshift=None):
         if (path is None) & (map is None):
             raise ValueError("Need to provide either path to map, or provide map values in healpix ring configuration")
         elif isinstance(path, str):
-            if not path.endswith(".npy"):
-                raise NotImplementedError("only .npy maps can be read here (FITS needs healpy)")
-            self.map = np.load(path)
+            if path.endswith(".npy"):
+                self.map = np.load(path)
+            else:
+                from .fits import read_healpix_map
+                self.map = read_healpix_map(path)                         # io.py:347 hp.read_map(path)
         elif isinstance(map, np.ndarray):
             self.map = map
 

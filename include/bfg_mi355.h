@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BFG_ABI_VERSION 3
+#define BFG_ABI_VERSION 4
 
 typedef enum {
     BFG_OK = 0,
@@ -300,6 +300,11 @@ int bfg_baryonify_offsets(bfg_ctx *ctx, const bfg_shell_args *args, const bfg_ta
  * they -- like the tiles -- are added to what the buffer holds (accumulate INTO; BFG_SHELL_OUT_IS_ZERO: to the zeros the
  * caller vouched for).                                                                                                 */
 typedef int (*bfg_slice_fn)(void *user, int slice, int n_slices, int64_t elem_begin, int64_t elem_end);
+/* The ranges a sliced call will report, without making the call: elem_cuts[0] = 0 < ... < elem_cuts[*n_out] = all elements
+ * (elem_cuts holds at least 17 entries; offsets = 0: bfg_paint_shell_sliced, 1: bfg_baryonify_offsets_sliced).  Lets the
+ * caller decide BEFORE the call which pixels a rank will own after the slices' reduce-scatters -- and upload only those of the
+ * input map (the distributed BaryonifyShell, Runners/HealpixRunner.py:357-370 on a rank's own pixel range).  Needs no GPU. */
+int bfg_shell_slice_cuts(int64_t nside, int offsets, int n_slices, int64_t *elem_cuts, int *n_out);
 int bfg_paint_shell_sliced(bfg_ctx *ctx, const bfg_shell_args *args, const bfg_table *table,
                            const bfg_spline *da_spline, double *d_map, int n_slices, bfg_slice_fn fn, void *user);
 int bfg_baryonify_offsets_sliced(bfg_ctx *ctx, const bfg_shell_args *args, const bfg_table *table,

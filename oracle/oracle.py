@@ -201,12 +201,21 @@ T_NCDM = 0.71611
 RHO_CRITICAL = (3.0 * 100.0 * 100.0) / (8.0 * np.pi * GNEWT) * (1000.0 * 1000.0 * MPC_TO_METER / SOLAR_MASS)
 
 
+# Omega_nu,rel of the massless neutrinos = N_eff 7/8 x^4 Omega_gamma: "T_ncdm" x = 0.71611 (pyccl's T_nu = T_CMB T_ncdm, as recalled
+# from its source; the default) or "4/11" x = (4/11)^(1/3) (instantaneous decoupling).  The choice moves D_A by 2.5e-7 at z = 0.5;
+# a cosmology dict may carry it as cosmo["nu_rel"] (what a run against live pyccl must settle).
+NU_REL = "T_ncdm"
+
+
 def _omegas(cosmo):
     h = cosmo["h"]
     rho_crit_si = RHO_CRITICAL * SOLAR_MASS / MPC_TO_METER ** 3 * h * h
     rho_g = 4.0 * STBOLTZ / CLIGHT ** 3 * T_CMB ** 4
     Om_g = rho_g / rho_crit_si
-    Om_nu = N_EFF * 7.0 / 8.0 * T_NCDM ** 4 * Om_g
+    conv = cosmo.get("nu_rel", NU_REL)
+    assert conv in ("T_ncdm", "4/11")
+    x = T_NCDM if conv == "T_ncdm" else (4.0 / 11.0) ** (1.0 / 3.0)
+    Om_nu = N_EFF * 7.0 / 8.0 * x ** 4 * Om_g
     Om_m = cosmo["Omega_m"]
     Om_l = 1.0 - Om_m - Om_g - Om_nu
     return Om_m, Om_l, Om_g + Om_nu

@@ -101,7 +101,9 @@ def main():
         import warnings
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            bout = bfg.SplitJoinParallel(BR, collective=coll).process()
+            BSJ = bfg.SplitJoinParallel(BR, collective=coll)
+            bout = BSJ.process()
+        info[f"bary_{coll}_h2d_bytes"] = int(BSJ.last_ops.h2d_bytes)      # of the input map: the pixels this rank owns, nothing else
         np.save(os.path.join(a.out, f"bary_{coll}_{a.rank}.npy"), bout)
     # one rank's shard EMPTY (a partial-sky catalog cut into declination stripes: every halo north of dec = +10 deg, so rank 1 of 2
     # gets none): the sliced exchange must still issue the same collectives on both ranks (bfg_*_sliced reports slices that do

@@ -60,30 +60,46 @@ class OracleBaryonifyOps(object):
 
     def __init__(self, runner, offsets_fn, regrid_fn):
         self.runner, self.offsets_fn, self.regrid_fn = runner, offsets_fn, regrid_fn
+        self.h2d_bytes = 0
+        self.cuts = None
 
-    def upload(self, flat):
-        return torch.from_numpy(np.array(flat, dtype=np.float64))
+    def slice_cuts(self, nside, slices):
+        npix = 12 * nside * nside
+        if slices <= 1:
+            return [0, 3 * npix]
+        # cuts on pixel boundaries, some lengths divisible by the world size and some not (both exchange paths)
+        cuts = sorted(set([0, npix] + [int(npix * (i / slices) ** 1.2) // 4 * 4 + (i % 2) for i in range(1, slices)]))
+        self.cuts = cuts
+        return [3 * c for c in cuts]
+
+    def upload_ranges(self, flat, ranges, npix):
+        d = torch.zeros(npix, dtype=torch.float64)
+        for lo, hi in ranges:
+            d[lo:hi] = torch.from_numpy(np.array(flat[lo:hi], dtype=np.float64))
+            self.h2d_bytes += 8 * (hi - lo)
+        return d
 
     def zeros(self, *shape):
         return torch.zeros(*shape, dtype=torch.float64)
 
-    def absmax_sum(self, t):
-        return float(t.abs().max()), float(t.sum())
+    def count_above(self, d_in, ranges, threshold, d_dst):
+        d_dst[0] = float(sum(int((d_in[lo:hi].abs() > threshold).sum()) for lo, hi in ranges))
 
     def offsets(self, slices=1, on_slice=None):
         d = torch.from_numpy(np.ascontiguousarray(self.offsets_fn(self.runner), dtype=np.float64))
         if on_slice is not None:
             flat = d.view(-1)
-            npix = d.shape[0]
-            # cuts on pixel boundaries, some lengths divisible by the world size and some not (both exchange paths)
-            cuts = sorted(set([0, npix] + [int(npix * (i / slices) ** 1.2) // 4 * 4 + (i % 2) for i in range(1, slices)]))
-            self.cuts = cuts
+            cuts = self.slice_cuts(self.runner.LightconeShell.NSIDE, slices)
             for k in range(len(cuts) - 1):
-                on_slice(k, len(cuts) - 1, 3 * cuts[k], 3 * cuts[k + 1], flat)
+                on_slice(k, len(cuts) - 1, cuts[k], cuts[k + 1], flat)
         return d
 
-    def regrid(self, nside, d_off, d_in, d_out):
-        d_out += torch.from_numpy(np.ascontiguousarray(self.regrid_fn(nside, d_off.numpy(), d_in.numpy())))
+    def regrid(self, nside, d_off, d_in, d_out, d_sums=None):
+        dep = np.ascontiguousarray(self.regrid_fn(nside, d_off.numpy(), d_in.numpy()))
+        d_out += torch.from_numpy(dep)
+        if d_sums is not None:
+            d_sums[0] = float(d_in.sum())
+            d_sums[1] = float(dep.sum())
 
     def to_host(self, t):
         return t.numpy()

@@ -121,6 +121,7 @@ def _worker(rank, world, port, out_dir):
     bops = OracleBaryonifyOps(BSJ5.Runner_list[0], oracle_offsets, oracle_regrid)
     bout5 = BSJ5.process(ops=bops)
     assert len(bops.cuts) == 6
+    np.save(os.path.join(out_dir, f"bh2d_{rank}.npy"), np.array([bops.h2d_bytes]))      # bytes of the input map this rank uploaded
     np.testing.assert_allclose(bout5, bout, rtol=1e-12, atol=1e-12 * np.abs(bout).max())
     np.save(os.path.join(out_dir, f"bsrc5_{rank}.npy"), calls["regrid_sources"])
     calls["regrid_sources"] = calls2["regrid_sources"]
@@ -186,6 +187,9 @@ def test_splitjoin_ranks_gloo(tmp_path, world):
     bsrc5 = [np.load(tmp_path / f"bsrc5_{r}.npy") for r in range(world)]
     assert np.array_equal(np.sort(np.concatenate(bsrc5)), np.flatnonzero(m_in))  # ... also when every slice is cut N ways
     assert all(s.size > 0 for s in bsrc)
+    # every rank uploads the pixels it owns and nothing else: together exactly one copy of the map (8 Npix / N bytes each)
+    h2d = [int(np.load(tmp_path / f"bh2d_{r}.npy")[0]) for r in range(world)]
+    assert sum(h2d) == 8 * m_in.size and max(h2d) <= 8 * (m_in.size // world + 8 * world)
     assert not np.allclose(bref, m_in)
     for m in bmaps:
         np.testing.assert_allclose(m, bref, rtol=1e-9, atol=1e-9 * np.abs(bref).max())

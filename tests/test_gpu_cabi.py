@@ -218,6 +218,69 @@ def test_cabi_comm_world_of_one_and_collectives():
     _lib.check(L.bfg_ctx_destroy(ctx))
 
 
+def test_cabi_reduce_scatter_begin_and_allgather_world_of_one():
+    """bfg_reduce_scatter_f64_begin (with a ticket) and bfg_allgather_f64 on a communicator of ONE rank: rank 0 owns [0, count), so both
+    leave every element as it was; the ticket is 0 (nothing was enqueued on the communication stream) and bfg_comm_wait takes it;
+    bad arguments are refused before RCCL is touched"""
+    L = _lib.load()
+    ctx = C.c_void_p()
+    _lib.check(L.bfg_ctx_create(0, C.c_void_p(-1), C.byref(ctx)), "ctx")
+    ident = C.create_string_buffer(_lib.BFG_COMM_ID_BYTES)
+    _lib.check(L.bfg_comm_unique_id(ident, _lib.BFG_COMM_ID_BYTES), "unique id")
+    _lib.check(L.bfg_comm_init(ctx, ident.raw, _lib.BFG_COMM_ID_BYTES, 0, 1), "comm init")
+    x = np.random.default_rng(11).normal(size=3 * 12 * 16 * 16)                     # an offset field of NSIDE 16
+    d = Dev(L, ctx, x.nbytes).up(x)
+    for count in (x.size, 12, 1):
+        tk = C.c_int64(-7)
+        _lib.check(L.bfg_reduce_scatter_f64_begin(ctx, d.p, count, C.byref(tk)), "reduce-scatter begin")
+        assert tk.value == 0
+        _lib.check(L.bfg_comm_wait(ctx, tk.value), "wait")
+        _lib.check(L.bfg_allgather_f64(ctx, d.p, count), "all-gather")
+        _lib.check(L.bfg_ctx_synchronize(ctx))
+        assert np.array_equal(d.down(x.shape), x)
+    assert L.bfg_reduce_scatter_f64_begin(ctx, None, 8, None) == -1
+    assert L.bfg_allgather_f64(ctx, None, 8) == -1
+    assert L.bfg_reduce_scatter_f64_begin(ctx, d.p, -1, None) == -1
+    _lib.check(L.bfg_reduce_scatter_f64_begin(ctx, d.p, 0, None), "nothing to exchange")
+    _lib.check(L.bfg_comm_destroy(ctx))
+    d.free()
+    _lib.check(L.bfg_ctx_destroy(ctx))
+
+
+def test_cabi_slice_cuts_are_what_the_sliced_calls_report(cosmo):
+    """bfg_shell_slice_cuts (no GPU call) == the ranges bfg_paint_shell_sliced / bfg_baryonify_offsets_sliced hand to their callback,
+    with halos and without"""
+    from baryonforge_amd.engine import get_context
+    ctx = get_context()
+    bg = Background(cosmo)
+    spline = ctx.da_spline(bg, 0.6)
+    md = ctx.massdef_struct(bg, None)
+    zax, Max, rax, T = syn.pressure_table()
+    zd, Md, rd, dd = syn.displacement_table()
+    with np.errstate(all="ignore"):
+        tp = ctx.table([zax, Max, rax], np.log(T), log_values=True)
+    td = ctx.table([zd, Md, rd], dd, log_values=False)
+    for nside in (8, 64, 256):
+        npix = 12 * nside * nside
+        for n in (0, 300):
+            ra, dec, M, z = syn.catalog(max(n, 1), seed=21)
+            d_cat = ctx.to_device(np.stack([M, z, ra, dec], axis=1)[:n])
+            for slices in (1, 2, 5, 16, 40):
+                for offsets in (False, True):
+                    want = _lib.shell_slice_cuts(nside, offsets, slices)
+                    assert want[0] == 0 and want[-1] == (3 if offsets else 1) * npix and all(a < b for a, b in zip(want, want[1:]))
+                    seen = []
+                    cb = lambda k, m, lo, hi: seen.append((k, m, lo, hi))
+                    if offsets:
+                        args = ctx.shell_args(nside, d_cat, n, 4, 0, 10.0, md, model_md=md, model_epsilon_max=20.0, out_overwrite=True)
+                        ctx.baryonify_offsets(args, td, spline, ctx.empty(npix, 3), slices=slices, on_slice=cb)
+                    else:
+                        args = ctx.shell_args(nside, d_cat, n, 4, 0, 10.0, md, out_overwrite=True)
+                        ctx.paint_shell(args, tp, spline, ctx.empty(npix), slices=slices, on_slice=cb)
+                    assert [(lo, hi) for _, _, lo, hi in seen] == list(zip(want, want[1:])), (nside, n, slices, offsets)
+                    assert [k for k, _, _, _ in seen] == list(range(len(want) - 1)) and all(m == len(want) - 1 for _, m, _, _ in seen)
+
+
 def test_cabi_set_stream_orders_work_across_streams(cosmo):
     """bfg_ctx_set_stream: a context created on its own stream is moved to a second stream; the paint enqueued there
     sees the zero-fill enqueued on the first one (event ordering, no host synchronisation in between)"""

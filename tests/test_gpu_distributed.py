@@ -80,6 +80,9 @@ def test_two_ranks_real_kernels_paint_and_baryonify(tmp_path):
             assert_maps_close(bgot, bref, 1e-5, floor=1e-9, what=f"2-rank baryonify ({backend}/{coll}), rank {r}")
             assert np.isclose(bgot.sum(), I["m_in"].sum(), rtol=1e-10)            # mass conservation (:368-370)
         assert np.array_equal(np.load(tmp_path / f"paint_{coll}_0.npy"), np.load(tmp_path / f"paint_{coll}_1.npy"))
+        # distributed BaryonifyShell: every rank uploaded the pixels it owns -- together one copy of the input map
+        assert sum(info[f"bary_{coll}_h2d_bytes"] for info in infos) == 8 * 12 * W.NSIDE ** 2
+        assert max(info[f"bary_{coll}_h2d_bytes"] for info in infos) <= 8 * (12 * W.NSIDE ** 2 // world + 64)
         # the list API: every shell equals its own serial oracle run on every rank; every (halo, pixel) pair painted once
         ptot_list = 0
         for k, (lo, hi) in enumerate(W.LIST_CUTS):

@@ -117,6 +117,25 @@ def test_paint_headline_full_size_vs_oracle(cosmo):
     assert_maps_close(got, ref, RTOL, what="headline paint 1e6 halos")
 
 
+def test_paint_config1_full_size_vs_oracle(cosmo):
+    """BASELINE configs[1] at full size (PaintProfilesShell, 1e5 halos, NSIDE 1024, eps 10, TabulatedProfile(Pressure), seed 42) against
+    the oracle, halo for halo: identical pixel-update count, identical non-zero pixel set, every non-zero pixel within 1e-5 relative"""
+    import os
+    nside, n = 1024, 100000
+    ra, dec, M, z = syn.catalog(n, seed=42)
+    zax, Max, rax, T = syn.pressure_table()
+    a, R, D = orc.halo_scalars(cosmo, M, z)
+    with np.errstate(all="ignore"):
+        ref, ptot = orc.paint_shell(nside, ra, dec, M, a, D, R, (zax, Max, rax), np.log(T), 10, njobs=max(1, min(16, os.cpu_count() or 1)))
+    Run = bfg.PaintProfilesShell(bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo),
+                                 bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), 10,
+                                 _paint_model(zax, Max, rax, T), verbose=False)
+    got = Run.process()
+    assert Run.last_stats["pixel_updates"] == ptot and Run.last_stats["fallback_halos"] == 0
+    assert np.array_equal(got != 0, ref != 0)
+    assert_maps_close(got, ref, RTOL, what="configs[1]: paint 1e5 halos")
+
+
 def test_baryonify_config2_full_size_vs_oracle(cosmo):
     """BASELINE config[2] at full size (1e5 halos, NSIDE 1024, eps 10, model eps 20), the whole BaryonifyShell pipeline
     (offsets + regrid) against the oracle; mass conserved as the reference asserts (HealpixRunner.py:368-370)"""

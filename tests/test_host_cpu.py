@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.bfg_abi_version() == _lib.ABI_VERSION == 3
+    assert L.bfg_abi_version() == _lib.ABI_VERSION == 4
     assert L.bfg_status_string(0) == b"ok" and b"invalid" in L.bfg_status_string(-1)
 
 
@@ -531,6 +531,29 @@ def test_background_against_independent_quadrature_and_closed_form():
     np.testing.assert_allclose(orc.get_radius(cosmo, M, a), R_exact, rtol=1e-12)
 
 
+def test_massless_neutrino_convention_is_a_parameter_and_moves_distances_by_parts_in_1e7():
+    """The one constants-level ambiguity of the background: Omega_nu,rel = N_eff 7/8 x^4 Omega_gamma with x = T_ncdm =
+    0.71611 (the default, pyccl's T_nu = T_CMB T_ncdm as recalled) or x = (4/11)^(1/3).  Both are selectable in the product's
+    Background and in the oracle (cosmo["nu_rel"]); they agree with each other convention by convention, and the choice moves D_A by
+    2.5e-7 at z = 0.5 and ~1.2e-6 at z = 3 -- far inside the 1e-5 map tolerance, recorded so that a run against live pyccl can settle it."""
+    cosmo = dict(syn.COSMO)
+    zs = np.array([0.1, 0.5, 1.0, 3.0])
+    a = 1 / (1 + zs)
+    d = {}
+    for conv in ("T_ncdm", "4/11"):
+        bg = Background(cosmo, nu_rel=conv)
+        d[conv] = bg.angular_diameter_distance(a)
+        np.testing.assert_allclose(orc.angular_diameter_distance(dict(cosmo, nu_rel=conv), a), d[conv], rtol=1e-12)
+        x = 0.71611 if conv == "T_ncdm" else (4 / 11) ** (1 / 3)
+        Og = bg.Omega_r / (1 + 3.044 * 7 / 8 * x ** 4)
+        np.testing.assert_allclose(bg.Omega_r - Og, 3.044 * 7 / 8 * x ** 4 * Og, rtol=1e-12)
+    np.testing.assert_array_equal(Background(cosmo).angular_diameter_distance(a), d["T_ncdm"])       # the default
+    rel = np.abs(d["4/11"] / d["T_ncdm"] - 1)
+    assert 1.5e-7 < rel[1] < 3.5e-7 and 0.8e-6 < rel[3] < 1.6e-6 and np.all(rel < 2e-6), rel
+    with pytest.raises(ValueError):
+        Background(cosmo, nu_rel="other")
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_stripe_shards_partition_and_extents_cover_the_painted_pixels(world):
     """sharding.shard_by_stripes: every halo exactly once, equal-area stripes get ~equal counts; stripe_extent: a RING pixel
@@ -554,3 +577,32 @@ def test_stripe_shards_partition_and_extents_cover_the_painted_pixels(world):
         assert (e1 - e0) < (1.0 / world + 0.25) * npix                     # own part + borders (NSIDE 128: large discs)
     assert sharding.stripe_extent(nside, np.array([]), np.array([])) == (0, 0)
     assert sharding.stripe_extent(nside, np.array([10.0]), np.array([np.pi])) == (0, npix)     # a disc over the whole sky
+
+
+def test_slice_cuts_depend_on_nside_and_slice_count_only():
+    """bfg_shell_slice_cuts needs no GPU: the slices of a sliced call are whole bands of the loop's tile geometry (32 rings for paint,
+    16 for the offset field, 3 elements per pixel), at most 16, covering the output once -- what lets every rank of a process group
+    issue the same collectives whatever its shard holds"""
+    from baryonforge_amd import _lib
+    for nside in (1, 2, 8, 64, 1024, 2048):
+        npix = 12 * nside * nside
+        nrings = 4 * nside - 1
+        for offsets, tr, per in ((False, 32, 1), (True, 16, 3)):
+            nbands = (nrings + tr - 1) // tr
+            for slices in (1, 2, 3, 4, 7, 16, 17, 100):
+                cuts = _lib.shell_slice_cuts(nside, offsets, slices)
+                K = len(cuts) - 1
+                assert K == max(1, min(slices, 16, nbands))
+                assert cuts[0] == 0 and cuts[-1] == per * npix and all(a < b for a, b in zip(cuts, cuts[1:]))
+                assert all(c % per == 0 for c in cuts)
+                assert cuts == _lib.shell_slice_cuts(nside, offsets, slices)
+    # power-of-two NSIDE: band boundaries fall on multiples of 32 pixels, so the slices of the offset field split evenly over 2 / 4 / 8 ranks
+    for nside in (64, 1024, 2048):
+        cuts = _lib.shell_slice_cuts(nside, True, 4)
+        assert all(((b - a) // 3) % 8 == 0 for a, b in zip(cuts, cuts[1:]))
+    L = _lib.load()
+    import ctypes
+    buf, n = (ctypes.c_int64 * 17)(), ctypes.c_int(0)
+    assert L.bfg_shell_slice_cuts(0, 0, 4, buf, ctypes.byref(n)) == -1
+    assert L.bfg_shell_slice_cuts(64, 0, 0, buf, ctypes.byref(n)) == -1
+    assert L.bfg_shell_slice_cuts(64, 0, 4, None, ctypes.byref(n)) == -1
