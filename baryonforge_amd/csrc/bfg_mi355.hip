@@ -807,7 +807,10 @@ struct __align__(16) RgRow {
     int32_t nr, istart, w, shifted;  // ring length; first ring index of the LDS row (may be < 0: modulo nr); row width
     double theta;                    // ring colatitude as get_ring_info2 gives it (get_interpol's theta1 / theta2)
     double z, sth, phistep, phioff;  // pixel-centre geometry of the ring (ring_geom)
+    double inv_dth;                  // 1 / (colatitude of the next ring - this ring's); 0 for the last ring
+    double pad;
 };
+static_assert(sizeof(RgRow) == 80, "RgRow is five 16-byte pieces");
 
 // (sin, cos) of an angle in [0, 2 pi] without libm: Cody-Waite reduction by pi/2, degree-13 / -14 series on
 // [-pi/4, pi/4] (<= 2 ulp); libm's version carries a large-argument path that is never needed here
@@ -866,9 +869,15 @@ __global__ __launch_bounds__(256, BFG_RG_WAVES) void regrid_tile_kernel(Hpx hp, 
         const int ring = row_ring0 + tid;
         RgRow r;
         r.start = 0; r.nr = 0; r.istart = 0; r.w = 0; r.shifted = 0; r.theta = 0; r.z = 0; r.sth = 0; r.phistep = 0; r.phioff = 0;
+        r.inv_dth = 0; r.pad = 0;
         if (ring >= 1 && ring <= nl4 - 1 && ring <= ring_hi + kRgHalo) {
             int64_t sp, nr; bool sh; double th;
             ring_info2(hp, ring, sp, nr, th, sh);
+            if (ring + 1 <= nl4 - 1) {
+                int64_t sp2_, nr2_; bool sh2_; double th2_;
+                ring_info2(hp, ring + 1, sp2_, nr2_, th2_, sh2_);
+                r.inv_dth = 1.0 / (th2_ - th);
+            }
             const int k0 = (int)(((int64_t)sector * nr) / NS), k1 = (int)(((int64_t)(sector + 1) * nr) / NS);
             r.start = sp; r.nr = (int)nr; r.shifted = sh ? 1 : 0; r.theta = th;
             r.w = min(k1 - k0 + 2 * kRgHalo, (int)nr);
@@ -932,13 +941,97 @@ __global__ __launch_bounds__(256, BFG_RG_WAVES) void regrid_tile_kernel(Hpx hp, 
         // reference carries as well --, at ~400 instructions per pixel; on a sparse shell most pixels take this exit: regrid at
         // NSIDE 1024 behind 1e4 halos 0.298 -> 0.253 ms.  No difference from 1e5 halos up -- and what is left there is not this
         // arithmetic but the loads (32 B per pixel) and the ~1.3 flush atomics per pixel: profiles/r03_regrid_ab.txt.)
-        if (ox == 0.0 && oy == 0.0 && oz == 0.0 && !no_shortcut) {
+        if (ox == 0.0 && oy == 0.0 && oz == 0.0 && !(no_shortcut & 1)) {
             deposit(row + kRgHalo, sr.start, ip, val);
             v_dep += val;
             continue;
         }
         double sphi, cphi;
-        sincos_2pi(((double)ip + sr.phioff) * sr.phistep, sphi, cphi);
+        const double phi_p = ((double)ip + sr.phioff) * sr.phistep;
+        sincos_2pi(phi_p, sphi, cphi);
+        // ---- the usual case: a displacement of a fraction of a pixel, away from the poles.  The displaced direction is the pixel's
+        // own centre (theta_p, phi_p) plus small angles, so hp.vec2ang (:358) is taken DIFFERENTIALLY: with the offset rotated into
+        // the pixel's meridian plane, tan(dphi) = cross / dot and tan(dtheta) = (rho z_p - v_z sin theta_p) / (rho sin theta_p +
+        // v_z z_p), rho = dot sqrt(1 + tan^2 dphi) -- two reciprocals and three short series (|tan| <= 2^-7: truncation < 1e-16)
+        // instead of two square roots, a division and two full-range atan2; and healpix_cxx's get_interpol (:361) needs no
+        // ring_above(z): the ring pair is found by comparing dtheta with the colatitudes of the neighbouring rings in the LDS row
+        // table, 1 / (theta_2 - theta_1) comes from there too.  Same weights as the general code below to ~1e-13 (both are
+        // continuous in the angles; the reference's own acos / atan2 carry rounding of that order): ~200 instead of ~500
+        // instructions per pixel, and this kernel is VALU-issue bound (profiles/r04_sq_counters_regrid.txt).
+        if (!(no_shortcut & 2)) {
+            const double dotp = sr.sth + (ox * cphi + oy * sphi);      // rho cos(dphi)
+            const double crs = oy * cphi - ox * sphi;                  // rho sin(dphi)
+            const double vzz = sr.z + oz;
+            if (dotp > 0.0 && fabs(crs) <= 0.0078125 * dotp) {
+                const double u = crs * rcp_newton(dotp), u2 = u * u;
+                double pa = fma(u2, -1.0 / 7.0, 0.2);
+                pa = fma(u2, pa, -1.0 / 3.0);
+                const double dph = fma(u * u2, pa, u);                 // atan(u)
+                double pr = fma(u2, 0.0625, -0.125);
+                pr = fma(u2, pr, 0.5);
+                const double rho = fma(dotp * u2, pr, dotp);           // dot sqrt(1 + u^2)
+                const double aa = rho * sr.z - vzz * sr.sth, bb = rho * sr.sth + vzz * sr.z;
+                if (bb > 0.25 && fabs(aa) <= 0.0078125 * bb) {
+                    const double tq = aa * rcp_newton(bb), tq2 = tq * tq;
+                    double pt = fma(tq2, -1.0 / 7.0, 0.2);
+                    pt = fma(tq2, pt, -1.0 / 3.0);
+                    const double dth = fma(tq * tq2, pt, tq);          // theta - theta_p
+                    int lrA = row + kRgHalo + ((dth >= 0.0) ? 0 : -1);
+                    double phi = phi_p + dph;
+                    if (phi < 0.0) phi += kTwoPi;
+                    // (phi == 2 pi after rounding is healpix_cxx's unwrapped-index case: left to the general code, which keeps it)
+                    bool found = false;
+                    double dA = 0.0;
+#pragma unroll
+                    for (int it = 0; it < 3 && !found && phi < kTwoPi; ++it) {
+                        if (lrA < 0 || lrA + 1 >= kRgRows) break;
+                        const RgRow &ta = rows[lrA], &tb = rows[lrA + 1];
+                        if (ta.nr <= 0 || tb.nr <= 0) break;
+                        dA = ta.theta - sr.theta;
+                        const double dB = tb.theta - sr.theta;
+                        if (dth < dA) lrA -= 1;
+                        else if (dth >= dB) lrA += 1;
+                        else found = true;
+                    }
+                    if (found) {
+                        const RgRow &ta = rows[lrA], &tb = rows[lrA + 1];
+                        const double wtheta = (dth - dA) * ta.inv_dth;
+                        auto ring_w = [&](const RgRow &t, int &ia, int &ib, double &ww) {
+                            const double tmp = fma(phi, (double)t.nr * kInvTwoPi, t.shifted ? -0.5 : 0.0);
+                            const double fl = floor(tmp);
+                            ia = (int)fl;
+                            ww = tmp - fl;
+                            ib = ia + 1;
+                            if (ia < 0) ia += t.nr;
+                            if (ia >= t.nr) ia -= t.nr;
+                            if (ib >= t.nr) ib -= t.nr;
+                        };
+                        int a0, a1, b0, b1;
+                        double wa, wb;
+                        ring_w(ta, a0, a1, wa);
+                        ring_w(tb, b0, b1, wb);
+                        const double d0 = ((1 - wa) * (1 - wtheta)) * val, d1 = (wa * (1 - wtheta)) * val;
+                        const double d2 = ((1 - wb) * wtheta) * val, d3 = (wb * wtheta) * val;   // :64-68
+                        v_dep += d0; v_dep += d1; v_dep += d2; v_dep += d3;
+                        // the two deposits of a ring share its row record (already in registers) and the index arithmetic
+                        auto deposit2 = [&](int lr, const RgRow &t, int ia, int ib, double da, double db) {
+                            int ra = ia - t.istart;
+                            ra += (ra < 0) ? t.nr : 0;
+                            ra -= (ra >= t.nr) ? t.nr : 0;
+                            int rb = ib - t.istart;
+                            rb += (rb < 0) ? t.nr : 0;
+                            rb -= (rb >= t.nr) ? t.nr : 0;
+                            double *base = &acc[lr * kRgWidth];
+                            if (da != 0.0) { if (ra < t.w) unsafeAtomicAdd(base + ra, da); else unsafeAtomicAdd(out_map + t.start + ia, da); }
+                            if (db != 0.0) { if (rb < t.w) unsafeAtomicAdd(base + rb, db); else unsafeAtomicAdd(out_map + t.start + ib, db); }
+                        };
+                        deposit2(lrA, ta, a0, a1, d0, d1);
+                        deposit2(lrA + 1, tb, b0, b1, d2, d3);
+                        continue;
+                    }
+                }
+            }
+        }
         const double vx = sr.sth * cphi + ox;                          // :357
         const double vy = sr.sth * sphi + oy;
         const double vz = sr.z + oz;
@@ -2231,7 +2324,8 @@ int bfg_regrid_shell(bfg_ctx *c, int64_t nside, const double *d_offsets, const d
     if (use_tiles)
         hipLaunchKernelGGL(regrid_tile_kernel, dim3((unsigned)c->tiles[kRegridSet].geo.ntiles), dim3(256), 0, c->stream, hp,
                            c->tiles[kRegridSet].geo, d_offsets, d_in_map, d_out_map, d_sums, c->d_mathtab + 2 * kLogTab + kExpTab,
-                           (rg_env && rg_env[0] == 'f') ? 1 : 0);    // BFG_REGRID=full: no exit for undisplaced pixels (A/B)
+                           // A/B: BFG_REGRID=full: no exit for undisplaced pixels; =general: no differential path; =all: neither
+                           !rg_env ? 0 : (rg_env[0] == 'f' ? 1 : (rg_env[0] == 'g' ? 2 : (rg_env[0] == 'a' ? 3 : 0))));
     else
         hipLaunchKernelGGL(regrid_kernel, dim3((unsigned)((hp.npix + 255) / 256)), dim3(256), 0, c->stream, hp,
                            d_offsets, d_in_map, d_out_map, d_sums);
