@@ -17,6 +17,51 @@ constexpr double kInvTwoPi = 1.0 / kTwoPi;
 constexpr double kTwoThird = 2.0 / 3.0;
 constexpr double kDeg2Rad = kPi / 180.0;
 
+// (sin, cos) of an angle in [0, 2 pi] without libm: Cody-Waite reduction by pi/2, degree-13 / -14 series on
+// [-pi/4, pi/4] (<= 2 ulp); libm's version carries a large-argument path that is never needed here
+__device__ inline void sincos_2pi(double a, double &s, double &c)
+{
+    const double qf = rint(a * 0.63661977236758134308);                       // 2 / pi
+    const int q = (int)qf;
+    double r = fma(qf, -1.57079632679489655800e+00, a);                       // pi/2 hi
+    r = fma(qf, -6.12323399573676603587e-17, r);                              // pi/2 lo
+    const double r2 = r * r;
+    double ps = fma(r2, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(r2, ps, 2.75573137070700676789e-06);
+    ps = fma(r2, ps, -1.98412698298579493134e-04);
+    ps = fma(r2, ps, 8.33333333332248946124e-03);
+    ps = fma(r2, ps, -1.66666666666666324348e-01);
+    const double sn = fma(r * r2, ps, r);
+    double pc = fma(r2, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(r2, pc, -2.75573143513906633035e-07);
+    pc = fma(r2, pc, 2.48015872894767294178e-05);
+    pc = fma(r2, pc, -1.38888888888741095749e-03);
+    pc = fma(r2, pc, 4.16666666666666019037e-02);
+    const double cs = fma(r2 * r2, pc, fma(r2, -0.5, 1.0));
+    const double s0 = (q & 1) ? cs : sn, c0 = (q & 1) ? sn : cs;
+    s = (q & 2) ? -s0 : s0;
+    c = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// sin / cos of any argument: the lean routine inside [0, 2 pi] (|x| for the even / odd symmetry), libm outside (and for NaN)
+__device__ inline void sincos_range(double a, double &s, double &c)
+{
+    if (a >= 0.0 && a <= kTwoPi) sincos_2pi(a, s, c);
+    else sincos(a, &s, &c);
+}
+__device__ inline double cos_range(double a)
+{
+    const double x = fabs(a);
+    if (x <= kTwoPi) { double s, c; sincos_2pi(x, s, c); return c; }
+    return cos(a);
+}
+__device__ inline double sin_range(double a)
+{
+    const double x = fabs(a);
+    if (x <= kTwoPi) { double s, c; sincos_2pi(x, s, c); return (a < 0.0) ? -s : s; }
+    return sin(a);
+}
+
 struct Hpx {
     int64_t nside, npix, ncap;
     double fact1, fact2;

@@ -252,6 +252,10 @@ __device__ inline double spline_eval(int n, const double *__restrict__ x, const 
 constexpr int kPrepKnots = 1024;     // D_A spline knots staged in LDS (the reference uses 1000, HealpixRunner.py:297)
 constexpr int kPrepAxis = 64;        // nodes of a non-radial table axis staged in LDS
 constexpr int kPrepRadial = 512;     // nodes of the radial axis staged in LDS (the window search is one more bisection)
+// dynamic LDS of halo_prep_kernel ahead of the row phase's corner arrays: cell weights [5][256] f64, ln(pixfac) [256] f64, cell
+// indices [5][256] i32, window starts and flags [2][256] i32 -- present only when the kernel builds row windows or the table has
+// extra axes (see the kernel)
+constexpr size_t kPrepRowLds = (size_t)(BFG_MAX_DIM - 1) * 256 * 8 + 256 * 8 + (size_t)(BFG_MAX_DIM - 1) * 256 * 4 + 2 * 256 * 4;
 
 // knots / axes: the D_A spline knots and the non-radial table axes, in LDS (the prep kernel stages them) or in global memory
 template <class AxisFn, class CellFn>
@@ -265,13 +269,21 @@ __device__ inline void halo_calc(const PrepParams &P, int64_t j, const double *_
     const double D = spline_eval(P.spl_n, knots, P.spl_coef, zred);         // :321/:455
     // hp.ang2vec(ra, dec, lonlat=True)                                      // :327/:460
     const double theta = kHalfPi - dec * kDeg2Rad, phi = ra * kDeg2Rad;
+    // (trigonometry without libm where the argument is in range -- sincos_range / atan2_upper: <= 2 ulp, a third of ocml's
+    // instructions; this kernel runs at ~45 % VALU utilisation on chains of dependent f64 operations, so instructions are time:
+    // profiles/r04_prep_ab.txt.  Out-of-range arguments -- |dec| > 90, ra outside [0, 360] -- take libm as before.)
     double st, ct, sp, cp;
-    sincos(theta, &st, &ct);
-    sincos(phi, &sp, &cp);
+    sincos_range(theta, st, ct);
+    sincos_range(phi, sp, cp);
     const double x0 = st * cp, y0 = st * sp, z0v = ct;
     // pointing(vec3) inside query_disc
-    double ptheta = atan2(sqrt(x0 * x0 + y0 * y0), z0v);
-    double pphi = (x0 == 0.0 && y0 == 0.0) ? 0.0 : atan2(y0, x0);
+    const double rxy = sqrt(x0 * x0 + y0 * y0);
+    double ptheta = (rxy == rxy && z0v == z0v) ? atan2_upper(rxy, z0v) : atan2(rxy, z0v);
+    double pphi = 0.0;
+    if (!(x0 == 0.0 && y0 == 0.0)) {
+        if (x0 == x0 && y0 == y0) { const double ap = atan2_upper(fabs(y0), x0); pphi = (y0 < 0.0) ? -ap : ap; }
+        else pphi = atan2(y0, x0);
+    }
     if (pphi < 0.0) pphi += kTwoPi;
     const double radius = R * P.eps_run / D;                                 // :329/:462
     o.x0 = x0; o.y0 = y0; o.z0v = z0v; o.ptheta = ptheta; o.pphi = pphi; o.D = D; o.a = a; o.radius = radius;
@@ -289,10 +301,10 @@ __device__ inline void halo_calc(const PrepParams &P, int64_t j, const double *_
         rfirst = 1; rlast = (int32_t)(nl4 - 1); irmin = (int32_t)nl4; irmax = (int32_t)nl4;  // every ring complete
     } else {
         const double rlat1 = ptheta - radius;
-        const double zmax = cos(rlat1);
+        const double zmax = cos_range(rlat1);
         int64_t imin = ring_above(P.hpx, zmax) + 1;
         const double rlat2 = ptheta + radius;
-        const double zmin = cos(rlat2);
+        const double zmin = cos_range(rlat2);
         int64_t imax = ring_above(P.hpx, zmin);
         bool north = (rlat1 <= 0) && (imin > 1);
         bool south = (rlat2 >= kPi) && (imax + 1 < nl4);
@@ -303,7 +315,9 @@ __device__ inline void halo_calc(const PrepParams &P, int64_t j, const double *_
     // table cell of the halo in the outer (non-radial) dimensions
     bool oob = false;
     uint32_t warn = 0;
-    for (int k = 0; k < P.tab.nouter; ++k) {
+#pragma unroll
+    for (int k = 0; k < BFG_MAX_DIM - 1; ++k) {          // (unrolled: k is a constant in every copy, so the callers' cell functors can
+        if (k >= P.tab.nouter) break;                    // keep the first two cells in registers)
         double x = (k == 0) ? lnz : (k == 1) ? lnM : c[4 + (k - 2)];
         int n = P.tab.oshape[k];
         const double *g = axis(k);
@@ -352,12 +366,19 @@ __global__ __launch_bounds__(256, BFG_PREP_WAVES) void halo_prep_kernel(const Pr
     __shared__ double s_knots[kPrepKnots];
     __shared__ double s_axis[BFG_MAX_DIM - 1][kPrepAxis];
     __shared__ double s_raxis[kPrepRadial];
-    // per halo of the block, for the row phase at the end: outer cell (index, weight per axis), window start, flags, ln(pixfac)
-    __shared__ int32_t s_ci[BFG_MAX_DIM - 1][256];
-    __shared__ double s_cy[BFG_MAX_DIM - 1][256];
-    __shared__ int32_t s_wl[256], s_fl[256];
-    __shared__ double s_ln[256];
-    extern __shared__ double smem_prep[];               // row phase: corner weights / row offsets of the halos of one pass
+    // Dynamic LDS, present only when the kernel builds row windows (P.hwin) or the table has extra axes (kPrepRowLds bytes + the
+    // row phase's corner arrays): per halo of the block the outer cell (index, weight per axis), window start, flags, ln(pixfac).
+    // The usual call -- 3-D table, windows blended in the tile kernel -- keeps the two cells in registers and the block at 15 KB of
+    // LDS instead of 34 KB.
+    extern __shared__ double smem_prep[];
+    const bool cells_lds = P.hwin != nullptr || P.tab.nouter > 2;
+    double (*s_cy)[256] = reinterpret_cast<double (*)[256]>(smem_prep);                                   // [5][256]
+    double *s_ln = smem_prep + (BFG_MAX_DIM - 1) * 256;                                                   // [256]
+    int32_t (*s_ci)[256] = reinterpret_cast<int32_t (*)[256]>(smem_prep + (BFG_MAX_DIM) * 256);          // [5][256]
+    int32_t *s_wl = reinterpret_cast<int32_t *>(smem_prep + (BFG_MAX_DIM) * 256) + (BFG_MAX_DIM - 1) * 256, *s_fl = s_wl + 256;
+    double *smem_rows = smem_prep + kPrepRowLds / 8;     // row phase: corner weights / row offsets of the halos of one pass
+    int32_t ci0 = 0, ci1 = 0;                            // the halo's cell on the z and M axes when it stays in registers
+    double cy0 = 0.0, cy1 = 0.0;
     const bool knots_lds = P.spl_n <= kPrepKnots;
     const bool raxis_lds = P.ht && P.tab.nr <= kPrepRadial;
     if (raxis_lds) for (int i = threadIdx.x; i < P.tab.nr; i += blockDim.x) s_raxis[i] = P.tab.raxis[i];
@@ -367,12 +388,16 @@ __global__ __launch_bounds__(256, BFG_PREP_WAVES) void halo_prep_kernel(const Pr
             for (int i = threadIdx.x; i < P.tab.oshape[k]; i += blockDim.x) s_axis[k][i] = P.tab.oaxis[k][i];
     __syncthreads();
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    s_fl[threadIdx.x] = HF_SKIP; s_wl[threadIdx.x] = 0; s_ln[threadIdx.x] = 0.0;
+    if (cells_lds) { s_fl[threadIdx.x] = HF_SKIP; s_wl[threadIdx.x] = 0; s_ln[threadIdx.x] = 0.0; }
     if (j < P.n_halo) {
     HaloCalc hc;
     halo_calc(P, j, knots_lds ? s_knots : P.spl_knots,
               [&](int k) -> const double * { return (P.tab.oshape[k] <= kPrepAxis) ? s_axis[k] : P.tab.oaxis[k]; },
-              [&](int k, int i, double y) { s_ci[k][threadIdx.x] = i; s_cy[k][threadIdx.x] = y; }, hc);
+              [&](int k, int i, double y) {
+                  if (k == 0) { ci0 = i; cy0 = y; }
+                  if (k == 1) { ci1 = i; cy1 = y; }
+                  if (cells_lds) { s_ci[k][threadIdx.x] = i; s_cy[k][threadIdx.x] = y; }
+              }, hc);
     if (hc.oob) {
         atomicAdd((unsigned long long *)&P.stats->halos_out_of_table, 1ull);
         atomicOr(&P.stats->warn_mask, hc.warn);
@@ -417,7 +442,11 @@ __global__ __launch_bounds__(256, BFG_PREP_WAVES) void halo_prep_kernel(const Pr
     // scatter kernel after the fact -- pair buffer exhausted -- tile_fill_kernel recomputes the rows: halo_calc is pure.)
     if (!P.lazy_soa || (flags & HF_SCATTER) || ovf != 0ull) {
         halo_write_soa(P, j, hc, flags);
-        for (int k = 0; k < P.tab.nouter; ++k) { P.cidx[k * P.cap + j] = s_ci[k][threadIdx.x]; P.cw[k * P.cap + j] = s_cy[k][threadIdx.x]; }
+        if (cells_lds) for (int k = 0; k < P.tab.nouter; ++k) { P.cidx[k * P.cap + j] = s_ci[k][threadIdx.x]; P.cw[k * P.cap + j] = s_cy[k][threadIdx.x]; }
+        else {
+            if (P.tab.nouter > 0) { P.cidx[j] = ci0; P.cw[j] = cy0; }
+            if (P.tab.nouter > 1) { P.cidx[P.cap + j] = ci1; P.cw[P.cap + j] = cy1; }
+        }
     }
     if (P.left && (flags & HF_SCATTER) && !(flags & HF_SKIP)) P.left[1 + atomicAdd(P.left_n, 1)] = (int32_t)j;
     if ((flags & HF_SLOW) && !(flags & (HF_SKIP | HF_OOB))) atomicAdd(&P.stats->halos_scatter_fallback, 1u);
@@ -425,13 +454,13 @@ __global__ __launch_bounds__(256, BFG_PREP_WAVES) void halo_prep_kernel(const Pr
         HaloTile h;
         h.st = hc.st; h.ct = hc.z0v; h.pphi = pphi;
         h.S = (D / a) * (D / a);
-        h.cosr = cos(radius);
-        h.z0 = cos(ptheta);
+        h.cosr = cos_range(radius);
+        h.z0 = cos_range(ptheta);
         h.xa = 1.0 / sqrt((1.0 - h.z0) * (1.0 + h.z0));
         h.pixfac = hc.pixfac;
         h.rfirst = rfirst; h.rlast = rlast; h.irmin = irmin; h.irmax = irmax;
         // staged row window: ends at the node above the largest radius of the disc (on the table's radial axis)
-        const double sr = sin(0.5 * fmin(radius, kPi));
+        const double sr = sin_range(0.5 * fmin(radius, kPi));
         const double axis_shift = (P.hd && P.rdelta) ? log(hc.Rm_com) : 0.0;
         const double rho_max = 0.5 * log(4.0 * h.S * sr * sr) - axis_shift;
         int win_lo = find_interval(raxis_lds ? s_raxis : P.tab.raxis, P.tab.nr, rho_max) + 1 - (P.win_nodes - 1);
@@ -446,11 +475,11 @@ __global__ __launch_bounds__(256, BFG_PREP_WAVES) void halo_prep_kernel(const Pr
             P.hd[j] = hd;
         }
         h.win_lo = win_lo; h.flags = flags;
-        h.ci0 = s_ci[0][threadIdx.x]; h.ci1 = (P.tab.nouter > 1) ? s_ci[1][threadIdx.x] : 0;
-        h.spare[0] = hc.lnpf; h.spare[1] = s_cy[0][threadIdx.x]; h.spare[2] = (P.tab.nouter > 1) ? s_cy[1][threadIdx.x] : 0.0;
+        h.ci0 = ci0; h.ci1 = (P.tab.nouter > 1) ? ci1 : 0;
+        h.spare[0] = hc.lnpf; h.spare[1] = cy0; h.spare[2] = (P.tab.nouter > 1) ? cy1 : 0.0;
         h.spare[3] = 0.0;
         P.ht[j] = h;
-        s_wl[threadIdx.x] = win_lo; s_fl[threadIdx.x] = flags; s_ln[threadIdx.x] = hc.lnpf;
+        if (cells_lds) { s_wl[threadIdx.x] = win_lo; s_fl[threadIdx.x] = flags; s_ln[threadIdx.x] = hc.lnpf; }
     }
     }   // j < n_halo
     // ---- row phase (what halo_row4_kernel does, same arithmetic): hwin[j][e] = sum over the corners of the halo's outer cell of
@@ -464,8 +493,8 @@ __global__ __launch_bounds__(256, BFG_PREP_WAVES) void halo_prep_kernel(const Pr
         const int W = P.win_nodes, tph = W >> 2, hpb = min(256 / tph, 64);
         const int hl = threadIdx.x / tph, q = threadIdx.x - hl * tph;
         const int ncorner = 1 << T.nouter;
-        double *s_w = smem_prep;                                               // [64][ncorner]
-        int64_t *s_off = reinterpret_cast<int64_t *>(smem_prep + 64 * ncorner);
+        double *s_w = smem_rows;                                               // [64][ncorner]
+        int64_t *s_off = reinterpret_cast<int64_t *>(smem_rows + 64 * ncorner);
         const int64_t j0 = (int64_t)blockIdx.x * blockDim.x;
         for (int h0 = 0; h0 < 256 && j0 + h0 < P.n_halo; h0 += hpb) {
             const int hh = h0 + hl;
@@ -811,32 +840,6 @@ struct __align__(16) RgRow {
     double pad;
 };
 static_assert(sizeof(RgRow) == 80, "RgRow is five 16-byte pieces");
-
-// (sin, cos) of an angle in [0, 2 pi] without libm: Cody-Waite reduction by pi/2, degree-13 / -14 series on
-// [-pi/4, pi/4] (<= 2 ulp); libm's version carries a large-argument path that is never needed here
-__device__ inline void sincos_2pi(double a, double &s, double &c)
-{
-    const double qf = rint(a * 0.63661977236758134308);                       // 2 / pi
-    const int q = (int)qf;
-    double r = fma(qf, -1.57079632679489655800e+00, a);                       // pi/2 hi
-    r = fma(qf, -6.12323399573676603587e-17, r);                              // pi/2 lo
-    const double r2 = r * r;
-    double ps = fma(r2, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = fma(r2, ps, 2.75573137070700676789e-06);
-    ps = fma(r2, ps, -1.98412698298579493134e-04);
-    ps = fma(r2, ps, 8.33333333332248946124e-03);
-    ps = fma(r2, ps, -1.66666666666666324348e-01);
-    const double sn = fma(r * r2, ps, r);
-    double pc = fma(r2, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = fma(r2, pc, -2.75573143513906633035e-07);
-    pc = fma(r2, pc, 2.48015872894767294178e-05);
-    pc = fma(r2, pc, -1.38888888888741095749e-03);
-    pc = fma(r2, pc, 4.16666666666666019037e-02);
-    const double cs = fma(r2 * r2, pc, fma(r2, -0.5, 1.0));
-    const double s0 = (q & 1) ? cs : sn, c0 = (q & 1) ? sn : cs;
-    s = (q & 2) ? -s0 : s0;
-    c = ((q + 1) & 2) ? -c0 : c0;
-}
 
 // Waves per SIMD: the long dependent chain per pixel (sincos -> sqrt -> atan2 x 2 -> divisions) needs wavefronts to overlap, spills
 // cost more.  Round 1's body: 184 VGPRs spill-free (2 waves) 0.43 ms, 128 VGPRs + 172 B of scratch (4 waves) 0.33 ms.  With the
@@ -1936,10 +1939,10 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     if (const char *e = std::getenv("BFG_ROWS")) if (!std::strcmp(e, "separate")) fuse_rows = false;
     // the row phase needs 64 x 2^nouter x 16 B of dynamic LDS on top of the kernel's 34 KB of static LDS: tables with three extra
     // axes would pass 64 KB -- those take the separate row kernel
-    if (fuse_rows && 34816 + (size_t)64 * ((size_t)1 << t->dev.nouter) * 16 > std::min<size_t>(c->max_dyn_lds, 65536)) fuse_rows = false;
+    if (fuse_rows && 15360 + kPrepRowLds + (size_t)64 * ((size_t)1 << t->dev.nouter) * 16 > std::min<size_t>(c->max_dyn_lds, 65536)) fuse_rows = false;
     pp.hwin = fuse_rows ? c->d_hwin : nullptr;
     pp.lazy_soa = (tile && t->dev.nouter == 2 && !std::getenv("BFG_EAGER_SOA")) ? 1 : 0;
-    const size_t prep_lds = fuse_rows ? (size_t)64 * ((size_t)1 << t->dev.nouter) * 16 : 0;
+    const size_t prep_lds = fuse_rows ? kPrepRowLds + (size_t)64 * ((size_t)1 << t->dev.nouter) * 16 : (t->dev.nouter > 2 ? kPrepRowLds : 0);
     timing_begin(c, 0);
     hipLaunchKernelGGL(halo_prep_kernel, dim3((unsigned)((a->n_halo + 255) / 256)), dim3(256), prep_lds, c->stream, pp);
     HIP_TRY(hipGetLastError());
