@@ -19,6 +19,7 @@ _vp = C.c_void_p
 BFG_OK = 0
 BFG_MAX_DIM = 6
 BFG_MAX_EXTRA = 3
+BFG_ND_MAX_OUTER = 12            # z, M and up to 10 p_keys axes on the N-dimensional row path (csrc/bfg_ndtable.hpp)
 BFG_TABLE_LOG_VALUES = 1
 
 VARIANT_AUTO, VARIANT_SCATTER_WAVE, VARIANT_SCATTER_QUARTER, VARIANT_TILE_LDS = 0, 1, 2, 3
@@ -44,6 +45,7 @@ SYMBOLS = [
     "bfg_reduce_scatter_f64_begin", "bfg_paint_shell_sliced", "bfg_baryonify_offsets_sliced",
     "bfg_disc_enumerate_count", "bfg_disc_enumerate", "bfg_map_add_values", "bfg_offsets_add_displacements",
     "bfg_copy_to_mapped_host", "bfg_shell_slice_cuts",
+    "bfg_ndtable_create", "bfg_ndtable_destroy", "bfg_ndtable_rows", "bfg_ndtable_read",
 ]
 ABI_VERSION = 4
 # bfg_slice_fn: int (*)(void *user, int slice, int n_slices, int64_t elem_begin, int64_t elem_end)
@@ -166,6 +168,11 @@ def load(build_if_missing=True):
     L.bfg_regrid_shell.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp]
     L.bfg_copy_to_mapped_host.argtypes = [_vp, _vp, _vp, _vp, C.c_size_t]
     L.bfg_shell_slice_cuts.argtypes = [_i64, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(C.c_int)]
+    L.bfg_ndtable_create.argtypes = [_vp, C.c_int, C.POINTER(_i64), C.POINTER(C.POINTER(_dbl)), _i64, C.POINTER(_dbl),
+                                     C.POINTER(_dbl), C.POINTER(_vp)]
+    L.bfg_ndtable_destroy.argtypes = [_vp, _vp]
+    L.bfg_ndtable_rows.argtypes = [_vp, _vp, _vp, _i64, C.c_int, _vp]
+    L.bfg_ndtable_read.argtypes = [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp]
     L.bfg_disc_enumerate_count.argtypes = [_vp, C.POINTER(ShellArgs), _vp, C.c_int, _vp]
     L.bfg_disc_enumerate.argtypes = [_vp, C.POINTER(ShellArgs), _vp, C.c_int, _vp, _vp, _vp, _vp]
     L.bfg_map_add_values.argtypes = [_vp, _vp, _vp, _vp, _i64]

@@ -220,7 +220,6 @@ __device__ inline void halo_calc(const PrepParams &P, int64_t j, const double *_
                                  HaloCalc &o);
 __device__ inline void halo_write_soa(const PrepParams &P, int64_t j, const HaloCalc &o, int32_t flags);
 #include "bfg_tile.hpp"
-#include "bfg_wtile.hpp"
 
 __device__ inline double massdef_radius(const bfg_massdef &md, double M, double a)
 {
@@ -355,6 +354,7 @@ __device__ inline void halo_write_soa(const PrepParams &P, int64_t j, const Halo
 }
 
 #include "bfg_enum.hpp"
+#include "bfg_ndtable.hpp"
 
 #ifndef BFG_PREP_WAVES
 #define BFG_PREP_WAVES 1
@@ -1852,15 +1852,13 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     if (variant == BFG_VARIANT_AUTO) variant = tile_ok ? BFG_VARIANT_TILE_LDS : BFG_VARIANT_SCATTER_QUARTER;
     if (variant == BFG_VARIANT_TILE_LDS && !tile_ok) variant = BFG_VARIANT_SCATTER_QUARTER;
     const bool tile = (variant == BFG_VARIANT_TILE_LDS);
-    bool use_wave = false;         // wave-private chunks (bfg_wtile.hpp): BFG_TILE_KERNEL=wave, an A/B variant
-    if (const char *tk = std::getenv("BFG_TILE_KERNEL")) use_wave = (tk[0] == 'w');
     if (const char *e = std::getenv("BFG_OUT_ZERO")) out_zero = std::atoi(e) != 0;                // A/B switches
     if (const char *e = std::getenv("BFG_OUT_OVERWRITE")) overwrite = overwrite && std::atoi(e) != 0;
-    if (overwrite && (!tile || use_wave)) {
+    if (overwrite && !tile) {
         HIP_TRY(hipMemsetAsync(d_out, 0, out_bytes, c->stream));
         overwrite = false; out_zero = true;
     }
-    if ((a->flags & BFG_SHELL_OUT_OVERWRITE) && !overwrite && tile && !use_wave) {       // switched off by the environment
+    if ((a->flags & BFG_SHELL_OUT_OVERWRITE) && !overwrite && tile) {       // switched off by the environment
         HIP_TRY(hipMemsetAsync(d_out, 0, out_bytes, c->stream));
         out_zero = true;
     }
@@ -1883,7 +1881,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         // L2-resident table (the BLEND instantiation of shell_tile_kernel; BFG_BLEND=0: the windows of round 2, built by the prep
         // kernel and fetched by LDS-DMA).  Measured (profiles/r03_blend_ab.txt): 1e6 halos step 1.27 -> 1.14 ms (prep 0.223 ->
         // 0.156, tile kernel 1.01 -> 0.95), 1e5 halos 0.242 -> 0.235, steep mass function 0.533 -> 0.446.
-        const bool can_blend = mode == MODE_PAINT && !win_table && win_nodes == kWinLds && t->dev.nouter == 2 && !use_wave;
+        const bool can_blend = mode == MODE_PAINT && !win_table && win_nodes == kWinLds && t->dev.nouter == 2;
         blend = can_blend;
         if (const char *e = std::getenv("BFG_BLEND")) blend = can_blend && std::atoi(e) != 0;
         const int64_t want = (win_table || blend) ? 0 : a->n_halo * (int64_t)win_nodes;
@@ -2008,8 +2006,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         // sliced call: cut the tiles into n_slices runs of whole bands (contiguous ring ranges = contiguous RING pixel ranges)
         SliceCuts cuts;
         std::memset(&cuts, 0, sizeof(cuts));
-        const bool wave_requested = use_wave && win_nodes == kWinLds && !win_table;
-        if (slice_fn && slice_K > 1 && persist > 0 && !wave_requested) {
+        if (slice_fn && slice_K > 1 && persist > 0) {
             const int K = slice_K;
             if (ts.geo.nbands != slice_nbands || ts.geo.tr != slice_tr) { g_last_error = "slice cuts: tile geometry mismatch"; return BFG_ERR_INVALID; }
             int b = 0, tile0 = 0;
@@ -2085,18 +2082,12 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lb));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_tile_kernel<MODE_BARYONIFY, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_wave_kernel<MODE_PAINT>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)wave_lds_bytes<MODE_PAINT>()));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_wave_kernel<MODE_BARYONIFY>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)wave_lds_bytes<MODE_BARYONIFY>()));
             c->tile_attr_set = true;
         }
         const dim3 tgrid((unsigned)tile_grid), tblock(kTileThreads);
         tp.work_counter = persist > 0 ? ts.d_counters : nullptr;
         tp.n_counters = n_counters;
         const bool wl = win_nodes <= kWinLds;
-        // wave-private chunks (bfg_wtile.hpp) need the 32-node LDS-staged windows
-        use_wave = use_wave && wl && win_nodes == kWinLds && !win_table;
         sp.only_flagged = 1;     // leftovers: halos the binning left to the global-atomic kernel
         sp.left = c->d_left; sp.left_n = pp.left_n;
         sp.pair_total_ptr = ts.d_tile_start + ts.geo.ntiles; sp.pair_cap = c->pair_cap;
@@ -2118,13 +2109,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         for (int islice = 0; islice < n_launch; ++islice) {
         if (cuts.n > 0) { tp.slice = cuts.range + 2 * islice; tp.work_counter = ts.d_counters + (size_t)(1 + islice) * kMaxCounters * kCounterStride; }
         timing_begin(c, 1);
-        if (use_wave) {
-            const dim3 wblock(kWaveThreads), wgrid((unsigned)items_max);      // one workgroup per work item
-            if (mode == MODE_PAINT)
-                hipLaunchKernelGGL((shell_wave_kernel<MODE_PAINT>), wgrid, wblock, wave_lds_bytes<MODE_PAINT>(), c->stream, tp);
-            else
-                hipLaunchKernelGGL((shell_wave_kernel<MODE_BARYONIFY>), wgrid, wblock, wave_lds_bytes<MODE_BARYONIFY>(), c->stream, tp);
-        } else if (light && wl) {
+        if (light && wl) {
             constexpr int ntp = TileCfg<MODE_PAINT, 1>::NT, ntb = TileCfg<MODE_BARYONIFY, 1>::NT;
             constexpr size_t ldp = tile_lds_bytes<MODE_PAINT, 1>(), ldb = tile_lds_bytes<MODE_BARYONIFY, 1>();
             if (mode == MODE_PAINT && blend)
@@ -2145,7 +2130,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         }
         HIP_TRY(hipGetLastError());
         timing_end(c, 1);
-        if (mode == MODE_PAINT && tp.defer && !tp.defer_tail && !use_wave) {
+        if (mode == MODE_PAINT && tp.defer && !tp.defer_tail) {
             timing_begin(c, 5);
             hipLaunchKernelGGL(tile_deferred_kernel, dim3((unsigned)std::min((tile_grid + 3) / 4, 8 * c->n_cu)), dim3(256), 0, c->stream, tp, tile_grid);
             HIP_TRY(hipGetLastError());
@@ -2839,3 +2824,98 @@ extern "C" int bfg_debug_stage_cycles(bfg_ctx *c, unsigned long long *out16, int
     return 0;
 }
 #endif
+
+// ---- tables with more p_keys axes than the shell kernels read (bfg_ndtable.hpp) ------------------------------------------
+struct bfg_ndtable {
+    bfg::NdTable dev;
+    double *d_blob;
+};
+
+int bfg_ndtable_create(bfg_ctx *c, int n_outer, const int64_t *outer_shape, const double *const *outer_axes, int64_t nr,
+                       const double *raxis, const double *values, bfg_ndtable **out)
+{
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
+    if (rc) return rc;
+    if (!outer_shape || !outer_axes || !raxis || !values || !out) return BFG_ERR_INVALID;
+    if (n_outer < 2 || nr < 2 || nr > (1 << 24)) return BFG_ERR_INVALID;
+    if (n_outer > bfg::kNdMaxOuter) return BFG_ERR_UNSUPPORTED;
+    size_t n_axes = (size_t)nr;
+    int64_t rows = 1;
+    for (int k = 0; k < n_outer; ++k) {
+        if (outer_shape[k] < 2 || outer_shape[k] > (1 << 24) || !outer_axes[k]) return BFG_ERR_INVALID;
+        for (int64_t i = 1; i < outer_shape[k]; ++i) if (!(outer_axes[k][i] > outer_axes[k][i - 1])) return BFG_ERR_INVALID;
+        n_axes += (size_t)outer_shape[k];
+        rows *= outer_shape[k];
+        if (rows > ((int64_t)1 << 40) / nr) return BFG_ERR_UNSUPPORTED;
+    }
+    for (int64_t i = 1; i < nr; ++i) if (!(raxis[i] > raxis[i - 1])) return BFG_ERR_INVALID;
+    const size_t total = (size_t)rows * (size_t)nr;
+    bfg_ndtable *t = new bfg_ndtable();
+    std::memset(&t->dev, 0, sizeof(t->dev));
+    t->d_blob = nullptr;
+    if (hipMalloc((void **)&t->d_blob, (n_axes + total) * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); delete t; return BFG_ERR_NOMEM; }
+    std::vector<double> ax(n_axes);
+    size_t pos = 0;
+    bfg::NdTable &D = t->dev;
+    D.nouter = n_outer; D.nr = (int)nr;
+    { int64_t st = nr; for (int k = n_outer - 1; k >= 0; --k) { D.ostride[k] = st; st *= outer_shape[k]; } }
+    for (int k = 0; k < n_outer; ++k) {
+        std::copy(outer_axes[k], outer_axes[k] + outer_shape[k], ax.begin() + pos);
+        D.oaxis[k] = t->d_blob + pos; D.oshape[k] = (int)outer_shape[k];
+        pos += (size_t)outer_shape[k];
+    }
+    std::copy(raxis, raxis + nr, ax.begin() + pos);
+    D.raxis = t->d_blob + pos; pos += (size_t)nr;
+    D.values = t->d_blob + pos;
+    if (hipMemcpyAsync(t->d_blob, ax.data(), n_axes * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(t->d_blob + n_axes, values, total * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) {
+        g_last_error = std::string("bfg_ndtable_create upload: ") + hipGetErrorString(hipGetLastError());
+        (void)hipFree(t->d_blob); delete t;
+        return BFG_ERR_HIP;
+    }
+    *out = t;
+    return BFG_OK;
+}
+
+int bfg_ndtable_destroy(bfg_ctx *c, bfg_ndtable *t)
+{
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
+    if (rc) return rc;
+    if (!t) return BFG_ERR_INVALID;
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(t->d_blob);
+    delete t;
+    return BFG_OK;
+}
+
+int bfg_ndtable_rows(bfg_ctx *c, const bfg_ndtable *t, const double *d_catalog, int64_t n_halo, int cat_stride, double *d_rows)
+{
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
+    if (rc) return rc;
+    if (!t || n_halo < 0 || (n_halo > 0 && (!d_catalog || !d_rows)) || cat_stride < 2 + t->dev.nouter) return BFG_ERR_INVALID;
+    if (n_halo == 0) return BFG_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>((n_halo + 3) / 4, (int64_t)c->n_cu * 16);
+    hipLaunchKernelGGL(bfg::nd_rows_kernel, dim3(grid), dim3(256), 0, c->stream, t->dev, d_catalog, n_halo, cat_stride, d_rows);
+    HIP_TRY(hipGetLastError());
+    return BFG_OK;
+}
+
+int bfg_ndtable_read(bfg_ctx *c, const bfg_ndtable *t, const double *d_rows, int64_t n, const int32_t *d_halo, const double *d_r_com,
+                     const double *d_shift, const double *d_rcut, const double *d_scale, int exp_values, double *d_out,
+                     unsigned int *d_r_oob)
+{
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
+    if (rc) return rc;
+    if (!t || n < 0 || (n > 0 && (!d_rows || !d_halo || !d_r_com || !d_out))) return BFG_ERR_INVALID;
+    if (n == 0) return BFG_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)c->n_cu * 16);
+    hipLaunchKernelGGL(bfg::nd_read_kernel, dim3(grid), dim3(256), 0, c->stream, d_rows, t->dev.nr, t->dev.raxis, n, d_halo, d_r_com,
+                       d_shift, d_rcut, d_scale, exp_values ? 1 : 0, d_out, d_r_oob);
+    HIP_TRY(hipGetLastError());
+    return BFG_OK;
+}

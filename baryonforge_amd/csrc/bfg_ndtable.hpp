@@ -1,0 +1,106 @@
+// bfg_ndtable.hpp -- tables with MORE p_keys axes than the shell kernels read (BFG_MAX_EXTRA = 3), on the device.
+//
+// ParamTabulatedProfile / BaryonificationClass tables are N-dimensional in the reference (utils/Tabulate.py:497-650,
+// Profiles/BaryonCorrection.py:211-227, :404-408): (z, M, r, p_1 ... p_n) with one scipy RegularGridInterpolator call per halo.
+// A multilinear read-out factors: all the non-radial coordinates of a (halo, pixel) query are the HALO's, so the 2^(n+2) corner
+// blend over (z, M, p_1 ... p_n) is done ONCE per halo -- nd_rows_kernel: one wavefront per halo, lanes over the radial nodes --
+// and what is left per pixel is a linear interpolation along r of the halo's row (nd_read_kernel).  The pixels come from the disc
+// enumeration of bfg_enum.hpp and go back through its scatter-add kernels, so the hot tile kernels are not touched; the host
+// evaluates nothing (round 3 sent these tables through scipy, per halo, on the host).
+// Corner order and products as in halo_row_kernel / scipy's _evaluate_linear: w = prod_k (bit_k ? y_k : 1 - y_k), corners in
+// index order, NaN where the halo lies outside the hull of any axis (fill_value = nan).
+#pragma once
+
+namespace bfg {
+
+constexpr int kNdMaxOuter = 12;      // z, M and up to 10 p_keys axes
+
+struct NdTable {
+    int nouter, nr;
+    int oshape[kNdMaxOuter];
+    int64_t ostride[kNdMaxOuter];    // in doubles; the radial axis is the fastest
+    const double *oaxis[kNdMaxOuter];
+    const double *raxis;
+    const double *values;            // [z][M][p_1]...[p_n][r]
+};
+
+__global__ __launch_bounds__(256) void nd_rows_kernel(const NdTable T, const double *__restrict__ cat, int64_t n_halo, int cat_stride,
+                                                      double *__restrict__ rows)
+{
+    __shared__ double s_y[4][kNdMaxOuter];
+    __shared__ int32_t s_ci[4][kNdMaxOuter];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int ncorner = 1 << T.nouter;
+    for (int64_t j = (int64_t)blockIdx.x * 4 + grp; j < n_halo; j += (int64_t)gridDim.x * 4) {
+        const double *c = cat + j * (int64_t)cat_stride;
+        bool oob = false;
+        if (lane < T.nouter) {
+            const double a = 1.0 / (1.0 + c[1]);
+            const double x = (lane == 0) ? log(1.0 / a) : (lane == 1) ? log(c[0]) : c[4 + (lane - 2)];   // Tabulate.py:308, :312, :620
+            const double *g = T.oaxis[lane];
+            const int n = T.oshape[lane];
+            oob = !(x >= g[0]) || !(x <= g[n - 1]);
+            const int i = find_interval(g, n, x);
+            s_ci[grp][lane] = i;
+            s_y[grp][lane] = (x - g[i]) / (g[i + 1] - g[i]);
+        }
+        const bool any_oob = __any(oob);
+        __builtin_amdgcn_wave_barrier();
+        for (int r0 = 0; r0 < T.nr; r0 += 64) {
+            const int ir = r0 + lane;
+            double acc = 0.0;
+            if (any_oob) acc = __builtin_nan("");
+            else {
+                for (int cc = 0; cc < ncorner; ++cc) {
+                    double w = 1.0;
+                    int64_t off = 0;
+                    for (int k = 0; k < T.nouter; ++k) {
+                        const int bit = (cc >> (T.nouter - 1 - k)) & 1;
+                        const double y = s_y[grp][k];
+                        w = w * (bit ? y : 1.0 - y);
+                        off += (int64_t)(s_ci[grp][k] + bit) * T.ostride[k];
+                    }
+                    if (ir < T.nr) acc = fma(T.values[off + ir], w, acc);
+                }
+            }
+            if (ir < T.nr) rows[j * (int64_t)T.nr + ir] = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// One (halo, pixel) entry: the halo's row at ln(r_com) [- shift_j: Rdelta_sampling tables, BaryonCorrection.py:406-408], NaN outside the
+// radial axis.  exp_values (paint, Tabulate.py:640-650 + HealpixRunner.py:473, :478): exp of it, non-finite -> 0, times scale_j
+// (pixarea D_j^2).  Otherwise (displacement, BaryonCorrection.py:410-411): the value itself, 0 where r_com >= rcut_j; NaN is
+// left for the offsets kernel, which zeroes non-finite offsets (:347).
+__global__ __launch_bounds__(256) void nd_read_kernel(const double *__restrict__ rows, int nr, const double *__restrict__ raxis, int64_t n,
+                                                      const int32_t *__restrict__ halo, const double *__restrict__ r_com,
+                                                      const double *__restrict__ shift, const double *__restrict__ rcut,
+                                                      const double *__restrict__ scale, int exp_values, double *__restrict__ out,
+                                                      unsigned int *__restrict__ r_oob)
+{
+    unsigned int n_out = 0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = halo[e];
+        const double rc = r_com[e];
+        const double x = log(rc) - (shift ? shift[j] : 0.0);
+        const bool inside = (x >= raxis[0]) && (x <= raxis[nr - 1]);
+        double v = __builtin_nan("");
+        if (inside) {
+            const int i = find_interval(raxis, nr, x);
+            const double f = (x - raxis[i]) / (raxis[i + 1] - raxis[i]);
+            const double *row = rows + j * (int64_t)nr;
+            const double b0 = row[i], b1 = row[i + 1];
+            v = b0 * (1.0 - f) + b1 * f;
+        } else n_out += 1;
+        if (exp_values) {
+            v = exp(v);
+            if (!isfinite(v)) v = 0.0;
+            if (scale) v *= scale[j];
+        } else if (rcut && !(rc < rcut[j])) v = 0.0;
+        out[e] = v;
+    }
+    if (r_oob && n_out) atomicAdd(r_oob, n_out);
+}
+
+}  // namespace bfg

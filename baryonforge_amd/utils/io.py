@@ -93,13 +93,25 @@ class HaloLightConeCatalog(object):
             out[:, i] = self.cat[c]
         return out
 
+    def _sample_stamp(self):
+        """a cheap content stamp of `cat`: its size and the bytes of ~256 records spread over it.  Writes through a view taken BEFORE
+        the array was locked stay possible (numpy cannot revoke them); a bulk edit through such a view -- m = Cat.cat['M'] before the
+        first process(), m *= 2 after it -- changes every record and so this stamp, and the device copy is refreshed.  An edit of a
+        single element through such a view is not detectable short of re-reading all 32 B per halo on every call: unlock() (or
+        BFG_CATALOG_CACHE=0) is the documented way to edit a catalog between calls."""
+        cat = self.cat
+        step = max(1, cat.size // 256)
+        sample = np.ascontiguousarray(cat[::step])
+        return (cat.size, cat.dtype.str, sample.tobytes())
+
     def device_records(self, ctx, extra_keys=()):
         """(device record matrix, doubles per record) on the GPU of `ctx`, uploaded once per catalog.
 
         The reference re-reads `cat` on every process() call.  To keep that guarantee without re-uploading 32 B per halo
         per call, the structured array is made READ-ONLY while a device copy exists (numpy then refuses in-place edits
         with a ValueError instead of letting the copy go stale); `unlock()` makes it writable again and drops the copies,
-        and replacing `self.cat` by another array is noticed by identity.  BFG_CATALOG_CACHE=0 uploads on every call."""
+        replacing `self.cat` by another array is noticed by identity, and a sampled content stamp catches bulk edits made through
+        views that existed before the lock (see _sample_stamp).  BFG_CATALOG_CACHE=0 uploads on every call."""
         import os
         recs = self.records(extra_keys)
         if os.environ.get("BFG_CATALOG_CACHE", "1") == "0":
@@ -107,26 +119,24 @@ class HaloLightConeCatalog(object):
         cache = self.__dict__.setdefault("_device_copies", {})
         key = (ctx.device_index, tuple(extra_keys))
         hit = cache.get(key)
-        if hit is not None and hit[0] is self.cat and not self.cat.flags.writeable:
+        stamp = self._sample_stamp()
+        if hit is not None and hit[0] is self.cat and not self.cat.flags.writeable and hit[3] == stamp:
             return hit[1], hit[2]
-        if hit is None or hit[0] is not self.cat or self.cat.flags.writeable:
-            cache.clear()                                                # another array, or it was writable in between
+        cache.clear()                                                    # another array, writable in between, or edited through a view
+        self.__dict__.pop("_zmax", None)
         d = ctx.to_device(recs)
-        try:
-            self.cat.setflags(write=False)
-        except ValueError:                                               # a view of someone else's buffer: cannot lock it
-            return d, recs.shape[1]
-        cache[key] = (self.cat, d, recs.shape[1])
+        self.cat.setflags(write=False)                                   # (never raises for write=False)
+        cache[key] = (self.cat, d, recs.shape[1], stamp)
         return d, recs.shape[1]
 
     def z_max(self):
         """max(z) of the catalog (HealpixRunner.py:297 / :429 take it on every call: 0.5 ms per 1e6 halos); remembered while the
-        array is locked by device_records(), recomputed otherwise"""
+        array is locked by device_records() and its sampled stamp is unchanged, recomputed otherwise"""
         hit = self.__dict__.get("_zmax")
-        if hit is not None and hit[0] is self.cat and not self.cat.flags.writeable:
+        if hit is not None and hit[0] is self.cat and not self.cat.flags.writeable and hit[2] == self._sample_stamp():
             return hit[1]
         z_m = float(np.max(self.cat["z"])) if self.cat.size else 0.0
-        self.__dict__["_zmax"] = (self.cat, z_m)
+        self.__dict__["_zmax"] = (self.cat, z_m, self._sample_stamp())
         return z_m
 
     def unlock(self):

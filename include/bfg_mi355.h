@@ -381,6 +381,32 @@ int bfg_comm_wait(bfg_ctx *ctx, int64_t ticket);
 int bfg_reduce_scatter_f64(bfg_ctx *ctx, double *d_buf, int64_t count);
 int bfg_allgather_f64(bfg_ctx *ctx, double *d_buf, int64_t count);
 
+/* ---- tables with MORE p_keys axes than the shell kernels read (BFG_MAX_EXTRA) ---------------------------------------
+ * ParamTabulatedProfile / BaryonificationClass tables are N-dimensional (utils/Tabulate.py:497-650,
+ * Profiles/BaryonCorrection.py:211-227, :404-408).  All non-radial coordinates of a (halo, pixel) query are the halo's, so the
+ * multilinear read-out factors: bfg_ndtable_rows blends the 2^n_outer corners ONCE per halo into the halo's radial row, and
+ * bfg_ndtable_read interpolates that row per (halo, pixel) entry of a disc enumeration (bfg_disc_enumerate); the values go
+ * back through bfg_map_add_values / bfg_offsets_add_displacements.  Nothing is evaluated on the host.
+ *   bfg_ndtable_create   n_outer = 2 + number of p_keys axes (<= 12): axes (ln(1+z), ln M, p_1 ...), strictly ascending; the
+ *                        radial axis ln r [or ln r/R_delta]; values[z][M][p_1]...[p_n][r] (radial index fastest): ln T for
+ *                        paint, d for displacement tables;
+ *   bfg_ndtable_rows     d_rows[j][0 .. nr) for the n_halo records (M, z, ra, dec, p_1 ...) of d_catalog; NaN rows for halos
+ *                        outside the hull of any axis (RegularGridInterpolator fill_value = nan);
+ *   bfg_ndtable_read     d_out[e] for entries (d_halo[e], d_r_com[e]): the row at ln(r_com) - d_shift[halo] (d_shift NULL: 0;
+ *                        Rdelta_sampling: ln R_delta,com), NaN outside the radial axis; exp_values != 0 (paint,
+ *                        HealpixRunner.py:472-478): exp of it, non-finite -> 0, times d_scale[halo] (NULL: 1; pixarea D^2);
+ *                        exp_values == 0 (displacement, BaryonCorrection.py:410-411): 0 where r_com >= d_rcut[halo] (NULL: no
+ *                        cut).  d_r_oob (device, may be NULL): incremented by the entries outside the radial axis.          */
+typedef struct bfg_ndtable bfg_ndtable;
+int bfg_ndtable_create(bfg_ctx *ctx, int n_outer, const int64_t *outer_shape, const double *const *outer_axes, int64_t nr,
+                       const double *raxis, const double *values, bfg_ndtable **out);
+int bfg_ndtable_destroy(bfg_ctx *ctx, bfg_ndtable *table);
+int bfg_ndtable_rows(bfg_ctx *ctx, const bfg_ndtable *table, const double *d_catalog, int64_t n_halo, int cat_stride,
+                     double *d_rows);
+int bfg_ndtable_read(bfg_ctx *ctx, const bfg_ndtable *table, const double *d_rows, int64_t n, const int32_t *d_halo,
+                     const double *d_r_com, const double *d_shift, const double *d_rcut, const double *d_scale, int exp_values,
+                     double *d_out, unsigned int *d_r_oob);
+
 /* max |x| over a device array (np.allclose(orig_map, 0) early return, :293-294) and sum. */
 int bfg_reduce_absmax_sum(bfg_ctx *ctx, int64_t n, const double *d_x, double *absmax, double *sum);
 

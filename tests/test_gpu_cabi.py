@@ -28,7 +28,8 @@ class Dev(object):
         _lib.check(L.bfg_dev_malloc(ctx, nbytes, C.byref(self.p)), "malloc")
 
     def up(self, arr):
-        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        arr = np.ascontiguousarray(arr) if np.asarray(arr).dtype in (np.int32, np.uint32, np.int64) else \
+            np.ascontiguousarray(arr, dtype=np.float64)
         _lib.check(self.L.bfg_memcpy_h2d(self.ctx, self.p, arr.ctypes.data, arr.nbytes), "h2d")
         return self
 
@@ -36,8 +37,8 @@ class Dev(object):
         _lib.check(self.L.bfg_dev_memset_zero(self.ctx, self.p, self.n), "memset")
         return self
 
-    def down(self, shape):
-        out = np.empty(shape)
+    def down(self, shape, dtype=np.float64):
+        out = np.empty(shape, dtype=dtype)
         _lib.check(self.L.bfg_memcpy_d2h(self.ctx, out.ctypes.data, self.p, out.nbytes), "d2h")
         return out
 
@@ -439,4 +440,75 @@ def test_cabi_disc_enumeration_and_value_scatter(cosmo):
     assert L.bfg_map_add_values(ctx, None, None, None, 5) == -1
     d_cat.free()
     _lib.check(L.bfg_spline_destroy(ctx, spl))
+    _lib.check(L.bfg_ctx_destroy(ctx))
+
+
+def test_cabi_ndtable_rows_and_read_equal_scipy_rgi():
+    """bfg_ndtable_create / _rows / _read through plain ctypes pointers: a 7-dimensional table (z, M, r + four parameter axes) read
+    out at (halo, r) entries == scipy's RegularGridInterpolator (the reference's read-out, utils/Tabulate.py:585-590) to 1e-13,
+    NaN for halos outside an axis and for radii outside the radial axis; the exp / scale / cut variants"""
+    from scipy.interpolate import RegularGridInterpolator
+    L = _lib.load()
+    ctx = C.c_void_p()
+    _lib.check(L.bfg_ctx_create(0, C.c_void_p(-1), C.byref(ctx)), "ctx")
+    rng = np.random.default_rng(12)
+    axes = [np.log(1 + np.array([0.0, 0.3, 0.7, 1.2])), np.log(np.geomspace(1e12, 1e16, 6)), np.log(np.geomspace(1e-2, 50, 40)),
+            np.array([0.5, 1.0, 2.0]), np.array([-1.0, 1.0]), np.array([3.0, 4.0, 6.0]), np.array([0.0, 0.1, 0.25, 1.0])]
+    vals = rng.normal(size=[a.size for a in axes])
+    vals[1, 2, 5, 0, 0, 1, 2] = np.nan
+    outer = [axes[0], axes[1]] + axes[3:]
+    rlast = np.ascontiguousarray(np.moveaxis(vals, 2, -1))
+    shape = (C.c_int64 * len(outer))(*[a.size for a in outer])
+    ptrs = (C.POINTER(C.c_double) * len(outer))(*[_lib.dptr(a) for a in outer])
+    t = C.c_void_p()
+    assert L.bfg_ndtable_create(ctx, 13, shape, ptrs, 40, _lib.dptr(axes[2]), _lib.dptr(rlast), C.byref(t)) == -4      # unsupported
+    _lib.check(L.bfg_ndtable_create(ctx, len(outer), shape, ptrs, 40, _lib.dptr(axes[2]), _lib.dptr(rlast), C.byref(t)), "ndtable")
+    n = 500
+    M = 10 ** rng.uniform(11.8, 16.2, n)
+    z = rng.uniform(-0.05, 1.3, n)
+    ex = np.stack([rng.uniform(0.4, 2.1, n), rng.uniform(-1.1, 1.1, n), rng.uniform(3, 6, n), rng.uniform(0, 1, n)], 1)
+    cat = np.ascontiguousarray(np.concatenate([np.stack([M, z, rng.uniform(0, 360, n), rng.uniform(-90, 90, n)], 1), ex], 1))
+    d_cat = Dev(L, ctx, cat.nbytes).up(cat)
+    d_rows = Dev(L, ctx, n * 40 * 8)
+    assert L.bfg_ndtable_rows(ctx, t, d_cat.p, n, 7, d_rows.p) == -1                 # stride too small for the table's axes
+    _lib.check(L.bfg_ndtable_rows(ctx, t, d_cat.p, n, 8, d_rows.p), "rows")
+    ne = 4000
+    halo = rng.integers(0, n, ne).astype(np.int32)
+    r = np.exp(rng.uniform(np.log(5e-3), np.log(80), ne))
+    shift = rng.uniform(-0.3, 0.3, n)
+    rcut = np.exp(rng.uniform(0, 3, n))
+    scale = rng.uniform(1, 2, n)
+    d_halo, d_r = Dev(L, ctx, halo.nbytes).up(halo), Dev(L, ctx, r.nbytes).up(r)
+    d_shift, d_rcut, d_scale = Dev(L, ctx, shift.nbytes).up(shift), Dev(L, ctx, rcut.nbytes).up(rcut), Dev(L, ctx, scale.nbytes).up(scale)
+    d_out = Dev(L, ctx, ne * 8)
+    oob = np.zeros(1, dtype=np.uint32)
+    d_oob = Dev(L, ctx, 4).up(oob)
+    rgi = RegularGridInterpolator(tuple(axes), vals, method="linear", bounds_error=False, fill_value=np.nan)
+
+    def ref(shifted):
+        lnr = np.log(r) - (shift[halo] if shifted else 0.0)
+        pts = np.concatenate([np.log(1.0 / (1.0 / (1.0 + z[halo])))[:, None], np.log(M[halo])[:, None], lnr[:, None], ex[halo]], 1)
+        return rgi(pts)
+    _lib.check(L.bfg_ndtable_read(ctx, t, d_rows.p, ne, d_halo.p, d_r.p, None, None, None, 0, d_out.p, d_oob.p), "read")
+    _lib.check(L.bfg_ctx_synchronize(ctx))
+    got, want = d_out.down((ne,)), ref(False)
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and 0.2 * ne < np.isnan(want).sum() < 0.8 * ne
+    np.testing.assert_allclose(got[~np.isnan(got)], want[~np.isnan(want)], rtol=1e-13, atol=1e-14)
+    lnr = np.log(r)
+    assert d_oob.down((1,), np.uint32)[0] == np.count_nonzero((lnr < axes[2][0]) | (lnr > axes[2][-1]))
+    # displacement flavour: shifted radial coordinate, zero beyond the cut (NaN inside it stays NaN)
+    _lib.check(L.bfg_ndtable_read(ctx, t, d_rows.p, ne, d_halo.p, d_r.p, d_shift.p, d_rcut.p, None, 0, d_out.p, None), "read (cut)")
+    _lib.check(L.bfg_ctx_synchronize(ctx))
+    got, want = d_out.down((ne,)), np.where(r < rcut[halo], ref(True), 0.0)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    np.testing.assert_allclose(got[~np.isnan(got)], want[~np.isnan(want)], rtol=1e-13, atol=1e-14)
+    # paint flavour: exp, non-finite -> 0, times the halo's scale
+    _lib.check(L.bfg_ndtable_read(ctx, t, d_rows.p, ne, d_halo.p, d_r.p, None, None, d_scale.p, 1, d_out.p, None), "read (exp)")
+    _lib.check(L.bfg_ctx_synchronize(ctx))
+    e = np.exp(ref(False))
+    np.testing.assert_allclose(d_out.down((ne,)), np.where(np.isfinite(e), e, 0.0) * scale[halo], rtol=1e-13, atol=0)
+    assert L.bfg_ndtable_read(ctx, t, None, ne, d_halo.p, d_r.p, None, None, None, 0, d_out.p, None) == -1
+    for d in (d_cat, d_rows, d_halo, d_r, d_shift, d_rcut, d_scale, d_out, d_oob):
+        d.free()
+    _lib.check(L.bfg_ndtable_destroy(ctx, t))
     _lib.check(L.bfg_ctx_destroy(ctx))

@@ -100,38 +100,66 @@ def test_callable_model_argument_checks(cosmo):
         bfg.PaintProfilesShell(Cat, Shell, 5, None, verbose=False).process()
 
 
-def test_tables_with_more_than_three_extra_axes_run_per_halo_on_the_host(cosmo):
+@pytest.mark.parametrize("n_extra", [4, 5])
+@pytest.mark.parametrize("batched", [False, True])
+def test_tables_with_more_than_three_extra_axes_on_the_device(cosmo, n_extra, batched, monkeypatch):
     """ParamTabulatedProfile / BaryonificationClass are N-dimensional in the reference (utils/Tabulate.py:497-650,
-    BaryonCorrection.py:211-227); the kernels read at most three p_keys axes (BFG_MAX_EXTRA).  A table with four goes through the
-    callable-model path: its .projected / .displacement -- scipy's N-linear interpolation on the host, as in the reference -- is
-    evaluated per halo, the geometry and the scatter-add stay on the GPU.  Against the oracle's own N-linear loops."""
+    BaryonCorrection.py:211-227, :404-408); the shell kernels read at most three p_keys axes (BFG_MAX_EXTRA).  Tables with four and
+    five take the N-dimensional row path (csrc/bfg_ndtable.hpp): the 2^(n + 2) corner blend once per halo and the radial read-out per
+    (halo, pixel) entry on the device, nothing on the host -- the models' own scipy read-out must not be called.  Against the
+    oracle's N-linear loops, incl. halos outside the hull of a parameter axis (NaN -> nothing painted / no displacement)."""
     from util import oracle_baryonify, oracle_paint
     nside, n, eps = 128, 300, 6.0
+    if batched:
+        monkeypatch.setenv("BFG_CALLABLE_BATCH", "4000")                  # several batches of entries ...
+        monkeypatch.setenv("BFG_ND_ROW_BYTES", str(8 * 60 * 37))          # ... and of rows (37 halos each)
     ra, dec, M, z = syn.catalog(n, seed=77, logM=(13.0, 15.3))
     rng = np.random.default_rng(8)
-    p = [rng.uniform(0.7, 1.4, n), rng.uniform(-1.0, 2.0, n), rng.uniform(10.0, 20.0, n), rng.uniform(0.0, 1.0, n)]
-    ax = [np.array([0.6, 1.0, 1.5]), np.array([-1.5, 0.0, 2.5]), np.array([5.0, 25.0]), np.array([-0.5, 0.5, 1.5])]
-    f4 = ((1.0 + 0.3 * (ax[0] - 1.0))[:, None, None, None] * (1.0 + 0.05 * ax[1] ** 2)[None, :, None, None]
-          * (ax[2] / 10.0)[None, None, :, None] * (1.0 + 0.2 * ax[3])[None, None, None, :])
+    p = [rng.uniform(0.7, 1.4, n), rng.uniform(-1.0, 2.0, n), rng.uniform(10.0, 20.0, n), rng.uniform(0.0, 1.0, n),
+         rng.uniform(2.0, 3.0, n)][:n_extra]
+    p[1][:7] = 2.6                                                        # outside the second parameter axis: NaN rows
+    ax = [np.array([0.6, 1.0, 1.5]), np.array([-1.5, 0.0, 2.5]), np.array([5.0, 25.0]), np.array([-0.5, 0.5, 1.5]),
+          np.array([1.5, 2.5, 3.5])][:n_extra]
+    fac = np.ones([a.size for a in ax])
+    for k, (a, f) in enumerate(zip(ax, [lambda x: 1.0 + 0.3 * (x - 1.0), lambda x: 1.0 + 0.05 * x ** 2, lambda x: x / 10.0,
+                                        lambda x: 1.0 + 0.2 * x, lambda x: 0.5 + 0.2 * x])):
+        shape = [1] * n_extra
+        shape[k] = a.size
+        fac = fac * f(a).reshape(shape)
     zax, Max, rax, T = syn.pressure_table(3, 8, 60)
-    T7 = T[..., None, None, None, None] * f4[None, None, None]
-    keys = ["pa", "pb", "pc", "pd"]
+    TN = T.reshape(T.shape + (1,) * n_extra) * fac[None, None, None]
+    keys = ["pa", "pb", "pc", "pd", "pe"][:n_extra]
     extra = np.stack(p, 1)
     Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo, **dict(zip(keys, p)))
-    ref, ptot = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax, *ax), T7, nside, eps, extra=extra)
-    model = bfg.ParamTabulatedProfile.from_arrays(zax, Max, rax, T7, other_params=dict(zip(keys, ax)))
-    R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), eps, model, verbose=False)
-    got = R.process()
-    assert R.last_stats["pixel_updates"] == ptot and np.array_equal(got != 0, ref != 0)
-    assert_maps_close(got, ref, 1e-9, what="paint, four extra table axes")
+    ref, ptot = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax, *ax), TN, nside, eps, extra=extra)
+    model = bfg.ParamTabulatedProfile.from_arrays(zax, Max, rax, TN, other_params=dict(zip(keys, ax)))
 
-    zd, Md, rd, d = syn.displacement_table(3, 8, 60)
-    d7 = d[..., None, None, None, None] * f4[None, None, None]
-    m_in = syn.mass_map(nside)
-    refb = oracle_baryonify(cosmo, ra, dec, M, z, (zd, Md, rd, *ax), d7, nside, eps, 20, m_in, extra=extra)
-    bm = bfg.Baryonification2D.from_arrays(zd, Md, rd, d7, cosmo, epsilon_max=20, other_params=dict(zip(keys, ax)))
-    import warnings
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        gotb = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo), eps, bm, verbose=False).process()
-    assert_maps_close(gotb, refb, 1e-5, floor=1e-9, what="baryonify, four extra table axes")
+    def forbidden(*a, **k):
+        raise AssertionError("the host read-out of the table was called")
+    monkeypatch.setattr(model, "projected", forbidden, raising=False)
+    for pix_size in (False, True):
+        R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), eps, model,
+                                   include_pixel_size=pix_size, verbose=False)
+        got = R.process()
+        if pix_size:
+            ref, ptot = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax, *ax), TN, nside, eps, extra=extra, include_pixel_size=True)
+        assert R.last_stats["pixel_updates"] == ptot and np.array_equal(got != 0, ref != 0)
+        assert_maps_close(got, ref, 1e-9, what=f"paint, {n_extra} extra table axes (pixel size {pix_size})")
+    d2 = R.process_device(d_map=R.process_device())                       # accumulates INTO a given map
+    assert_maps_close(d2.cpu().numpy(), 2 * ref, 1e-9, what="accumulate into a given map")
+
+    for rdelta in (False, True):
+        zd, Md, rd, d = syn.displacement_table(3, 8, 60, rdelta=rdelta)
+        dN = d.reshape(d.shape + (1,) * n_extra) * fac[None, None, None]
+        m_in = syn.mass_map(nside)
+        refb = oracle_baryonify(cosmo, ra, dec, M, z, (zd, Md, rd, *ax), dN, nside, eps, 20, m_in, extra=extra, rdelta=rdelta)
+        bm = bfg.Baryonification2D.from_arrays(zd, Md, rd, dN, cosmo, epsilon_max=20, other_params=dict(zip(keys, ax)),
+                                               **({"Rdelta_sampling": True} if rdelta else {}))
+        monkeypatch.setattr(bm, "displacement", forbidden, raising=False)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            gotb = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo), eps, bm, verbose=False).process()
+        assert not np.allclose(gotb, m_in)
+        assert np.isclose(gotb.sum(), m_in.sum())
+        assert_maps_close(gotb, refb, 1e-5, floor=1e-9, what=f"baryonify, {n_extra} extra table axes (Rdelta_sampling {rdelta})")

@@ -1065,7 +1065,7 @@ def test_paint_and_baryonify_any_nside(cosmo, nside, variant):
     assert_maps_close(gotb, refb, RTOL, floor=BFLOOR, what=f"baryonify nside {nside}")
 
 
-@pytest.mark.parametrize("switch", ["BFG_TILE_KERNEL=wave", "BFG_TILE_LIGHT=1", "BFG_TILE_LIGHT=0", "BFG_TILE_PERSIST=0", "BFG_TILE_PERSIST=7",
+@pytest.mark.parametrize("switch", ["BFG_TILE_LIGHT=1", "BFG_TILE_LIGHT=0", "BFG_TILE_PERSIST=0", "BFG_TILE_PERSIST=7",
                                     "BFG_FINAL_DRAIN=inline", "BFG_FINAL_DRAIN=kernel", "BFG_TILE_SCAN=1", "BFG_OUT_OVERWRITE=0",
                                     "BFG_ROWS=separate", "BFG_BLEND=0", "BFG_BLEND=0 BFG_ROWS=separate", "BFG_EAGER_SOA=1",
                                     "BFG_ITEM_COUNTERS=1", "BFG_ITEM_COUNTERS=3", "BFG_ITEM_COUNTERS=16 BFG_TILE_PERSIST=40"])
@@ -1674,6 +1674,18 @@ def test_catalog_device_copy_is_locked_not_stale(cosmo):
     Cat.cat["M"] /= 2.0
     ref, _ = oracle_paint(cosmo, ra, dec, M, z, (zax, Max, rax), T, 64, 10)
     assert_maps_close(R.process(), ref, RTOL, what="after replacing cat")
+    # a bulk edit through a view that existed BEFORE the lock (numpy cannot revoke it): the sampled stamp notices
+    Cat2 = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    m_view, z_view = Cat2.cat["M"], Cat2.cat["z"]
+    R2 = bfg.PaintProfilesShell(Cat2, bfg.LightconeShell(map=np.zeros(12 * 64 * 64), cosmo=cosmo), 10,
+                                _paint_model(zax, Max, rax, T), verbose=False)
+    R2.process()
+    assert m_view.flags.writeable and not Cat2.cat.flags.writeable
+    m_view *= 3.0
+    z_view += 0.02
+    assert Cat2.z_max() == pytest.approx(float(np.max(z + 0.02)), rel=1e-15)
+    ref, _ = oracle_paint(cosmo, ra, dec, 3 * M, z + 0.02, (zax, Max, rax), T, 64, 10)
+    assert_maps_close(R2.process(), ref, RTOL, what="after a bulk edit through an older view")
 
 
 # --------------------------------------------------------------------------- a8 pin at the BASELINE resolutions

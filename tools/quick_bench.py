@@ -3,7 +3,7 @@
 
   python tools/quick_bench.py [--modes VAR=a,b,...] [--workloads paint1e6,paint1e5,bary1e5,steep,bary1e6,eps20,n2048] [--reps 2]
 
-Default: BFG_TILE_KERNEL=block,wave.  The library reads its switches with getenv at every call, so the modes are toggled
+Default: BFG_TILE_LIGHT=0,1.  The library reads its switches with getenv at every call, so the modes are toggled
 in-process; for every workload the first mode's output is the reference the others are compared with (maximum relative
 difference on its non-zero pixels, identical non-zero sets, identical P_tot)."""
 import argparse
@@ -39,7 +39,7 @@ WORK = {
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--modes", default="BFG_TILE_KERNEL=block,wave")
+    ap.add_argument("--modes", default="BFG_TILE_LIGHT=0,1")
     ap.add_argument("--out-zero", action="store_true", help="set BFG_SHELL_OUT_IS_ZERO (the step clears the output first)")
     ap.add_argument("--overwrite", action="store_true", help="BFG_SHELL_OUT_OVERWRITE: no clearing pass, the call defines the output")
     ap.add_argument("--workloads", default="paint1e6,paint1e5,bary1e5,steep")

@@ -2,7 +2,7 @@
 # GPU box: randomised soak of the round's final build against the oracle (default paths -- PaintProfilesShell.process() goes
 # through the sliced call with 8 slices --, then the A/B paths)
 cd ${GRAFT_REPO_ROOT:-.}
-O=gpurun_out/r03_soak.txt
+O=gpurun_out/r04_soak.txt
 : > $O
 # SOAK_SEED (added to every seed) and SOAK_SCALE (multiplies every duration) give a second, different, longer soak
 run() { d=$(( $2 * ${SOAK_SCALE:-1} )); sd=$(( $3 + ${SOAK_SEED:-0} )); echo "== $1 ($d s, seed $sd)" >> $O; env $1 timeout -k 10 $(( d + 120 )) python3 tests/soak/soak.py $d $sd 2>&1 | grep -v "^ok\|amdgpu.ids" | tail -3 >> $O; }
@@ -11,10 +11,10 @@ run "BFG_BLEND=0" 90 3002
 run "BFG_TILE_CAP=3 BFG_TILE_SCAN=1" 90 3003
 run "BFG_D2H_SLICES=1 BFG_EAGER_SOA=1" 60 3004
 run "BFG_TILE_CAP=2 BFG_PAIR_CAP=100" 45 3005
-run "BFG_TILE_KERNEL=wave" 45 3006
+run "BFG_REGRID=general" 45 3006
 run "BFG_TILE_LIGHT=1" 90 3008
 run "BFG_TILE_LIGHT=0 BFG_ITEM_COUNTERS=1" 60 3009
-run "BFG_ITEM_COUNTERS=16 BFG_REGRID=full" 45 3010
+run "BFG_ITEM_COUNTERS=16 BFG_REGRID=all" 45 3010
 echo "== callable models" >> $O
 timeout -k 10 200 python3 tests/soak/soak_callable.py 60 $(( 3011 + ${SOAK_SEED:-0} )) 2>&1 | grep -v "^ok\|amdgpu.ids" | tail -3 >> $O
 echo "== aux (snapshot / deposit / grid)" >> $O
