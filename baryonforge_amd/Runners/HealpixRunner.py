@@ -632,6 +632,17 @@ def _checks_or_zero_map(runner, orig_map):
     return False
 
 
+def _regrid_band_groups(NSIDE, n_groups):
+    """the source bands of bfg_regrid_shell_bands cut into n_groups runs: (band cuts, RING pixel cuts)"""
+    from .._lib import load
+    from ..sharding import _ring_start
+    tr = int(load().bfg_regrid_band_rings())
+    nbands = (4 * NSIDE - 1 + tr - 1) // tr
+    g = max(1, min(int(n_groups), nbands))
+    cuts_b = [nbands * k // g for k in range(g + 1)]
+    return cuts_b, [_ring_start(NSIDE, 1 + b * tr) for b in cuts_b]
+
+
 def _baryonify_pipelined(runners, in_flight=2):
     """BaryonifyShell.process (HealpixRunner.py:252-373) for one or several shells on ONE GPU with the host transfers off the
     critical path.  Per shell the reference does: map to the device, offsets, regrid, map back -- 1.8 + 0.6 + 0.3 + 1.8 ms at
@@ -655,15 +666,18 @@ def _baryonify_pipelined(runners, in_flight=2):
         todo.append(k)
     if not todo:
         return results
+    import os
     import torch
     ctx = get_context()
     dev = ctx.device
     up, down = ctx.upload_stream(), ctx.copy_stream()
 
     def finish(item):
-        k, orig, h, h_small, ev = item
+        k, orig, h, h_small, ev, d_out = item
         ev.synchronize()
-        absmax, old_sum, new_sum = (float(x) for x in h_small.tolist())
+        absmax, old_sum, new_sum, far = (float(x) for x in h_small.tolist())
+        if far > 0:                                                       # a displacement of more than 4 rings somewhere: slices that had
+            h.copy_(d_out)                                                # left may have received deposits since -- the whole map again
         if not (absmax > 1e-8) and np.allclose(orig, 0):                  # :293-294 (False for NaN maps)
             results[k] = orig
             return
@@ -673,6 +687,7 @@ def _baryonify_pipelined(runners, in_flight=2):
 
     ctx.stats_reset()
     ran = []
+    n_slices = int(os.environ.get("BFG_BARY_SLICES", "8"))
     for k in todo:
         R = runners[k]
         orig = R.LightconeShell.map
@@ -684,32 +699,63 @@ def _baryonify_pipelined(runners, in_flight=2):
         d_off = R.offsets_device(sync_stats=False)                        # :313-355, enqueued; the GPU works while the host copies
         ran.append(R)
         flat = np.ascontiguousarray(orig, dtype=np.float64).ravel()
-        with torch.cuda.stream(up):
-            d_orig = torch.from_numpy(flat).to(dev)
-        main.wait_stream(up)
-        d_orig.record_stream(main)
-        d_out, d_small = ctx.zeros(npix), ctx.zeros(3)
-        d_small[0] = d_orig.abs().max()                                   # np.allclose(orig_map, 0) <=> max |map| <= 1e-8
-        ctx.regrid_shell(NSIDE, d_off, d_orig, d_out, d_small[1:])        # :357-365; {sum(in), sum(deposits)} from the kernel
         try:
             h = torch.empty(npix, dtype=torch.float64, pin_memory=True)
-            h_small = torch.empty(3, dtype=torch.float64, pin_memory=True)
+            h_small = torch.empty(4, dtype=torch.float64, pin_memory=True)
         except RuntimeError:                                              # no page-locked memory to be had
-            h, h_small = torch.empty(npix, dtype=torch.float64), torch.empty(3, dtype=torch.float64)
-        down.wait_stream(main)
-        with torch.cuda.stream(down):
-            if h.is_pinned() and n > 1:
-                # a copy KERNEL, not the DMA engine: the next shell's upload is a DMA copy, and two DMA copies in opposite directions
-                # take turns on this platform (tools/copy_probe.py: 3.7 ms for the pair, 2.3 ms with the kernel)
-                ctx.copy_to_pinned(h, d_out)
+            h, h_small = torch.empty(npix, dtype=torch.float64), torch.empty(4, dtype=torch.float64)
+        d_out, d_small = ctx.zeros(npix), ctx.zeros(4)                    # d_small = {max |in|, sum(in), sum(deposits), far deposits}
+        # The map in band slices (bfg_regrid_shell_bands): slice s is regridded as soon as it has arrived, and leaves once slice
+        # s + 1 has been regridded too (deposits reach 4 rings beyond a band; anything farther is counted and, should it ever
+        # happen, the whole map is copied again at the end) -- the upload, the regrid and the download of one shell overlap
+        # instead of following each other: 1.8 + 0.3 + 1.8 ms at BASELINE configs[2] (tools/bary_api_probe.py).
+        if NSIDE >= 32 and n_slices > 1 and n == 1:                      # (in a list the shells overlap each other: whole maps are faster)
+            cuts_b, cuts_p = _regrid_band_groups(NSIDE, n_slices)
+        else:
+            cuts_b, cuts_p = None, [0, npix]
+        S = len(cuts_p) - 1
+        with torch.cuda.stream(up):
+            d_orig = torch.empty(npix, dtype=torch.float64, device=dev)
+        d_orig.record_stream(main)
+
+        def send(lo, hi):                                                 # d_out[lo:hi] -> h[lo:hi] on the download stream
+            if hi <= lo:
+                return
+            if h.is_pinned() and (n > 1 or S > 1):
+                # a copy KERNEL, not the DMA engine: an upload is (or will be) running as a DMA copy, and two DMA copies in opposite
+                # directions take turns on this platform (tools/copy_probe.py: 3.7 ms for the pair, 2.3 ms with the kernel)
+                ctx.copy_to_pinned(h[lo:hi], d_out[lo:hi])
             else:
-                h.copy_(d_out, non_blocking=True)
+                h[lo:hi].copy_(d_out[lo:hi], non_blocking=True)
+        prev_ev = None
+        for sl in range(S):
+            lo, hi = cuts_p[sl], cuts_p[sl + 1]
+            with torch.cuda.stream(up):
+                d_orig[lo:hi].copy_(torch.from_numpy(flat[lo:hi]), non_blocking=True)
+                ev_up = torch.cuda.Event()
+                ev_up.record(up)
+            main.wait_event(ev_up)
+            d_small[0] = torch.maximum(d_small[0], d_orig[lo:hi].abs().max())   # np.allclose(orig_map, 0) <=> max |map| <= 1e-8; NaN sticks
+            if cuts_b is None:
+                ctx.regrid_shell(NSIDE, d_off, d_orig, d_out, d_small[1:3])     # :357-365; {sum(in), sum(deposits)} from the kernel
+            else:
+                ctx.regrid_shell_bands(NSIDE, d_off, d_orig, d_out, d_small[1:], cuts_b[sl], cuts_b[sl + 1])
+            ev_rg = torch.cuda.Event()
+            ev_rg.record(main)
+            if sl >= 1:                                                   # slice sl - 1 is final now
+                down.wait_event(ev_rg)
+                with torch.cuda.stream(down):
+                    send(cuts_p[sl - 1], cuts_p[sl])
+            prev_ev = ev_rg
+        down.wait_event(prev_ev)
+        with torch.cuda.stream(down):
+            send(cuts_p[S - 1], cuts_p[S])
             h_small.copy_(d_small, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(down)
         d_out.record_stream(down)
         d_small.record_stream(down)
-        pend.append((k, orig, h, h_small, ev))
+        pend.append((k, orig, h, h_small, ev, d_out))
     for item in pend:
         finish(item)
     if ran:

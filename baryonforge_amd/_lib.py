@@ -46,6 +46,7 @@ SYMBOLS = [
     "bfg_disc_enumerate_count", "bfg_disc_enumerate", "bfg_map_add_values", "bfg_offsets_add_displacements",
     "bfg_copy_to_mapped_host", "bfg_shell_slice_cuts",
     "bfg_ndtable_create", "bfg_ndtable_destroy", "bfg_ndtable_rows", "bfg_ndtable_read",
+    "bfg_regrid_band_rings", "bfg_regrid_shell_bands",
 ]
 ABI_VERSION = 4
 # bfg_slice_fn: int (*)(void *user, int slice, int n_slices, int64_t elem_begin, int64_t elem_end)
@@ -167,6 +168,8 @@ def load(build_if_missing=True):
     L.bfg_baryonify_offsets_sliced.argtypes = [_vp, C.POINTER(ShellArgs), _vp, _vp, _vp, C.c_int, SLICE_FN, _vp]
     L.bfg_regrid_shell.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp]
     L.bfg_copy_to_mapped_host.argtypes = [_vp, _vp, _vp, _vp, C.c_size_t]
+    L.bfg_regrid_band_rings.argtypes = []
+    L.bfg_regrid_shell_bands.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_uint32]
     L.bfg_shell_slice_cuts.argtypes = [_i64, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(C.c_int)]
     L.bfg_ndtable_create.argtypes = [_vp, C.c_int, C.POINTER(_i64), C.POINTER(C.POINTER(_dbl)), _i64, C.POINTER(_dbl),
                                      C.POINTER(_dbl), C.POINTER(_vp)]

@@ -851,14 +851,14 @@ static_assert(sizeof(RgRow) == 80, "RgRow is five 16-byte pieces");
 __global__ __launch_bounds__(256, BFG_RG_WAVES) void regrid_tile_kernel(Hpx hp, TileGeom geo, const double *__restrict__ off,
                                                           const double *__restrict__ in_map,
                                                           double *__restrict__ out_map, double *sums,
-                                                          const double *__restrict__ atantab, int no_shortcut)
+                                                          const double *__restrict__ atantab, int no_shortcut, int tile0, double *far)
 {
     __shared__ double acc[kRgRows * kRgWidth];
     __shared__ double s_atan[kAtanTab];
     if (threadIdx.x < kAtanTab) s_atan[threadIdx.x] = atantab[threadIdx.x];
     __shared__ RgRow rows[kRgRows];
     __shared__ double s_in[4], s_dep[4];
-    const int tile = blockIdx.x;
+    const int tile = tile0 + (int)blockIdx.x;      // (a launch over the tiles of some bands only: bfg_regrid_shell_bands)
     const int band = geo.tile_band[tile];
     const int sector = tile - geo.band_tile0[band];
     const int NS = geo.band_ns[band];
@@ -909,6 +909,7 @@ __global__ __launch_bounds__(256, BFG_RG_WAVES) void regrid_tile_kernel(Hpx hp, 
         }
     };
     // deposit d on ring index i of ring row lr (lr < 0: not an LDS row) / pixel sp + i
+    bool far_hit = false;
     auto deposit = [&](int lr, int64_t sp, int i, double d) {
         if (d == 0.0) return;
         bool local = lr >= 0;
@@ -921,7 +922,10 @@ __global__ __launch_bounds__(256, BFG_RG_WAVES) void regrid_tile_kernel(Hpx hp, 
             local = (rel >= 0) && (rel < t.w);
         }
         if (local) unsafeAtomicAdd(&acc[lr * kRgWidth + rel], d);
-        else unsafeAtomicAdd(out_map + sp + i, d);
+        else {
+            unsafeAtomicAdd(out_map + sp + i, d);
+            far_hit = far_hit || (lr < 0);                           // beyond the tile's halo of rings: may land in any band
+        }
     };
 
     double v_in = 0.0, v_dep = 0.0;
@@ -1126,6 +1130,7 @@ __global__ __launch_bounds__(256, BFG_RG_WAVES) void regrid_tile_kernel(Hpx hp, 
         if (ii >= t.nr) ii -= t.nr;
         unsafeAtomicAdd(out_map + t.start + ii, v);
     }
+    if (far && far_hit) unsafeAtomicAdd(far, 1.0);                       // (rare: a displacement of more than kRgHalo rings)
     if (sums) {
         for (int o = 32; o > 0; o >>= 1) { v_in += __shfl_down(v_in, o, 64); v_dep += __shfl_down(v_dep, o, 64); }
         const int w = tid >> 6;
@@ -2313,10 +2318,46 @@ int bfg_regrid_shell(bfg_ctx *c, int64_t nside, const double *d_offsets, const d
         hipLaunchKernelGGL(regrid_tile_kernel, dim3((unsigned)c->tiles[kRegridSet].geo.ntiles), dim3(256), 0, c->stream, hp,
                            c->tiles[kRegridSet].geo, d_offsets, d_in_map, d_out_map, d_sums, c->d_mathtab + 2 * kLogTab + kExpTab,
                            // A/B: BFG_REGRID=full: no exit for undisplaced pixels; =general: no differential path; =all: neither
-                           !rg_env ? 0 : (rg_env[0] == 'f' ? 1 : (rg_env[0] == 'g' ? 2 : (rg_env[0] == 'a' ? 3 : 0))));
+                           !rg_env ? 0 : (rg_env[0] == 'f' ? 1 : (rg_env[0] == 'g' ? 2 : (rg_env[0] == 'a' ? 3 : 0))), 0, nullptr);
     else
         hipLaunchKernelGGL(regrid_kernel, dim3((unsigned)((hp.npix + 255) / 256)), dim3(256), 0, c->stream, hp,
                            d_offsets, d_in_map, d_out_map, d_sums);
+    HIP_TRY(hipGetLastError());
+    timing_end(c, 2);
+    return BFG_OK;
+}
+
+// The regrid of the SOURCE pixels of ring bands [band_lo, band_hi) only (bands of bfg_regrid_band_rings() rings, counted from the
+// north pole): what lets a caller regrid a map slice by slice while the rest of it is still arriving over PCIe, and send a
+// finished slice back while the next one is regridded (Runners/HealpixRunner.py:357-365 on a band of source pixels).
+int bfg_regrid_band_rings(void) { return kRegridTR; }
+
+int bfg_regrid_shell_bands(bfg_ctx *c, int64_t nside, const double *d_offsets, const double *d_in_map, double *d_out_map,
+                           double *d_sums3, int band_lo, int band_hi, uint32_t flags)
+{
+    DeviceGuard dg_;
+    int rc = ctx_enter(c, dg_);
+    if (rc) return rc;
+    if (nside < 1 || nside > (1 << 20) || !d_offsets || !d_in_map || !d_out_map) return BFG_ERR_INVALID;
+    if (nside < 8) return BFG_ERR_UNSUPPORTED;                       // (no tile geometry below NSIDE 8: use bfg_regrid_shell)
+    const int nbands = (int)((4 * nside - 1 + kRegridTR - 1) / kRegridTR);
+    if (band_lo < 0 || band_hi > nbands || band_lo > band_hi) return BFG_ERR_INVALID;
+    rc = ensure_tiles(c, kRegridSet, kRegridTR, kTileWidth, nside, 0);
+    if (rc) return rc;
+    if (d_sums3 && (flags & 1u)) HIP_TRY(hipMemsetAsync(d_sums3, 0, 3 * sizeof(double), c->stream));
+    if (band_lo == band_hi) return BFG_OK;
+    int tile_lo = 0, tile_hi = 0;
+    for (int b = 0; b < band_hi; ++b) {
+        const int ns = band_sectors_host(nside, kRegridTR, kTileWidth, b);
+        if (b < band_lo) tile_lo += ns;
+        tile_hi += ns;
+    }
+    const char *rg_env = std::getenv("BFG_REGRID");
+    timing_begin(c, 2);
+    hipLaunchKernelGGL(regrid_tile_kernel, dim3((unsigned)(tile_hi - tile_lo)), dim3(256), 0, c->stream, make_hpx(nside),
+                       c->tiles[kRegridSet].geo, d_offsets, d_in_map, d_out_map, d_sums3, c->d_mathtab + 2 * kLogTab + kExpTab,
+                       !rg_env ? 0 : (rg_env[0] == 'f' ? 1 : (rg_env[0] == 'g' ? 2 : (rg_env[0] == 'a' ? 3 : 0))), tile_lo,
+                       d_sums3 ? d_sums3 + 2 : nullptr);
     HIP_TRY(hipGetLastError());
     timing_end(c, 2);
     return BFG_OK;

@@ -483,6 +483,14 @@ class Context(object):
                                              C.c_void_p(d_sums.data_ptr()) if d_sums is not None else None),
                    "bfg_regrid_shell")
 
+    def regrid_shell_bands(self, nside, d_offsets, d_in_map, d_out_map, d_sums3, band_lo, band_hi, clear_sums=False):
+        """bfg_regrid_shell_bands: the sources of ring bands [band_lo, band_hi); d_sums3 = {sum(in), sum(deposits), far deposits}"""
+        self._on_current_stream()
+        _lib.check(self.lib.bfg_regrid_shell_bands(self.handle, int(nside), C.c_void_p(d_offsets.data_ptr()),
+                                                   C.c_void_p(d_in_map.data_ptr()), C.c_void_p(d_out_map.data_ptr()),
+                                                   C.c_void_p(d_sums3.data_ptr()) if d_sums3 is not None else None,
+                                                   int(band_lo), int(band_hi), 1 if clear_sums else 0), "bfg_regrid_shell_bands")
+
     def baryonify_snapshot(self, d_part, d_halo, ndim, L, a, epsilon_max, runner_md, model_md, model_epsilon_max,
                            rdelta_sampling, n_extra, table, d_out):
         """bfg_baryonify_snapshot_strided: d_part / d_out float64[n, ndim] tensors or column views of wider record

@@ -318,6 +318,17 @@ int bfg_baryonify_offsets_sliced(bfg_ctx *ctx, const bfg_shell_args *args, const
 int bfg_regrid_shell(bfg_ctx *ctx, int64_t nside, const double *d_offsets, const double *d_in_map,
                      double *d_out_map, double *d_sums);
 
+/* The same regrid for the SOURCE pixels of ring bands [band_lo, band_hi) only -- bands of bfg_regrid_band_rings() rings counted
+ * from the north pole, i.e. contiguous RING pixel ranges.  Deposits reach at most 4 rings beyond a band's own rings, except
+ * for displacements of more than 4 rings, which are added wherever they land and COUNTED: d_sums3 = {sum(in), sum(deposits),
+ * number of threads with such a far deposit}, accumulated over the calls (flags bit 0: cleared first).  So the output of band
+ * group k is final once groups k - 1, k and k + 1 have been regridded and the far count is zero: a map can be regridded while
+ * it is still arriving over PCIe and leave while its other bands are regridded (Runners/HealpixRunner.py:357-365 band by
+ * band).  NSIDE >= 8.                                                                                                    */
+int bfg_regrid_band_rings(void);
+int bfg_regrid_shell_bands(bfg_ctx *ctx, int64_t nside, const double *d_offsets, const double *d_in_map, double *d_out_map,
+                           double *d_sums3, int band_lo, int band_hi, uint32_t flags);
+
 /* Device -> page-locked host memory by a copy kernel on `stream` (a hipStream_t; NULL: the context's stream; the context's own
  * stream binding is left alone) (host_dst: hipHostMalloc'd / registered memory, 16-byte aligned; bytes a multiple of 8): it overlaps a host -> device DMA copy running on another stream, which a second DMA
  * copy in the opposite direction does not on every platform (the map of shell k leaves while the map of shell k + 1 arrives).  */

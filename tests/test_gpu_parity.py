@@ -893,6 +893,80 @@ def test_regrid_phi_two_pi_quirk(nside, monkeypatch):
         assert_maps_close(out.cpu().numpy(), ref, RTOL, floor=BFLOOR, what=f"regrid {path}")
 
 
+@pytest.mark.parametrize("nside", [32, 256])
+def test_regrid_by_bands_equals_the_whole_regrid(nside):
+    """bfg_regrid_shell_bands: the regrid of the source pixels band group by band group (any cut of the 64-ring bands) sums to the
+    whole regrid (atomics reorder: rounding), {sum(in), sum(deposits)} accumulate over the calls, and displacements of more than
+    4 rings are counted; against the oracle as well"""
+    from baryonforge_amd.engine import get_context
+    from baryonforge_amd.Runners.HealpixRunner import _regrid_band_groups
+    ctx = get_context(0)
+    npix = 12 * nside * nside
+    rng = np.random.default_rng(nside + 5)
+    m_in = rng.uniform(1, 10, npix)
+    m_in[rng.uniform(size=npix) < 0.1] = 0.0
+    for far in (False, True):
+        off = rng.normal(0, 0.3 / nside, (npix, 3))                  # a third of a pixel
+        off[rng.uniform(size=npix) < 0.3] = 0.0
+        if far:
+            off[rng.integers(0, npix, 50)] += rng.normal(0, 12.0 / nside, (50, 3))    # ~10 pixels: beyond the 4-ring halo of a tile
+        d_off, d_in = ctx.to_device(off), ctx.to_device(m_in)
+        whole, sums = ctx.zeros(npix), ctx.zeros(2)
+        ctx.regrid_shell(nside, d_off, d_in, whole, sums)
+        ref = orc.regrid_shell(nside, off, m_in)
+        assert_maps_close(whole.cpu().numpy(), ref, RTOL, floor=BFLOOR, what="whole regrid")
+        for groups in (1, 2, 3, 8):
+            cuts_b, cuts_p = _regrid_band_groups(nside, groups)
+            assert cuts_p[0] == 0 and cuts_p[-1] == npix and all(a < b for a, b in zip(cuts_p, cuts_p[1:]))
+            out, s3 = ctx.zeros(npix), ctx.zeros(3)
+            for g in range(len(cuts_b) - 1):
+                ctx.regrid_shell_bands(nside, d_off, d_in, out, s3, cuts_b[g], cuts_b[g + 1], clear_sums=(g == 0))
+                if g + 1 < len(cuts_b) - 1:
+                    # what has been regridded so far deposits nothing beyond 4 rings past its last band -- unless counted as far
+                    beyond = out[cuts_p[g + 1] + 5 * 4 * nside:]
+                    if not far:
+                        assert not beyond.any()
+            np.testing.assert_allclose(out.cpu().numpy(), whole.cpu().numpy(), rtol=1e-11, atol=1e-11)
+            s3h, sh = s3.cpu().numpy(), sums.cpu().numpy()
+            np.testing.assert_allclose(s3h[:2], sh, rtol=1e-12)
+            assert (s3h[2] > 0) == far
+
+
+def test_baryonify_process_with_displacements_beyond_a_band_halo(cosmo, monkeypatch):
+    """BaryonifyShell.process() sends the map up, regrids it and sends it back band slice by band slice; a displacement of more
+    than 4 rings deposits into slices that may already have left -- counted by the kernel, and the whole map is copied again.
+    A displacement table of ~10 pixels at NSIDE 64, against the oracle; with one slice and with eight."""
+    import warnings
+    nside, n = 64, 400
+    ra, dec, M, z = syn.catalog(n, seed=91, logM=(14.0, 15.3), z=(0.05, 0.08))
+    zd, Md, rd, d = syn.displacement_table(4, 10, 60)
+    zd = np.log(1 + np.geomspace(0.01, 1.0, 4))
+    d = d * 1500.0                                                      # tens of Mpc at D_A ~ 250 Mpc: ~0.2 rad = a dozen pixels
+    m_in = syn.mass_map(nside)
+    ref = oracle_baryonify(cosmo, ra, dec, M, z, (zd, Md, rd), d, nside, 10, 20, m_in)
+    model = bfg.Baryonification2D.from_arrays(zd, Md, rd, d, cosmo, epsilon_max=20)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    outs = {}
+    for slices in ("1", "8"):
+        monkeypatch.setenv("BFG_BARY_SLICES", slices)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            outs[slices] = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo), 10, model, verbose=False).process()
+        assert np.isclose(outs[slices].sum(), m_in.sum(), rtol=1e-10)
+        assert_maps_close(outs[slices], ref, RTOL, floor=BFLOOR, what=f"baryonify, large displacements, {slices} slice(s)")
+    np.testing.assert_allclose(outs["8"], outs["1"], rtol=1e-10, atol=1e-10)
+    # the displacements really are larger than a band's halo: the far counter of the band-wise regrid is non-zero
+    from baryonforge_amd.engine import get_context
+    ctx = get_context(0)
+    R = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo), 10, model, verbose=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        d_off = R.offsets_device()
+    s3 = ctx.zeros(3)
+    ctx.regrid_shell_bands(nside, d_off, ctx.to_device(m_in), ctx.zeros(12 * nside * nside), s3, 0, 4, clear_sums=True)
+    assert float(s3[2].item()) > 0
+
+
 # --------------------------------------------------------------------------- full-size properties (no oracle)
 def test_paint_full_size_linearity_1e5(cosmo):
     """BASELINE config[1] at full size (1e5 halos, NSIDE 1024): painting is linear in halos
