@@ -93,6 +93,9 @@ struct bfg_ctx {
     double *d_cw;       // [BFG_MAX_DIM-1][cap]
     bfg_stats *d_stats;
     double *d_red;      // scratch for reductions [4]
+    int64_t *d_rg_slow; // regrid: pixels the tile kernel's differential path leaves to regrid_list_kernel (grow-only, one per pixel)
+    int64_t rg_slow_cap;
+    unsigned long long *d_rg_slow_n;
     // tile variant: geometry of the current nside, binning buffers, ln / exp tables
     struct TileSet {                // tile geometry + binning buffers of one (nside, rings-per-tile)
         int64_t nside;
@@ -851,11 +854,10 @@ static_assert(sizeof(RgRow) == 80, "RgRow is five 16-byte pieces");
 __global__ __launch_bounds__(256, BFG_RG_WAVES) void regrid_tile_kernel(Hpx hp, TileGeom geo, const double *__restrict__ off,
                                                           const double *__restrict__ in_map,
                                                           double *__restrict__ out_map, double *sums,
-                                                          const double *__restrict__ atantab, int no_shortcut, int tile0, double *far)
+                                                          int no_shortcut, int tile0, int64_t *__restrict__ slow_list,
+                                                          unsigned long long *slow_n)
 {
     __shared__ double acc[kRgRows * kRgWidth];
-    __shared__ double s_atan[kAtanTab];
-    if (threadIdx.x < kAtanTab) s_atan[threadIdx.x] = atantab[threadIdx.x];
     __shared__ RgRow rows[kRgRows];
     __shared__ double s_in[4], s_dep[4];
     const int tile = tile0 + (int)blockIdx.x;      // (a launch over the tiles of some bands only: bfg_regrid_shell_bands)
@@ -893,23 +895,7 @@ __global__ __launch_bounds__(256, BFG_RG_WAVES) void regrid_tile_kernel(Hpx hp, 
     }
     __syncthreads();
 
-    // one bilinear neighbour ring of get_interpol: (start, nr, theta, shift) from the LDS table when the ring is one
-    // of the tile's rows (almost always), else recomputed
-    auto ring_of = [&](int ir, int64_t &sp, int &nr, double &th, bool &sh, int &lr, double &dphi) {
-        lr = ir - row_ring0;
-        if (lr >= 0 && lr < kRgRows && rows[lr].nr > 0) {
-            const RgRow &t = rows[lr];
-            sp = t.start; nr = t.nr; th = t.theta; sh = t.shifted != 0;
-            dphi = t.phistep;                                       // 2 pi / nr to a rounding error: moves a weight by as much
-        } else {
-            int64_t n64;
-            ring_info2(hp, ir, sp, n64, th, sh);
-            nr = (int)n64; lr = -1;
-            dphi = kTwoPi / (double)nr;
-        }
-    };
-    // deposit d on ring index i of ring row lr (lr < 0: not an LDS row) / pixel sp + i
-    bool far_hit = false;
+    // deposit d on ring index i of ring row lr / pixel sp + i
     auto deposit = [&](int lr, int64_t sp, int i, double d) {
         if (d == 0.0) return;
         bool local = lr >= 0;
@@ -922,10 +908,7 @@ __global__ __launch_bounds__(256, BFG_RG_WAVES) void regrid_tile_kernel(Hpx hp, 
             local = (rel >= 0) && (rel < t.w);
         }
         if (local) unsafeAtomicAdd(&acc[lr * kRgWidth + rel], d);
-        else {
-            unsafeAtomicAdd(out_map + sp + i, d);
-            far_hit = far_hit || (lr < 0);                           // beyond the tile's halo of rings: may land in any band
-        }
+        else unsafeAtomicAdd(out_map + sp + i, d);                   // (same ring rows, beyond the window's width)
     };
 
     double v_in = 0.0, v_dep = 0.0;
@@ -962,9 +945,9 @@ __global__ __launch_bounds__(256, BFG_RG_WAVES) void regrid_tile_kernel(Hpx hp, 
         // v_z z_p), rho = dot sqrt(1 + tan^2 dphi) -- two reciprocals and three short series (|tan| <= 2^-7: truncation < 1e-16)
         // instead of two square roots, a division and two full-range atan2; and healpix_cxx's get_interpol (:361) needs no
         // ring_above(z): the ring pair is found by comparing dtheta with the colatitudes of the neighbouring rings in the LDS row
-        // table, 1 / (theta_2 - theta_1) comes from there too.  Same weights as the general code below to ~1e-13 (both are
-        // continuous in the angles; the reference's own acos / atan2 carry rounding of that order): ~200 instead of ~500
-        // instructions per pixel, and this kernel is VALU-issue bound (profiles/r04_sq_counters_regrid.txt).
+        // table, 1 / (theta_2 - theta_1) comes from there too.  Same weights as the general code (regrid_list_kernel) to ~1e-13 (both
+        // are continuous in the angles; the reference's own acos / atan2 carry rounding of that order): ~280 instead of ~500
+        // instructions per pixel, and this kernel is VALU-issue bound (profiles/r04_sq_counters_bary1e5_*.txt).
         if (!(no_shortcut & 2)) {
             const double dotp = sr.sth + (ox * cphi + oy * sphi);      // rho cos(dphi)
             const double crs = oy * cphi - ox * sphi;                  // rho sin(dphi)
@@ -990,7 +973,7 @@ __global__ __launch_bounds__(256, BFG_RG_WAVES) void regrid_tile_kernel(Hpx hp, 
                     bool found = false;
                     double dA = 0.0;
 #pragma unroll
-                    for (int it = 0; it < 3 && !found && phi < kTwoPi; ++it) {
+                    for (int it = 0; it < 5 && !found && phi < kTwoPi; ++it) {     // (the row table reaches kRgHalo rings either way)
                         if (lrA < 0 || lrA + 1 >= kRgRows) break;
                         const RgRow &ta = rows[lrA], &tb = rows[lrA + 1];
                         if (ta.nr <= 0 || tb.nr <= 0) break;
@@ -1039,86 +1022,11 @@ __global__ __launch_bounds__(256, BFG_RG_WAVES) void regrid_tile_kernel(Hpx hp, 
                 }
             }
         }
-        const double vx = sr.sth * cphi + ox;                          // :357
-        const double vy = sr.sth * sphi + oy;
-        const double vz = sr.z + oz;
-        const double n2 = vx * vx + vy * vy + vz * vz;                 // |pixel vector + offset|^2: 1 + a small offset
-        const double dnorm = (n2 > 1e-200 && n2 < 1e200) ? sqrt_unit(n2) : sqrt(n2);   // hp.vec2ang :358
-        const double z = vz / dnorm;                                   // = cos(theta) to rounding
-        const double s2 = (1.0 - z) * (1.0 + z);
-        const double theta = atan2_upper_tab((s2 > 1e-200) ? sqrt_unit(s2) : sqrt(s2), z, s_atan);     // acos(z)
-        const double aphi = (vx == 0.0 && vy == 0.0) ? 0.0 : atan2_upper_tab(fabs(vy), vx, s_atan);
-        const double phi = (vy < 0.0) ? kTwoPi - aphi : aphi;          // atan2(vy, vx) brought to [0, 2 pi)
-        // healpix_cxx get_interpol (:361), ring by ring, with (ring, index) kept instead of pixel numbers
-        const int ir1 = (int)ring_above(hp, z), ir2 = ir1 + 1;
-        double theta1 = 0.0, theta2 = 0.0;
-        int64_t sp1 = 0, sp2 = 0;
-        int i1a = 0, i1b = 0, i2a = 0, i2b = 0, lr1 = -1, lr2 = -1, nr1 = 0, nr2 = 0;
-        double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
-        if (ir1 > 0) {
-            bool sh;
-            double dphi;
-            ring_of(ir1, sp1, nr1, theta1, sh, lr1, dphi);
-            // phi / dphi as phi * (nr / 2 pi): the weights move by a rounding error and a pixel index can only flip where its
-            // weight is ~0 (the interpolation is continuous) -- except in healpix_cxx's phi == 2 pi case below, which is
-            // decided with the reference's own division
-            const double inv_dphi = (double)nr1 * kInvTwoPi;
-            const double hs = sh ? 0.5 : 0.0;
-            double tmp = phi * inv_dphi - hs;
-            if (phi >= kTwoPi) tmp = phi / (kTwoPi / (double)nr1) - hs;
-            int ia = (tmp < 0) ? (int)tmp - 1 : (int)tmp;
-            const double ww = (phi - ((double)ia + hs) * dphi) * inv_dphi;
-            int ib = ia + 1;
-            if (ia < 0) ia += nr1;
-            if (ib >= nr1) ib -= nr1;
-            // healpix_cxx quirk kept literally: for phi == 2 pi exactly (a pixel at phi = 0 nudged by a y-offset of 1e-20) on
-            // an unshifted ring, tmp = phi / dphi is exactly nr, i1 = nr is not wrapped, and the weight-1 deposit lands on
-            // pixel startpix + nr -- the first pixel of the NEXT ring.  Not this ring's LDS row: global atomics (lr = -1).
-            if (ia >= nr1) lr1 = -1;
-            i1a = ia; i1b = ib; w0 = 1 - ww; w1 = ww;
-        }
-        if (ir2 < nl4) {
-            bool sh;
-            double dphi;
-            ring_of(ir2, sp2, nr2, theta2, sh, lr2, dphi);
-            const double inv_dphi = (double)nr2 * kInvTwoPi;
-            const double hs = sh ? 0.5 : 0.0;
-            double tmp = phi * inv_dphi - hs;
-            if (phi >= kTwoPi) tmp = phi / (kTwoPi / (double)nr2) - hs;
-            int ia = (tmp < 0) ? (int)tmp - 1 : (int)tmp;
-            const double ww = (phi - ((double)ia + hs) * dphi) * inv_dphi;
-            int ib = ia + 1;
-            if (ia < 0) ia += nr2;
-            if (ib >= nr2) ib -= nr2;
-            if (ia >= nr2) lr2 = -1;                                   // same quirk on the lower ring
-            i2a = ia; i2b = ib; w2 = 1 - ww; w3 = ww;
-        }
-        if (ir1 == 0) {                                                // above the first ring: its 4 pixels share the rest
-            const double wtheta = theta / theta2;
-            w2 *= wtheta; w3 *= wtheta;
-            const double fac = (1 - wtheta) * 0.25;
-            w0 = fac; w1 = fac; w2 += fac; w3 += fac;
-            sp1 = 0; lr1 = (1 - row_ring0 < kRgRows && 1 - row_ring0 >= 0 && rows[1 - row_ring0].nr > 0) ? 1 - row_ring0 : -1;
-            i1a = (i2a + 2) & 3; i1b = (i2b + 2) & 3;                  // ring 1 starts at pixel 0
-        } else if (ir2 == nl4) {                                       // below the last ring
-            const double wtheta = (theta - theta1) / (kPi - theta1);
-            w0 *= 1 - wtheta; w1 *= 1 - wtheta;
-            const double fac = wtheta * 0.25;
-            w0 += fac; w1 += fac; w2 = fac; w3 = fac;
-            const int lrl = (nl4 - 1) - row_ring0;
-            sp2 = hp.npix - 4; lr2 = (lrl >= 0 && lrl < kRgRows && rows[lrl].nr > 0) ? lrl : -1;
-            i2a = (i1a + 2) & 3; i2b = (i1b + 2) & 3;                  // the last ring holds pixels npix-4 .. npix-1
-        } else {
-            const double wtheta = (theta - theta1) / (theta2 - theta1);
-            w0 *= 1 - wtheta; w1 *= 1 - wtheta;
-            w2 *= wtheta; w3 *= wtheta;
-        }
-        const double d0 = w0 * val, d1 = w1 * val, d2 = w2 * val, d3 = w3 * val;   // :64-68
-        v_dep += d0; v_dep += d1; v_dep += d2; v_dep += d3;
-        deposit(lr1, sp1, i1a, d0);
-        deposit(lr1, sp1, i1b, d1);
-        deposit(lr2, sp2, i2a, d2);
-        deposit(lr2, sp2, i2b, d3);
+        // Everything else -- next to the poles, displaced by more than a few pixels, phi == 2 pi -- is left to regrid_list_kernel
+        // (healpix_cxx's get_interpol in full, one thread per pixel, global atomics): rare, and keeping that code out of THIS kernel is
+        // what lets it run at 68 instead of 168 VGPRs -- five workgroups per CU (LDS-limited) instead of three wavefronts per SIMD:
+        // 0.265 -> 0.183 ms at NSIDE 1024 (profiles/r04_regrid_split_ab.txt).
+        slow_list[atomicAdd(slow_n, 1ull)] = p;
     }
     __syncthreads();
     for (int i = tid; i < kRgRows * kRgWidth; i += 256) {
@@ -1130,7 +1038,6 @@ __global__ __launch_bounds__(256, BFG_RG_WAVES) void regrid_tile_kernel(Hpx hp, 
         if (ii >= t.nr) ii -= t.nr;
         unsafeAtomicAdd(out_map + t.start + ii, v);
     }
-    if (far && far_hit) unsafeAtomicAdd(far, 1.0);                       // (rare: a displacement of more than kRgHalo rings)
     if (sums) {
         for (int o = 32; o > 0; o >>= 1) { v_in += __shfl_down(v_in, o, 64); v_dep += __shfl_down(v_dep, o, 64); }
         const int w = tid >> 6;
@@ -1140,6 +1047,57 @@ __global__ __launch_bounds__(256, BFG_RG_WAVES) void regrid_tile_kernel(Hpx hp, 
             unsafeAtomicAdd(sums + 0, s_in[0] + s_in[1] + s_in[2] + s_in[3]);
             unsafeAtomicAdd(sums + 1, s_dep[0] + s_dep[1] + s_dep[2] + s_dep[3]);
         }
+    }
+}
+
+// The pixels regrid_tile_kernel leaves aside (next to the poles, displaced by more than a few pixels, phi == 2 pi): healpix_cxx's
+// get_interpol in full, one thread per pixel of the list, global atomics -- the arithmetic of regrid_kernel.  band_rings > 0
+// (bfg_regrid_shell_bands): a deposit more than kRgHalo rings outside the source pixel's band is counted in *far.
+__global__ __launch_bounds__(256) void regrid_list_kernel(Hpx hp, const int64_t *__restrict__ list, const unsigned long long *n_ptr,
+                                                          const double *__restrict__ off, const double *__restrict__ in_map,
+                                                          double *__restrict__ out_map, double *sums, int band_rings, double *far)
+{
+    const int64_t n = (int64_t)*n_ptr;
+    double v_dep = 0.0;
+    bool far_hit = false;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = list[e];
+        const double val = in_map[p];
+        int64_t ring, ip;
+        pix2ring(hp, p, ring, ip);
+        RingGeom g = ring_geom(hp, ring);
+        double sphi, cphi;
+        sincos(((double)ip + g.phioff) * g.phistep, &sphi, &cphi);
+        const double vx = g.sth * cphi + off[3 * p + 0];               // :357
+        const double vy = g.sth * sphi + off[3 * p + 1];
+        const double vz = g.z + off[3 * p + 2];
+        const double dnorm = sqrt(vx * vx + vy * vy + vz * vz);        // hp.vec2ang :358
+        const double theta = acos(vz / dnorm);
+        double phi = atan2(vy, vx);
+        if (phi < 0) phi += kTwoPi;
+        int64_t cp[4]; double cw[4];
+        get_interpol(hp, theta, phi, cp, cw);                          // :361
+        int64_t lo_pix = 0, hi_pix = hp.npix;
+        if (band_rings > 0) {                                          // the pixel range within kRgHalo rings of the source's band
+            const int64_t band = (ring - 1) / band_rings;
+            const int64_t r0 = 1 + band * band_rings - kRgHalo, r1 = band * band_rings + band_rings + kRgHalo + 1;
+            int64_t nr_; bool sh_;
+            if (r0 >= 1) ring_info_small(hp, r0, lo_pix, nr_, sh_);
+            if (r1 <= 4 * hp.nside - 1) ring_info_small(hp, r1, hi_pix, nr_, sh_);
+        }
+        for (int k = 0; k < 4; ++k) {
+            const double d = cw[k] * val;                              // :64-68
+            if (d != 0.0) {
+                unsafeAtomicAdd(out_map + cp[k], d);
+                far_hit = far_hit || cp[k] < lo_pix || cp[k] >= hi_pix;
+            }
+            v_dep += d;
+        }
+    }
+    if (far && far_hit) unsafeAtomicAdd(far, 1.0);                       // (rare: a displacement of more than kRgHalo rings)
+    if (sums && n > 0) {
+        for (int o = 32; o > 0; o >>= 1) v_dep += __shfl_down(v_dep, o, 64);
+        if ((threadIdx.x & 63) == 0 && v_dep != 0.0) unsafeAtomicAdd(sums + 1, v_dep);
     }
 }
 
@@ -1343,6 +1301,8 @@ static void ctx_free_all(bfg_ctx *c)
     }
     if (c->d_hd) (void)hipFree(c->d_hd);
     if (c->d_left) (void)hipFree(c->d_left);
+    if (c->d_rg_slow) (void)hipFree(c->d_rg_slow);
+    if (c->d_rg_slow_n) (void)hipFree(c->d_rg_slow_n);
     for (int k = 0; k < 8; ++k) if (c->snap_buf[k]) (void)hipFree(c->snap_buf[k]);
     for (int k = 0; k < 6; ++k) if (c->grid_buf[k]) (void)hipFree(c->grid_buf[k]);
     for (int k = 0; k < 5; ++k) if (c->dep_buf[k]) (void)hipFree(c->dep_buf[k]);
@@ -2298,6 +2258,28 @@ int bfg_offsets_add_displacements(bfg_ctx *c, const bfg_shell_args *a, const bfg
     return BFG_OK;
 }
 
+// the list of pixels the tile kernel leaves to regrid_list_kernel: one slot per pixel (every pixel could be one), grow-only
+static int ensure_regrid_list(bfg_ctx *c, int64_t npix)
+{
+    if (!c->d_rg_slow_n) HIP_TRY(hipMalloc((void **)&c->d_rg_slow_n, sizeof(unsigned long long)));
+    if (npix > c->rg_slow_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_rg_slow) (void)hipFree(c->d_rg_slow);
+        c->d_rg_slow = nullptr; c->rg_slow_cap = 0;
+        HIP_TRY(hipMalloc((void **)&c->d_rg_slow, (size_t)npix * sizeof(int64_t)));
+        c->rg_slow_cap = npix;
+    }
+    return BFG_OK;
+}
+
+static int regrid_debug_mode()
+{
+    // A/B: BFG_REGRID=full: no exit for undisplaced pixels; =general: no differential path (every displaced pixel through the list
+    // kernel); =all: neither
+    const char *rg_env = std::getenv("BFG_REGRID");
+    return !rg_env ? 0 : (rg_env[0] == 'f' ? 1 : (rg_env[0] == 'g' ? 2 : (rg_env[0] == 'a' ? 3 : 0)));
+}
+
 int bfg_regrid_shell(bfg_ctx *c, int64_t nside, const double *d_offsets, const double *d_in_map,
                      double *d_out_map, double *d_sums)
 {
@@ -2313,13 +2295,19 @@ int bfg_regrid_shell(bfg_ctx *c, int64_t nside, const double *d_offsets, const d
         if (rc) return rc;
     }
     if (d_sums) HIP_TRY(hipMemsetAsync(d_sums, 0, 2 * sizeof(double), c->stream));
+    if (use_tiles) {
+        rc = ensure_regrid_list(c, hp.npix);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(c->d_rg_slow_n, 0, sizeof(unsigned long long), c->stream));
+    }
     timing_begin(c, 2);
-    if (use_tiles)
+    if (use_tiles) {
         hipLaunchKernelGGL(regrid_tile_kernel, dim3((unsigned)c->tiles[kRegridSet].geo.ntiles), dim3(256), 0, c->stream, hp,
-                           c->tiles[kRegridSet].geo, d_offsets, d_in_map, d_out_map, d_sums, c->d_mathtab + 2 * kLogTab + kExpTab,
-                           // A/B: BFG_REGRID=full: no exit for undisplaced pixels; =general: no differential path; =all: neither
-                           !rg_env ? 0 : (rg_env[0] == 'f' ? 1 : (rg_env[0] == 'g' ? 2 : (rg_env[0] == 'a' ? 3 : 0))), 0, nullptr);
-    else
+                           c->tiles[kRegridSet].geo, d_offsets, d_in_map, d_out_map, d_sums, regrid_debug_mode(), 0,
+                           c->d_rg_slow, c->d_rg_slow_n);
+        hipLaunchKernelGGL(regrid_list_kernel, dim3((unsigned)(2 * c->n_cu)), dim3(256), 0, c->stream, hp, c->d_rg_slow, c->d_rg_slow_n,
+                           d_offsets, d_in_map, d_out_map, d_sums, 0, (double *)nullptr);
+    } else
         hipLaunchKernelGGL(regrid_kernel, dim3((unsigned)((hp.npix + 255) / 256)), dim3(256), 0, c->stream, hp,
                            d_offsets, d_in_map, d_out_map, d_sums);
     HIP_TRY(hipGetLastError());
@@ -2352,12 +2340,16 @@ int bfg_regrid_shell_bands(bfg_ctx *c, int64_t nside, const double *d_offsets, c
         if (b < band_lo) tile_lo += ns;
         tile_hi += ns;
     }
-    const char *rg_env = std::getenv("BFG_REGRID");
+    const Hpx hp = make_hpx(nside);
+    rc = ensure_regrid_list(c, hp.npix);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_rg_slow_n, 0, sizeof(unsigned long long), c->stream));
     timing_begin(c, 2);
-    hipLaunchKernelGGL(regrid_tile_kernel, dim3((unsigned)(tile_hi - tile_lo)), dim3(256), 0, c->stream, make_hpx(nside),
-                       c->tiles[kRegridSet].geo, d_offsets, d_in_map, d_out_map, d_sums3, c->d_mathtab + 2 * kLogTab + kExpTab,
-                       !rg_env ? 0 : (rg_env[0] == 'f' ? 1 : (rg_env[0] == 'g' ? 2 : (rg_env[0] == 'a' ? 3 : 0))), tile_lo,
-                       d_sums3 ? d_sums3 + 2 : nullptr);
+    hipLaunchKernelGGL(regrid_tile_kernel, dim3((unsigned)(tile_hi - tile_lo)), dim3(256), 0, c->stream, hp,
+                       c->tiles[kRegridSet].geo, d_offsets, d_in_map, d_out_map, d_sums3, regrid_debug_mode(), tile_lo,
+                       c->d_rg_slow, c->d_rg_slow_n);
+    hipLaunchKernelGGL(regrid_list_kernel, dim3((unsigned)(2 * c->n_cu)), dim3(256), 0, c->stream, hp, c->d_rg_slow, c->d_rg_slow_n,
+                       d_offsets, d_in_map, d_out_map, d_sums3, kRegridTR, d_sums3 ? d_sums3 + 2 : (double *)nullptr);
     HIP_TRY(hipGetLastError());
     timing_end(c, 2);
     return BFG_OK;
