@@ -407,53 +407,12 @@ __global__ __launch_bounds__(256, BFG_PREP_WAVES) void halo_prep_kernel(const Pr
     }
     int32_t flags = hc.flags;
     const int32_t rfirst = hc.rfirst, rlast = hc.rlast, irmin = hc.irmin, irmax = hc.irmax;
-    const double radius = hc.radius, ptheta = hc.ptheta, pphi = hc.pphi, D = hc.D, a = hc.a;
-    unsigned long long ovf = 0ull;
+    const double radius = hc.radius, ptheta = hc.ptheta, pphi = hc.pphi;
+    // Everything that is stored per halo goes out BEFORE the binning (with the flags as they stand; the binning may add
+    // HF_SCATTER / HF_SLOW, patched in afterwards with one 4-byte store): what stays live across the binning's atomics is the disc's
+    // ring range and pointing, not the twenty doubles of the record.
     if (P.ht) {
-        if (P.bin.mode == MODE_BARYONIFY && !(flags & HF_SKIP) && rlast >= rfirst && rlast - rfirst < 8) {
-            // small disc: count its pixels exactly; fewer than 4 -> 4-neighbour fallback (HealpixRunner.py:333-334),
-            // which only the scatter kernel implements
-            const double cosr = cos(radius), zc = cos(ptheta);
-            const double xa_ = 1.0 / sqrt((1.0 - zc) * (1.0 + zc));
-            int total = 0;
-            for (int ring = rfirst; ring <= rlast; ++ring) {
-                int64_t sp_, nr_; bool sh_;
-                ring_info_small(P.hpx, ring, sp_, nr_, sh_);
-                if (ring < irmin || ring > irmax) { total += (int)nr_; continue; }
-                const double zr = ring2z(P.hpx, ring);
-                const double xx = (cosr - zr * zc) * xa_;
-                const double ysq = 1.0 - zr * zr - xx * xx;
-                const double dphi = (ysq <= 0.0) ? 0.0 : atan2(sqrt(ysq), xx);
-                if (dphi > 0.0) {
-                    const double shift = sh_ ? 0.5 : 0.0;
-                    const int64_t l64 = (int64_t)floor((double)nr_ * kInvTwoPi * (pphi - dphi) - shift) + 1;
-                    const int64_t h64 = (int64_t)floor((double)nr_ * kInvTwoPi * (pphi + dphi) - shift);
-                    int64_t cc = h64 - l64 + 1;
-                    if (cc > nr_) cc = nr_;
-                    if (cc > 0) total += (int)cc;
-                }
-            }
-            if (total < 4) flags |= HF_SCATTER;
-        }
-        if (!(flags & HF_SCATTER))
-            flags = tile_bin_halo(P.bin, false, j, flags, rfirst, rlast, irmin, irmax, ptheta, pphi, radius, ovf);
-        P.bin.ovf_mask[j] = ovf;
-    }
-    // The SoA workspace is what the scatter kernel and the fill pass of the binning read.  On the tile path with a 3-D table
-    // (lazy_soa) only the halos they will touch get it: the ones left to the scatter kernel and the ones with pairs in overflow
-    // lists -- none at all for a catalog spread over the sky: 124 B per halo less to write.  (Should the call degrade to the
-    // scatter kernel after the fact -- pair buffer exhausted -- tile_fill_kernel recomputes the rows: halo_calc is pure.)
-    if (!P.lazy_soa || (flags & HF_SCATTER) || ovf != 0ull) {
-        halo_write_soa(P, j, hc, flags);
-        if (cells_lds) for (int k = 0; k < P.tab.nouter; ++k) { P.cidx[k * P.cap + j] = s_ci[k][threadIdx.x]; P.cw[k * P.cap + j] = s_cy[k][threadIdx.x]; }
-        else {
-            if (P.tab.nouter > 0) { P.cidx[j] = ci0; P.cw[j] = cy0; }
-            if (P.tab.nouter > 1) { P.cidx[P.cap + j] = ci1; P.cw[P.cap + j] = cy1; }
-        }
-    }
-    if (P.left && (flags & HF_SCATTER) && !(flags & HF_SKIP)) P.left[1 + atomicAdd(P.left_n, 1)] = (int32_t)j;
-    if ((flags & HF_SLOW) && !(flags & (HF_SKIP | HF_OOB))) atomicAdd(&P.stats->halos_scatter_fallback, 1u);
-    if (P.ht) {
+        const double D = hc.D, a = hc.a;
         HaloTile h;
         h.st = hc.st; h.ct = hc.z0v; h.pphi = pphi;
         h.S = (D / a) * (D / a);
@@ -484,6 +443,66 @@ __global__ __launch_bounds__(256, BFG_PREP_WAVES) void halo_prep_kernel(const Pr
         P.ht[j] = h;
         if (cells_lds) { s_wl[threadIdx.x] = win_lo; s_fl[threadIdx.x] = flags; s_ln[threadIdx.x] = hc.lnpf; }
     }
+    // The SoA workspace is what the scatter kernel and the fill pass of the binning read.  On the tile path with a 3-D table
+    // (lazy_soa) only the halos they will touch get it -- the ones left to the scatter kernel and the ones with pairs in overflow
+    // lists: none at all for a catalog spread over the sky, 124 B per halo less to write --, and those recompute their record after
+    // the binning (halo_calc is pure: the rare halo pays twice, no halo keeps its record in registers across the atomics).
+    // (Should the call degrade to the scatter kernel after the fact -- pair buffer exhausted -- tile_fill_kernel recomputes the rows.)
+    auto write_soa = [&](const HaloCalc &o, int32_t fl) {
+        halo_write_soa(P, j, o, fl);
+        if (cells_lds) for (int k = 0; k < P.tab.nouter; ++k) { P.cidx[k * P.cap + j] = s_ci[k][threadIdx.x]; P.cw[k * P.cap + j] = s_cy[k][threadIdx.x]; }
+        else {
+            if (P.tab.nouter > 0) { P.cidx[j] = ci0; P.cw[j] = cy0; }
+            if (P.tab.nouter > 1) { P.cidx[P.cap + j] = ci1; P.cw[P.cap + j] = cy1; }
+        }
+    };
+    if (!P.lazy_soa) write_soa(hc, flags);
+    unsigned long long ovf = 0ull;
+    const int32_t flags0 = flags;
+    if (P.ht) {
+        if (P.bin.mode == MODE_BARYONIFY && !(flags & HF_SKIP) && rlast >= rfirst && rlast - rfirst < 8) {
+            // small disc: count its pixels exactly; fewer than 4 -> 4-neighbour fallback (HealpixRunner.py:333-334),
+            // which only the scatter kernel implements
+            const double cosr = cos(radius), zc = cos(ptheta);
+            const double xa_ = 1.0 / sqrt((1.0 - zc) * (1.0 + zc));
+            int total = 0;
+            for (int ring = rfirst; ring <= rlast; ++ring) {
+                int64_t sp_, nr_; bool sh_;
+                ring_info_small(P.hpx, ring, sp_, nr_, sh_);
+                if (ring < irmin || ring > irmax) { total += (int)nr_; continue; }
+                const double zr = ring2z(P.hpx, ring);
+                const double xx = (cosr - zr * zc) * xa_;
+                const double ysq = 1.0 - zr * zr - xx * xx;
+                const double dphi = (ysq <= 0.0) ? 0.0 : atan2(sqrt(ysq), xx);
+                if (dphi > 0.0) {
+                    const double shift = sh_ ? 0.5 : 0.0;
+                    const int64_t l64 = (int64_t)floor((double)nr_ * kInvTwoPi * (pphi - dphi) - shift) + 1;
+                    const int64_t h64 = (int64_t)floor((double)nr_ * kInvTwoPi * (pphi + dphi) - shift);
+                    int64_t cc = h64 - l64 + 1;
+                    if (cc > nr_) cc = nr_;
+                    if (cc > 0) total += (int)cc;
+                }
+            }
+            if (total < 4) flags |= HF_SCATTER;
+        }
+        if (!(flags & HF_SCATTER))
+            flags = tile_bin_halo(P.bin, false, j, flags, rfirst, rlast, irmin, irmax, ptheta, pphi, radius, ovf);
+        P.bin.ovf_mask[j] = ovf;
+        if (flags != flags0) {
+            P.ht[j].flags = flags;
+            if (cells_lds) s_fl[threadIdx.x] = flags;
+            if (!P.lazy_soa) P.irec[I_FLAGS * P.cap + j] = flags;
+        }
+    }
+    if (P.lazy_soa && ((flags & HF_SCATTER) || ovf != 0ull)) {
+        HaloCalc again;
+        halo_calc(P, j, knots_lds ? s_knots : P.spl_knots,
+                  [&](int k) -> const double * { return (P.tab.oshape[k] <= kPrepAxis) ? s_axis[k] : P.tab.oaxis[k]; },
+                  [&](int, int, double) {}, again);
+        write_soa(again, flags);
+    }
+    if (P.left && (flags & HF_SCATTER) && !(flags & HF_SKIP)) P.left[1 + atomicAdd(P.left_n, 1)] = (int32_t)j;
+    if ((flags & HF_SLOW) && !(flags & (HF_SKIP | HF_OOB))) atomicAdd(&P.stats->halos_scatter_fallback, 1u);
     }   // j < n_halo
     // ---- row phase (what halo_row4_kernel does, same arithmetic): hwin[j][e] = sum over the corners of the halo's outer cell of
     // w_c T[c][win_lo + e] (+ ln(pixfac) for ln tables), four nodes per thread.  Done here the rows cost neither a second
