@@ -676,7 +676,7 @@ def _baryonify_pipelined(runners, in_flight=2):
         k, orig, h, h_small, ev, d_out = item
         ev.synchronize()
         absmax, old_sum, new_sum, far = (float(x) for x in h_small.tolist())
-        if far > 0:                                                       # a displacement of more than 4 rings somewhere: slices that had
+        if far > 0:                                                       # a displacement of more than 3 rings somewhere: slices that had
             h.copy_(d_out)                                                # left may have received deposits since -- the whole map again
         if not (absmax > 1e-8) and np.allclose(orig, 0):                  # :293-294 (False for NaN maps)
             results[k] = orig
@@ -706,7 +706,7 @@ def _baryonify_pipelined(runners, in_flight=2):
             h, h_small = torch.empty(npix, dtype=torch.float64), torch.empty(4, dtype=torch.float64)
         d_out, d_small = ctx.zeros(npix), ctx.zeros(4)                    # d_small = {max |in|, sum(in), sum(deposits), far deposits}
         # The map in band slices (bfg_regrid_shell_bands): slice s is regridded as soon as it has arrived, and leaves once slice
-        # s + 1 has been regridded too (deposits reach 4 rings beyond a band; anything farther is counted and, should it ever
+        # s + 1 has been regridded too (deposits reach 3 rings beyond a band; anything farther is counted and, should it ever
         # happen, the whole map is copied again at the end) -- the upload, the regrid and the download of one shell overlap
         # instead of following each other: 1.8 + 0.3 + 1.8 ms at BASELINE configs[2] (tools/bary_api_probe.py).
         if NSIDE >= 32 and n_slices > 1 and n == 1:                      # (in a list the shells overlap each other: whole maps are faster)

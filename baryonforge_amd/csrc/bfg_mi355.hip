@@ -850,18 +850,20 @@ __global__ __launch_bounds__(256) void regrid_kernel(Hpx hp, const double *__res
 // are a few pixels at most, so almost every deposit lands inside the tile grown by a halo of kRgHalo rings /
 // pixels: those are accumulated in LDS (ds_add_f64) and flushed once with row-contiguous global atomics
 // (~1.4 per pixel instead of 4 scattered ones); the rare far deposit goes straight to a global atomic.
-constexpr int kRgHalo = 4;
+#ifndef BFG_RG_HALO
+#define BFG_RG_HALO 3
+#endif
+constexpr int kRgHalo = BFG_RG_HALO;
 constexpr int kRgRows = 64 + 2 * kRgHalo;
 constexpr int kRgWidth = kTileWidth + 2 * kRgHalo;
 struct __align__(16) RgRow {
     int64_t start;                   // first pixel of the ring
     int32_t nr, istart, w, shifted;  // ring length; first ring index of the LDS row (may be < 0: modulo nr); row width
     double theta;                    // ring colatitude as get_ring_info2 gives it (get_interpol's theta1 / theta2)
-    double z, sth, phistep, phioff;  // pixel-centre geometry of the ring (ring_geom)
+    double z, sth, phistep;          // pixel-centre geometry of the ring (ring_geom); phi offset = 0.5 where `shifted`, else 0
     double inv_dth;                  // 1 / (colatitude of the next ring - this ring's); 0 for the last ring
-    double pad;
 };
-static_assert(sizeof(RgRow) == 80, "RgRow is five 16-byte pieces");
+static_assert(sizeof(RgRow) == 64, "RgRow is four 16-byte pieces");
 
 // Waves per SIMD: the long dependent chain per pixel (sincos -> sqrt -> atan2 x 2 -> divisions) needs wavefronts to overlap, spills
 // cost more.  Round 1's body: 184 VGPRs spill-free (2 waves) 0.43 ms, 128 VGPRs + 172 B of scratch (4 waves) 0.33 ms.  With the
@@ -892,8 +894,8 @@ __global__ __launch_bounds__(256, BFG_RG_WAVES) void regrid_tile_kernel(Hpx hp, 
     if (tid < kRgRows) {
         const int ring = row_ring0 + tid;
         RgRow r;
-        r.start = 0; r.nr = 0; r.istart = 0; r.w = 0; r.shifted = 0; r.theta = 0; r.z = 0; r.sth = 0; r.phistep = 0; r.phioff = 0;
-        r.inv_dth = 0; r.pad = 0;
+        r.start = 0; r.nr = 0; r.istart = 0; r.w = 0; r.shifted = 0; r.theta = 0; r.z = 0; r.sth = 0; r.phistep = 0;
+        r.inv_dth = 0;
         if (ring >= 1 && ring <= nl4 - 1 && ring <= ring_hi + kRgHalo) {
             int64_t sp, nr; bool sh; double th;
             ring_info2(hp, ring, sp, nr, th, sh);
@@ -908,7 +910,7 @@ __global__ __launch_bounds__(256, BFG_RG_WAVES) void regrid_tile_kernel(Hpx hp, 
             r.w = min(r.w, kRgWidth);
             r.istart = k0 - kRgHalo;                                // may be negative: taken modulo nr
             const RingGeom g = ring_geom(hp, ring);
-            r.z = g.z; r.sth = g.sth; r.phistep = g.phistep; r.phioff = g.phioff;
+            r.z = g.z; r.sth = g.sth; r.phistep = g.phistep;         // (g.phioff == 0.5 exactly where sh: same parity rule)
         }
         rows[tid] = r;
     }
@@ -956,7 +958,7 @@ __global__ __launch_bounds__(256, BFG_RG_WAVES) void regrid_tile_kernel(Hpx hp, 
             continue;
         }
         double sphi, cphi;
-        const double phi_p = ((double)ip + sr.phioff) * sr.phistep;
+        const double phi_p = ((double)ip + (sr.shifted ? 0.5 : 0.0)) * sr.phistep;
         sincos_2pi(phi_p, sphi, cphi);
         // ---- the usual case: a displacement of a fraction of a pixel, away from the poles.  The displaced direction is the pixel's
         // own centre (theta_p, phi_p) plus small angles, so hp.vec2ang (:358) is taken DIFFERENTIALLY: with the offset rotated into

@@ -319,8 +319,8 @@ int bfg_regrid_shell(bfg_ctx *ctx, int64_t nside, const double *d_offsets, const
                      double *d_out_map, double *d_sums);
 
 /* The same regrid for the SOURCE pixels of ring bands [band_lo, band_hi) only -- bands of bfg_regrid_band_rings() rings counted
- * from the north pole, i.e. contiguous RING pixel ranges.  Deposits reach at most 4 rings beyond a band's own rings, except
- * for displacements of more than 4 rings, which are added wherever they land and COUNTED: d_sums3 = {sum(in), sum(deposits),
+ * from the north pole, i.e. contiguous RING pixel ranges.  Deposits reach at most 3 rings beyond a band's own rings, except
+ * for displacements of more than 3 rings, which are added wherever they land and COUNTED: d_sums3 = {sum(in), sum(deposits),
  * number of threads with such a far deposit}, accumulated over the calls (flags bit 0: cleared first).  So the output of band
  * group k is final once groups k - 1, k and k + 1 have been regridded and the far count is zero: a map can be regridded while
  * it is still arriving over PCIe and leave while its other bands are regridded (Runners/HealpixRunner.py:357-365 band by
