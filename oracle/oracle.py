@@ -204,6 +204,8 @@ RHO_CRITICAL = (3.0 * 100.0 * 100.0) / (8.0 * np.pi * GNEWT) * (1000.0 * 1000.0 
 # Omega_nu,rel of the massless neutrinos = N_eff 7/8 x^4 Omega_gamma: "T_ncdm" x = 0.71611 (pyccl's T_nu = T_CMB T_ncdm, as recalled
 # from its source; the default) or "4/11" x = (4/11)^(1/3) (instantaneous decoupling).  The choice moves D_A by 2.5e-7 at z = 0.5;
 # a cosmology dict may carry it as cosmo["nu_rel"] (what a run against live pyccl must settle).
+# The two chi differences live pyccl printed in the reference's example notebooks (tests/golden/pyccl_notebook_outputs.json) lie
+# BETWEEN the two conventions: -1.4e-7 with "T_ncdm", +1.0e-7 with "4/11" (tests/test_oracle_golden.py).
 NU_REL = "T_ncdm"
 
 

@@ -28,6 +28,7 @@ What is executed verbatim from the reference:
                             regrid_pixels_hpix
 
 Usage:  python tests/golden/make_golden.py [section] [--real-deps] [--out DIR]     (writes tests/golden/*.npz)
+        python tests/golden/make_golden.py --notebook-outputs [--out DIR]          (writes pyccl_notebook_outputs.json)
 
 --real-deps: the closing path for the two rows the stand-ins cannot pin (HEALPix geometry = a8, CCL
 background = a9).  Wherever the real `healpy`, `pyccl` or `numba` is importable in the interpreter that runs this script,
@@ -646,8 +647,64 @@ def grid_section(io, make_tabulated, make_disp, mdef):
     save("grid.npz", **out)
 
 
+def notebook_outputs():
+    """--notebook-outputs: the numbers LIVE pyccl printed in the reference's example notebooks (stored cell outputs; nothing is
+    imported or run): shell_thickness = chi(max_z) - chi(min_z), with the ccl.Cosmology arguments and redshifts of the same
+    notebook -> tests/golden/pyccl_notebook_outputs.json.  The only a9 numbers in the reference that came out of the real libccl."""
+    import glob
+    import re
+    cases, seen = [], {}
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(REF), "examples", "*.ipynb"))):
+        nb = json.load(open(path))
+        src_all, printed, where = "", None, {}
+        for i, c in enumerate(nb["cells"]):
+            if c["cell_type"] != "code":
+                continue
+            src = "".join(c["source"])
+            src_all += src + "\n"
+            for key in ("ccl.Cosmology(", "min_z", "SHELL IS"):
+                if key in src and key not in where:
+                    where[key] = i
+            for o in c.get("outputs", []):
+                m = re.search(r"SHELL IS ([0-9.eE+-]+) MPC", "".join(o.get("text", "")) if o.get("output_type") == "stream" else "")
+                if m:
+                    printed = float(m.group(1))
+        if printed is None:
+            continue
+        call = re.search(r"ccl\.Cosmology\((.*?)\)", src_all, re.S).group(1)
+        num = lambda expr: float(eval(expr, {"__builtins__": {}}, {}))      # "0.3175 - 0.049": plain arithmetic only
+        cosmo = {k: num(re.search(k + r"\s*=\s*([0-9.eE+\- ]+?)\s*[,)\n]", call + ")").group(1))
+                 for k in ("Omega_c", "Omega_b", "h", "sigma8", "n_s")}
+        zmin = num(re.search(r"^min_z\s*=\s*([0-9.eE+-]+)", src_all, re.M).group(1))
+        zmax = num(re.search(r"^max_z\s*=\s*([0-9.eE+-]+)", src_all, re.M).group(1))
+        name = "examples/" + os.path.basename(path)
+        key = (tuple(sorted(cosmo.items())), zmin, zmax, printed)
+        if key in seen:
+            seen[key]["source"] += "; " + name
+            continue
+        case = {"source": name + " cells " + ", ".join(str(where[k]) for k in ("ccl.Cosmology(", "min_z", "SHELL IS")),
+                "cosmology": cosmo, "min_z": zmin, "max_z": zmax, "shell_thickness_mpc": printed}
+        seen[key] = case
+        cases.append(case)
+    doc = {"_what": "Numbers that LIVE pyccl printed in the reference's own example notebooks (cell outputs stored in the .ipynb "
+                    "files): shell_thickness = ccl.comoving_radial_distance(cosmo, 1/(max_z + 1)) - ccl.comoving_radial_distance("
+                    "cosmo, 1/(min_z + 1)), print(f\"SHELL IS {shell_thickness} MPC\").  Data only: the printed value, the redshifts "
+                    "and the ccl.Cosmology arguments of the same notebook.  Written by tests/golden/make_golden.py --notebook-outputs.",
+           "cases": cases}
+    with open(os.path.join(OUT, "pyccl_notebook_outputs.json"), "w") as f:
+        json.dump(doc, f, indent=2)
+        f.write("\n")
+    for c in cases:
+        print(c["source"], c["shell_thickness_mpc"])
+
+
 if __name__ == "__main__":
     argv = sys.argv[1:]
+    if "--notebook-outputs" in argv:
+        if "--out" in argv:
+            OUT = os.path.abspath(argv[argv.index("--out") + 1])
+        notebook_outputs()
+        sys.exit(0)
     if "--real-deps" in argv:
         REAL_DEPS = True
         argv.remove("--real-deps")

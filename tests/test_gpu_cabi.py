@@ -512,3 +512,57 @@ def test_cabi_ndtable_rows_and_read_equal_scipy_rgi():
         d.free()
     _lib.check(L.bfg_ndtable_destroy(ctx, t))
     _lib.check(L.bfg_ctx_destroy(ctx))
+
+
+def test_device_distances_reproduce_what_live_pyccl_printed_in_the_reference_notebooks():
+    """a9 on the DEVICE against the real libccl: two halos at the notebooks' min_z / max_z, their discs enumerated through the C-ABI;
+    every entry's r_com / |vec_pix - vec_j| is the comoving distance the device used for that halo (D_A spline on the device,
+    HealpixRunner.py:297-299, :464-469), and chi(max_z) - chi(min_z) reproduces the 17-digit number pyccl printed in the reference's
+    example notebooks (tests/golden/pyccl_notebook_outputs.json) to 3e-7"""
+    import json
+    import os
+    from scipy import interpolate
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pyccl_notebook_outputs.json")) as f:
+        cases = json.load(f)["cases"]
+    L = _lib.load()
+    ctx = C.c_void_p()
+    _lib.check(L.bfg_ctx_create(0, C.c_void_p(-1), C.byref(ctx)), "ctx")
+    for case in cases:
+        c = case["cosmology"]
+        cosmo = {"Omega_m": c["Omega_c"] + c["Omega_b"], "Omega_b": c["Omega_b"], "h": c["h"], "sigma8": c["sigma8"], "n_s": c["n_s"], "w0": -1.0}
+        bg = Background(cosmo)
+        nside, n = 256, 2
+        z = np.array([case["min_z"], case["max_z"]])
+        M, ra, dec = np.array([4e14, 4e14]), np.array([40.0, 200.0]), np.array([10.0, -35.0])
+        z_t = np.linspace(0, z.max() + 0.1, 1000)                               # the runners' spline (HealpixRunner.py:297-299)
+        cs = interpolate.CubicSpline(z_t, bg.angular_diameter_distance(1 / (1 + z_t)))
+        spl = C.c_void_p()
+        knots, coef = np.ascontiguousarray(cs.x), np.ascontiguousarray(cs.c)
+        _lib.check(L.bfg_spline_create(ctx, knots.size, _dp(knots), _dp(coef), C.byref(spl)), "spline")
+        d_cat = Dev(L, ctx, n * 32).up(np.stack([M, z, ra, dec], 1))
+        args = _lib.ShellArgs()
+        args.nside, args.n_halo, args.d_catalog, args.cat_stride, args.n_extra = nside, n, d_cat.p.value, 4, 0
+        args.epsilon_max, args.runner_md, args.model_md = 8.0, _massdef(bg), _massdef(bg)
+        d_counts = Dev(L, ctx, n * 8)
+        _lib.check(L.bfg_disc_enumerate_count(ctx, C.byref(args), spl, 0, d_counts.p), "count")
+        counts = d_counts.down(n, np.int64)
+        assert counts.min() > 20
+        base = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)
+        total = int(counts.sum())
+        d_base = Dev(L, ctx, n * 8).up(base)
+        d_pix, d_r, d_halo = Dev(L, ctx, total * 8), Dev(L, ctx, total * 8), Dev(L, ctx, total * 4)
+        _lib.check(L.bfg_disc_enumerate(ctx, C.byref(args), spl, 0, d_base.p, d_pix.p, d_r.p, d_halo.p), "enumerate")
+        pix, r_com = d_pix.down(total, np.int64), d_r.down(total)
+        chi = np.empty(n)
+        for j in range(n):
+            sl = slice(base[j], base[j] + counts[j])
+            vec = np.stack(orc.pix2vec(nside, pix[sl]), axis=1)
+            chord = np.sqrt(np.sum((vec - orc.ang2vec(ra[j], dec[j], lonlat=True)) ** 2, axis=1))
+            ratio = r_com[sl] / chord
+            assert np.ptp(ratio) < 1e-9 * ratio.mean()                          # one distance per halo
+            chi[j] = ratio.mean()
+        assert abs((chi[1] - chi[0]) / case["shell_thickness_mpc"] - 1) < 3e-7, (case["source"], chi)
+        for b in (d_cat, d_counts, d_base, d_pix, d_r, d_halo):
+            b.free()
+        _lib.check(L.bfg_spline_destroy(ctx, spl))
+    _lib.check(L.bfg_ctx_destroy(ctx))

@@ -554,6 +554,25 @@ def test_massless_neutrino_convention_is_a_parameter_and_moves_distances_by_part
         Background(cosmo, nu_rel="other")
 
 
+def test_product_background_reproduces_what_live_pyccl_printed_in_the_reference_notebooks():
+    """the product's Background (host side of every D_A spline and R_200c the GPU path uses) against the two numbers live pyccl
+    printed in the reference's example notebooks (tests/golden/pyccl_notebook_outputs.json): chi(z_max) - chi(z_min) to 2e-7"""
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pyccl_notebook_outputs.json")) as f:
+        cases = json.load(f)["cases"]
+    assert len(cases) >= 2
+    for case in cases:
+        c = case["cosmology"]
+        cosmo = {"Omega_m": c["Omega_c"] + c["Omega_b"], "Omega_b": c["Omega_b"], "h": c["h"], "sigma8": c["sigma8"], "n_s": c["n_s"], "w0": -1.0}
+        bg = Background(cosmo)
+        chi = bg.comoving_radial_distance(np.array([1 / (1 + case["max_z"]), 1 / (1 + case["min_z"])]))
+        assert abs((chi[0] - chi[1]) / case["shell_thickness_mpc"] - 1) < 2e-7, case["source"]
+        # and through the angular diameter distance, which is what the runners spline (HealpixRunner.py:297-299)
+        zz = np.array([case["max_z"], case["min_z"]])
+        chi2 = bg.angular_diameter_distance(1 / (1 + zz)) * (1 + zz)
+        assert abs((chi2[0] - chi2[1]) / case["shell_thickness_mpc"] - 1) < 2e-7
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_stripe_shards_partition_and_extents_cover_the_painted_pixels(world):
     """sharding.shard_by_stripes: every halo exactly once, equal-area stripes get ~equal counts; stripe_extent: a RING pixel
