@@ -1237,30 +1237,47 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     // the ring rows are wave 1's (stage b is their first reader): wave 0 goes straight to stage a of the first chunk, and the one
     // barrier after stage a covers the cleared accumulator, the rows and the pair records alike
     constexpr int kRowWave = (NT >= 128) ? 64 : 0;
+    // ... and the sector starts of the rows are wave 2's: two f64 divisions and four 64-bit products per ring, as long again as the
+    // ring's geometry (a square root and a division), and every wavefront waits for the rows at the barrier after stage a
+    // (paint: - 2 % at 1e6 and 1e5 halos; the offsets kernel, 16 rings per tile, lost 0.5 % and keeps both on wave 1: profiles/r04_prep_ab.txt)
+    constexpr int kSecWave = (MODE == MODE_PAINT && NT >= 192) ? 128 : kRowWave;
     if (tid >= kRowWave && tid < kRowWave + TR) {
         const int rtid = tid - kRowWave;
         const int ring = ring_lo + rtid;
-        RingRow rr;
-        rr.z = 0; rr.sth = 0; rr.phistep = 0; rr.phioff = 0; rr.nr = 1; rr.k0 = 0; rr.k1 = 0; rr.rowoff = 0; rr.start = 0; rr.pad = 0;
+        double rz = 0, rsth = 0, rstep = 0, roff = 0;
+        int64_t rstart = 0;
         if (ring <= ring_hi) {
             const RingGeom g = ring_geom(hp, ring);
-            rr.z = g.z;                // identical formula to ring2z, which query_disc uses
-            rr.sth = g.sth; rr.phistep = g.phistep; rr.phioff = g.phioff; rr.nr = g.nr; rr.start = g.start;
-            // floor(sector nr / NS) without a 64-bit integer division (~80 instructions each, on the one wavefront every item
+            rz = g.z;                  // identical formula to ring2z, which query_disc uses
+            rsth = g.sth; rstep = g.phistep; roff = g.phioff; rstart = g.start;
+        }
+        RingRow &rr = rows[rtid];
+        rr.z = rz; rr.sth = rsth; rr.phistep = rstep; rr.phioff = roff; rr.start = rstart; rr.pad = 0;
+    }
+    if (tid >= kSecWave && tid < kSecWave + TR) {
+        const int rtid = tid - kSecWave;
+        const int ring = ring_lo + rtid;
+        int rnr = 1, rk0 = 0, rk1 = 0, rrowoff = 0;
+        if (ring <= ring_hi) {
+            const int nside = (int)hp.nside;
+            const int gnr = 4 * min(min(ring, nside), 4 * nside - ring);       // ring_geom's nr
+            // floor(sector nr / NS) without a 64-bit integer division (~80 instructions each, on a wavefront every item
             // waits for): the double quotient of two integers below 2^53 lies at least 1 / NS from the next integer, far more
             // than its rounding error, and one multiply-compare makes it exact regardless
             auto sector_start = [&](int sct) -> int {
-                const uint64_t prod = (uint64_t)sct * (uint64_t)g.nr;
+                const uint64_t prod = (uint64_t)sct * (uint64_t)gnr;
                 uint64_t q = (uint64_t)((double)prod / (double)NS);
                 if ((q + 1) * (uint64_t)NS <= prod) ++q;
                 if (q * (uint64_t)NS > prod) --q;
                 return (int)q;
             };
-            rr.k0 = sector_start(sector);
-            rr.k1 = sector_start(sector + 1);
-            rr.rowoff = rtid * TW - rr.k0;
+            rnr = gnr;
+            rk0 = sector_start(sector);
+            rk1 = sector_start(sector + 1);
+            rrowoff = rtid * TW - rk0;
         }
-        rows[rtid] = rr;
+        RingRow &rr = rows[rtid];
+        rr.nr = rnr; rr.k0 = rk0; rr.k1 = rk1; rr.rowoff = rrowoff;
     }
     BFG_ITICK(10);
 
