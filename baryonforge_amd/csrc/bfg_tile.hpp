@@ -1264,9 +1264,11 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
             // floor(sector nr / NS) without a 64-bit integer division (~80 instructions each, on a wavefront every item
             // waits for): the double quotient of two integers below 2^53 lies at least 1 / NS from the next integer, far more
             // than its rounding error, and one multiply-compare makes it exact regardless
+            // (and no f64 division either: the reciprocal of NS by Newton, once; the quotient only has to land within 1)
+            const double inv_ns = rcp_newton((double)NS);
             auto sector_start = [&](int sct) -> int {
                 const uint64_t prod = (uint64_t)sct * (uint64_t)gnr;
-                uint64_t q = (uint64_t)((double)prod / (double)NS);
+                uint64_t q = (uint64_t)((double)prod * inv_ns);
                 if ((q + 1) * (uint64_t)NS <= prod) ++q;
                 if (q * (uint64_t)NS > prod) --q;
                 return (int)q;
