@@ -201,8 +201,6 @@ struct PrepParams {
     double *hwin;            // tile variant, row windows of 4 k nodes: the kernel also builds the halos' blended rows (null: a
                              // separate halo_row*_kernel does)
     int lazy_soa;            // tile path, 3-D table: the SoA workspace rows only of halos the scatter kernel / the fill pass will read
-    int chord;               // paint tile path with in-kernel blend: disc membership by chord (bfg_tile.hpp, stage b of the BLEND instantiation):
-                             // discs too small for its relative guard band go to the global-atomic kernel
 };
 
 #define MODE_PAINT 0
@@ -441,7 +439,7 @@ __global__ __launch_bounds__(256, BFG_PREP_WAVES) void halo_prep_kernel(const Pr
         h.win_lo = win_lo; h.flags = flags;
         h.ci0 = ci0; h.ci1 = (P.tab.nouter > 1) ? ci1 : 0;
         h.spare[0] = hc.lnpf; h.spare[1] = cy0; h.spare[2] = (P.tab.nouter > 1) ? cy1 : 0.0;
-        h.spare[3] = 4.0 * h.S * sr * sr;       // r_com^2 at the disc's rim: S * chord^2, chord = 2 sin(radius / 2)
+        h.spare[3] = 0.0;
         P.ht[j] = h;
         if (cells_lds) { s_wl[threadIdx.x] = win_lo; s_fl[threadIdx.x] = flags; s_ln[threadIdx.x] = hc.lnpf; }
     }
@@ -487,10 +485,6 @@ __global__ __launch_bounds__(256, BFG_PREP_WAVES) void halo_prep_kernel(const Pr
             }
             if (total < 4) flags |= HF_SCATTER;
         }
-        // chord membership (bfg_tile.hpp) decides a pixel by a RELATIVE guard band around the rim (kChordBand); query_disc's own
-        // rounding is ~4e-16 ABSOLUTE in chord^2, so discs below 1e-4 rad (at most a pixel or two up to NSIDE 8192) keep the
-        // ring-window enumeration of the global-atomic kernel
-        if (P.chord && !(flags & HF_SKIP) && !(radius >= 1.0e-4)) flags |= HF_SCATTER;
         if (!(flags & HF_SCATTER))
             flags = tile_bin_halo(P.bin, false, j, flags, rfirst, rlast, irmin, irmax, ptheta, pphi, radius, ovf);
         P.bin.ovf_mask[j] = ovf;
@@ -1932,7 +1926,6 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     if (fuse_rows && 15360 + kPrepRowLds + (size_t)64 * ((size_t)1 << t->dev.nouter) * 16 > std::min<size_t>(c->max_dyn_lds, 65536)) fuse_rows = false;
     pp.hwin = fuse_rows ? c->d_hwin : nullptr;
     pp.lazy_soa = (tile && t->dev.nouter == 2 && !std::getenv("BFG_EAGER_SOA")) ? 1 : 0;
-    pp.chord = blend ? 1 : 0;
     const size_t prep_lds = fuse_rows ? kPrepRowLds + (size_t)64 * ((size_t)1 << t->dev.nouter) * 16 : (t->dev.nouter > 2 ? kPrepRowLds : 0);
     timing_begin(c, 0);
     hipLaunchKernelGGL(halo_prep_kernel, dim3((unsigned)((a->n_halo + 255) / 256)), dim3(256), prep_lds, c->stream, pp);

@@ -166,28 +166,6 @@ struct __align__(16) Seg {           // one ring segment of one halo inside one 
 };
 static_assert(sizeof(Seg) == 48, "Seg must be 48 bytes");
 
-// The same 48 bytes as the BLEND instantiation (paint, 3-D table) fills them -- disc membership by chord, see stage b there:
-// excl and abyte share a word (both < 2^16), which makes room for the rim threshold.
-struct __align__(16) SegChord {
-    uint32_t ex_ab;                  // excl | abyte << 16
-    int32_t wbyte, pk;               // as in Seg
-    float xlo;                       // r_com^2 below which a pixel is certainly inside the disc (rim - guard band)
-    double hstep, c0, Aq, Bq;
-};
-static_assert(sizeof(SegChord) == 48, "SegChord must be 48 bytes");
-// Chord membership.  A pixel centre lies in the disc iff chord^2 < 4 sin^2(radius / 2), i.e. r_com^2 = Aq + Bq sin^2(dphi / 2) <
-// xmax = S chord_max^2 (HaloTile::spare[3]) -- in exact arithmetic the same set as query_disc's ring windows
-// |phi - phi0| < acos((cos r - z z0) / (sin theta sin theta0)).  The two differ by rounding only: ~1e-13 relative on r_com^2 here
-// (+ 4e-10 of the sin^2 series), ~4e-16 / radius^2 in query_disc's cosines.  So the pixel stage decides by r_com^2 alone where it
-// is more than kChordBand away from the rim and hands the few pixels inside the band (2e-6 of a disc's pixels) to the exact
-// window test (rim_member: the arithmetic this kernel used for every ring before): the painted set is query_disc's, bit for
-// bit.  Stage b then only needs a ring window that CONTAINS the candidates -- from the same r_com^2 bound in float32 plus
-// margins -- instead of one that decides them: no atan2, no f64 square root or division per (pair, ring).
-constexpr double kChordBand = 1.9073486328125e-06;            // 2^-19: half-width of the guard band, relative to xmax
-constexpr double kChordLo = 1.0 - kChordBand;                 // xlo = float(xmax kChordLo): certainly inside below
-constexpr double kChordOut = 1.0 + 2.5 * kChordBand;          // r_com^2 > xlo kChordOut: certainly outside (covers xmax (1 + band))
-constexpr double kChordWin = 1.0 + 3.0 * kChordBand;          // the candidate windows reach xmax kChordWin (> xlo kChordOut in float32 too)
-
 // extra per-halo constants of the baryonify offsets path (written by halo_prep_kernel next to HaloTile)
 struct __align__(16) HaloDisp {
     double cp0, sp0;                 // cos / sin of the halo longitude
@@ -1090,30 +1068,6 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// query_disc's ring window for ONE pixel (kw-th pixel of a ring with nr pixels at height z; shifted: phi = (k + 1/2) 2 pi / nr):
-// the arithmetic stage b of the tile kernel uses for every (pair, ring) slot where it enumerates a disc ring by ring
-// (HealpixRunner.py:463 -> healpix_cxx query_disc_internal).  The BLEND instantiation calls it for the pixels its chord test
-// leaves undecided (SegChord); out of line so that this cold path costs the pixel loop no registers.
-__device__ __noinline__ bool disc_rim_member(const HaloTile *h, double z, int nr, int shifted, int ring, int kw)
-{
-    if (ring < h->irmin || ring > h->irmax) return true;                   // ring entirely inside the disc
-    const double x = (h->cosr - z * h->z0) * h->xa;
-    const double ysq = 1.0 - z * z - x * x;
-    const double dphi = (ysq > 0.0) ? atan2_upper(sqrt_unit(ysq), x) : 0.0;
-    if (!(dphi > 0.0)) return false;
-    const double shift = shifted ? 0.5 : 0.0;
-    const double fn = (double)nr * kInvTwoPi;
-    const int l32 = (int)floor(fn * (h->pphi - dphi) - shift) + 1;
-    const int h32 = (int)floor(fn * (h->pphi + dphi) - shift);
-    const int c = min(h32 - l32 + 1, nr);
-    if (c <= 0) return false;
-    int d = kw - l32;                                                      // in (-1.5 nr, 2 nr): the window is unwrapped
-    if (d < 0) d += nr;
-    if (d < 0) d += nr;
-    if (d >= nr) d -= nr;
-    return d < c;
-}
-
 // BLEND: the instantiation whose stage b blends the pairs' row windows from the table itself (TileParams::blend; paint, 3-D
 // tables, dense catalogs).  A template parameter, not a run-time branch: the blend code costs the other path registers (20 -> 36 B
 // of scratch and + 4 % on the 1e5-halo run when it was a branch).
@@ -1593,71 +1547,6 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         }
     };
 
-    // ---- BLEND instantiation: pixels of SegChord records (disc membership by chord) ---------------------------------
-    unsigned int n_rej32 = 0;                          // candidates of the ring windows that turned out to lie outside their disc
-    // A pixel whose r_com^2 lies inside the guard band around the rim: query_disc's own ring window decides, with the arithmetic
-    // stage b used for every ring before (HealpixRunner.py:463; the oracle's query_disc).  acc_index = row * TW + column.
-    [[maybe_unused]] auto rim_member = [&](int pidx, int acc_index) -> bool {
-        const int row = acc_index / TW, col = acc_index - row * TW;
-        const RingRow &rr = rows[row];
-        return disc_rim_member(P.ht + pinfo[pidx].halo, rr.z, rr.nr, rr.phioff != 0.0 ? 1 : 0, ring_lo + row, rr.k0 + col);
-    };
-    [[maybe_unused]] auto do_pixel_chord = [&](int q, const SegChord &sg) {
-        const int k = q - (int)(sg.ex_ab & 0xffffu);                       // pixel index inside the segment
-        const unsigned abyte = lds_base + (sg.ex_ab >> 16) + 8u * (unsigned)k;
-        const double h = fma((double)k, sg.hstep, sg.c0);
-        const double h2 = h * h;
-        {
-            // the common case behind ONE branch (small angle, certainly inside the disc, cell inside the staged window, value inside
-            // exp's range); a pixel that fails any of the four falls through to the general code below, which starts over
-            const double xf = fma(sg.Bq, sin_squared_small(h2), sg.Aq);
-            const double t1f = fma(fast_log_biased(xf, logtab), t_m, t_c1);
-            const int i1f = (int)t1f;
-            const int icf = med3_i32(i1f, sg.pk, sg.pk + W - 2);
-            const lds_double *wpf = lds_ptr<double>(lds_base + sg.wbyte + 8 * icf);
-            const double B0f = wpf[0], B1f = wpf[1];
-            const double Lf = fma(t1f - (double)icf, B1f - B0f, B0f);
-            if ((h2 <= kSinSmall) && (icf == i1f) && (fabs(Lf) < 709.0) && ((float)xf < sg.xlo)) {
-                __hip_atomic_fetch_add(lds_ptr<double>(abyte), fast_exp(Lf, exptab), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                return;
-            }
-        }
-        double s2 = sin_squared_small(h2);
-        if (__any(h2 > kSinSmall)) {                                       // wave-uniform branch: only near the poles
-            if (h2 > kSinSmall) s2 = sin_squared_wide(h);
-        }
-        const double x = fma(sg.Bq, s2, sg.Aq);                            // r_com^2
-        const int wl1 = sg.pk;
-        const int pidx = (sg.wbyte + 8 * wl1 - pwin_off) / (8 * kWinLds);
-        const double xlo = (double)sg.xlo;
-        if (!(x < xlo)) {                                                  // not certainly inside (NaN: outside)
-            const bool band = (x <= xlo * kChordOut) || (P.debug & 256);   // debug bit 256: every such pixel through the exact test (tests)
-            if (!band || !rim_member(pidx, (int)((abyte - lds_base - (unsigned)acc_off) >> 3))) { n_rej32 += 1; return; }
-        }
-        // x = 0 never lands in the window (ln of the bit pattern is hugely negative)
-        const double t1 = fma(fast_log_biased(x, logtab), t_m, t_c1);
-        const int i1 = (int)t1;                                            // saturating conversion
-        const int ic = med3_i32(i1, wl1, wl1 + W - 2);
-        bool in = (ic == i1);
-        const lds_double *wp = lds_ptr<double>(lds_base + sg.wbyte + 8 * ic);
-        const double B0 = wp[0], B1 = wp[1];
-        double L = fma(t1 - (double)ic, B1 - B0, B0);
-        if (!in) {                                                         // divergent and rare
-            const double t = t1 - 1.0;
-            if ((t >= 0.0) && (t <= (double)NRm1)) {
-                const int qi = (kQCap > 0) ? atomicAdd(&ctl[5], 1) : kQCap;
-                if (qi < qcap) {
-                    DeferredPixel e;
-                    e.halo = pinfo[pidx].halo; e.abyte = (int)(abyte - lds_base); e.t = t;
-                    rq[qi] = e;
-                } else { L = direct_row(pidx, t); in = true; }             // queue full: inline
-            } else n_oob32 += 1;
-        }
-        const bool go = in && (fabs(L) < 709.0);                           // false for NaN too
-        const double v = fast_exp(L, exptab);                              // garbage when !go, never added
-        if (go) __hip_atomic_fetch_add(lds_ptr<double>(abyte), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-
 #if BFG_STAGE_TIMING
     BFG_TICK(6);                                       // prologue: LDS clear, tables, ring rows, first pair records
 #endif
@@ -1699,22 +1588,95 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         // ---- stage b: one thread per (pair, ring) slot; row windows -> LDS -----------------------------
         // With full-width windows the copy is an LDS-DMA (global_load_lds_dwordx4: no VGPRs, asynchronous;
         // drained by the barrier that ends stage b).  dest = wave-uniform base + lane * 16 B == pwin[2 * tid].
-        if constexpr (BLEND) {
-            // ---- stage b of the BLEND instantiation: chord membership (see SegChord) ---------------------------
-            // Every thread has up to two jobs: blend unit NT - 1 - tid (pair, four nodes of its row window: dealt from the LAST
-            // thread down) and (pair, ring) slot tid (dealt from thread 0 up).  Program order: the halo-record loads of both
-            // jobs together (one L2 round trip for both), then the blend unit (eight table loads, arithmetic, LDS store), then the
-            // slot's arithmetic (LDS only).  (Holding the blend's 16 doubles across the slot work spilled: 216 B of scratch.)
-            typedef double double2u __attribute__((ext_vector_type(2), aligned(8)));
-            const int bu = NT - 1 - tid;
-            const bool do_blend = bu < n_take * (kWinLds / 4) && !(P.debug & 64);
-            const bool slot_wave = wave * 64 < nslots && !(P.debug & 8);       // whole wavefronts: kSlotMax <= NT, one pass
+        if constexpr (win_in_lds) {
+            if (P.debug & 64) {                                       // profiling: no window copy at all (wrong results)
+            } else if constexpr (BLEND) {
+                // No windows in HBM: one thread per (pair, 4 nodes) blends them from the four corner rows of the halo's (z, M)
+                // cell -- the table is L2-resident -- with the arithmetic of halo_row4_kernel (corner order, fma chain from
+                // 0, + ln(pixarea D^2)): the same bits.  All eight 16-byte loads of a thread are in flight together.
+                typedef double double2u __attribute__((ext_vector_type(2), aligned(8)));
+                // from the LAST thread down: the (pair, ring) slots below are dealt from thread 0 up, so in a chunk that does not
+                // fill the workgroup (sparse catalogs) the blend -- two dependent L2 round trips -- runs in wavefronts that have
+                // no slot, beside the slot work instead of in front of it
+                const int i = NT - 1 - tid;
+                if (i < n_take * (kWinLds / 4)) {
+                    const int p = i >> 3, q = i & 7;
+                    const Pair &pi = pinfo[p];
+                    const HaloTile &hb = P.ht[pi.halo];                // the line the slot threads of this pair fetch as well
+                    const int c0 = hb.ci0, c1 = hb.ci1;
+                    const double y0 = hb.spare[1], y1 = hb.spare[2];
+                    const double *r0 = T.values + (int64_t)c0 * T.ostride[0] + (int64_t)c1 * T.ostride[1] + (pi.win_lo + 4 * q);
+                    const double *r1 = r0 + T.ostride[1], *r2 = r0 + T.ostride[0], *r3 = r2 + T.ostride[1];
+                    const double2u a0 = *reinterpret_cast<const double2u *>(r0), b0 = *reinterpret_cast<const double2u *>(r0 + 2);
+                    const double2u a1 = *reinterpret_cast<const double2u *>(r1), b1 = *reinterpret_cast<const double2u *>(r1 + 2);
+                    const double2u a2 = *reinterpret_cast<const double2u *>(r2), b2 = *reinterpret_cast<const double2u *>(r2 + 2);
+                    const double2u a3 = *reinterpret_cast<const double2u *>(r3), b3 = *reinterpret_cast<const double2u *>(r3 + 2);
+                    const double w0 = (1.0 * (1.0 - y0)) * (1.0 - y1), w1 = (1.0 * (1.0 - y0)) * y1;
+                    const double w2 = (1.0 * y0) * (1.0 - y1), w3 = (1.0 * y0) * y1;
+                    double add = 0.0;
+                    if constexpr (MODE == MODE_PAINT) add = hb.spare[0];
+                    double2 o0, o1;
+                    o0.x = fma(a3.x, w3, fma(a2.x, w2, fma(a1.x, w1, fma(a0.x, w0, 0.0)))) + add;
+                    o0.y = fma(a3.y, w3, fma(a2.y, w2, fma(a1.y, w1, fma(a0.y, w0, 0.0)))) + add;
+                    o1.x = fma(b3.x, w3, fma(b2.x, w2, fma(b1.x, w1, fma(b0.x, w0, 0.0)))) + add;
+                    o1.y = fma(b3.y, w3, fma(b2.y, w2, fma(b1.y, w1, fma(b0.y, w0, 0.0)))) + add;
+                    double2 *dst = reinterpret_cast<double2 *>(pwin + p * kWinLds + 4 * q);
+                    dst[0] = o0; dst[1] = o1;
+                }
+            } else if (W == kWinLds) {
+                for (int i = tid; i - lane < n_take * (kWinLds / 2); i += NT) {          // whole wavefronts step together
+                    if (i < n_take * (kWinLds / 2)) {
+                        const double *src = P.hwin + pinfo[i / (kWinLds / 2)].hoff + 2 * (i % (kWinLds / 2));
+                        double *dst = pwin + 2 * (i - lane);                              // wave-uniform; lane * 16 B added by HW
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+                    }
+                }
+            } else {
+                for (int idx = tid; idx < n_take * W; idx += NT) {
+                    const int p = idx / W, e = idx - p * W;
+                    pwin[p * kWinLds + e] = P.hwin[pinfo[p].hoff + e];
+                }
+            }
+        }
+        if constexpr (!win_in_lds) {
+            if (P.win_table && wave == kTileWaves - 1 && lane < n_take) {   // corner rows of the pair's halo
+                const int64_t j = pinfo[lane].halo;
+                const int ncorner = 1 << T.nouter;
+                double *cwn = pwin + lane * kWinLds;
+                int64_t *con = reinterpret_cast<int64_t *>(cwn + ncorner);
+                for (int c = 0; c < ncorner; ++c) {                        // corner order and products of halo_row_kernel
+                    double w = 1.0;
+                    int64_t off = 0;
+                    for (int k = 0; k < T.nouter; ++k) {
+                        const int bit = (c >> (T.nouter - 1 - k)) & 1;
+                        const double y = halo_cell_weight(P.ht, P.cw, P.cap, T.nouter, j, k);
+                        w = w * (bit ? y : 1.0 - y);
+                        off += (int64_t)(halo_cell_index(P.ht, P.cidx, P.cap, T.nouter, j, k) + bit) * T.ostride[k];
+                    }
+                    cwn[c] = w; con[c] = off;
+                }
+                if constexpr (MODE == MODE_PAINT) { if (ncorner == 4) cwn[8] = pinfo[lane].lnpf; }   // the fast path's record
+            }
+        }
+        if constexpr (MODE == MODE_BARYONIFY) {
+            static_assert(MODE != MODE_BARYONIFY || kSlotMax <= NT - 64, "the last wavefront has no slots");
+            if (wave == kTileWaves - 1 && lane < n_take) {              // per-pair constants of the pixel stage
+                Pair &pi = pinfo[lane];
+                const int j = pi.halo;
+                const HaloTile &h = P.ht[j];
+                const HaloDisp &hd = P.hd[j];
+                pi.cp0 = hd.cp0; pi.sp0 = hd.sp0; pi.st = h.st; pi.ct = h.ct;
+                pi.a = hd.a; pi.D = hd.D; pi.xcut = hd.xcut; pi.tshift = hd.tshift; pi.a_over_D = hd.a / hd.D;
+            }
+        }
+        if (wave * 64 < nslots && !(P.debug & 8)) {                 // whole wavefronts: kSlotMax <= NT, one pass
             const int slot = tid;
-            const bool live = slot_wave && slot < nslots;
-            int p = 0;
-            if (slot_wave) {
-                // pair p with pr_off[p] <= slot < pr_off[p+1]: one LDS read, then a wave-uniform loop over the pairs
-                // that start inside this wavefront's 64 slots
+            const bool live = slot < nslots;
+            // pair p with pr_off[p] <= slot < pr_off[p+1]: one LDS read, then a wave-uniform loop over the pairs
+            // that start inside this wavefront's 64 slots
+            int p;
+            {
                 const int sb = wave * 64;
                 const int myoff = pr_off[lane];
                 p = __popcll(__ballot(myoff <= sb)) - 1;
@@ -1726,349 +1688,108 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                     p += (slot >= o) ? 1 : 0;
                 }
             }
-            // (1) halo records
-            int b_c0 = 0, b_c1 = 0, b_wl = 0;
-            double b_y0 = 0.0, b_y1 = 0.0, b_add = 0.0;
-            if (do_blend) {
-                const Pair &pb = pinfo[bu >> 3];
-                const HaloTile &hb = P.ht[pb.halo];
-                b_c0 = hb.ci0; b_c1 = hb.ci1; b_y0 = hb.spare[1]; b_y1 = hb.spare[2]; b_add = hb.spare[0];
-                b_wl = pb.win_lo;
-            }
-            // (2) the blend unit's corner rows (the table is L2-resident): eight 16-byte loads in flight
-            double2u a0 = {0.0, 0.0}, b0 = a0, a1 = a0, b1 = a0, a2 = a0, b2 = a0, a3 = a0, b3 = a0;
-            if (do_blend) {
-                const double *r0 = T.values + (int64_t)b_c0 * T.ostride[0] + (int64_t)b_c1 * T.ostride[1] + (b_wl + 4 * (bu & 7));
-                const double *r1 = r0 + T.ostride[1], *r2 = r0 + T.ostride[0], *r3 = r2 + T.ostride[1];
-                a0 = *reinterpret_cast<const double2u *>(r0); b0 = *reinterpret_cast<const double2u *>(r0 + 2);
-                a1 = *reinterpret_cast<const double2u *>(r1); b1 = *reinterpret_cast<const double2u *>(r1 + 2);
-                a2 = *reinterpret_cast<const double2u *>(r2); b2 = *reinterpret_cast<const double2u *>(r2 + 2);
-                a3 = *reinterpret_cast<const double2u *>(r3); b3 = *reinterpret_cast<const double2u *>(r3 + 2);
-                // the arithmetic of halo_row4_kernel (corner order, fma chain from 0, + ln(pixarea D^2)): the same bits
-                const double w0 = (1.0 * (1.0 - b_y0)) * (1.0 - b_y1), w1 = (1.0 * (1.0 - b_y0)) * b_y1;
-                const double w2 = (1.0 * b_y0) * (1.0 - b_y1), w3 = (1.0 * b_y0) * b_y1;
-                double2 o0, o1;
-                o0.x = fma(a3.x, w3, fma(a2.x, w2, fma(a1.x, w1, fma(a0.x, w0, 0.0)))) + b_add;
-                o0.y = fma(a3.y, w3, fma(a2.y, w2, fma(a1.y, w1, fma(a0.y, w0, 0.0)))) + b_add;
-                o1.x = fma(b3.x, w3, fma(b2.x, w2, fma(b1.x, w1, fma(b0.x, w0, 0.0)))) + b_add;
-                o1.y = fma(b3.y, w3, fma(b2.y, w2, fma(b1.y, w1, fma(b0.y, w0, 0.0)))) + b_add;
-                double2 *dst = reinterpret_cast<double2 *>(pwin + (bu >> 3) * kWinLds + 4 * (bu & 7));
-                dst[0] = o0; dst[1] = o1;
-            }
-            double h_st = 0.0, h_ct = 0.0, h_pphi = 0.0, h_S = 0.0, h_xmax = 0.0;
-            int h_irmin = 0, h_irmax = 0;
+            BFG_SUBTICK(0);                                          // window DMA issued, pair of the slot found
+            int cnt1 = 0, cnt2 = 0, aa1 = 0, aa2 = 0, ab1 = 0, ab2 = 0;
+            Seg sg;
+            sg.excl = 0; sg.abyte = 0; sg.wbyte = 0; sg.pk = 0; sg.hstep = 0; sg.c0 = 0; sg.Aq = 0; sg.Bq = 0;
             if (live) {
-                const HaloTile &h = P.ht[pinfo[p].halo];
-                h_st = h.st; h_ct = h.ct; h_pphi = h.pphi; h_S = h.S; h_xmax = h.spare[3];
-                h_irmin = h.irmin; h_irmax = h.irmax;
-            }
-            // (3) the slot: ring window that contains every pixel with r_com^2 <= xmax kChordWin, clipped to the sector
-            if (slot_wave) {
-                int cnt1 = 0, cnt2 = 0, aa1 = 0, aa2 = 0, ab1 = 0, ab2 = 0;
-                SegChord sg;
-                sg.ex_ab = 0u; sg.wbyte = 0; sg.pk = 0; sg.xlo = 0.0f; sg.hstep = 0; sg.c0 = 0; sg.Aq = 0; sg.Bq = 0;
-                if (live) {
-                    const int ring = pinfo[p].ra + (slot - pr_off[p]);
-                    const int row = ring - ring_lo;
-                    const RingRow rr = rows[row];
-                    const int nr = rr.nr;
-                    const double ds = rr.sth - h_st, dz = rr.z - h_ct;
-                    sg.Aq = (ds * ds + dz * dz) * h_S;
-                    sg.Bq = 4.0 * rr.sth * h_st * h_S;
-                    sg.xlo = (float)(h_xmax * kChordLo);
-                    int lo = 0, cnt = 0;
-                    // sin^2(dphi / 2) <= (xmax kChordWin - Aq) / Bq.  The padding 1e-12 xmax covers the rounding of Aq where the two
-                    // nearly cancel (top and bottom rings of a disc); from there on float32 with a relative margin is enough.
-                    const double num = fma(h_xmax, kChordWin + 1.0e-12, -sg.Aq);
-                    if (num > 0.0) {
-                        const float sm = (float)num * __builtin_amdgcn_rcpf((float)sg.Bq);
-                        {
-                            const float u = __builtin_amdgcn_sqrtf(sm), u2 = u * u;
-                            // asin(u) for u <= 1/4: the series to u^7 (next term 105 / 3456 u^9 < 5e-7 u) and a margin of 8e-6
-                            float as = fmaf(u2, 15.0f / 336.0f, 3.0f / 40.0f);
-                            as = fmaf(u2, as, 1.0f / 6.0f);
-                            as = fmaf(u2, as, 1.0f);
-                            // wide angles (next to a pole; Bq = 0; NaN): the whole ring, as the window of dphi = pi -- centred on the
-                            // halo's longitude, so that |phi - phi0| <= pi for every pixel (the pixel stage's sin^2 wants |h| <= pi / 2)
-                            const double dphi = (sm <= 0.0625f) ? (double)(u * as * 2.000016f) : kPi;
-                            const double shift = (rr.phioff != 0.0) ? 0.5 : 0.0;
-                            const double fn = (double)nr * kInvTwoPi;
-                            // (1e-9 of a pixel on either side: the window must also contain a centre that lies ON its edge)
-                            const int l32 = (int)floor(fma(fn, h_pphi - dphi, -(shift + 1.0e-9))) + 1;
-                            const int h32 = (int)floor(fma(fn, h_pphi + dphi, -(shift - 1.0e-9)));
-                            const int c = min(h32 - l32 + 1, nr);
-                            if (c > 0) { cnt = c; lo = l32; }                 // unwrapped: lo in (-nr, 1.5 nr)
-                        }
-                    }
-                    if (ring < h_irmin || ring > h_irmax) { cnt = nr; lo = 0; }   // ring entirely inside the disc
-                    const int wl = pinfo[p].win_lo;
-                    // window start + 1 and the LDS address of node (cell - 1): see window_row
-                    sg.wbyte = pwin_off + p * (kWinLds * 8) - 8 * (wl + 1);
-                    sg.pk = wl + 1;
-                    sg.hstep = 0.5 * rr.phistep;
-                    sg.c0 = 0.5 * (rr.phioff * rr.phistep - h_pphi);       // + first pixel * hstep, below
-                    // clip to the sector; a window that wraps around the ring can meet it twice
-                    if (cnt > 0) {
-                        const bool wraps = (lo < 0) || (lo + cnt > nr);
-                        if (!__any(wraps)) {                                // the usual case for a whole wavefront
-                            const int aa = max(lo, rr.k0), bb = min(lo + cnt, rr.k1);
-                            if (bb > aa) { cnt1 = bb - aa; aa1 = aa; ab1 = acc_off + 8 * NACC * (rr.rowoff + aa); }
-                        } else {
-#pragma unroll
-                            for (int mi = 0; mi < 3; ++mi) {
-                                const int m = (mi == 0) ? 0 : (mi == 1 ? -1 : 1);
-                                const int aa = max(lo, rr.k0 + m * nr), bb = min(lo + cnt, rr.k1 + m * nr);
-                                if (bb > aa) {
-                                    const int ab = acc_off + 8 * NACC * (rr.rowoff - m * nr + aa);
-                                    if (cnt1 == 0) { cnt1 = bb - aa; aa1 = aa; ab1 = ab; }
-                                    else if (cnt2 == 0) { cnt2 = bb - aa; aa2 = aa; ab2 = ab; }
-                                }
-                            }
-                        }
-                    }
-                }
-                // a second piece needs its own segment record; should the chunk run out of them (only possible where a
-                // sector spans a whole ring, at the poles) the piece is painted right here, through the direct read-out
-                int idx2 = 0;
-                bool spill2 = false;
-                if (cnt2 > 0) { idx2 = nslots + atomicAdd(&ctl[2], 1); spill2 = idx2 >= kSegMax || (P.debug & 16); }   // debug bit 16: force the spill path (tests)
-                // offsets in the chunk's flattened pixel list: wave scan + one LDS atomic per wavefront (any order will do)
-                const int tot = cnt1 + (spill2 ? 0 : cnt2);
-                const int incl = wave_scan_incl(tot);
-                const int wtot = __builtin_amdgcn_readlane(incl, 63);
-                int wbase = 0;
-                if (lane == 0 && wtot > 0) wbase = atomicAdd(&ctl[3], wtot);
-                wbase = __builtin_amdgcn_readfirstlane(wbase);
-                const int e1 = wbase + incl - tot;
-                if (live) {
-                    scnt[slot] = (uint8_t)cnt1;
-                    if (cnt1 > 0) {
-                        const double c0b = sg.c0;
-                        SegChord *sc = reinterpret_cast<SegChord *>(segs);
-                        sg.ex_ab = (uint32_t)e1 | ((uint32_t)ab1 << 16); sg.c0 = fma((double)aa1, sg.hstep, c0b);
-                        sc[slot] = sg;
-                        fill_ptab(e1, min(e1 + cnt1, kPixMax), (uint32_t)(slot * (int)sizeof(Seg)));
-                        if (cnt2 > 0 && !spill2) {
-                            scnt[idx2] = (uint8_t)cnt2;
-                            const int e2 = e1 + cnt1;
-                            sg.ex_ab = (uint32_t)e2 | ((uint32_t)ab2 << 16); sg.c0 = fma((double)aa2, sg.hstep, c0b);
-                            sc[idx2] = sg;
-                            fill_ptab(e2, min(e2 + cnt2, kPixMax), (uint32_t)(idx2 * (int)sizeof(Seg)));
-                        } else if (cnt2 > 0) {
-                            constexpr int wlf = 1 << 18;                   // a window no cell falls into -> direct_row()
-                            sg.ex_ab = (uint32_t)ab2 << 16; sg.c0 = fma((double)aa2, sg.hstep, c0b);
-                            sg.wbyte = pwin_off + p * (kWinLds * 8) - 8 * wlf;
-                            sg.pk = wlf;
-                            for (int k = 0; k < cnt2; ++k) do_pixel_chord(k, sg);
-                            my_pixels += (unsigned long long)cnt2;
-                        }
-                    }
-                }
-            }
-        } else {
-            if constexpr (win_in_lds) {
-                if (P.debug & 64) {                                       // profiling: no window copy at all (wrong results)
-                } else if constexpr (BLEND) {
-                    // No windows in HBM: one thread per (pair, 4 nodes) blends them from the four corner rows of the halo's (z, M)
-                    // cell -- the table is L2-resident -- with the arithmetic of halo_row4_kernel (corner order, fma chain from
-                    // 0, + ln(pixarea D^2)): the same bits.  All eight 16-byte loads of a thread are in flight together.
-                    typedef double double2u __attribute__((ext_vector_type(2), aligned(8)));
-                    // from the LAST thread down: the (pair, ring) slots below are dealt from thread 0 up, so in a chunk that does not
-                    // fill the workgroup (sparse catalogs) the blend -- two dependent L2 round trips -- runs in wavefronts that have
-                    // no slot, beside the slot work instead of in front of it
-                    const int i = NT - 1 - tid;
-                    if (i < n_take * (kWinLds / 4)) {
-                        const int p = i >> 3, q = i & 7;
-                        const Pair &pi = pinfo[p];
-                        const HaloTile &hb = P.ht[pi.halo];                // the line the slot threads of this pair fetch as well
-                        const int c0 = hb.ci0, c1 = hb.ci1;
-                        const double y0 = hb.spare[1], y1 = hb.spare[2];
-                        const double *r0 = T.values + (int64_t)c0 * T.ostride[0] + (int64_t)c1 * T.ostride[1] + (pi.win_lo + 4 * q);
-                        const double *r1 = r0 + T.ostride[1], *r2 = r0 + T.ostride[0], *r3 = r2 + T.ostride[1];
-                        const double2u a0 = *reinterpret_cast<const double2u *>(r0), b0 = *reinterpret_cast<const double2u *>(r0 + 2);
-                        const double2u a1 = *reinterpret_cast<const double2u *>(r1), b1 = *reinterpret_cast<const double2u *>(r1 + 2);
-                        const double2u a2 = *reinterpret_cast<const double2u *>(r2), b2 = *reinterpret_cast<const double2u *>(r2 + 2);
-                        const double2u a3 = *reinterpret_cast<const double2u *>(r3), b3 = *reinterpret_cast<const double2u *>(r3 + 2);
-                        const double w0 = (1.0 * (1.0 - y0)) * (1.0 - y1), w1 = (1.0 * (1.0 - y0)) * y1;
-                        const double w2 = (1.0 * y0) * (1.0 - y1), w3 = (1.0 * y0) * y1;
-                        double add = 0.0;
-                        if constexpr (MODE == MODE_PAINT) add = hb.spare[0];
-                        double2 o0, o1;
-                        o0.x = fma(a3.x, w3, fma(a2.x, w2, fma(a1.x, w1, fma(a0.x, w0, 0.0)))) + add;
-                        o0.y = fma(a3.y, w3, fma(a2.y, w2, fma(a1.y, w1, fma(a0.y, w0, 0.0)))) + add;
-                        o1.x = fma(b3.x, w3, fma(b2.x, w2, fma(b1.x, w1, fma(b0.x, w0, 0.0)))) + add;
-                        o1.y = fma(b3.y, w3, fma(b2.y, w2, fma(b1.y, w1, fma(b0.y, w0, 0.0)))) + add;
-                        double2 *dst = reinterpret_cast<double2 *>(pwin + p * kWinLds + 4 * q);
-                        dst[0] = o0; dst[1] = o1;
-                    }
-                } else if (W == kWinLds) {
-                    for (int i = tid; i - lane < n_take * (kWinLds / 2); i += NT) {          // whole wavefronts step together
-                        if (i < n_take * (kWinLds / 2)) {
-                            const double *src = P.hwin + pinfo[i / (kWinLds / 2)].hoff + 2 * (i % (kWinLds / 2));
-                            double *dst = pwin + 2 * (i - lane);                              // wave-uniform; lane * 16 B added by HW
-                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-                        }
-                    }
-                } else {
-                    for (int idx = tid; idx < n_take * W; idx += NT) {
-                        const int p = idx / W, e = idx - p * W;
-                        pwin[p * kWinLds + e] = P.hwin[pinfo[p].hoff + e];
-                    }
-                }
-            }
-            if constexpr (!win_in_lds) {
-                if (P.win_table && wave == kTileWaves - 1 && lane < n_take) {   // corner rows of the pair's halo
-                    const int64_t j = pinfo[lane].halo;
-                    const int ncorner = 1 << T.nouter;
-                    double *cwn = pwin + lane * kWinLds;
-                    int64_t *con = reinterpret_cast<int64_t *>(cwn + ncorner);
-                    for (int c = 0; c < ncorner; ++c) {                        // corner order and products of halo_row_kernel
-                        double w = 1.0;
-                        int64_t off = 0;
-                        for (int k = 0; k < T.nouter; ++k) {
-                            const int bit = (c >> (T.nouter - 1 - k)) & 1;
-                            const double y = halo_cell_weight(P.ht, P.cw, P.cap, T.nouter, j, k);
-                            w = w * (bit ? y : 1.0 - y);
-                            off += (int64_t)(halo_cell_index(P.ht, P.cidx, P.cap, T.nouter, j, k) + bit) * T.ostride[k];
-                        }
-                        cwn[c] = w; con[c] = off;
-                    }
-                    if constexpr (MODE == MODE_PAINT) { if (ncorner == 4) cwn[8] = pinfo[lane].lnpf; }   // the fast path's record
-                }
-            }
-            if constexpr (MODE == MODE_BARYONIFY) {
-                static_assert(MODE != MODE_BARYONIFY || kSlotMax <= NT - 64, "the last wavefront has no slots");
-                if (wave == kTileWaves - 1 && lane < n_take) {              // per-pair constants of the pixel stage
-                    Pair &pi = pinfo[lane];
-                    const int j = pi.halo;
-                    const HaloTile &h = P.ht[j];
-                    const HaloDisp &hd = P.hd[j];
-                    pi.cp0 = hd.cp0; pi.sp0 = hd.sp0; pi.st = h.st; pi.ct = h.ct;
-                    pi.a = hd.a; pi.D = hd.D; pi.xcut = hd.xcut; pi.tshift = hd.tshift; pi.a_over_D = hd.a / hd.D;
-                }
-            }
-            if (wave * 64 < nslots && !(P.debug & 8)) {                 // whole wavefronts: kSlotMax <= NT, one pass
-                const int slot = tid;
-                const bool live = slot < nslots;
-                // pair p with pr_off[p] <= slot < pr_off[p+1]: one LDS read, then a wave-uniform loop over the pairs
-                // that start inside this wavefront's 64 slots
-                int p;
+                const int j = pinfo[p].halo;
+                const int ring = pinfo[p].ra + (slot - pr_off[p]);
+                const int row = ring - ring_lo;
+                const RingRow rr = rows[row];
+                const HaloTile &h = P.ht[j];
+                const double st = h.st, ct = h.ct, pphi = h.pphi, S = h.S;
+                const int nr = rr.nr;
+                // query_disc ring window.  Evaluated unconditionally so that every field of the halo record is
+                // fetched in one burst (a branch on irmin / irmax first serialises three L2 round trips); rings that
+                // lie entirely inside the disc (ring outside [irmin, irmax]) override the result.
+                const int irmin = h.irmin, irmax = h.irmax;
+#if BFG_STAGE_TIMING == 2
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                BFG_SUBTICK(1);                                      // halo record arrived
+#endif
+                int lo = 0, cnt = 0;
                 {
-                    const int sb = wave * 64;
-                    const int myoff = pr_off[lane];
-                    p = __popcll(__ballot(myoff <= sb)) - 1;
-                    unsigned long long inside = __ballot(myoff > sb && myoff <= sb + 63);
-                    while (inside) {
-                        const int kk = __ffsll((long long)inside) - 1;
-                        inside &= inside - 1;
-                        const int o = __builtin_amdgcn_readlane(myoff, kk);
-                        p += (slot >= o) ? 1 : 0;
+                    const double x = (h.cosr - rr.z * h.z0) * h.xa;
+                    const double ysq = 1.0 - rr.z * rr.z - x * x;
+                    const double dphi = (ysq > 0.0) ? atan2_upper_tab(sqrt_unit(ysq), x, atantab) : 0.0;
+                    if (dphi > 0.0) {
+                        const double shift = (rr.phioff != 0.0) ? 0.5 : 0.0;
+                        // |nr (pphi -+ dphi) / 2 pi| < 2 nr <= 8 nside: 32-bit is enough (the tile variant needs nside <= 2^24)
+                        const double fn = (double)nr * kInvTwoPi;
+                        const int l32 = (int)floor(fn * (pphi - dphi) - shift) + 1;
+                        const int h32 = (int)floor(fn * (pphi + dphi) - shift);
+                        const int c = min(h32 - l32 + 1, nr);
+                        if (c > 0) { cnt = c; lo = l32; }                // unwrapped: lo in (-nr, 1.5 nr)
                     }
                 }
-                BFG_SUBTICK(0);                                          // window DMA issued, pair of the slot found
-                int cnt1 = 0, cnt2 = 0, aa1 = 0, aa2 = 0, ab1 = 0, ab2 = 0;
-                Seg sg;
-                sg.excl = 0; sg.abyte = 0; sg.wbyte = 0; sg.pk = 0; sg.hstep = 0; sg.c0 = 0; sg.Aq = 0; sg.Bq = 0;
-                if (live) {
-                    const int j = pinfo[p].halo;
-                    const int ring = pinfo[p].ra + (slot - pr_off[p]);
-                    const int row = ring - ring_lo;
-                    const RingRow rr = rows[row];
-                    const HaloTile &h = P.ht[j];
-                    const double st = h.st, ct = h.ct, pphi = h.pphi, S = h.S;
-                    const int nr = rr.nr;
-                    // query_disc ring window.  Evaluated unconditionally so that every field of the halo record is
-                    // fetched in one burst (a branch on irmin / irmax first serialises three L2 round trips); rings that
-                    // lie entirely inside the disc (ring outside [irmin, irmax]) override the result.
-                    const int irmin = h.irmin, irmax = h.irmax;
-    #if BFG_STAGE_TIMING == 2
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    BFG_SUBTICK(1);                                      // halo record arrived
-    #endif
-                    int lo = 0, cnt = 0;
-                    {
-                        const double x = (h.cosr - rr.z * h.z0) * h.xa;
-                        const double ysq = 1.0 - rr.z * rr.z - x * x;
-                        const double dphi = (ysq > 0.0) ? atan2_upper_tab(sqrt_unit(ysq), x, atantab) : 0.0;
-                        if (dphi > 0.0) {
-                            const double shift = (rr.phioff != 0.0) ? 0.5 : 0.0;
-                            // |nr (pphi -+ dphi) / 2 pi| < 2 nr <= 8 nside: 32-bit is enough (the tile variant needs nside <= 2^24)
-                            const double fn = (double)nr * kInvTwoPi;
-                            const int l32 = (int)floor(fn * (pphi - dphi) - shift) + 1;
-                            const int h32 = (int)floor(fn * (pphi + dphi) - shift);
-                            const int c = min(h32 - l32 + 1, nr);
-                            if (c > 0) { cnt = c; lo = l32; }                // unwrapped: lo in (-nr, 1.5 nr)
-                        }
-                    }
-                    if (ring < irmin || ring > irmax) { cnt = nr; lo = 0; }  // ring entirely inside the disc
-                    const int wl = pinfo[p].win_lo;
-                    // window start + 1 and the LDS address of node (cell - 1): see window_row
-                    sg.wbyte = win_in_lds ? pwin_off + p * (kWinLds * 8) - 8 * (wl + 1) : p;
-                    if constexpr (MODE == MODE_PAINT) sg.pk = wl + 1;
-                    else sg.pk = p | (row << 6) | ((wl + 1) << 12);
-                    sg.hstep = 0.5 * rr.phistep;
-                    sg.c0 = 0.5 * (rr.phioff * rr.phistep - pphi);          // + first pixel * hstep, below
-                    const double ds = rr.sth - st, dz = rr.z - ct;
-                    sg.Aq = (ds * ds + dz * dz) * S;
-                    sg.Bq = 4.0 * rr.sth * st * S;
-                    // clip to the sector; a window that wraps around the ring can meet it twice
-                    if (cnt > 0) {
-                        const bool wraps = (lo < 0) || (lo + cnt > nr);
-                        if (!__any(wraps)) {                                // the usual case for a whole wavefront
-                            const int aa = max(lo, rr.k0), bb = min(lo + cnt, rr.k1);
-                            if (bb > aa) { cnt1 = bb - aa; aa1 = aa; ab1 = acc_off + 8 * NACC * (rr.rowoff + aa); }
-                        } else {
-    #pragma unroll
-                            for (int mi = 0; mi < 3; ++mi) {
-                                const int m = (mi == 0) ? 0 : (mi == 1 ? -1 : 1);
-                                const int aa = max(lo, rr.k0 + m * nr), bb = min(lo + cnt, rr.k1 + m * nr);
-                                if (bb > aa) {
-                                    const int ab = acc_off + 8 * NACC * (rr.rowoff - m * nr + aa);
-                                    if (cnt1 == 0) { cnt1 = bb - aa; aa1 = aa; ab1 = ab; }
-                                    else if (cnt2 == 0) { cnt2 = bb - aa; aa2 = aa; ab2 = ab; }
-                                }
+                if (ring < irmin || ring > irmax) { cnt = nr; lo = 0; }  // ring entirely inside the disc
+                const int wl = pinfo[p].win_lo;
+                // window start + 1 and the LDS address of node (cell - 1): see window_row
+                sg.wbyte = win_in_lds ? pwin_off + p * (kWinLds * 8) - 8 * (wl + 1) : p;
+                if constexpr (MODE == MODE_PAINT) sg.pk = wl + 1;
+                else sg.pk = p | (row << 6) | ((wl + 1) << 12);
+                sg.hstep = 0.5 * rr.phistep;
+                sg.c0 = 0.5 * (rr.phioff * rr.phistep - pphi);          // + first pixel * hstep, below
+                const double ds = rr.sth - st, dz = rr.z - ct;
+                sg.Aq = (ds * ds + dz * dz) * S;
+                sg.Bq = 4.0 * rr.sth * st * S;
+                // clip to the sector; a window that wraps around the ring can meet it twice
+                if (cnt > 0) {
+                    const bool wraps = (lo < 0) || (lo + cnt > nr);
+                    if (!__any(wraps)) {                                // the usual case for a whole wavefront
+                        const int aa = max(lo, rr.k0), bb = min(lo + cnt, rr.k1);
+                        if (bb > aa) { cnt1 = bb - aa; aa1 = aa; ab1 = acc_off + 8 * NACC * (rr.rowoff + aa); }
+                    } else {
+#pragma unroll
+                        for (int mi = 0; mi < 3; ++mi) {
+                            const int m = (mi == 0) ? 0 : (mi == 1 ? -1 : 1);
+                            const int aa = max(lo, rr.k0 + m * nr), bb = min(lo + cnt, rr.k1 + m * nr);
+                            if (bb > aa) {
+                                const int ab = acc_off + 8 * NACC * (rr.rowoff - m * nr + aa);
+                                if (cnt1 == 0) { cnt1 = bb - aa; aa1 = aa; ab1 = ab; }
+                                else if (cnt2 == 0) { cnt2 = bb - aa; aa2 = aa; ab2 = ab; }
                             }
                         }
                     }
                 }
-                BFG_SUBTICK(2);                                          // ring window, clipping, segment constants
-                // a second piece needs its own segment record; should the chunk run out of them (only possible where a
-                // sector spans a whole ring, at the poles) the piece is painted right here, through the direct read-out
-                int idx2 = 0;
-                bool spill2 = false;
-                if (cnt2 > 0) { idx2 = nslots + atomicAdd(&ctl[2], 1); spill2 = idx2 >= kSegMax || (P.debug & 16); }   // debug bit 16: force the spill path (tests)
-                // offsets in the chunk's flattened pixel list: wave scan + one LDS atomic per wavefront (any order will do)
-                const int tot = cnt1 + (spill2 ? 0 : cnt2);
-                const int incl = wave_scan_incl(tot);
-                const int wtot = __builtin_amdgcn_readlane(incl, 63);
-                int wbase = 0;
-                if (lane == 0 && wtot > 0) wbase = atomicAdd(&ctl[3], wtot);
-                wbase = __builtin_amdgcn_readfirstlane(wbase);
-                const int e1 = wbase + incl - tot;
-                BFG_SUBTICK(3);                                          // pixel-list offsets (scan + LDS atomics)
-                if (live) {
-                    scnt[slot] = (uint8_t)cnt1;
-                    if (cnt1 > 0) {
-                        const double c0b = sg.c0;
-                        sg.excl = e1; sg.abyte = ab1; sg.c0 = fma((double)aa1, sg.hstep, c0b);
-                        segs[slot] = sg;
-                        fill_ptab(e1, min(e1 + cnt1, kPixMax), (uint32_t)(slot * (int)sizeof(Seg)));
-                        if (cnt2 > 0 && !spill2) {
-                            scnt[idx2] = (uint8_t)cnt2;
-                            const int e2 = e1 + cnt1;
-                            sg.excl = e2; sg.abyte = ab2; sg.c0 = fma((double)aa2, sg.hstep, c0b);
-                            segs[idx2] = sg;
-                            fill_ptab(e2, min(e2 + cnt2, kPixMax), (uint32_t)(idx2 * (int)sizeof(Seg)));
-                        } else if (cnt2 > 0) {
-                            constexpr int wlf = 1 << 18;                   // a window no cell falls into -> direct_row()
-                            sg.excl = 0; sg.abyte = ab2; sg.c0 = fma((double)aa2, sg.hstep, c0b);
-                            sg.wbyte = win_in_lds ? pwin_off + p * (kWinLds * 8) - 8 * wlf : p;
-                            if constexpr (MODE == MODE_PAINT) sg.pk = wlf;
-                            else sg.pk = (sg.pk & 0xFFF) | (wlf << 12);
-                            for (int k = 0; k < cnt2; ++k) do_pixel(k, sg);
-                            my_pixels += (unsigned long long)cnt2;
-                        }
+            }
+            BFG_SUBTICK(2);                                          // ring window, clipping, segment constants
+            // a second piece needs its own segment record; should the chunk run out of them (only possible where a
+            // sector spans a whole ring, at the poles) the piece is painted right here, through the direct read-out
+            int idx2 = 0;
+            bool spill2 = false;
+            if (cnt2 > 0) { idx2 = nslots + atomicAdd(&ctl[2], 1); spill2 = idx2 >= kSegMax || (P.debug & 16); }   // debug bit 16: force the spill path (tests)
+            // offsets in the chunk's flattened pixel list: wave scan + one LDS atomic per wavefront (any order will do)
+            const int tot = cnt1 + (spill2 ? 0 : cnt2);
+            const int incl = wave_scan_incl(tot);
+            const int wtot = __builtin_amdgcn_readlane(incl, 63);
+            int wbase = 0;
+            if (lane == 0 && wtot > 0) wbase = atomicAdd(&ctl[3], wtot);
+            wbase = __builtin_amdgcn_readfirstlane(wbase);
+            const int e1 = wbase + incl - tot;
+            BFG_SUBTICK(3);                                          // pixel-list offsets (scan + LDS atomics)
+            if (live) {
+                scnt[slot] = (uint8_t)cnt1;
+                if (cnt1 > 0) {
+                    const double c0b = sg.c0;
+                    sg.excl = e1; sg.abyte = ab1; sg.c0 = fma((double)aa1, sg.hstep, c0b);
+                    segs[slot] = sg;
+                    fill_ptab(e1, min(e1 + cnt1, kPixMax), (uint32_t)(slot * (int)sizeof(Seg)));
+                    if (cnt2 > 0 && !spill2) {
+                        scnt[idx2] = (uint8_t)cnt2;
+                        const int e2 = e1 + cnt1;
+                        sg.excl = e2; sg.abyte = ab2; sg.c0 = fma((double)aa2, sg.hstep, c0b);
+                        segs[idx2] = sg;
+                        fill_ptab(e2, min(e2 + cnt2, kPixMax), (uint32_t)(idx2 * (int)sizeof(Seg)));
+                    } else if (cnt2 > 0) {
+                        constexpr int wlf = 1 << 18;                   // a window no cell falls into -> direct_row()
+                        sg.excl = 0; sg.abyte = ab2; sg.c0 = fma((double)aa2, sg.hstep, c0b);
+                        sg.wbyte = win_in_lds ? pwin_off + p * (kWinLds * 8) - 8 * wlf : p;
+                        if constexpr (MODE == MODE_PAINT) sg.pk = wlf;
+                        else sg.pk = (sg.pk & 0xFFF) | (wlf << 12);
+                        for (int k = 0; k < cnt2; ++k) do_pixel(k, sg);
+                        my_pixels += (unsigned long long)cnt2;
                     }
                 }
             }
@@ -2096,7 +1817,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                 for (int sidx = tid; sidx < nseg; sidx += NT) {
                     const int cnt = scnt[sidx];
                     if (cnt > 0) {
-                        const int ex = BLEND ? (int)(reinterpret_cast<const SegChord *>(segs)[sidx].ex_ab & 0xffffu) : segs[sidx].excl;
+                        const int ex = segs[sidx].excl;
                         const int a0 = max(ex, pbase), a1 = min(ex + cnt, pbase + kPixMax);
                         for (int q = a0; q < a1; ++q) ptab[q - pbase] = (uint16_t)(sidx * (int)sizeof(Seg));
                     }
@@ -2118,23 +1839,9 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                 sg.excl = s0.x; sg.abyte = s0.y; sg.wbyte = s0.z; sg.pk = s0.w; sg.hstep = s1.x; sg.c0 = s1.y; sg.Aq = s2.x; sg.Bq = s2.y;
                 return sg;
             };
-            if constexpr (BLEND) {
-                for (int q = pbase + tid; q < pend; q += NT, pp += NT) {
-                    typedef int v4i_t __attribute__((ext_vector_type(4)));
-                    typedef double v2d_t __attribute__((ext_vector_type(2)));
-                    const unsigned sa = (unsigned)segs_off + (unsigned)*pp;
-                    const v4i_t s0 = *lds_ptr<const v4i_t>(sa);
-                    const v2d_t s1 = *lds_ptr<const v2d_t>(sa + 16), s2 = *lds_ptr<const v2d_t>(sa + 32);
-                    SegChord sg;
-                    sg.ex_ab = (uint32_t)s0.x; sg.wbyte = s0.y; sg.pk = s0.z; sg.xlo = __int_as_float(s0.w);
-                    sg.hstep = s1.x; sg.c0 = s1.y; sg.Aq = s2.x; sg.Bq = s2.y;
-                    do_pixel_chord(q, sg);
-                }
-            } else {
-                for (int q = pbase + tid; q < pend; q += NT, pp += NT) {
-                    const Seg sg = load_seg(pp);
-                    do_pixel(q, sg);
-                }
+            for (int q = pbase + tid; q < pend; q += NT, pp += NT) {
+                const Seg sg = load_seg(pp);
+                do_pixel(q, sg);
             }
         }
         if (wave == 0 && last_chunk && have_next) {     // the next item's first candidates: their records arrive during the write-back
@@ -2295,7 +2002,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         }
     }
     }
-    px_total += my_pixels - (unsigned long long)n_rej32;     // (per thread, modulo 2^64: thread 0 holds the chunks' candidate totals)
+    px_total += my_pixels;
     oob_total += n_oob32;
     BFG_ITICK(14);
     BFG_LTICK(7);
