@@ -77,7 +77,8 @@ struct bfg_spline {
 };
 
 namespace bfg { struct HaloTile; struct HaloDisp; struct DeferredOut; }
-constexpr int kTimingSlots = 6;     // bfg_timing_read: prep, dominant shell kernel, regrid, binning, left-overs, deferred pixels
+constexpr int kTimingSlots = 8;     // bfg_timing_read: prep, dominant shell kernel, regrid, binning, left-overs, deferred pixels,
+                                    // snapshot particle kernel, tiled deposit kernel
 struct bfg_ctx {
     int device;
     hipStream_t stream;
@@ -2498,9 +2499,11 @@ int bfg_baryonify_snapshot_strided(bfg_ctx *c, const bfg_snapshot_args *a, const
         if (!std::strcmp(e, "cell")) grouped = a->n_part < (int64_t)0x7fffffff;
     if (!grouped) {
         const unsigned pgrid = (unsigned)std::min<int64_t>((a->n_part + 255) / 256, 8192);       // grid-stride
+        timing_begin(c, 6);
         if (a->ndim == 3) hipLaunchKernelGGL(snap_particle_kernel<3>, dim3(pgrid), dim3(256), 0, c->stream, P);
         else hipLaunchKernelGGL(snap_particle_kernel<2>, dim3(pgrid), dim3(256), 0, c->stream, P);
         HIP_TRY(hipGetLastError());
+        timing_end(c, 6);
         return BFG_OK;
     }
     const size_t dwant[5] = {(size_t)a->n_part * sizeof(int32_t), (size_t)a->n_part * sizeof(int32_t),
@@ -2745,12 +2748,14 @@ int bfg_deposit_grid_strided(bfg_ctx *c, int ndim, int64_t n_part, const double 
         else if (mode == BFG_DEPOSIT_CIC) hipLaunchKernelGGL((KERNEL<2, BFG_DEPOSIT_CIC>), dim3(GRID), dim3(THREADS), 0, c->stream, S);         \
         else hipLaunchKernelGGL((KERNEL<2, BFG_DEPOSIT_NGP>), dim3(GRID), dim3(THREADS), 0, c->stream, S);                                      \
     } while (0)
+    timing_begin(c, 7);
     BFG_DEP_LAUNCH(dep_key_kernel, pgrid, 256);
     BFG_DEP_LAUNCH(dep_tile_kernel, (unsigned)ntile, kDepThreads);
 #undef BFG_DEP_LAUNCH
     if (ndim == 3) hipLaunchKernelGGL(dep_overflow_kernel<3>, dim3(1024), dim3(256), 0, c->stream, S);
     else hipLaunchKernelGGL(dep_overflow_kernel<2>, dim3(1024), dim3(256), 0, c->stream, S);
     HIP_TRY(hipGetLastError());
+    timing_end(c, 7);
     return BFG_OK;
 }
 

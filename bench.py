@@ -6,7 +6,7 @@ halos/s + achieved HBM GB/s, NSIDE = 1024 shell, 1e6 halos, at 1/2/4/8 GPUs).
   python bench.py --gpus N --steps K --warmup W          # any N: for N > 1 the process spawns its own N ranks (below)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W [--scaling strong|weak] [--collective torch|bfg]
-         [--exchange allreduce|owner|auto] [--legs auto|none|weak,owner,configs3]
+         [--exchange allreduce|owner|auto] [--legs auto|none|weak,owner,configs3,configs1,configs2,steep,configs4]
 
 Launch.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) every process is one rank.  Started as plain
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE, the process becomes a LAUNCHER: before anything touches the GPU (it
@@ -29,8 +29,11 @@ flight (two rotating map buffers) and hands every map to the all-reduce in --sli
 (bfg_paint_shell_sliced).  `api_single_call_ms` = one SplitJoinParallel(runner).process_device() on its own (nothing to
 overlap with but its own slices; `api_single_call_unsliced_ms`: one all-reduce after the call).
 The main number is the robust one (strong scaling, all-reduce).  After it has been measured the run adds EXTRA LEGS
-(`legs` in the line; --legs) -- the weak-scaling run, the owner-computes join (half the bytes), and BASELINE configs[3]
-(BaryonifyShell, NSIDE 2048, 1.25e6 halos per GPU) -- each guarded: a leg that fails, or hangs past
+(`legs` in the line; --legs), each a full measurement with its own `roofline` block -- N > 1: the weak-scaling run, the
+owner-computes join (half the bytes) and BASELINE configs[3] (BaryonifyShell, NSIDE 2048, 1.25e6 halos per GPU); N = 1: the other
+BASELINE configurations that fit one GPU -- configs1 (PaintProfilesShell, 1e5 halos), configs2 (BaryonifyShell, 1e5 halos, regrid
+included), configs4 (BaryonifySnapshot, 512^3 particles, 1e5 halos, CIC deposit), configs3's per-GPU share, and `steep` (the
+dn/dlnM ~ M^-0.9 catalog) -- each guarded: a leg that fails, or hangs past
 BFG_BENCH_LEGS_DEADLINE_S (default 240 s), is recorded as an error and the main line is printed all the same, exit 0.
 Before the W warm-up steps the run executes BFG_BENCH_RAMP_S (default 0.25 s) of the very same steps (`ramp_steps` in the line):
 an idle MI355X needs ~50 ms of load to reach its sustained clocks, W = 5 steps are 6 ms of it.
@@ -40,7 +43,10 @@ BFG_BENCH_DEADLINE_S (default 1500 s; a watchdog THREAD, so it also fires while 
 
 Rank 0 prints ONE JSON line (see the contract in the task statement) with these extra objects:
   "roofline":     algorithmic bytes of the dominant kernel / its mean duration (HIP events on the
-                  kernel's own stream, live in this process) against the 8 TB/s HBM peak
+                  kernel's own stream, live in this process) against the 8 TB/s HBM peak; `traffic` (PMC FETCH / WRITE_SIZE) and
+                  `valu_issue_frac` / `lds_pipe_frac` (SQ counters) are stored measurements of the same command on the build named
+                  in profiles/pmc_traffic.json / profiles/sq_counters.json; `bound` is "valu+lds" where the HBM yardstick does not
+                  bound the kernel (its updates are resolved in LDS: frac > 1, or measured traffic far below the algorithmic bytes)
   "cpu_baseline": the CPU oracle (a C port of the reference loop; kind "port") timed on this
                   box's host cores on a bounded sample of the same workload (N = 1 only)
   "ranks":        N > 1: per-rank shard size, compute-only ms, collective-only ms, how much of the collective
@@ -68,6 +74,21 @@ REFERENCE_PUBLISHED = {"value": 3365.69, "unit": "halos/s", "what": "PaintProfil
                        "source": "examples/05_Paint_tSZ_shell.ipynb:271"}
 
 
+LEG_ARGS = {
+    # name: overrides of the parsed arguments (the main run is strong scaling, all-reduce, the headline paint workload)
+    "weak": dict(scaling="weak", exchange="allreduce"),                       # --halos per GPU: the all-reduce hides behind the painting
+    "owner": dict(exchange="owner"),                                          # the owner-computes join: half the bytes of the all-reduce
+    "configs3": dict(workload="baryonify", nside=2048, halos=1_250_000, scaling="weak", exchange="allreduce",   # BASELINE configs[3]:
+                     table="default", steep=False, eps=10.0),                 # 1e7 halos over 8 GPUs = 1.25e6 per GPU
+    # N = 1 only: the other BASELINE configurations that fit one GPU, and the realistic (steep) mass function
+    "configs1": dict(workload="paint", nside=1024, halos=100_000, table="default", steep=False, eps=10.0),        # BASELINE configs[1]
+    "configs2": dict(workload="baryonify", nside=1024, halos=100_000, table="default", steep=False, eps=10.0),    # BASELINE configs[2]
+    "steep": dict(workload="paint", nside=1024, halos=1_000_000, table="default", steep=True, eps=10.0),
+    "configs4": dict(workload="snapshot", halos=100_000),                                                        # BASELINE configs[4]
+}
+N1_ONLY_LEGS = ("configs1", "configs2", "steep", "configs4")
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -78,8 +99,10 @@ def parse():
                    help="strong (default; BASELINE's metric): --halos halos in total at every N; weak: --halos per GPU")
     p.add_argument("--legs", default="auto",
                    help="guarded extra legs after the main measurement, comma separated: weak (weak-scaling run), owner (owner-computes "
-                        "join), configs3 (BaryonifyShell NSIDE 2048, 1.25e6 halos per GPU); auto = all three for N > 1 on the default "
-                        "paint workload, configs3 alone at N = 1; none = no legs")
+                        "join), configs3 (BaryonifyShell NSIDE 2048, 1.25e6 halos per GPU); N = 1 only: configs1 (paint 1e5 halos), "
+                        "configs2 (BaryonifyShell 1e5 halos), steep (dn/dlnM ~ M^-0.9), configs4 (BaryonifySnapshot 512^3 + CIC); "
+                        "auto = weak, owner, configs3 for N > 1 and configs1, configs2, steep, configs4, configs3 at N = 1, on the "
+                        "default paint workload; none = no legs")
     p.add_argument("--collective", choices=["torch", "bfg"], default="torch")
     p.add_argument("--slices", type=int, default=4, help="N > 1: pieces in which a painted map is handed to the all-reduce")
     p.add_argument("--layout", choices=["interleaved", "contiguous"], default="interleaved", help="sky-patch sharding layout")
@@ -91,14 +114,22 @@ def parse():
                         "used if its map equals the all-reduce's on every rank AND it is the faster of the two")
     p.add_argument("--nside", type=int, default=1024)
     p.add_argument("--eps", type=float, default=10.0)
-    p.add_argument("--workload", choices=["paint", "baryonify"], default="paint")
+    p.add_argument("--workload", choices=["paint", "baryonify", "snapshot"], default="paint",
+                   help="paint (BASELINE's metric), baryonify (BaryonifyShell incl. regrid), snapshot (N = 1: BASELINE configs[4], "
+                        "BaryonifySnapshot 512^3 particles + CIC deposit, --halos halos)")
     p.add_argument("--variant", default="auto")
     p.add_argument("--table", choices=["default", "stress"], default="default")
     p.add_argument("--steep", action="store_true", help="dn/dlnM ~ M^-0.9 catalog instead of uniform log M")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-e2e", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the single-thread baseline leg")
-    return p.parse_args()
+    a = p.parse_args()
+    # (before anything touches the GPU or spawns a rank: a typo here must not cost the run its main line)
+    if a.legs not in ("auto", "none"):
+        unknown = [x for x in a.legs.split(",") if x and x != "none" and x not in LEG_ARGS]
+        if unknown:
+            p.error(f"unknown --legs entries {unknown}; known: {sorted(LEG_ARGS)}")
+    return a
 
 
 def usable_cores():
@@ -393,15 +424,6 @@ def main():
     WATCHDOG.disarm()
 
 
-LEG_ARGS = {
-    # name: overrides of the parsed arguments (the main run is strong scaling, all-reduce, the headline paint workload)
-    "weak": dict(scaling="weak", exchange="allreduce"),                       # --halos per GPU: the all-reduce hides behind the painting
-    "owner": dict(exchange="owner"),                                          # the owner-computes join: half the bytes of the all-reduce
-    "configs3": dict(workload="baryonify", nside=2048, halos=1_250_000, scaling="weak", exchange="allreduce",   # BASELINE configs[3]:
-                     table="default", steep=False, eps=10.0),                 # 1e7 halos over 8 GPUs = 1.25e6 per GPU
-}
-
-
 def _main(args, torch, dist, rank, local_rank, world, backend):
     """the main measurement (-> the line's top-level fields), then the guarded extra legs, then rank 0 prints the ONE line"""
     import copy
@@ -416,28 +438,42 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
             rccl["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:
             pass
-    out = run_config(args, torch, dist, rank, local_rank, world, backend, main=True)
+    if args.workload == "snapshot":
+        if world > 1:
+            die("--workload snapshot is a single-GPU configuration (BASELINE configs[4])")
+        out = run_snapshot(args, torch, local_rank)
+        out.update({"n_gpus": 1, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None, "data": "synthetic",
+                    "cpu_baseline": None})
+    else:
+        out = run_config(args, torch, dist, rank, local_rank, world, backend, main=True)
     if rank == 0:
         out.update(rccl)
     # ---- guarded extra legs: whatever happens from here on, the main line above is printed and the run exits 0 -----------
     if args.legs == "auto":
         default_paint = args.workload == "paint" and args.nside == 1024 and args.table == "default" and not args.steep
-        legs = (["weak", "owner", "configs3"] if world > 1 else ["configs3"]) if default_paint else []
+        legs = (["weak", "owner", "configs3"] if world > 1 else ["configs1", "configs2", "steep", "configs4", "configs3"]) if default_paint else []
     else:
-        legs = [x for x in args.legs.split(",") if x and x != "none"]
-    unknown = [x for x in legs if x not in LEG_ARGS]
-    if unknown:
-        die(f"unknown --legs entries {unknown}; known: {sorted(LEG_ARGS)}")
+        legs = [x for x in args.legs.split(",") if x and x != "none"]       # (names validated in parse())
     if world == 1:
-        legs = [x for x in legs if x == "configs3"]                # the other two are the main run itself at N = 1
+        legs = [x for x in legs if x not in ("weak", "owner")]     # those two are the main run itself at N = 1
+    else:
+        legs = [x for x in legs if x not in N1_ONLY_LEGS]          # single-GPU configurations
     done = {}
+    # ONE line, whoever gets there first: the legs' deadline fires on the watchdog's thread while the main thread may be on its way
+    # to the same print (Timer.cancel() does not stop a callback that is already running)
+    import threading
+    emit_lock, emitted = threading.Lock(), [False]
 
     def emit(note=None):
-        if rank == 0:
-            out["legs"] = dict(done)
-            if note:
-                out["legs"]["_aborted"] = note
-            print(json.dumps(out), flush=True)
+        with emit_lock:
+            if emitted[0]:
+                return
+            emitted[0] = True
+            if rank == 0:
+                out["legs"] = dict(done)
+                if note:
+                    out["legs"]["_aborted"] = note
+                print(json.dumps(out), flush=True)
 
     def legs_overdue():
         emit(f"the extra legs exceeded BFG_BENCH_LEGS_DEADLINE_S = {legs_deadline:g} s; the main measurement above is complete")
@@ -451,13 +487,18 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
             for k, v in LEG_ARGS[name].items():
                 setattr(largs, k, v)
             if name == "owner" and (12 * largs.nside ** 2) % world:
-                done[name] = {"error": "12 NSIDE^2 does not divide by the number of ranks"}
+                with emit_lock:
+                    done[name] = {"error": "12 NSIDE^2 does not divide by the number of ranks"}
                 continue
             t0 = time.perf_counter()
             try:
-                res = run_config(largs, torch, dist, rank, local_rank, world, backend, main=False)
+                if largs.workload == "snapshot":
+                    res = run_snapshot(largs, torch, local_rank)
+                else:
+                    res = run_config(largs, torch, dist, rank, local_rank, world, backend, main=False)
                 if rank == 0:
-                    done[name] = leg_summary(res, time.perf_counter() - t0)
+                    with emit_lock:                # (the deadline's thread copies `done` under the same lock)
+                        done[name] = leg_summary(res, time.perf_counter() - t0)
                 del res
                 import gc
                 gc.collect()
@@ -465,8 +506,10 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
             except BaseException as exc:       # a failing leg is recorded; the peers of a rank that failed alone end at the legs' deadline
                 if isinstance(exc, (SystemExit, KeyboardInterrupt)):
                     raise
-                done[name] = {"error": f"{type(exc).__name__}: {str(exc).splitlines()[0] if str(exc) else ''}"}
-                break                          # the ranks may be out of step now: no further collective
+                with emit_lock:
+                    done[name] = {"error": f"{type(exc).__name__}: {str(exc).splitlines()[0] if str(exc) else ''}"}
+                if world > 1:
+                    break                      # the ranks may be out of step now: no further collective
     finally:
         WATCHDOG.disarm()
     emit()
@@ -477,21 +520,54 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
 
 
 def leg_summary(res, wall_s):
-    """the compact record of one extra leg (the same measurement as the main line, fewer fields)"""
-    keep = ("value", "unit", "ms_per_step", "scaling", "steps", "ramp_steps")
-    o = {k: res[k] for k in keep}
+    """the compact record of one extra leg (the same measurement as the main line, fewer fields; its roofline block in full)"""
+    keep = ("value", "unit", "ms_per_step", "scaling", "steps", "ramp_steps", "dtype")
+    o = {k: res.get(k) for k in keep}
     o["workload"] = res["config"]["workload"]
     o["halos_total"] = res["config"]["halos_total"]
     o["sharding"] = res["config"]["sharding"]
-    rf = res["roofline"]
-    o["roofline"] = {k: rf[k] for k in ("kernel", "frac", "achieved", "kernel_ms", "algorithmic_bytes_per_launch", "regrid_kernel_ms",
-                                       "prep_kernel_ms", "step_frac")}
+    o["roofline"] = dict(res["roofline"])
+    for k in ("other_kernels_timed_in", "lds_atomic_ceiling_per_s"):
+        o["roofline"].pop(k, None)
+    if res.get("deposit_roofline"):
+        o["deposit_roofline"] = res["deposit_roofline"]
     if res.get("ranks"):
         o["ranks"] = [{k: r.get(k) for k in ("rank", "shard_halos", "compute_ms", "allreduce_ms", "overlap_ms", "kernel_ms",
                                               "roofline_frac")} for r in res["ranks"]]
         o["exchange"] = res.get("exchange")
     o["leg_wall_s"] = wall_s
     return o
+
+
+def stored_counters(key):
+    """(traffic, traffic_source, sq) of a bench key: rocprofv3 PMC passes cannot run inside this process, so the HBM-side bytes per
+    launch (profiles/pmc_traffic.json) and the SQ counters (profiles/sq_counters.json: VALU issue and LDS pipe occupancy of the
+    dominant kernel) are the stored measurements of tools/r05_profile.sh for this key; None where a workload was not measured"""
+    traffic, traffic_source, sq = None, None, None
+    try:
+        tj = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+        traffic = tj.get(key)
+        if traffic is not None:
+            traffic_source = f"stored: {tj.get('_source', 'profiles/pmc_traffic.json')}"
+    except Exception:
+        pass
+    try:
+        sj = json.load(open(os.path.join(REPO, "profiles", "sq_counters.json")))
+        if isinstance(sj.get(key), dict):
+            sq = dict(sj[key], source=f"stored: {sj.get('_source', 'profiles/sq_counters.json')}")
+    except Exception:
+        pass
+    return traffic, traffic_source, sq
+
+
+def bound_of(frac, traffic, kernel_s):
+    """"hbm" is the yardstick the metric prescribes; it BOUNDS a kernel only if the kernel's bytes actually travel.  The tile kernels
+    resolve their updates in LDS: where the algorithmic fraction passes 1, or the measured HBM-side traffic per launch moves at less
+    than a quarter of the HBM peak, what limits them is VALU issue and the LDS pipe (valu_issue_frac / lds_pipe_frac say how close
+    they are to THAT)"""
+    if frac > 1.0 or (traffic is not None and kernel_s > 0 and traffic / kernel_s < 0.25 * HBM_PEAK):
+        return "valu+lds"
+    return "hbm"
 
 
 def run_config(args, torch, dist, rank, local_rank, world, backend, main=True):
@@ -819,27 +895,21 @@ def run_config(args, torch, dist, rank, local_rank, world, backend, main=True):
     kernel_bytes = 32.0 * idx.size + per_px * ptot_step
     kernel_s = (k_ms / max(k_n, 1)) * 1e-3
     achieved = kernel_bytes / kernel_s if kernel_s > 0 else 0.0
-    # HBM traffic of the dominant kernel per launch: rocprofv3 PMC passes cannot run inside this process, so the value
-    # is the stored measurement of tools/pmc_run.sh for this workload key (profiles/pmc_traffic.json names the build it
-    # was taken on); null for workloads that were not measured
-    traffic, traffic_source = None, None
-    tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
-    if os.path.exists(tfile):
-        try:
-            tj = json.load(open(tfile))
-            key = f"{args.workload}_{args.variant}_n{idx.size}_nside{nside}"
-            if args.table != "default" or args.steep or args.eps != 10.0:      # only the default catalog / table / eps were measured
-                key += f"_{args.table}{'_steep' if args.steep else ''}_eps{args.eps:g}"
-            traffic = tj.get(key)
-            if traffic is not None:
-                traffic_source = f"stored: {tj.get('_source', 'profiles/pmc_traffic.json')}"
-        except Exception:
-            traffic = None
+    # HBM traffic and SQ counters of the dominant kernel per launch: stored measurements (see stored_counters)
+    key = f"{args.workload}_{args.variant}_n{idx.size}_nside{nside}"
+    if args.table != "default" or args.steep or args.eps != 10.0:          # non-default catalog / table / eps: their own keys
+        key += f"_{args.table}{'_steep' if args.steep else ''}_eps{args.eps:g}"
+    traffic, traffic_source, sq = stored_counters(key)
     tile = args.variant in ("auto", "tile_lds")
     step_bytes = kernel_bytes + 16.0 * npix * (1 if args.workload == "paint" else 8)
-    roofline = {"bound": "hbm", "kernel": "shell_tile_kernel" if tile else "shell_scatter_kernel",
+    roofline = {"bound": bound_of(achieved / HBM_PEAK, traffic, kernel_s), "kernel": "shell_tile_kernel" if tile else "shell_scatter_kernel",
                 "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source,
+                # what actually limits a kernel whose updates stay in LDS (stored SQ counters of the same command, same build):
+                # share of the VALU issue cycles of the chip's 1024 SIMDs in use, share of the 256 CUs' LDS pipe cycles in use
+                "valu_issue_frac": sq.get("valu_issue_frac") if sq else None,
+                "lds_pipe_frac": sq.get("lds_pipe_frac") if sq else None,
+                "counters": sq, "counters_key": key,
                 "kernel_ms": k_ms / max(k_n, 1), "kernel_launches": k_n,
                 "algorithmic_bytes_per_launch": kernel_bytes,
                 "bytes_per_halo": kernel_bytes / max(idx.size, 1),
@@ -948,6 +1018,95 @@ def run_config(args, torch, dist, rank, local_rank, world, backend, main=True):
     else:
         out["cpu_baseline"] = None
     return out
+
+
+def run_snapshot(args, torch, local_rank, n1=512, L=1000.0, ngrid=512, zs=0.25):
+    """BASELINE configs[4] on one GPU: BaryonifySnapshot 3D on n1^3 particles (a jittered lattice built on the device) and
+    `--halos` halos in a periodic box, followed by the CIC deposit of the displaced particles on an ngrid^3 mesh
+    (SnapshotRunner.py:176-275, io.py:629-677).  One step = displacement pass + deposit, inputs resident in HBM (the C-ABI calls
+    BaryonifySnapshot.process() / ParticleSnapshot.make_map(device=True) make; tools/snapshot_scale.py is the same workload).
+    Dominant kernel: snap_particle_kernel (timing class 6), 48 B per particle (position read, displaced position written) + 48 B per
+    (halo, particle) pair inside 10 R_200c (the pair's separation and its displacement); the deposit (class 7: its three kernels)
+    moves 152 B per particle (24 B position + 8 x 16 B corner updates)."""
+    from baryonforge_amd import synthetic as syn
+    from baryonforge_amd.background import Background
+    from baryonforge_amd.engine import get_context
+    ctx = get_context(local_rank)
+    dev = ctx.device
+    cosmo = dict(syn.COSMO)
+    nhalo, npart = int(args.halos), n1 ** 3
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    ax = (torch.arange(n1, device=dev, dtype=torch.float64) + 0.5) * (L / n1)
+    P = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), dim=-1).reshape(-1, 3)
+    P = (P + (torch.rand(P.shape, generator=g, device=dev, dtype=torch.float64) - 0.5) * (L / n1)) % L
+    rng = np.random.default_rng(3)
+    H = rng.uniform(0, L, (nhalo, 3)).astype(">f4").astype(np.float64)         # HaloNDCatalog stores big-endian float32 (io.py:204)
+    hM = (10 ** rng.uniform(13.0, 15.3, nhalo)).astype(">f4")
+    d_halo = ctx.to_device(np.stack([hM.astype(np.float64), np.log(hM).astype(np.float64), H[:, 0], H[:, 1], H[:, 2]], axis=1))
+    zax, Max, rax, d = syn.displacement_table()
+    table = ctx.table([zax, Max, rax], d, log_values=False)
+    md = ctx.massdef_struct(Background(cosmo), None)
+    d_out = torch.empty_like(P)
+    a = 1.0 / (1.0 + zs)
+    keep = {}
+
+    def step():
+        ctx.baryonify_snapshot(P, d_halo, 3, L, a, 10.0, md, md, 20.0, False, 0, table, d_out)
+        keep["grid"] = ctx.deposit_grid(d_out, None, L, ngrid, "cic")
+
+    def timed(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    t = timed(2)
+    ramp_steps = 2
+    for _ in range(min(50, int(float(os.environ.get("BFG_BENCH_RAMP_S", "0.25")) / max(t / 2, 1e-4)))):
+        step()
+        ramp_steps += 1
+    steps = max(1, min(args.steps, 20))
+    timed(max(1, min(args.warmup, 3)))
+    ctx.stats_reset()
+    ctx.timing_enable(True, which=[6, 7])
+    dt = timed(steps)
+    pairs = ctx.stats()["pixel_updates"] / steps
+    k_ms, k_n = ctx.timing_read(6)
+    d_ms, d_n = ctx.timing_read(7)
+    ctx.timing_enable(False)
+    mass = float(keep["grid"].sum())
+    kernel_bytes = 48.0 * npart + 48.0 * pairs
+    kernel_s = k_ms / max(k_n, 1) * 1e-3
+    dep_bytes = 152.0 * npart
+    dep_s = d_ms / max(d_n, 1) * 1e-3
+    key = f"snapshot_n{nhalo}_part{n1}"
+    traffic, traffic_source, sq = stored_counters(key)
+    _, _, sq_dep = stored_counters(key + "_deposit")
+    frac = kernel_bytes / kernel_s / HBM_PEAK if kernel_s > 0 else 0.0
+    roofline = {"bound": bound_of(frac, traffic, kernel_s), "kernel": "snap_particle_kernel",
+                "achieved": kernel_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": frac,
+                "traffic": traffic, "traffic_source": traffic_source,
+                "valu_issue_frac": sq.get("valu_issue_frac") if sq else None, "lds_pipe_frac": sq.get("lds_pipe_frac") if sq else None,
+                "counters": sq, "counters_key": key,
+                "kernel_ms": k_ms / max(k_n, 1), "kernel_launches": k_n, "algorithmic_bytes_per_launch": kernel_bytes,
+                "halo_particle_pairs_per_launch": pairs, "particles": npart,
+                "step_algorithmic_GBps": (kernel_bytes + dep_bytes) / (dt / steps) / 1e9,
+                "step_frac": (kernel_bytes + dep_bytes) / (dt / steps) / HBM_PEAK}
+    dep_frac = dep_bytes / dep_s / HBM_PEAK if dep_s > 0 else 0.0
+    deposit = {"bound": "hbm", "kernel": "dep_key_kernel + dep_tile_kernel + dep_overflow_kernel (the whole deposit)", "achieved": dep_bytes / dep_s / 1e9 if dep_s > 0 else 0.0,
+               "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": dep_frac, "kernel_ms": d_ms / max(d_n, 1), "kernel_launches": d_n,
+               "algorithmic_bytes_per_launch": dep_bytes, "grid_mass": mass, "grid_mass_expected": float(npart),
+               "valu_issue_frac": sq_dep.get("valu_issue_frac") if sq_dep else None,
+               "lds_pipe_frac": sq_dep.get("lds_pipe_frac") if sq_dep else None, "counters": sq_dep}
+    del P, d_out, keep
+    return {"metric": "halos_per_s", "value": nhalo / (dt / steps), "unit": "halos/s", "ms_per_step": dt / steps * 1e3,
+            "scaling": "weak", "steps": steps, "ramp_steps": ramp_steps, "dtype": "f64",
+            "config": {"workload": f"BaryonifySnapshot 3D: {n1}^3 particles (jittered lattice), {nhalo} halos, L = {L:g} Mpc, z = {zs:g}, "
+                                   f"epsilon_max 10, Baryonification3D table 10x30x100, + CIC deposit on a {ngrid}^3 mesh",
+                       "halos_total": nhalo, "sharding": "none"},
+            "roofline": roofline, "deposit_roofline": deposit}
 
 
 def n1_anchor(args, torch, ctx, syn, bg, cosmo, shape, md, cat=None):

@@ -429,7 +429,8 @@ int bfg_stats_read(bfg_ctx *ctx, bfg_stats *out);   /* synchronises the stream *
  * (tile kernel, or the scatter kernel of the scatter variants), 2 = regrid kernel,
  * 3 = tile binning (work list + overflow fill + row windows), 4 = left-over scatter kernel of the tile
  * variant, 5 = the follow-up kernel that adds the tile kernel's deferred pixels (paint; launched only with BFG_FINAL_DRAIN=kernel,
- * by default the tile workgroups add them themselves, inside class 1).
+ * by default the tile workgroups add them themselves, inside class 1), 6 = snap_particle_kernel of bfg_baryonify_snapshot*
+ * (the per-particle displacement pass), 7 = the three kernels of the tile-privatised deposit of bfg_deposit_grid*.
  * Returns the accumulated milliseconds and launch count since the last enable.
  * bfg_timing_select restricts the events to the classes in `which_mask` (bit k = class k; the default, and what
  * bfg_timing_enable restores, is all of them): every event pair costs a few microseconds of stream time, which a step of

@@ -107,3 +107,44 @@ def test_watchdog_fires_while_the_main_thread_is_blocked_in_a_c_call(tmp_path):
     t0 = time.monotonic()
     pr = subprocess.run([sys.executable, stub], capture_output=True, text=True, timeout=120)
     assert pr.returncode == 5 and "deadline line" in pr.stderr and time.monotonic() - t0 < 60
+
+
+def test_unknown_legs_are_refused_before_anything_runs():
+    """a typo in --legs ends the run at argument parsing: exit 2, usage line, no GPU touched, no rank spawned"""
+    t0 = time.monotonic()
+    pr = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--legs", "weak,confgs3"],
+                        capture_output=True, text=True, timeout=120)
+    assert pr.returncode == 2 and "unknown --legs entries ['confgs3']" in pr.stderr and pr.stdout == ""
+    assert time.monotonic() - t0 < 30
+    import bench
+    assert set(bench.N1_ONLY_LEGS) <= set(bench.LEG_ARGS) and {"weak", "owner", "configs3"} <= set(bench.LEG_ARGS)
+
+
+def test_the_line_is_printed_once_when_the_legs_deadline_races_the_main_thread(tmp_path):
+    """the legs' deadline fires on the watchdog's thread while the main thread reaches its own emit(): ONE line.
+    The stub runs bench._main's leg loop with a run_config stand-in (no GPU): the single leg ends just as the deadline fires."""
+    stub = _stub(tmp_path, f"""
+        import sys, time, types, json
+        sys.path.insert(0, {REPO!r})
+        import bench
+        calls = []
+
+        def fake_run_config(args, torch, dist, rank, local_rank, world, backend, main=True):
+            if not main:
+                time.sleep(0.5)                                      # the leg ends when the legs' deadline (0.5 s) fires
+            return {{"value": 1.0, "unit": "halos/s", "ms_per_step": 1.0, "scaling": "strong", "steps": 1, "ramp_steps": 0,
+                    "config": {{"workload": "w", "halos_total": 1, "sharding": "none"}}, "roofline": {{"frac": 0.5}}}}
+        bench.run_config = fake_run_config
+        fake_torch = types.SimpleNamespace(cuda=types.SimpleNamespace(empty_cache=lambda: None))
+        sys.argv = ["bench.py", "--legs", "configs1"]
+        args = bench.parse()
+        import os
+        os.environ["BFG_BENCH_LEGS_DEADLINE_S"] = "0.5"
+        bench._main(args, fake_torch, None, 0, 0, 1, "nccl")
+        time.sleep(0.3)
+    """)
+    for _ in range(3):
+        pr = subprocess.run([sys.executable, stub], capture_output=True, text=True, timeout=120)
+        lines = [ln for ln in pr.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, pr.stdout + pr.stderr
+        assert "legs" in json.loads(lines[0])
