@@ -23,7 +23,6 @@ geometry, the regrid): `_callable_batches`.
 import numpy as np
 
 from ..background import Background, MassDef
-from .._lib import BFG_MAX_EXTRA
 from ..engine import emit_fallback_warning, emit_range_warnings, get_context
 from ..utils.Tabulate import ParamTabulatedProfile, _get_parameter
 from ..Profiles.BaryonCorrection import BaryonificationClass
@@ -125,7 +124,7 @@ class DefaultRunner(object):
         return bg, spline, d_cat, stride
 
 
-def _callable_batches(runner, ctx, fallback4, keys=(), host=True, max_halos=None):
+def _callable_batches(runner, ctx, fallback4, keys=()):
     """The geometry of the reference loops for a model that is a Python callable (csrc/bfg_enum.hpp): yields, batch of halos by
     batch, (j0, args, counts, base, pix, r_com, halo, D_j) -- host arrays counts / base / r_com / D_j and device tensors pix / halo
     -- where entry e of halo j0 + j (base[j] <= e < base[j] + counts[j]) is pixel pix[e] of its disc (:463 / :330-334) at
@@ -148,15 +147,10 @@ def _callable_batches(runner, ctx, fallback4, keys=(), host=True, max_halos=None
     while j0 < n:
         csum = np.cumsum(counts_all[j0:])
         j1 = j0 + max(1, int(np.searchsorted(csum, cap, side="right")))
-        if max_halos:
-            j1 = min(j1, j0 + int(max_halos))
         args = ctx.shell_args(NSIDE, d_cat[j0:j1], j1 - j0, stride, 0, runner.epsilon_max, md)
         counts, base, pix, r_com, halo = ctx.disc_enumerate(args, spline, fallback4)
-        if host:
-            yield j0, args, spline, counts.cpu().numpy(), base.cpu().numpy(), pix, r_com.cpu().numpy(), halo, \
-                D_a(np.asarray(cat["z"][j0:j1], dtype=np.float64))
-        else:                                                             # everything stays on the device (the N-dimensional table path)
-            yield j0, j1, args, spline, d_cat[j0:j1], stride, pix, r_com, halo, D_a(np.asarray(cat["z"][j0:j1], dtype=np.float64))
+        yield j0, args, spline, counts.cpu().numpy(), base.cpu().numpy(), pix, r_com.cpu().numpy(), halo, \
+            D_a(np.asarray(cat["z"][j0:j1], dtype=np.float64))
         j0 = j1
 
 
@@ -175,9 +169,8 @@ class PaintProfilesShell(DefaultRunner):
                 raise TypeError(f"PaintProfilesShell needs a tabulated model (TabulatedProfile / ParamTabulatedProfile with "
                                 f"raw_input_2D) or an object with a .projected(cosmo, r, M, a) method; got {type(self.model)}")
             self._callable_model = True                                   # (no p_keys here: :436-443 asserted above)
-        self._nd_table = _is_paint_table(self.model) and len(keys) > BFG_MAX_EXTRA
-        # (a table with more p_keys axes than the shell kernels read -- Tabulate.py:497-650 is N-dimensional -- takes the
-        # N-dimensional row path: _paint_nd, on the device)
+        # (a table with more p_keys axes than the shell kernels read -- Tabulate.py:497-650 is N-dimensional -- is the same call:
+        # the library blends every halo's radial row first and runs the tile path on the rows, csrc/bfg_ndtable.hpp)
         return keys
 
     def _paint_callable(self, d_map, fresh, keys=()):
@@ -209,37 +202,6 @@ class PaintProfilesShell(DefaultRunner):
         self.last_stats = dict(ctx.stats(), pixel_updates=total)
         return d_map
 
-    def _paint_nd(self, d_map, fresh, keys):
-        """HealpixRunner.py:449-481 for a table with more p_keys axes than the shell kernels read (BFG_MAX_EXTRA), all on the device:
-        the disc enumeration lists every (halo, pixel, r_sep / a) entry (csrc/bfg_enum.hpp), bfg_ndtable_rows blends the 2^(n + 2)
-        corners of the halo's (z, M, p_1 ... p_n) cell once per halo into its radial row, bfg_ndtable_read interpolates the row per
-        entry -- exp, non-finite -> 0 (:473), pixel factor (:478) -- and the values are added to the map (:481)."""
-        import os
-        ctx = get_context()
-        NSIDE = self.LightconeShell.NSIDE
-        npix = 12 * NSIDE * NSIDE
-        pixarea = 4.0 * np.pi / npix
-        if d_map is None:
-            d_map = ctx.zeros(npix)                                       # :424
-        elif fresh:
-            d_map.zero_()
-
-        def log_table():                                                  # Tabulate.py:582-590 keeps ln T
-            with np.errstate(all="ignore"):
-                return np.log(np.asarray(self.model.raw_input_2D, dtype=np.float64))
-        table = ctx.table(_table_axes(self.model, keys), log_table, log_values=True, cache_key=(self.model, "2D", self.model.raw_input_2D))
-        max_halos = max(1, int(float(os.environ.get("BFG_ND_ROW_BYTES", str(1 << 30))) // (8 * table.nr)))   # rows of a batch: <= 1 GB
-        total = 0
-        for j0, j1, args, spline, d_cat, stride, pix, r_com, halo, D in _callable_batches(self, ctx, False, keys, host=False,
-                                                                                             max_halos=max_halos):
-            d_rows = table.rows(d_cat, stride)
-            d_scale = ctx.to_device(pixarea * D ** 2) if self.include_pixel_size else None
-            vals = table.read(d_rows, halo, r_com, d_scale=d_scale, exp_values=True)
-            ctx.map_add_values(d_map, pix, vals)
-            total += int(r_com.numel())
-        self.last_stats = dict(ctx.stats(), pixel_updates=total)
-        return d_map
-
     def process_device(self, d_map=None, overwrite=None, slices=1, on_slice=None, sync_stats=True):
         """Paint into a device map (float64[Npix] torch tensor) and return it.
 
@@ -251,9 +213,9 @@ class PaintProfilesShell(DefaultRunner):
         sync_stats=False: do not read the counters back (that synchronises the stream); `collect_stats()` does it later --
         what a pipeline over several shells wants."""
         keys = self._validated_keys()
-        if self._callable_model or self._nd_table:
+        if self._callable_model:
             fresh = d_map is None or bool(overwrite)
-            d_map = self._paint_nd(d_map, fresh, keys) if self._nd_table else self._paint_callable(d_map, fresh, keys)
+            d_map = self._paint_callable(d_map, fresh, keys)
             if on_slice is not None:                                      # nothing to cut: the whole map as one slice
                 on_slice(0, 1, 0, int(d_map.numel()))
             return d_map
@@ -282,8 +244,8 @@ class PaintProfilesShell(DefaultRunner):
 
     def collect_stats(self):
         """read the device counters (synchronises the stream), keep them in `last_stats`, emit the warnings"""
-        if (getattr(self, "_callable_model", False) or getattr(self, "_nd_table", False)) and self.last_stats is not None:
-            return self.last_stats                                        # counted on the host (_paint_callable / _paint_nd)
+        if getattr(self, "_callable_model", False) and self.last_stats is not None:
+            return self.last_stats                                        # counted on the host (_paint_callable)
         self.last_stats = get_context().stats()
         emit_fallback_warning(self.last_stats)
         return self.last_stats
@@ -441,7 +403,6 @@ class BaryonifyShell(DefaultRunner):
                 raise TypeError(f"BaryonifyShell needs a BaryonificationClass model with a displacement table, or an object "
                                 f"with a .displacement(r, M, a) method; got {type(self.model)}")
             self._callable_model = True
-        self._nd_table = _is_disp_table(self.model) and len(keys) > BFG_MAX_EXTRA   # more p_keys axes than the shell kernels read
         return keys
 
     def _offsets_callable(self, keys=()):
@@ -466,57 +427,14 @@ class BaryonifyShell(DefaultRunner):
         self.last_stats = dict(ctx.stats(), pixel_updates=total)
         return d_off
 
-    def _offsets_nd(self, keys):
-        """HealpixRunner.py:313-355 for a displacement table with more p_keys axes than the shell kernels read, all on the device: disc
-        enumeration with the < 4 pixel rule, the halos' radial rows (bfg_ndtable_rows), the read-out per entry with Rdelta_sampling's
-        shift and the model's epsilon_max cut (BaryonCorrection.py:399-411; bfg_ndtable_read), then the offset geometry (:345-355)."""
-        import os
-        import torch
-        ctx = get_context()
-        NSIDE = self.LightconeShell.NSIDE
-        model = self.model
-        d_off = ctx.zeros(12 * NSIDE * NSIDE, 3)                          # :313
-        table = ctx.table(_table_axes(model, keys), lambda: np.asarray(model.raw_input_d, dtype=np.float64), log_values=False,
-                          cache_key=(model, "d", model.raw_input_d))
-        cat = self.HaloLightConeCatalog.cat
-        model_bg = Background(model.cosmo) if getattr(model, "cosmo", None) is not None else Background(self.cosmo)
-        from ..background import massdef_params
-        Delta, rho_type = massdef_params(getattr(model, "mass_def", None))
-        rdelta = bool(getattr(model, "Rdelta_sampling", False))
-        max_halos = max(1, int(float(os.environ.get("BFG_ND_ROW_BYTES", str(1 << 30))) // (8 * table.nr)))
-        d_oob = torch.zeros(1, dtype=torch.int32, device=d_off.device)
-        total = 0
-        for j0, j1, args, spline, d_cat, stride, pix, r_com, halo, _D in _callable_batches(self, ctx, True, keys, host=False,
-                                                                                              max_halos=max_halos):
-            M_b = np.asarray(cat["M"][j0:j1], dtype=np.float64)
-            a_b = 1.0 / (1.0 + np.asarray(cat["z"][j0:j1], dtype=np.float64))
-            R_com = MassDef(Delta, rho_type).get_radius(model_bg, M_b, a_b) / a_b           # BaryonCorrection.py:399, comoving Mpc
-            d_rows = table.rows(d_cat, stride)
-            disp = table.read(d_rows, halo, r_com, d_shift=ctx.to_device(np.log(R_com)) if rdelta else None,
-                              d_rcut=ctx.to_device(model.epsilon_max * R_com), exp_values=False,
-                              d_r_oob=None if rdelta else d_oob)
-            ctx.offsets_add_displacements(args, spline, pix, halo, disp, d_off)             # :345-355
-            total += int(r_com.numel())
-        # the range warnings of BaryonCorrection.py:382-394 (z and M from the catalog, r from the entries outside the radial axis)
-        warn = 0
-        if cat.size:
-            lz, lM = np.log(1.0 + np.asarray(cat["z"], dtype=np.float64)), np.log(np.asarray(cat["M"], dtype=np.float64))
-            zr, Mr = np.asarray(model.raw_input_z_range), np.asarray(model.raw_input_M_range)
-            warn |= 1 if (lz.min() < zr.min() or lz.max() > zr.max()) else 0
-            warn |= 2 if (lM.min() < Mr.min() or lM.max() > Mr.max()) else 0
-            warn |= 4 if int(d_oob.item()) > 0 else 0
-        self.last_stats = dict(ctx.stats(), pixel_updates=total, warn_mask=warn)
-        emit_range_warnings(self.last_stats, "table")
-        return d_off
-
     def offsets_device(self, slices=1, on_slice=None, sync_stats=True):
         """Accumulate the unit-vector offsets of all halos (:313-355); returns float64[Npix, 3] on the device.
         sync_stats=False: the counters are not read back (that synchronises the stream); `collect_stats()` does it later.
         slices, on_slice: bfg_baryonify_offsets_sliced -- on_slice(k, n, lo, hi) after the k-th band slice of the field has been
         enqueued; lo / hi are ELEMENT indices of the flattened field (3 per pixel)."""
         keys = self._checked_model_keys()
-        if self._callable_model or self._nd_table:
-            d_off = self._offsets_nd(keys) if self._nd_table else self._offsets_callable(keys)
+        if self._callable_model:
+            d_off = self._offsets_callable(keys)
             if on_slice is not None:                                      # nothing to cut: the whole field as one slice
                 on_slice(0, 1, 0, int(d_off.numel()), d_off.view(-1))
             return d_off
@@ -549,7 +467,7 @@ class BaryonifyShell(DefaultRunner):
 
     def collect_stats(self):
         """read the device counters (synchronises the stream), keep them in `last_stats`, emit the warnings"""
-        if (getattr(self, "_callable_model", False) or getattr(self, "_nd_table", False)) and self.last_stats is not None:
+        if getattr(self, "_callable_model", False) and self.last_stats is not None:
             return self.last_stats
         self.last_stats = get_context().stats()
         emit_range_warnings(self.last_stats, "table")                     # BaryonCorrection.py:382-394
@@ -580,7 +498,7 @@ class _BaryonifyDeviceOps(object):
         """ELEMENT cuts (3 per pixel) of the slices offsets() will report: known before the call (bfg_shell_slice_cuts), so the pixels
         this rank will own can be uploaded while the offsets are still being accumulated"""
         from .._lib import shell_slice_cuts
-        if getattr(self.runner, "_callable_model", False) or getattr(self.runner, "_nd_table", False) or slices <= 1:
+        if getattr(self.runner, "_callable_model", False) or slices <= 1:
             return [0, 3 * 12 * nside * nside]                            # (a host-evaluated model reports its field in one piece)
         return shell_slice_cuts(nside, True, slices)
 
@@ -761,7 +679,7 @@ def _baryonify_pipelined(runners, in_flight=2):
     if ran:
         stats = ran[0].collect_stats()                                    # one read-back for the whole list
         for R in ran[1:]:
-            if not (getattr(R, "_callable_model", False) or getattr(R, "_nd_table", False)):
+            if not getattr(R, "_callable_model", False):
                 R.last_stats = stats
     return results
 

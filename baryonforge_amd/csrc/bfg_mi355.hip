@@ -62,13 +62,23 @@ struct DevTable {
     int r_uniform;                  // ln r axis is a linspace to rounding
     int hot;                        // a log table with finite |ln T| > 650: exp() range handling stays with the scatter kernels
     double r0, inv_dr;
+    int64_t hstride;                // 0: one table for every halo.  > 0: `values` holds ONE radial row PER HALO, hstride doubles apart
+                                    // (nouter = 0: the corner blend over a table with more p_keys axes than these kernels read was done
+                                    // once per halo by nd_rows_kernel, bfg_ndtable.hpp); every corner offset starts at j * hstride
 };
 
+struct bfg_ndtable;
 struct bfg_table {
     DevTable dev;
     double *d_blob;                 // one allocation: axes + values
     std::vector<int64_t> shape;
+    bfg_ndtable *nd = nullptr;      // more than BFG_MAX_DIM dimensions: the table itself (dev then describes the halos' rows: see hstride)
 };
+
+// (bfg_ndtable is defined with its C-ABI functions at the end of this file)
+static const double *ndtable_raxis(const bfg_ndtable *t);
+static int run_shell_nd(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, const bfg_spline *s, double *d_out, int mode,
+                        int n_slices, bfg_slice_fn slice_fn, void *slice_user);
 
 struct bfg_spline {
     int n;
@@ -134,6 +144,8 @@ struct bfg_ctx {
     bfg::HaloTile *d_ht;            // [cap_halo]
     double *d_hwin;                 // [hwin_cap] pre-blended row windows
     int64_t hwin_cap;
+    double *d_ndrows = nullptr;     // [ndrows_cap] the halos' radial rows of an N-dimensional table (run_shell_nd)
+    int64_t ndrows_cap = 0;
     bool tile_attr_set;             // MaxDynamicSharedMemorySize raised for the tile kernels on this device
     // timing: a growing pool of event pairs per kernel class, resolved lazily in bfg_timing_read
     bool timing;
@@ -525,7 +537,7 @@ __global__ __launch_bounds__(256, BFG_PREP_WAVES) void halo_prep_kernel(const Pr
             if (in) {
                 for (int cc = q; cc < ncorner; cc += tph) {                    // corner order and products of halo_row_kernel
                     double w = 1.0;
-                    int64_t off = 0;
+                    int64_t off = (j0 + hh) * T.hstride;
                     for (int k = 0; k < T.nouter; ++k) {
                         const int bit = (cc >> (T.nouter - 1 - k)) & 1;
                         const double y = s_cy[k][hh];
@@ -595,7 +607,7 @@ __device__ __forceinline__ void scatter_halo(const ShellParams &P, const int64_t
     const int ncorner = 1 << T.nouter;
     for (int c = lane; c < ncorner; c += G) {
         double w = 1.0;
-        int64_t off = 0;
+        int64_t off = j * T.hstride;
         for (int k = 0; k < T.nouter; ++k) {
             int bit = (c >> (T.nouter - 1 - k)) & 1;
             double y = P.cw[k * cap + j];
@@ -1307,6 +1319,7 @@ static void ctx_free_all(bfg_ctx *c)
     if (c->d_cw) (void)hipFree(c->d_cw);
     if (c->d_ht) (void)hipFree(c->d_ht);
     if (c->d_hwin) (void)hipFree(c->d_hwin);
+    if (c->d_ndrows) (void)hipFree(c->d_ndrows);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_red) (void)hipFree(c->d_red);
     for (int m = 0; m < 3; ++m) {
@@ -1445,6 +1458,7 @@ int bfg_dev_memset_zero(bfg_ctx *c, void *d_ptr, size_t bytes)
 }
 
 // ---- tables -------------------------------------------------------------------------
+constexpr int kNdMaxOuterHost = 12;              // = bfg::kNdMaxOuter (bfg_ndtable.hpp): z, M and up to 10 p_keys axes
 int bfg_table_create(bfg_ctx *c, int ndim, const int64_t *shape, const double *const *axes,
                      const double *values, uint32_t flags, bfg_table **out)
 {
@@ -1453,7 +1467,14 @@ int bfg_table_create(bfg_ctx *c, int ndim, const int64_t *shape, const double *c
     if (rc) return rc;
     if (!shape || !axes || !values || !out) return BFG_ERR_INVALID;
     if (ndim < 3) return BFG_ERR_INVALID;
-    if (ndim > BFG_MAX_DIM) return BFG_ERR_UNSUPPORTED;
+    // More dimensions than the shell kernels read (BFG_MAX_DIM): the table is kept as an N-dimensional one (bfg_ndtable) and the shell
+    // calls blend every halo's radial row first (nd_rows_kernel), then run on those rows (DevTable::hstride); see run_shell_nd.
+    // (A displacement table with three p_keys axes takes the row path as well: measured at 1e6 halos, NSIDE 1024, 3-node axes --
+    // tools/nd_probe.py, profiles/r05_nd_tables.txt -- offsets 8.07 ms with the kernels blending 32 corners per window node against
+    // 3.64 ms on rows; paint tables and narrower displacement tables are faster read directly: 2.27 vs 2.86 ms, 2.95 vs 2.95 ms.)
+    bool nd = ndim > BFG_MAX_DIM || (ndim == BFG_MAX_DIM && !(flags & BFG_TABLE_LOG_VALUES));
+    if (const char *e = std::getenv("BFG_ND_FROM_DIM")) nd = ndim > BFG_MAX_DIM || ndim >= std::max(4, std::atoi(e));   // A/B switch
+    if (nd && ndim - 1 > kNdMaxOuterHost) return BFG_ERR_UNSUPPORTED;
     int64_t total = 1;
     for (int d = 0; d < ndim; ++d) {
         if (shape[d] < 2 || shape[d] > (1 << 24)) return BFG_ERR_INVALID;
@@ -1484,14 +1505,37 @@ int bfg_table_create(bfg_ctx *c, int ndim, const int64_t *shape, const double *c
         }
         for (int64_t ir = 0; ir < NR; ++ir) perm[(size_t)(row * NR + ir)] = values[src + ir * src_stride[2]];
     }
-    // one device blob: [outer axes...][r axis][values]
-    size_t n_axes = 0;
-    for (int d = 0; d < ndim; ++d) n_axes += (size_t)shape[d];
-    std::vector<double> blob(n_axes + (size_t)total);
     DevTable &D = t->dev;
     std::memset(&D, 0, sizeof(D));
     D.ndim = ndim; D.nouter = nouter; D.nr = (int)NR;
     D.log_values = (flags & BFG_TABLE_LOG_VALUES) ? 1 : 0;
+    if (nd) {
+        // the N-dimensional table proper (axes and permuted values on the device), and a DevTable that describes per-halo rows: no
+        // outer axes, the radial axis, `values` / `hstride` filled in per call
+        std::vector<int64_t> oshape(nouter);
+        std::vector<const double *> oaxes(nouter);
+        for (int k = 0; k < nouter; ++k) { oshape[k] = shape[odim[k]]; oaxes[k] = axes[odim[k]]; }
+        t->d_blob = nullptr;
+        rc = bfg_ndtable_create(c, nouter, oshape.data(), oaxes.data(), NR, axes[2], perm.data(), &t->nd);
+        if (rc) { delete t; return rc; }
+        D.nouter = 0;
+        D.raxis = ndtable_raxis(t->nd);
+        const double *r = axes[2];
+        double dr = (r[NR - 1] - r[0]) / (double)(NR - 1);
+        bool uni = dr > 0;
+        for (int64_t i = 0; i < NR && uni; ++i)
+            if (std::fabs(r[i] - (r[0] + dr * (double)i)) > 1e-9 * dr) uni = false;
+        D.r_uniform = uni ? 1 : 0; D.r0 = r[0]; D.inv_dr = uni ? 1.0 / dr : 0.0;
+        if (D.log_values)
+            for (double v : perm) if (std::isfinite(v) && std::fabs(v) > 650.0) { D.hot = 1; break; }
+        D.hstride = NR;
+        *out = t;
+        return BFG_OK;
+    }
+    // one device blob: [outer axes...][r axis][values]
+    size_t n_axes = 0;
+    for (int d = 0; d < ndim; ++d) n_axes += (size_t)shape[d];
+    std::vector<double> blob(n_axes + (size_t)total);
     if (hipMalloc((void **)&t->d_blob, blob.size() * sizeof(double)) != hipSuccess) {
         (void)hipGetLastError(); delete t; return BFG_ERR_NOMEM;
     }
@@ -1532,7 +1576,8 @@ int bfg_table_destroy(bfg_ctx *c, bfg_table *t)
     if (rc) return rc;
     if (!t) return BFG_ERR_INVALID;
     (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(t->d_blob);
+    if (t->nd) (void)bfg_ndtable_destroy(c, t->nd);
+    if (t->d_blob) (void)hipFree(t->d_blob);
     delete t;
     return BFG_OK;
 }
@@ -1543,6 +1588,7 @@ int bfg_table_eval(bfg_ctx *c, const bfg_table *t, int64_t npts, const double *c
     int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     if (!t || !coords || !out || npts < 0) return BFG_ERR_INVALID;
+    if (t->nd) return BFG_ERR_UNSUPPORTED;          // (N-dimensional tables: bfg_ndtable_rows / bfg_ndtable_read)
     if (npts == 0) return BFG_OK;
     double *d_c = nullptr, *d_o = nullptr;
     size_t nb = (size_t)npts * t->dev.ndim * sizeof(double);
@@ -1748,8 +1794,10 @@ static int check_args(const bfg_shell_args *a, const bfg_table *t, const bfg_spl
     if (a->n_halo < 0) return BFG_ERR_INVALID;
     if (a->n_halo > 0 && !a->d_catalog) return BFG_ERR_INVALID;
     if (a->n_extra < 0 || a->n_extra > BFG_MAX_EXTRA) return BFG_ERR_UNSUPPORTED;
-    if (a->cat_stride < 4 + a->n_extra) return BFG_ERR_INVALID;
+    if (a->cat_stride < 4) return BFG_ERR_INVALID;
+    if (t->dev.hstride == 0 && a->cat_stride < 4 + a->n_extra) return BFG_ERR_INVALID;
     if (t->dev.ndim != 3 + a->n_extra) return BFG_ERR_INVALID;
+    if (t->nd) return BFG_ERR_INVALID;               // (run_shell_nd hands run_shell the per-halo rows, never the N-dimensional table)
     if (!(a->epsilon_max >= 0)) return BFG_ERR_INVALID;
     return BFG_OK;
 }
@@ -1800,6 +1848,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     DeviceGuard dg_;
     int rc = ctx_enter(c, dg_);
     if (rc) return rc;
+    if (t && t->nd) return run_shell_nd(c, a, t, s, d_out, mode, n_slices, slice_fn, slice_user);
     rc = check_args(a, t, s, d_out);
     if (rc) return rc;
     if (mode == MODE_PAINT && !t->dev.log_values) return BFG_ERR_INVALID;
@@ -2428,6 +2477,7 @@ int bfg_baryonify_snapshot_strided(bfg_ctx *c, const bfg_snapshot_args *a, const
     if (!a || !t || (!d_out && a->n_part > 0) || (a->ndim != 2 && a->ndim != 3) || a->n_part < 0 || a->n_halo < 0 || !(a->L > 0) ||
         !(a->a > 0) || a->n_part >= (1ll << 31) || a->n_extra < 0 || a->halo_stride < 5 + a->n_extra)
         return BFG_ERR_INVALID;
+    if (t->nd) return BFG_ERR_UNSUPPORTED;          // (more p_keys axes than the kernels read: shell runners only)
     if (t->dev.ndim != 3 + a->n_extra || t->dev.log_values) return BFG_ERR_INVALID;       // linear displacement table
     if ((a->n_part > 0 && !a->d_part) || (a->n_halo > 0 && !a->d_halo)) return BFG_ERR_INVALID;
     if (a->n_part == 0) return BFG_OK;
@@ -2539,6 +2589,7 @@ static int run_grid(bfg_ctx *c, const bfg_grid_args *a, const bfg_table *t, doub
     if (!a || !t || !d_out || (a->ndim != 2 && a->ndim != 3) || a->n_halo < 0 || a->npix < 4 || !(a->a > 0) ||
         a->n_extra < 0 || a->halo_stride < 5 + a->n_extra || !a->d_bins)
         return BFG_ERR_INVALID;
+    if (t->nd) return BFG_ERR_UNSUPPORTED;          // (more p_keys axes than the kernels read: shell runners only)
     if (t->dev.ndim != 3 + a->n_extra) return BFG_ERR_INVALID;
     if ((mode == MODE_PAINT) != (t->dev.log_values != 0)) return BFG_ERR_INVALID;          // paint: ln T; baryonify: linear d
     if (a->n_halo == 0) return BFG_OK;
@@ -2890,6 +2941,64 @@ struct bfg_ndtable {
     double *d_blob;
 };
 
+static const double *ndtable_raxis(const bfg_ndtable *t) { return t->dev.raxis; }
+
+// bfg_paint_shell* / bfg_baryonify_offsets* with a table of more than BFG_MAX_DIM dimensions (ParamTabulatedProfile /
+// BaryonificationClass with more than three p_keys: utils/Tabulate.py:497-650, Profiles/BaryonCorrection.py:211-227, :404-408).
+// All non-radial coordinates of a (halo, pixel) query are the halo's, so the multilinear read-out factors: nd_rows_kernel blends
+// the 2^(n+2) corners of the halo's (z, M, p_1 ... p_n) cell into ITS radial row once (NaN rows outside the hull of any axis), and
+// the shell kernels -- prep, binning, tile kernel, left-over scatter kernel: the same code as for a 3-D table -- run on those rows
+// as a table without outer axes whose values start at j * hstride for halo j.  Rows are float64[n][nr]: catalogs whose rows pass
+// BFG_ND_ROW_BYTES (default 4 GiB) are painted in batches of halos, each batch accumulating into the output of the one before;
+// a sliced call in several batches reports its slices after the last batch (they are not final earlier).
+static int run_shell_nd(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, const bfg_spline *s, double *d_out, int mode,
+                        int n_slices, bfg_slice_fn slice_fn, void *slice_user)
+{
+    if (!a || !t || !s || !d_out) return BFG_ERR_INVALID;
+    const bfg::NdTable &N = t->nd->dev;
+    if (a->n_extra != N.nouter - 2 || a->cat_stride < 4 + a->n_extra || a->n_halo < 0) return BFG_ERR_INVALID;
+    if (a->n_halo > 0 && !a->d_catalog) return BFG_ERR_INVALID;
+    double cap_bytes = 4294967296.0;
+    if (const char *e = std::getenv("BFG_ND_ROW_BYTES")) cap_bytes = std::max(1.0, std::atof(e));
+    const int64_t per = std::max<int64_t>(1, (int64_t)(cap_bytes / (8.0 * (double)N.nr)));
+    const int64_t nb_max = std::min<int64_t>(std::max<int64_t>(a->n_halo, 1), per);
+    if (nb_max * N.nr > c->ndrows_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_ndrows) (void)hipFree(c->d_ndrows);
+        c->d_ndrows = nullptr; c->ndrows_cap = 0;
+        HIP_TRY(hipMalloc((void **)&c->d_ndrows, (size_t)(nb_max * N.nr) * sizeof(double)));
+        c->ndrows_cap = nb_max * N.nr;
+    }
+    bfg_table tv;
+    tv.dev = t->dev; tv.d_blob = nullptr; tv.nd = nullptr;
+    tv.dev.ndim = 3; tv.dev.nouter = 0; tv.dev.values = c->d_ndrows; tv.dev.hstride = N.nr;
+    const int64_t n_batches = std::max<int64_t>(1, (a->n_halo + nb_max - 1) / nb_max);
+    const bool sliced_here = slice_fn && n_batches == 1;
+    for (int64_t b = 0; b < n_batches; ++b) {
+        const int64_t j0 = b * nb_max, nb = std::min(nb_max, a->n_halo - j0);
+        bfg_shell_args ab = *a;
+        ab.d_catalog = a->d_catalog ? a->d_catalog + j0 * (int64_t)a->cat_stride : nullptr;
+        ab.n_halo = std::max<int64_t>(nb, 0);
+        ab.n_extra = 0;
+        if (b > 0) ab.flags &= ~(uint32_t)(BFG_SHELL_OUT_OVERWRITE | BFG_SHELL_OUT_IS_ZERO);      // accumulate into the batches before
+        if (nb > 0) {
+            const unsigned grid = (unsigned)std::min<int64_t>((nb + 3) / 4, (int64_t)c->n_cu * 16);
+            hipLaunchKernelGGL(bfg::nd_rows_kernel, dim3(grid), dim3(256), 0, c->stream, N, ab.d_catalog, nb, a->cat_stride, c->d_ndrows,
+                               c->d_stats);
+            HIP_TRY(hipGetLastError());
+        }
+        const int rc = run_shell(c, &ab, &tv, s, d_out, mode, sliced_here ? n_slices : 1, sliced_here ? slice_fn : nullptr, slice_user);
+        if (rc) return rc;
+    }
+    if (slice_fn && !sliced_here) {
+        int64_t cuts[kMaxSlices + 1];
+        const int K = shell_slice_cuts(a->nside, mode, n_slices, cuts);
+        for (int k = 0; k < K; ++k)
+            if (slice_fn(slice_user, k, K, cuts[k], cuts[k + 1]) != 0) { g_last_error = "the slice callback failed"; return BFG_ERR_INVALID; }
+    }
+    return BFG_OK;
+}
+
 int bfg_ndtable_create(bfg_ctx *c, int n_outer, const int64_t *outer_shape, const double *const *outer_axes, int64_t nr,
                        const double *raxis, const double *values, bfg_ndtable **out)
 {
@@ -2958,7 +3067,8 @@ int bfg_ndtable_rows(bfg_ctx *c, const bfg_ndtable *t, const double *d_catalog, 
     if (!t || n_halo < 0 || (n_halo > 0 && (!d_catalog || !d_rows)) || cat_stride < 2 + t->dev.nouter) return BFG_ERR_INVALID;
     if (n_halo == 0) return BFG_OK;
     const unsigned grid = (unsigned)std::min<int64_t>((n_halo + 3) / 4, (int64_t)c->n_cu * 16);
-    hipLaunchKernelGGL(bfg::nd_rows_kernel, dim3(grid), dim3(256), 0, c->stream, t->dev, d_catalog, n_halo, cat_stride, d_rows);
+    hipLaunchKernelGGL(bfg::nd_rows_kernel, dim3(grid), dim3(256), 0, c->stream, t->dev, d_catalog, n_halo, cat_stride, d_rows,
+                       (bfg_stats *)nullptr);
     HIP_TRY(hipGetLastError());
     return BFG_OK;
 }

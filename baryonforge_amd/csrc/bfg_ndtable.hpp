@@ -24,11 +24,17 @@ struct NdTable {
     const double *values;            // [z][M][p_1]...[p_n][r]
 };
 
+// stats (may be null): halos outside the hull of an axis are counted, and the z / M axes raise the range warnings the 3-D path raises
+// (BaryonCorrection.py:382-394).  The corner weights and row offsets of a halo are formed ONCE per chunk of 256 corners by the
+// wavefront's lanes together (LDS) instead of by every lane for itself: 2^(n+2) x n_outer products per halo, not per (halo, node).
 __global__ __launch_bounds__(256) void nd_rows_kernel(const NdTable T, const double *__restrict__ cat, int64_t n_halo, int cat_stride,
-                                                      double *__restrict__ rows)
+                                                      double *__restrict__ rows, bfg_stats *stats)
 {
+    constexpr int kChunk = 256;
     __shared__ double s_y[4][kNdMaxOuter];
     __shared__ int32_t s_ci[4][kNdMaxOuter];
+    __shared__ double s_w[4][kChunk];
+    __shared__ int64_t s_off[4][kChunk];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int ncorner = 1 << T.nouter;
     for (int64_t j = (int64_t)blockIdx.x * 4 + grp; j < n_halo; j += (int64_t)gridDim.x * 4) {
@@ -44,26 +50,52 @@ __global__ __launch_bounds__(256) void nd_rows_kernel(const NdTable T, const dou
             s_ci[grp][lane] = i;
             s_y[grp][lane] = (x - g[i]) / (g[i + 1] - g[i]);
         }
-        const bool any_oob = __any(oob);
+        const unsigned long long oob_mask = __ballot(oob);
+        const bool any_oob = oob_mask != 0ull;
+        if (any_oob && stats && lane == 0) {
+            atomicAdd((unsigned long long *)&stats->halos_out_of_table, 1ull);
+            const unsigned warn = ((oob_mask & 1ull) ? BFG_WARN_Z_RANGE : 0u) | ((oob_mask & 2ull) ? BFG_WARN_M_RANGE : 0u);
+            if (warn) atomicOr(&stats->warn_mask, warn);
+        }
         __builtin_amdgcn_wave_barrier();
-        for (int r0 = 0; r0 < T.nr; r0 += 64) {
-            const int ir = r0 + lane;
-            double acc = 0.0;
-            if (any_oob) acc = __builtin_nan("");
+        // two neighbouring nodes per lane (one 16-byte load per corner row: the table lives in the Infinity Cache for all but the
+        // smallest tables, where 8-byte accesses run at 0.5-0.7 of the 16-byte rate), 128 nodes per pass
+        typedef double nd_v2d __attribute__((ext_vector_type(2), aligned(8)));
+        for (int r0 = 0; r0 < T.nr; r0 += 128) {
+            const int ir = r0 + 2 * lane;
+            const bool two = ir + 1 < T.nr, one = ir < T.nr;
+            double acc0 = 0.0, acc1 = 0.0;
+            if (any_oob) { acc0 = __builtin_nan(""); acc1 = acc0; }
             else {
-                for (int cc = 0; cc < ncorner; ++cc) {
-                    double w = 1.0;
-                    int64_t off = 0;
-                    for (int k = 0; k < T.nouter; ++k) {
-                        const int bit = (cc >> (T.nouter - 1 - k)) & 1;
-                        const double y = s_y[grp][k];
-                        w = w * (bit ? y : 1.0 - y);
-                        off += (int64_t)(s_ci[grp][k] + bit) * T.ostride[k];
+                for (int c0 = 0; c0 < ncorner; c0 += kChunk) {
+                    const int nc = min(kChunk, ncorner - c0);
+                    for (int q = lane; q < nc; q += 64) {
+                        const int cc = c0 + q;
+                        double w = 1.0;
+                        int64_t off = 0;
+                        for (int k = 0; k < T.nouter; ++k) {
+                            const int bit = (cc >> (T.nouter - 1 - k)) & 1;
+                            const double y = s_y[grp][k];
+                            w = w * (bit ? y : 1.0 - y);
+                            off += (int64_t)(s_ci[grp][k] + bit) * T.ostride[k];
+                        }
+                        s_w[grp][q] = w; s_off[grp][q] = off;
                     }
-                    if (ir < T.nr) acc = fma(T.values[off + ir], w, acc);
+                    __builtin_amdgcn_wave_barrier();
+                    if (two) {
+                        for (int q = 0; q < nc; ++q) {
+                            const nd_v2d v = *reinterpret_cast<const nd_v2d *>(T.values + s_off[grp][q] + ir);
+                            const double w = s_w[grp][q];
+                            acc0 = fma(v.x, w, acc0); acc1 = fma(v.y, w, acc1);
+                        }
+                    } else if (one) {
+                        for (int q = 0; q < nc; ++q) acc0 = fma(T.values[s_off[grp][q] + ir], s_w[grp][q], acc0);
+                    }
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
-            if (ir < T.nr) rows[j * (int64_t)T.nr + ir] = acc;
+            if (two) { nd_v2d o; o.x = acc0; o.y = acc1; *reinterpret_cast<nd_v2d *>(rows + j * (int64_t)T.nr + ir) = o; }
+            else if (one) rows[j * (int64_t)T.nr + ir] = acc0;
         }
         __builtin_amdgcn_wave_barrier();
     }

@@ -144,7 +144,7 @@ __device__ inline void halo_row_pair(const DevTable &T, const HaloTile *ht, cons
     }
     const int ncorner = 1 << T.nouter;
     for (int c = 0; c < ncorner; ++c) {
-        double w = 1.0; int64_t off = 0;
+        double w = 1.0; int64_t off = j * T.hstride;
         for (int k = 0; k < T.nouter; ++k) {
             const int bit = (c >> (T.nouter - 1 - k)) & 1;
             const double y = cw[k * cap + j];
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(256) void halo_row_kernel(const RowParams P)
         if (e == 0) { s_winlo[hl] = P.ht[j].win_lo; s_add[hl] = T.log_values ? P.ht[j].spare[0] : 0.0; }
         for (int c = e; c < ncorner; c += W) {
             double w = 1.0;
-            int64_t off = 0;
+            int64_t off = j * T.hstride;
             for (int k = 0; k < T.nouter; ++k) {
                 const int bit = (c >> (T.nouter - 1 - k)) & 1;
                 const double y = halo_cell_weight(P.ht, P.cw, P.cap, T.nouter, j, k);
@@ -771,7 +771,7 @@ __global__ __launch_bounds__(256) void halo_row4_kernel(const RowParams P)
         if (q == 0) { s_winlo[hl] = P.ht[j].win_lo; s_add[hl] = T.log_values ? P.ht[j].spare[0] : 0.0; }
         for (int c = q; c < ncorner; c += tph) {
             double w = 1.0;
-            int64_t off = 0;
+            int64_t off = j * T.hstride;
             for (int k = 0; k < T.nouter; ++k) {
                 const int bit = (c >> (T.nouter - 1 - k)) & 1;
                 const double y = halo_cell_weight(P.ht, P.cw, P.cap, T.nouter, j, k);
@@ -1647,7 +1647,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                 int64_t *con = reinterpret_cast<int64_t *>(cwn + ncorner);
                 for (int c = 0; c < ncorner; ++c) {                        // corner order and products of halo_row_kernel
                     double w = 1.0;
-                    int64_t off = 0;
+                    int64_t off = j * T.hstride;
                     for (int k = 0; k < T.nouter; ++k) {
                         const int bit = (c >> (T.nouter - 1 - k)) & 1;
                         const double y = halo_cell_weight(P.ht, P.cw, P.cap, T.nouter, j, k);

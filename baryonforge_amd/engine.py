@@ -44,7 +44,9 @@ def require_gpu():
 
 
 class Table(object):
-    """An interpolation table resident in HBM (bfg_table)."""
+    """An interpolation table resident in HBM (bfg_table): (ln(1+z), ln M, ln r) + up to 10 p_keys axes.  Up to three extra axes
+    are read by the shell kernels directly; with more, the library blends every halo's radial row first (csrc/bfg_ndtable.hpp)
+    and runs the same kernels on those rows -- the same bfg_paint_shell / bfg_baryonify_offsets calls either way."""
 
     def __init__(self, ctx, axes, values, log_values):
         self.ctx = ctx
@@ -52,8 +54,8 @@ class Table(object):
         values = np.ascontiguousarray(values, dtype=np.float64)
         if values.ndim != len(axes) or any(a.ndim != 1 or a.size != s for a, s in zip(axes, values.shape)):
             raise ValueError("table axes do not match the shape of the table values")
-        if values.ndim > _lib.BFG_MAX_DIM:
-            raise NotImplementedError(f"tables with more than {_lib.BFG_MAX_EXTRA} extra (p_keys) dimensions "
+        if values.ndim - 1 > _lib.BFG_ND_MAX_OUTER:
+            raise NotImplementedError(f"tables with more than {_lib.BFG_ND_MAX_OUTER - 2} extra (p_keys) dimensions "
                                       "are not supported on the MI355X path")
         self.ndim = values.ndim
         self.shape = values.shape
@@ -80,59 +82,6 @@ class Table(object):
         try:
             if self.handle and self.ctx.handle:
                 self.ctx.lib.bfg_table_destroy(self.ctx.handle, self.handle)
-        except Exception:
-            pass
-
-
-class NdTable(object):
-    """A table with more p_keys axes than the shell kernels read, resident in HBM (bfg_ndtable): axes (ln(1+z), ln M, ln r, p_1 ...),
-    values of that shape (the reference's layout, Tabulate.py:582-590); stored [z][M][p...][r]."""
-
-    def __init__(self, ctx, axes, values):
-        self.ctx = ctx
-        axes = [np.ascontiguousarray(a, dtype=np.float64) for a in axes]
-        values = np.asarray(values, dtype=np.float64)
-        if values.ndim != len(axes) or values.ndim < 3 or any(a.ndim != 1 or a.size != s for a, s in zip(axes, values.shape)):
-            raise ValueError("table axes do not match the shape of the table values")
-        if values.ndim - 1 > _lib.BFG_ND_MAX_OUTER:
-            raise NotImplementedError(f"tables with more than {_lib.BFG_ND_MAX_OUTER - 2} extra (p_keys) dimensions are not supported")
-        outer = [axes[0], axes[1]] + axes[3:]
-        rlast = np.ascontiguousarray(np.moveaxis(values, 2, -1))
-        self.nr, self.n_outer = int(values.shape[2]), len(outer)
-        shape = (C.c_int64 * self.n_outer)(*[a.size for a in outer])
-        ax_ptrs = (C.POINTER(C.c_double) * self.n_outer)(*[_lib.dptr(a) for a in outer])
-        handle = C.c_void_p()
-        ctx._on_current_stream()
-        _lib.check(ctx.lib.bfg_ndtable_create(ctx.handle, self.n_outer, shape, ax_ptrs, self.nr, _lib.dptr(axes[2]), _lib.dptr(rlast),
-                                              C.byref(handle)), "bfg_ndtable_create")
-        self.handle = handle
-
-    def rows(self, d_catalog, cat_stride):
-        """float64[n_halo, nr] device tensor: every halo's radial row (bfg_ndtable_rows)"""
-        ctx = self.ctx
-        n = int(d_catalog.shape[0])
-        d_rows = ctx.empty(n, self.nr)
-        ctx._on_current_stream()
-        _lib.check(ctx.lib.bfg_ndtable_rows(ctx.handle, self.handle, C.c_void_p(d_catalog.data_ptr()), n, int(cat_stride),
-                                            C.c_void_p(d_rows.data_ptr())), "bfg_ndtable_rows")
-        return d_rows
-
-    def read(self, d_rows, d_halo, d_r_com, d_shift=None, d_rcut=None, d_scale=None, exp_values=False, d_r_oob=None):
-        """float64[n] device tensor: the rows read out at the (halo, r_com) entries (bfg_ndtable_read)"""
-        ctx = self.ctx
-        n = int(d_halo.numel())
-        d_out = ctx.empty(n)
-        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-        ctx._on_current_stream()
-        _lib.check(ctx.lib.bfg_ndtable_read(ctx.handle, self.handle, ptr(d_rows), n, ptr(d_halo), ptr(d_r_com), ptr(d_shift),
-                                            ptr(d_rcut), ptr(d_scale), 1 if exp_values else 0, ptr(d_out), ptr(d_r_oob)),
-                   "bfg_ndtable_read")
-        return d_out
-
-    def __del__(self):
-        try:
-            if self.handle and self.ctx.handle:
-                self.ctx.lib.bfg_ndtable_destroy(self.ctx.handle, self.handle)
         except Exception:
             pass
 
@@ -347,8 +296,7 @@ class Context(object):
                 return hit[0]
         if callable(values):
             values = values()
-        # more p_keys axes than the shell kernels read: the N-dimensional row path (csrc/bfg_ndtable.hpp)
-        t = NdTable(self, axes, values) if len(axes) > _lib.BFG_MAX_DIM else Table(self, axes, values, log_values)
+        t = Table(self, axes, values, log_values)
         if cache_key is not None:
             if len(self._table_cache) > 8:
                 self._table_cache.clear()

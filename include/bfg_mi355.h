@@ -43,8 +43,8 @@ typedef enum {
     BFG_ERR_COMM = -6          /* RCCL missing or a collective failed; see bfg_last_error() */
 } bfg_status;
 
-#define BFG_MAX_DIM 6          /* (ln(1+z), ln M, ln r) + up to 3 extra p_keys axes: what the kernels read; wider tables
-                                * are read out per halo on the host and enter through bfg_disc_enumerate / bfg_map_add_values */
+#define BFG_MAX_DIM 6          /* (ln(1+z), ln M, ln r) + up to 3 extra p_keys axes: what the kernels read directly; the shell
+                                * calls take wider tables too (up to 13 dimensions, see bfg_table_create) */
 #define BFG_MAX_EXTRA (BFG_MAX_DIM - 3)
 
 typedef struct bfg_ctx bfg_ctx;        /* one per GPU / stream                         */
@@ -92,7 +92,14 @@ int bfg_dev_memset_zero(bfg_ctx *ctx, void *d_ptr, size_t bytes);               
  * (ln(1+z), ln M, ln r, extras...), values is C-ordered with that shape.
  * BFG_TABLE_LOG_VALUES: values are ln(T) and the read-out is exp(interp)
  *   (Tabulate.py:314-315); otherwise the read-out is the interpolant itself
- *   (BaryonCorrection.py:403-408).                                                */
+ *   (BaryonCorrection.py:403-408).
+ * ndim <= BFG_MAX_DIM: the shell, grid and snapshot kernels read the table directly.
+ * BFG_MAX_DIM < ndim <= 13 (four to ten p_keys axes; the reference's tables are
+ *   N-dimensional): accepted by bfg_paint_shell* and bfg_baryonify_offsets* only -- every
+ *   halo's radial row is blended first (the non-radial coordinates of a query are the
+ *   halo's), then the same shell kernels run on the rows, in batches of halos whose rows
+ *   stay under BFG_ND_ROW_BYTES (environment, default 4 GiB); bfg_table_eval and the grid /
+ *   snapshot calls return BFG_ERR_UNSUPPORTED for such a table.                    */
 #define BFG_TABLE_LOG_VALUES 1u
 int bfg_table_create(bfg_ctx *ctx, int ndim, const int64_t *shape, const double *const *axes,
                      const double *values, uint32_t flags, bfg_table **out);

@@ -105,14 +105,14 @@ def test_callable_model_argument_checks(cosmo):
 def test_tables_with_more_than_three_extra_axes_on_the_device(cosmo, n_extra, batched, monkeypatch):
     """ParamTabulatedProfile / BaryonificationClass are N-dimensional in the reference (utils/Tabulate.py:497-650,
     BaryonCorrection.py:211-227, :404-408); the shell kernels read at most three p_keys axes (BFG_MAX_EXTRA).  Tables with four and
-    five take the N-dimensional row path (csrc/bfg_ndtable.hpp): the 2^(n + 2) corner blend once per halo and the radial read-out per
-    (halo, pixel) entry on the device, nothing on the host -- the models' own scipy read-out must not be called.  Against the
-    oracle's N-linear loops, incl. halos outside the hull of a parameter axis (NaN -> nothing painted / no displacement)."""
+    five are the same bfg_paint_shell / bfg_baryonify_offsets calls: the library blends the 2^(n + 2) corners once per halo into the
+    halo's radial row (csrc/bfg_ndtable.hpp) and runs the tile path on the rows, nothing on the host -- the models' own scipy
+    read-out must not be called.  Against the oracle's N-linear loops, incl. halos outside the hull of a parameter axis (NaN ->
+    nothing painted / no displacement); `batched`: rows of 37 halos at a time (each batch accumulates into the one before)."""
     from util import oracle_baryonify, oracle_paint
     nside, n, eps = 128, 300, 6.0
     if batched:
-        monkeypatch.setenv("BFG_CALLABLE_BATCH", "4000")                  # several batches of entries ...
-        monkeypatch.setenv("BFG_ND_ROW_BYTES", str(8 * 60 * 37))          # ... and of rows (37 halos each)
+        monkeypatch.setenv("BFG_ND_ROW_BYTES", str(8 * 60 * 37))          # rows of 37 halos per batch
     ra, dec, M, z = syn.catalog(n, seed=77, logM=(13.0, 15.3))
     rng = np.random.default_rng(8)
     p = [rng.uniform(0.7, 1.4, n), rng.uniform(-1.0, 2.0, n), rng.uniform(10.0, 20.0, n), rng.uniform(0.0, 1.0, n),
@@ -163,3 +163,28 @@ def test_tables_with_more_than_three_extra_axes_on_the_device(cosmo, n_extra, ba
         assert not np.allclose(gotb, m_in)
         assert np.isclose(gotb.sum(), m_in.sum())
         assert_maps_close(gotb, refb, 1e-5, floor=1e-9, what=f"baryonify, {n_extra} extra table axes (Rdelta_sampling {rdelta})")
+
+
+def test_nd_table_on_the_tile_path_equals_the_3d_table_at_full_size(cosmo):
+    """A table with four p_keys axes whose values do not depend on them IS its 3-D table: at BASELINE configs[1]'s size (1e5 halos,
+    NSIDE 1024) the N-dimensional call -- rows blended per halo, then the tile kernels on the rows -- must give the 3-D call's map
+    (the blend's weights sum to 1: rounding only), the same P_tot, and must not fall back to the global-atomic kernel."""
+    nside, n, eps = 1024, 100_000, 10.0
+    ra, dec, M, z = syn.catalog(n, seed=42)
+    zax, Max, rax, T = syn.pressure_table()
+    ax = [np.array([0.0, 1.0, 2.0]), np.array([-1.0, 1.0]), np.array([0.0, 0.5, 1.0]), np.array([10.0, 20.0])]
+    rng = np.random.default_rng(5)
+    p = [rng.uniform(a[0], a[-1], n) for a in ax]
+    TN = np.ascontiguousarray(np.broadcast_to(T.reshape(T.shape + (1,) * 4), T.shape + tuple(a.size for a in ax)))
+    keys = ["pa", "pb", "pc", "pd"]
+    Cat3 = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    CatN = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo, **dict(zip(keys, p)))
+    shell = lambda: bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo)
+    R3 = bfg.PaintProfilesShell(Cat3, shell(), eps, bfg.TabulatedProfile.from_arrays(zax, Max, rax, T), verbose=False)
+    RN = bfg.PaintProfilesShell(CatN, shell(), eps, bfg.ParamTabulatedProfile.from_arrays(zax, Max, rax, TN, other_params=dict(zip(keys, ax))),
+                                verbose=False)
+    ref, got = R3.process(), RN.process()
+    assert RN.last_stats["pixel_updates"] == R3.last_stats["pixel_updates"] > 2e7
+    assert RN.last_stats["fallback_halos"] == 0
+    assert np.array_equal(got != 0, ref != 0)
+    assert_maps_close(got, ref, 1e-11, what="4 degenerate p_keys axes vs the 3-D table")
