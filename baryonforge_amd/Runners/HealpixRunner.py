@@ -722,6 +722,12 @@ def _baryonify_process(runner, ops, exchange, slices=1):
     d_in = ops.upload_ranges(flat, owned, npix)                        # sources this rank does not own have no mass here
     d_out = ops.zeros(npix + 3)
     ops.count_above(d_in, owned, 1e-8, d_out[npix + 2:])              # np.allclose(orig_map, 0) <=> no |value| > 1e-8 (NaN: see below)
+    if not multi:
+        # one rank: nobody waits for this rank's collectives, so the all-zero test (:293-294) is read back BEFORE the offsets are
+        # accumulated and the map regridded -- an empty shell costs its upload and one small copy, as in the reference; with several
+        # ranks the count rides on the final all-reduce instead (a read-back here would cost every rank a synchronisation per shell)
+        if float(ops.to_host(d_out[npix + 2:])[0]) == 0 and np.allclose(orig_map, 0):
+            return orig_map
     handles, seen = [], []
 
     def on_slice(k, n, lo, hi, field):                                # element range [lo, hi) of the flattened field: final

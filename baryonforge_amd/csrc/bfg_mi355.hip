@@ -61,11 +61,13 @@ struct DevTable {
     int log_values;
     int r_uniform;                  // ln r axis is a linspace to rounding
     int hot;                        // a log table with finite |ln T| > 650: exp() range handling stays with the scatter kernels
-    double r0, inv_dr;
-    int64_t hstride;                // 0: one table for every halo.  > 0: `values` holds ONE radial row PER HALO, hstride doubles apart
+    int hstride;                    // 0: one table for every halo.  > 0: `values` holds ONE radial row PER HALO, hstride doubles apart
                                     // (nouter = 0: the corner blend over a table with more p_keys axes than these kernels read was done
-                                    // once per halo by nd_rows_kernel, bfg_ndtable.hpp); every corner offset starts at j * hstride
+                                    // once per halo by nd_rows_kernel, bfg_ndtable.hpp); every corner offset starts at j * hstride.
+                                    // (Sits in what was padding: the kernels' argument layout is the round-4 one.)
+    double r0, inv_dr;
 };
+static_assert(sizeof(DevTable) == 184, "DevTable grew: the tile kernels' argument layout (and with it their register allocation) changes");
 
 struct bfg_ndtable;
 struct bfg_table {
@@ -104,7 +106,8 @@ struct bfg_ctx {
     double *d_cw;       // [BFG_MAX_DIM-1][cap]
     bfg_stats *d_stats;
     double *d_red;      // scratch for reductions [4]
-    int64_t *d_rg_slow; // regrid: pixels the tile kernel's differential path leaves to regrid_list_kernel (grow-only, one per pixel)
+    void *d_rg_slow;    // regrid: pixels the tile kernel's differential path leaves to regrid_list_kernel (grow-only, one entry per
+                        // pixel: int32 while the map has fewer than 2^31 pixels, int64 beyond)
     int64_t rg_slow_cap;
     unsigned long long *d_rg_slow_n;
     // tile variant: geometry of the current nside, binning buffers, ln / exp tables
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(256, BFG_PREP_WAVES) void halo_prep_kernel(const Pr
             if (in) {
                 for (int cc = q; cc < ncorner; cc += tph) {                    // corner order and products of halo_row_kernel
                     double w = 1.0;
-                    int64_t off = (j0 + hh) * T.hstride;
+                    int64_t off = (j0 + hh) * (int64_t)T.hstride;
                     for (int k = 0; k < T.nouter; ++k) {
                         const int bit = (cc >> (T.nouter - 1 - k)) & 1;
                         const double y = s_cy[k][hh];
@@ -607,7 +610,7 @@ __device__ __forceinline__ void scatter_halo(const ShellParams &P, const int64_t
     const int ncorner = 1 << T.nouter;
     for (int c = lane; c < ncorner; c += G) {
         double w = 1.0;
-        int64_t off = j * T.hstride;
+        int64_t off = j * (int64_t)T.hstride;
         for (int k = 0; k < T.nouter; ++k) {
             int bit = (c >> (T.nouter - 1 - k)) & 1;
             double y = P.cw[k * cap + j];
@@ -885,10 +888,12 @@ static_assert(sizeof(RgRow) == 64, "RgRow is four 16-byte pieces");
 #ifndef BFG_RG_WAVES
 #define BFG_RG_WAVES 3
 #endif
+// IdxT: the type of the slow list's entries -- int32_t while 12 NSIDE^2 < 2^31 (NSIDE <= 8192: 4 B per pixel of list instead of 8)
+template <typename IdxT>
 __global__ __launch_bounds__(256, BFG_RG_WAVES) void regrid_tile_kernel(Hpx hp, TileGeom geo, const double *__restrict__ off,
                                                           const double *__restrict__ in_map,
                                                           double *__restrict__ out_map, double *sums,
-                                                          int no_shortcut, int tile0, int64_t *__restrict__ slow_list,
+                                                          int no_shortcut, int tile0, IdxT *__restrict__ slow_list,
                                                           unsigned long long *slow_n)
 {
     __shared__ double acc[kRgRows * kRgWidth];
@@ -1060,7 +1065,16 @@ __global__ __launch_bounds__(256, BFG_RG_WAVES) void regrid_tile_kernel(Hpx hp, 
         // (healpix_cxx's get_interpol in full, one thread per pixel, global atomics): rare, and keeping that code out of THIS kernel is
         // what lets it run at 68 instead of 168 VGPRs -- five workgroups per CU (LDS-limited) instead of three wavefronts per SIMD:
         // 0.265 -> 0.183 ms at NSIDE 1024 (profiles/r04_regrid_split_ab.txt).
-        slow_list[atomicAdd(slow_n, 1ull)] = p;
+        // (the wavefront's lanes that get here reserve their slots together: one atomic per wavefront, not per pixel -- with
+        // BFG_REGRID=general, or a shell displaced by several pixels everywhere, every pixel comes this way)
+        {
+            const unsigned long long m = __ballot(1);
+            const int lane_ = tid & 63, leader = __ffsll((long long)m) - 1;
+            unsigned long long base = 0ull;
+            if (lane_ == leader) base = atomicAdd(slow_n, (unsigned long long)__popcll(m));
+            base = __shfl(base, leader, 64);
+            slow_list[base + (unsigned long long)__popcll(m & ((1ull << lane_) - 1ull))] = (IdxT)p;
+        }
     }
     __syncthreads();
     for (int i = tid; i < kRgRows * kRgWidth; i += 256) {
@@ -1087,7 +1101,8 @@ __global__ __launch_bounds__(256, BFG_RG_WAVES) void regrid_tile_kernel(Hpx hp, 
 // The pixels regrid_tile_kernel leaves aside (next to the poles, displaced by more than a few pixels, phi == 2 pi): healpix_cxx's
 // get_interpol in full, one thread per pixel of the list, global atomics -- the arithmetic of regrid_kernel.  band_rings > 0
 // (bfg_regrid_shell_bands): a deposit more than kRgHalo rings outside the source pixel's band is counted in *far.
-__global__ __launch_bounds__(256) void regrid_list_kernel(Hpx hp, const int64_t *__restrict__ list, const unsigned long long *n_ptr,
+template <typename IdxT>
+__global__ __launch_bounds__(256) void regrid_list_kernel(Hpx hp, const IdxT *__restrict__ list, const unsigned long long *n_ptr,
                                                           const double *__restrict__ off, const double *__restrict__ in_map,
                                                           double *__restrict__ out_map, double *sums, int band_rings, double *far)
 {
@@ -1095,7 +1110,7 @@ __global__ __launch_bounds__(256) void regrid_list_kernel(Hpx hp, const int64_t 
     double v_dep = 0.0;
     bool far_hit = false;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t p = list[e];
+        const int64_t p = (int64_t)list[e];
         const double val = in_map[p];
         int64_t ring, ip;
         pix2ring(hp, p, ring, ip);
@@ -1509,15 +1524,19 @@ int bfg_table_create(bfg_ctx *c, int ndim, const int64_t *shape, const double *c
     std::memset(&D, 0, sizeof(D));
     D.ndim = ndim; D.nouter = nouter; D.nr = (int)NR;
     D.log_values = (flags & BFG_TABLE_LOG_VALUES) ? 1 : 0;
+    t->d_blob = nullptr;
     if (nd) {
-        // the N-dimensional table proper (axes and permuted values on the device), and a DevTable that describes per-halo rows: no
-        // outer axes, the radial axis, `values` / `hstride` filled in per call
+        // the N-dimensional table proper (axes and permuted values on the device) ...
         std::vector<int64_t> oshape(nouter);
         std::vector<const double *> oaxes(nouter);
         for (int k = 0; k < nouter; ++k) { oshape[k] = shape[odim[k]]; oaxes[k] = axes[odim[k]]; }
-        t->d_blob = nullptr;
         rc = bfg_ndtable_create(c, nouter, oshape.data(), oaxes.data(), NR, axes[2], perm.data(), &t->nd);
         if (rc) { delete t; return rc; }
+    }
+    if (ndim > BFG_MAX_DIM) {
+        // ... and, where the kernels cannot read the table themselves, a DevTable that only describes per-halo rows: no outer axes,
+        // the radial axis, `values` filled in per call (a table of at most BFG_MAX_DIM dimensions that takes the row path in the
+        // shell calls keeps its directly readable form too: the grid and snapshot calls and bfg_table_eval use that one)
         D.nouter = 0;
         D.raxis = ndtable_raxis(t->nd);
         const double *r = axes[2];
@@ -1528,7 +1547,7 @@ int bfg_table_create(bfg_ctx *c, int ndim, const int64_t *shape, const double *c
         D.r_uniform = uni ? 1 : 0; D.r0 = r[0]; D.inv_dr = uni ? 1.0 / dr : 0.0;
         if (D.log_values)
             for (double v : perm) if (std::isfinite(v) && std::fabs(v) > 650.0) { D.hot = 1; break; }
-        D.hstride = NR;
+        D.hstride = (int)NR;
         *out = t;
         return BFG_OK;
     }
@@ -1537,7 +1556,9 @@ int bfg_table_create(bfg_ctx *c, int ndim, const int64_t *shape, const double *c
     for (int d = 0; d < ndim; ++d) n_axes += (size_t)shape[d];
     std::vector<double> blob(n_axes + (size_t)total);
     if (hipMalloc((void **)&t->d_blob, blob.size() * sizeof(double)) != hipSuccess) {
-        (void)hipGetLastError(); delete t; return BFG_ERR_NOMEM;
+        (void)hipGetLastError();
+        if (t->nd) (void)bfg_ndtable_destroy(c, t->nd);
+        delete t; return BFG_ERR_NOMEM;
     }
     size_t pos = 0;
     for (int k = 0; k < nouter; ++k) {
@@ -1562,6 +1583,7 @@ int bfg_table_create(bfg_ctx *c, int ndim, const int64_t *shape, const double *c
     if (hipMemcpyAsync(t->d_blob, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess) {
         g_last_error = std::string("bfg_table_create upload: ") + hipGetErrorString(hipGetLastError());
+        if (t->nd) (void)bfg_ndtable_destroy(c, t->nd);
         (void)hipFree(t->d_blob); delete t;
         return BFG_ERR_HIP;
     }
@@ -1588,7 +1610,7 @@ int bfg_table_eval(bfg_ctx *c, const bfg_table *t, int64_t npts, const double *c
     int rc = ctx_enter(c, dg_);
     if (rc) return rc;
     if (!t || !coords || !out || npts < 0) return BFG_ERR_INVALID;
-    if (t->nd) return BFG_ERR_UNSUPPORTED;          // (N-dimensional tables: bfg_ndtable_rows / bfg_ndtable_read)
+    if (!t->d_blob) return BFG_ERR_UNSUPPORTED;     // (more than BFG_MAX_DIM dimensions: bfg_ndtable_rows / bfg_ndtable_read)
     if (npts == 0) return BFG_OK;
     double *d_c = nullptr, *d_o = nullptr;
     size_t nb = (size_t)npts * t->dev.ndim * sizeof(double);
@@ -2329,16 +2351,19 @@ int bfg_offsets_add_displacements(bfg_ctx *c, const bfg_shell_args *a, const bfg
     return BFG_OK;
 }
 
-// the list of pixels the tile kernel leaves to regrid_list_kernel: one slot per pixel (every pixel could be one), grow-only
+// the list of pixels the tile kernel leaves to regrid_list_kernel: one slot per pixel (every pixel could be one), grow-only;
+// 4-byte entries while pixel indices fit (rg_slow_cap counts BYTES)
+static inline bool regrid_idx32(int64_t npix) { return npix < ((int64_t)1 << 31); }
 static int ensure_regrid_list(bfg_ctx *c, int64_t npix)
 {
     if (!c->d_rg_slow_n) HIP_TRY(hipMalloc((void **)&c->d_rg_slow_n, sizeof(unsigned long long)));
-    if (npix > c->rg_slow_cap) {
+    const int64_t want = npix * (int64_t)(regrid_idx32(npix) ? sizeof(int32_t) : sizeof(int64_t));
+    if (want > c->rg_slow_cap) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->d_rg_slow) (void)hipFree(c->d_rg_slow);
         c->d_rg_slow = nullptr; c->rg_slow_cap = 0;
-        HIP_TRY(hipMalloc((void **)&c->d_rg_slow, (size_t)npix * sizeof(int64_t)));
-        c->rg_slow_cap = npix;
+        HIP_TRY(hipMalloc((void **)&c->d_rg_slow, (size_t)want));
+        c->rg_slow_cap = want;
     }
     return BFG_OK;
 }
@@ -2373,11 +2398,18 @@ int bfg_regrid_shell(bfg_ctx *c, int64_t nside, const double *d_offsets, const d
     }
     timing_begin(c, 2);
     if (use_tiles) {
-        hipLaunchKernelGGL(regrid_tile_kernel, dim3((unsigned)c->tiles[kRegridSet].geo.ntiles), dim3(256), 0, c->stream, hp,
-                           c->tiles[kRegridSet].geo, d_offsets, d_in_map, d_out_map, d_sums, regrid_debug_mode(), 0,
-                           c->d_rg_slow, c->d_rg_slow_n);
-        hipLaunchKernelGGL(regrid_list_kernel, dim3((unsigned)(2 * c->n_cu)), dim3(256), 0, c->stream, hp, c->d_rg_slow, c->d_rg_slow_n,
-                           d_offsets, d_in_map, d_out_map, d_sums, 0, (double *)nullptr);
+        const dim3 tg((unsigned)c->tiles[kRegridSet].geo.ntiles), lg((unsigned)(2 * c->n_cu));
+        if (regrid_idx32(hp.npix)) {
+            hipLaunchKernelGGL(regrid_tile_kernel<int32_t>, tg, dim3(256), 0, c->stream, hp, c->tiles[kRegridSet].geo, d_offsets, d_in_map,
+                               d_out_map, d_sums, regrid_debug_mode(), 0, (int32_t *)c->d_rg_slow, c->d_rg_slow_n);
+            hipLaunchKernelGGL(regrid_list_kernel<int32_t>, lg, dim3(256), 0, c->stream, hp, (const int32_t *)c->d_rg_slow, c->d_rg_slow_n,
+                               d_offsets, d_in_map, d_out_map, d_sums, 0, (double *)nullptr);
+        } else {
+            hipLaunchKernelGGL(regrid_tile_kernel<int64_t>, tg, dim3(256), 0, c->stream, hp, c->tiles[kRegridSet].geo, d_offsets, d_in_map,
+                               d_out_map, d_sums, regrid_debug_mode(), 0, (int64_t *)c->d_rg_slow, c->d_rg_slow_n);
+            hipLaunchKernelGGL(regrid_list_kernel<int64_t>, lg, dim3(256), 0, c->stream, hp, (const int64_t *)c->d_rg_slow, c->d_rg_slow_n,
+                               d_offsets, d_in_map, d_out_map, d_sums, 0, (double *)nullptr);
+        }
     } else
         hipLaunchKernelGGL(regrid_kernel, dim3((unsigned)((hp.npix + 255) / 256)), dim3(256), 0, c->stream, hp,
                            d_offsets, d_in_map, d_out_map, d_sums);
@@ -2416,11 +2448,19 @@ int bfg_regrid_shell_bands(bfg_ctx *c, int64_t nside, const double *d_offsets, c
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(c->d_rg_slow_n, 0, sizeof(unsigned long long), c->stream));
     timing_begin(c, 2);
-    hipLaunchKernelGGL(regrid_tile_kernel, dim3((unsigned)(tile_hi - tile_lo)), dim3(256), 0, c->stream, hp,
-                       c->tiles[kRegridSet].geo, d_offsets, d_in_map, d_out_map, d_sums3, regrid_debug_mode(), tile_lo,
-                       c->d_rg_slow, c->d_rg_slow_n);
-    hipLaunchKernelGGL(regrid_list_kernel, dim3((unsigned)(2 * c->n_cu)), dim3(256), 0, c->stream, hp, c->d_rg_slow, c->d_rg_slow_n,
-                       d_offsets, d_in_map, d_out_map, d_sums3, kRegridTR, d_sums3 ? d_sums3 + 2 : (double *)nullptr);
+    const dim3 tg((unsigned)(tile_hi - tile_lo)), lg((unsigned)(2 * c->n_cu));
+    double *const far = d_sums3 ? d_sums3 + 2 : (double *)nullptr;
+    if (regrid_idx32(hp.npix)) {
+        hipLaunchKernelGGL(regrid_tile_kernel<int32_t>, tg, dim3(256), 0, c->stream, hp, c->tiles[kRegridSet].geo, d_offsets, d_in_map,
+                           d_out_map, d_sums3, regrid_debug_mode(), tile_lo, (int32_t *)c->d_rg_slow, c->d_rg_slow_n);
+        hipLaunchKernelGGL(regrid_list_kernel<int32_t>, lg, dim3(256), 0, c->stream, hp, (const int32_t *)c->d_rg_slow, c->d_rg_slow_n,
+                           d_offsets, d_in_map, d_out_map, d_sums3, kRegridTR, far);
+    } else {
+        hipLaunchKernelGGL(regrid_tile_kernel<int64_t>, tg, dim3(256), 0, c->stream, hp, c->tiles[kRegridSet].geo, d_offsets, d_in_map,
+                           d_out_map, d_sums3, regrid_debug_mode(), tile_lo, (int64_t *)c->d_rg_slow, c->d_rg_slow_n);
+        hipLaunchKernelGGL(regrid_list_kernel<int64_t>, lg, dim3(256), 0, c->stream, hp, (const int64_t *)c->d_rg_slow, c->d_rg_slow_n,
+                           d_offsets, d_in_map, d_out_map, d_sums3, kRegridTR, far);
+    }
     HIP_TRY(hipGetLastError());
     timing_end(c, 2);
     return BFG_OK;
@@ -2477,7 +2517,7 @@ int bfg_baryonify_snapshot_strided(bfg_ctx *c, const bfg_snapshot_args *a, const
     if (!a || !t || (!d_out && a->n_part > 0) || (a->ndim != 2 && a->ndim != 3) || a->n_part < 0 || a->n_halo < 0 || !(a->L > 0) ||
         !(a->a > 0) || a->n_part >= (1ll << 31) || a->n_extra < 0 || a->halo_stride < 5 + a->n_extra)
         return BFG_ERR_INVALID;
-    if (t->nd) return BFG_ERR_UNSUPPORTED;          // (more p_keys axes than the kernels read: shell runners only)
+    if (!t->d_blob) return BFG_ERR_UNSUPPORTED;     // (more p_keys axes than the kernels read: shell runners only)
     if (t->dev.ndim != 3 + a->n_extra || t->dev.log_values) return BFG_ERR_INVALID;       // linear displacement table
     if ((a->n_part > 0 && !a->d_part) || (a->n_halo > 0 && !a->d_halo)) return BFG_ERR_INVALID;
     if (a->n_part == 0) return BFG_OK;
@@ -2589,7 +2629,7 @@ static int run_grid(bfg_ctx *c, const bfg_grid_args *a, const bfg_table *t, doub
     if (!a || !t || !d_out || (a->ndim != 2 && a->ndim != 3) || a->n_halo < 0 || a->npix < 4 || !(a->a > 0) ||
         a->n_extra < 0 || a->halo_stride < 5 + a->n_extra || !a->d_bins)
         return BFG_ERR_INVALID;
-    if (t->nd) return BFG_ERR_UNSUPPORTED;          // (more p_keys axes than the kernels read: shell runners only)
+    if (!t->d_blob) return BFG_ERR_UNSUPPORTED;     // (more p_keys axes than the kernels read: shell runners only)
     if (t->dev.ndim != 3 + a->n_extra) return BFG_ERR_INVALID;
     if ((mode == MODE_PAINT) != (t->dev.log_values != 0)) return BFG_ERR_INVALID;          // paint: ln T; baryonify: linear d
     if (a->n_halo == 0) return BFG_OK;

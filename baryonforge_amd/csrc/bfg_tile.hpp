@@ -126,11 +126,13 @@ __device__ inline double halo_cell_weight(const HaloTile *ht, const double *cw, 
 }
 
 // Nodes i, i + 1 of the blended row of halo j straight from the table, corners in index order (the arithmetic of halo_row_kernel)
+// ONLY2: the caller knows the table is 3-D (the BLEND instantiation of the tile kernel): the general corner loop is not compiled in
+template <bool ONLY2 = false>
 __device__ inline void halo_row_pair(const DevTable &T, const HaloTile *ht, const int32_t *cidx, const double *cw, int64_t cap,
                                      int64_t j, int i, double &c0v, double &c1v)
 {
     c0v = 0.0; c1v = 0.0;
-    if (T.nouter == 2) {
+    if (ONLY2 || T.nouter == 2) {
         const HaloTile &h = ht[j];
         const double y0 = h.spare[1], y1 = h.spare[2];
         const double *r0 = T.values + (int64_t)h.ci0 * T.ostride[0] + (int64_t)h.ci1 * T.ostride[1] + i;
@@ -142,17 +144,19 @@ __device__ inline void halo_row_pair(const DevTable &T, const HaloTile *ht, cons
         c1v = fma(b3, w3, fma(b2, w2, fma(b1, w1, fma(b0, w0, 0.0))));
         return;
     }
-    const int ncorner = 1 << T.nouter;
-    for (int c = 0; c < ncorner; ++c) {
-        double w = 1.0; int64_t off = j * T.hstride;
-        for (int k = 0; k < T.nouter; ++k) {
-            const int bit = (c >> (T.nouter - 1 - k)) & 1;
-            const double y = cw[k * cap + j];
-            w = w * (bit ? y : 1.0 - y);
-            off += (int64_t)(cidx[k * cap + j] + bit) * T.ostride[k];
+    if constexpr (!ONLY2) {
+        const int ncorner = 1 << T.nouter;
+        for (int c = 0; c < ncorner; ++c) {
+            double w = 1.0; int64_t off = j * (int64_t)T.hstride;
+            for (int k = 0; k < T.nouter; ++k) {
+                const int bit = (c >> (T.nouter - 1 - k)) & 1;
+                const double y = cw[k * cap + j];
+                w = w * (bit ? y : 1.0 - y);
+                off += (int64_t)(cidx[k * cap + j] + bit) * T.ostride[k];
+            }
+            c0v = fma(T.values[off + i], w, c0v);
+            c1v = fma(T.values[off + i + 1], w, c1v);
         }
-        c0v = fma(T.values[off + i], w, c0v);
-        c1v = fma(T.values[off + i + 1], w, c1v);
     }
 }
 
@@ -696,7 +700,7 @@ __global__ __launch_bounds__(256) void halo_row_kernel(const RowParams P)
         if (e == 0) { s_winlo[hl] = P.ht[j].win_lo; s_add[hl] = T.log_values ? P.ht[j].spare[0] : 0.0; }
         for (int c = e; c < ncorner; c += W) {
             double w = 1.0;
-            int64_t off = j * T.hstride;
+            int64_t off = j * (int64_t)T.hstride;
             for (int k = 0; k < T.nouter; ++k) {
                 const int bit = (c >> (T.nouter - 1 - k)) & 1;
                 const double y = halo_cell_weight(P.ht, P.cw, P.cap, T.nouter, j, k);
@@ -771,7 +775,7 @@ __global__ __launch_bounds__(256) void halo_row4_kernel(const RowParams P)
         if (q == 0) { s_winlo[hl] = P.ht[j].win_lo; s_add[hl] = T.log_values ? P.ht[j].spare[0] : 0.0; }
         for (int c = q; c < ncorner; c += tph) {
             double w = 1.0;
-            int64_t off = j * T.hstride;
+            int64_t off = j * (int64_t)T.hstride;
             for (int k = 0; k < T.nouter; ++k) {
                 const int bit = (c >> (T.nouter - 1 - k)) & 1;
                 const double y = halo_cell_weight(P.ht, P.cw, P.cap, T.nouter, j, k);
@@ -795,6 +799,7 @@ __global__ __launch_bounds__(256) void halo_row4_kernel(const RowParams P)
 
 // One deferred pixel: blend the halo's corner rows directly from the table (same corner order and arithmetic as
 // halo_row_kernel / the in-kernel drain) and add exp(.) to the map.  Several halos can leave the same pixel: an atomic.
+template <bool ONLY2 = false>
 __device__ inline void deferred_add(const TileParams &P, const DeferredOut &e, const double *__restrict__ exptab)
 {
     const DevTable &T = P.tab;
@@ -803,7 +808,7 @@ __device__ inline void deferred_add(const TileParams &P, const DeferredOut &e, c
     const double f = e.t - (double)i;
     const double lnpf = P.ht[j].spare[0];
     double c0v, c1v;
-    halo_row_pair(T, P.ht, P.cidx, P.cw, P.cap, j, i, c0v, c1v);
+    halo_row_pair<ONLY2>(T, P.ht, P.cidx, P.cw, P.cap, j, i, c0v, c1v);
     const double L = fma(f, c1v - c0v, c0v) + lnpf;
     if (fabs(L) < 709.0) unsafeAtomicAdd(P.out + e.pix, fast_exp(L, exptab));
 }
@@ -1319,7 +1324,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         const int i = min(max((int)t, 0), NRm1 - 1);
         const double f = t - (double)i;
         double c0v, c1v;
-        halo_row_pair(T, P.ht, P.cidx, P.cw, P.cap, j, i, c0v, c1v);
+        halo_row_pair<BLEND>(T, P.ht, P.cidx, P.cw, P.cap, j, i, c0v, c1v);
         return fma(f, c1v - c0v, c0v);
     };
     auto direct_row = [&](int pidx, double t) -> double {
@@ -1647,7 +1652,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                 int64_t *con = reinterpret_cast<int64_t *>(cwn + ncorner);
                 for (int c = 0; c < ncorner; ++c) {                        // corner order and products of halo_row_kernel
                     double w = 1.0;
-                    int64_t off = j * T.hstride;
+                    int64_t off = j * (int64_t)T.hstride;
                     for (int k = 0; k < T.nouter; ++k) {
                         const int bit = (c >> (T.nouter - 1 - k)) & 1;
                         const double y = halo_cell_weight(P.ht, P.cw, P.cap, T.nouter, j, k);
@@ -2060,7 +2065,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                 for (int i = tid; i < dfill; i += NT) {
                     DeferredOut e;
                     e.pix = slice[i].pix; e.t = slice[i].t; e.halo = slice[i].halo;
-                    deferred_add(P, e, exptab);
+                    deferred_add<BLEND>(P, e, exptab);
                 }
             } else if (tid == 0) P.defer_count[blockIdx.x] = dfill;
         }

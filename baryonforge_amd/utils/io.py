@@ -97,9 +97,17 @@ class HaloLightConeCatalog(object):
         """a cheap content stamp of `cat`: its size and the bytes of ~256 records spread over it.  Writes through a view taken BEFORE
         the array was locked stay possible (numpy cannot revoke them); a bulk edit through such a view -- m = Cat.cat['M'] before the
         first process(), m *= 2 after it -- changes every record and so this stamp, and the device copy is refreshed.  An edit of a
-        single element through such a view is not detectable short of re-reading all 32 B per halo on every call: unlock() (or
-        BFG_CATALOG_CACHE=0) is the documented way to edit a catalog between calls."""
+        single element through such a view is not detectable short of re-reading all 32 B per halo on every call: invalidate() /
+        unlock() (or BFG_CATALOG_CACHE=0: upload on every call; BFG_CATALOG_CACHE=full: a checksum of every byte on every call) is
+        the documented way to edit a catalog between calls."""
+        import os
         cat = self.cat
+        if os.environ.get("BFG_CATALOG_CACHE", "1") == "full":
+            # every byte, every call: a wrapping sum and an xor over the records as 8-byte words (~2 ms per 1e6 halos on one core --
+            # more than the painting itself takes on the GPU, which is why it is not the default); catches single-element edits too
+            words = np.ascontiguousarray(cat).view(np.uint8).reshape(-1)
+            words = words[:words.size - words.size % 8].view(np.uint64)
+            return (cat.size, cat.dtype.str, int(np.add.reduce(words, dtype=np.uint64)), int(np.bitwise_xor.reduce(words)))
         step = max(1, cat.size // 256)
         sample = np.ascontiguousarray(cat[::step])
         return (cat.size, cat.dtype.str, sample.tobytes())
@@ -144,6 +152,11 @@ class HaloLightConeCatalog(object):
         self.__dict__.pop("_device_copies", None)
         self.__dict__.pop("_zmax", None)
         self.cat.setflags(write=True)
+
+    def invalidate(self):
+        """tell the container that `cat` was (or is about to be) edited in place: the device copy and the cached max(z) are dropped
+        and the array is writable again; the next process() call uploads the catalog afresh (= unlock())"""
+        self.unlock()
 
     def __getstate__(self):                                              # device tensors do not travel
         st = dict(self.__dict__)

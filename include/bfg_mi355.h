@@ -99,7 +99,9 @@ int bfg_dev_memset_zero(bfg_ctx *ctx, void *d_ptr, size_t bytes);               
  *   halo's radial row is blended first (the non-radial coordinates of a query are the
  *   halo's), then the same shell kernels run on the rows, in batches of halos whose rows
  *   stay under BFG_ND_ROW_BYTES (environment, default 4 GiB); bfg_table_eval and the grid /
- *   snapshot calls return BFG_ERR_UNSUPPORTED for such a table.                    */
+ *   snapshot calls return BFG_ERR_UNSUPPORTED for such a table.  (The shell calls take the
+ *   same row path for a 6-dimensional displacement table, where it is the faster of the
+ *   two; such a table keeps its directly readable form for every other call.)      */
 #define BFG_TABLE_LOG_VALUES 1u
 int bfg_table_create(bfg_ctx *ctx, int ndim, const int64_t *shape, const double *const *axes,
                      const double *values, uint32_t flags, bfg_table **out);

@@ -1760,6 +1760,33 @@ def test_catalog_device_copy_is_locked_not_stale(cosmo):
     assert Cat2.z_max() == pytest.approx(float(np.max(z + 0.02)), rel=1e-15)
     ref, _ = oracle_paint(cosmo, ra, dec, 3 * M, z + 0.02, (zax, Max, rax), T, 64, 10)
     assert_maps_close(R2.process(), ref, RTOL, what="after a bulk edit through an older view")
+    # a SINGLE element poked through such a view: invisible to the sampled stamp (documented) -- invalidate() is the way to say so,
+    # and BFG_CATALOG_CACHE=full (a checksum of every byte per call) notices by itself
+    m_view[1] *= 2.0                                          # (record 1 is not one of the ~256 sampled records of 400? it may be: use both paths)
+    M2 = 3 * M
+    M2[1] *= 2.0
+    ref, _ = oracle_paint(cosmo, ra, dec, M2, z + 0.02, (zax, Max, rax), T, 64, 10)
+    Cat2.invalidate()
+    assert Cat2.cat.flags.writeable
+    assert_maps_close(R2.process(), ref, RTOL, what="after invalidate()")
+
+
+def test_catalog_full_checksum_notices_a_single_element_edit(cosmo, monkeypatch):
+    """BFG_CATALOG_CACHE=full: the content stamp covers every byte of the catalog, so one element poked through a view taken before
+    the lock refreshes the device copy (the default stamp samples ~256 records: documented, utils/io.py)"""
+    monkeypatch.setenv("BFG_CATALOG_CACHE", "full")
+    ra, dec, M, z = syn.catalog(3000, seed=6)                 # 3000 records: the sampled stamp would look at every 11th
+    zax, Max, rax, T = syn.pressure_table()
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    m_view = Cat.cat["M"]
+    R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * 64 * 64), cosmo=cosmo), 10,
+                               _paint_model(zax, Max, rax, T), verbose=False)
+    R.process()
+    m_view[5] *= 4.0                                          # record 5 is not sampled (step 11)
+    M2 = M.copy()
+    M2[5] *= 4.0
+    ref, _ = oracle_paint(cosmo, ra, dec, M2, z, (zax, Max, rax), T, 64, 10)
+    assert_maps_close(R.process(), ref, RTOL, what="single-element edit under BFG_CATALOG_CACHE=full")
 
 
 # --------------------------------------------------------------------------- a8 pin at the BASELINE resolutions
