@@ -819,7 +819,7 @@ def run_config(args, torch, dist, rank, local_rank, world, backend, main=True):
     dt = timed(args.steps)
     _mark("timed region done")
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         if backend == "nccl":
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         else:

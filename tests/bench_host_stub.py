@@ -1,0 +1,144 @@
+"""
+Test infrastructure: one rank of `bench.py --gpus N` WITHOUT a GPU.  The rank imports bench.py unchanged and replaces what sits
+below it by host stand-ins -- torch.cuda's front (is_available, device_count, ...), engine.get_context (a context whose paint /
+offsets / regrid calls are the CPU oracle's) and Parallelize._DeviceOps (tests/host_ops.py) -- so that the launcher, the process
+group, the sharding, the product API's exchange paths, the extra legs and the JSON line of an N-rank run are exercised under gloo
+on any machine (tests/test_bench_launcher.py: 8 ranks).  Timings are meaningless here; the line's structure is the point.
+Never imported by the product or by bench.py.
+"""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
+
+torch.cuda.is_available = lambda: True
+torch.cuda.device_count = lambda: int(os.environ.get("WORLD_SIZE", "1"))
+torch.cuda.set_device = lambda i: None
+torch.cuda.synchronize = lambda *a, **k: None
+torch.cuda.get_device_name = lambda *a, **k: "host stand-in"
+torch.cuda.current_device = lambda: 0
+torch.cuda.empty_cache = lambda: None
+
+import baryonforge_amd as bfg                                   # noqa: E402,F401
+from baryonforge_amd import engine, synthetic as syn           # noqa: E402
+from baryonforge_amd.utils import Parallelize                  # noqa: E402
+from host_ops import OraclePaintOps                            # noqa: E402
+from oracle import oracle as orc                               # noqa: E402
+import bench                                                   # noqa: E402
+
+COSMO = dict(syn.COSMO)
+
+
+def oracle_paint(nside, M, z, ra, dec, eps, axes, lnT):
+    if M.size == 0:
+        return np.zeros(12 * nside * nside), 0
+    a, R, D = orc.halo_scalars(COSMO, M, z)
+    return orc.paint_shell(nside, ra, dec, M, a, D, R, axes, lnT, eps)
+
+
+class FakeTable(object):
+    def __init__(self, axes, values, log_values):
+        self.axes, self.values, self.log_values = [np.asarray(a) for a in axes], np.asarray(values() if callable(values) else values), log_values
+
+
+class FakeCtx(object):
+    """what bench.py asks of engine.Context, computed by the oracle on torch CPU tensors"""
+    lib, comm_world, device, device_index = None, 1, torch.device("cpu"), 0
+
+    def __init__(self):
+        self.px, self.calls = 0, 0
+
+    def to_device(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64))
+
+    def da_spline(self, bg, z_max):
+        return ("spline", z_max)
+
+    def massdef_struct(self, bg, md):
+        return None
+
+    def zeros(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float64)
+
+    empty = zeros
+
+    def table(self, axes, values, log_values, cache_key=None):
+        return FakeTable(axes, values, log_values)
+
+    def shell_args(self, nside, d_cat, n_halo, cat_stride, n_extra, eps, md, **kw):
+        return dict(nside=nside, cat=d_cat, n=n_halo, eps=eps)
+
+    def paint_shell(self, a, table, spline, d_map, slices=1, on_slice=None):
+        c = a["cat"].numpy()[:a["n"]]
+        m, ptot = oracle_paint(a["nside"], c[:, 0], c[:, 1], c[:, 2], c[:, 3], a["eps"], table.axes, table.values)
+        d_map.copy_(torch.from_numpy(m))
+        self.px += int(ptot)
+        self.calls += 1
+
+    def baryonify_offsets(self, a, table, spline, d_off, slices=1, on_slice=None):
+        c = a["cat"].numpy()[:a["n"]]
+        M, z, ra, dec = c[:, 0], c[:, 1], c[:, 2], c[:, 3]
+        if M.size:
+            sa, R, D = orc.halo_scalars(COSMO, M, z)
+            off, ptot = orc.baryonify_offsets(a["nside"], ra, dec, M, sa, D, R, R / sa, table.axes, table.values, a["eps"], 20.0, False, None)
+            d_off.copy_(torch.from_numpy(off))
+            self.px += int(ptot)
+        else:
+            d_off.zero_()
+        self.calls += 1
+
+    def regrid_shell(self, nside, d_off, d_in, d_map, d_sums):
+        d_map += torch.from_numpy(orc.regrid_shell(nside, d_off.numpy(), d_in.numpy()))
+
+    def stats_reset(self):
+        self.px = 0
+
+    def stats(self):
+        return {"pixel_updates": self.px, "fallback_halos": 0, "warn_mask": 0, "halos_out_of_table": 0, "pixels_out_of_table": 0}
+
+    def timing_enable(self, on=True, which=None):
+        self.calls = 0
+
+    def timing_read(self, which):
+        return (1.0e-3 * max(self.calls, 1), max(self.calls, 1)) if which in (0, 1, 2) else (0.0, 0)
+
+
+CTX = FakeCtx()
+engine.get_context = lambda *a, **k: CTX
+
+
+class StubOps(OraclePaintOps):
+    """the device side of SplitJoinParallel (Parallelize._DeviceOps) on the oracle; collect() leaves the counters where bench.py reads them"""
+
+    def __init__(self):
+        self.ptot = 0
+        zax, Max, rax, T = syn.pressure_table()
+        lnT = np.log(T)
+
+        def paint_fn(runner):
+            c = runner.HaloLightConeCatalog.cat
+            m, p = oracle_paint(runner.LightconeShell.NSIDE, c["M"], c["z"], c["ra"], c["dec"], runner.epsilon_max, (zax, Max, rax), lnT)
+            self.ptot += int(p)
+            return m
+        super().__init__(paint_fn)
+
+    def reset_stats(self):
+        self.ptot = 0
+
+    def collect(self, runners):
+        for R in runners:
+            R.last_stats = {"pixel_updates": self.ptot, "fallback_halos": 0}
+        return super().collect(runners)
+
+
+Parallelize._DeviceOps = StubOps
+# the legs at rehearsal size (BASELINE configs[3] is 1.25e6 halos per GPU at NSIDE 2048: hours for the serial oracle)
+bench.LEG_ARGS["configs3"] = dict(bench.LEG_ARGS["configs3"], nside=32, halos=60)
+
+if __name__ == "__main__":
+    bench.main()

@@ -148,3 +148,33 @@ def test_the_line_is_printed_once_when_the_legs_deadline_races_the_main_thread(t
         lines = [ln for ln in pr.stdout.splitlines() if ln.strip()]
         assert len(lines) == 1, pr.stdout + pr.stderr
         assert "legs" in json.loads(lines[0])
+
+
+def test_eight_ranks_rehearsal_on_cpu_prints_the_strong_scaling_line_with_all_legs():
+    """`bench.py --gpus 8` as the driver runs it, rehearsed without a GPU: the launcher's eight ranks (tests/bench_host_stub.py: bench.py
+    unchanged, the device side replaced by the CPU oracle) form a gloo group, shard a small catalog, run the product API's sliced
+    all-reduce path, then the weak / owner / configs3 legs -- and rank 0 prints ONE line with `ranks` of length 8, `vs_n1` and the
+    three legs.  The maps themselves are checked in tests/test_distributed_cpu.py; here the point is that every N-rank code path of
+    bench.py runs to its end."""
+    import bench
+    out, err = io.StringIO(), io.StringIO()
+    env = {"BFG_BENCH_BACKEND": "gloo", "BFG_BENCH_ONE_DEVICE": "1", "BFG_BENCH_RAMP_S": "0", "BFG_BENCH_DEADLINE_S": "500",
+           "BFG_BENCH_LEGS_DEADLINE_S": "300", "OMP_NUM_THREADS": "1"}
+    rc = bench.spawn_ranks(8, ["--gpus", "8", "--steps", "2", "--warmup", "1", "--halos", "480", "--nside", "32", "--slices", "3",
+                               "--legs", "weak,owner,configs3"],
+                           script=os.path.join(REPO, "tests", "bench_host_stub.py"), extra_env=env, deadline=560, out=out, err=err)
+    assert rc == 0, err.getvalue()[-2000:]
+    lines = [ln for ln in out.getvalue().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.getvalue()
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["scaling"] == "strong" and r["metric"] == "halos_per_s" and r["value"] > 0
+    assert len(r["ranks"]) == 8 and sorted(x["rank"] for x in r["ranks"]) == list(range(8))
+    assert sum(x["shard_halos"] for x in r["ranks"]) == 480
+    assert r["vs_n1"] is not None and r["n1"]["halos"] == 480
+    assert r["rccl_ranks"] == 0 and r["backend"] == "gloo"            # a rehearsal: RCCL took no part
+    assert set(r["legs"]) == {"weak", "owner", "configs3"}
+    for name, leg in r["legs"].items():
+        assert "error" not in leg and leg["value"] > 0 and len(leg["ranks"]) == 8, (name, leg)
+    assert r["legs"]["weak"]["scaling"] == "weak" and r["legs"]["weak"]["halos_total"] == 8 * 480
+    assert "owner-computes" in r["legs"]["owner"]["exchange"]["mode"]
+    assert r["legs"]["configs3"]["workload"].startswith("BaryonifyShell")
