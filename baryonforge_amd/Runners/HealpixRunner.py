@@ -632,6 +632,15 @@ def _baryonify_pipelined(runners, in_flight=2):
         else:
             cuts_b, cuts_p = None, [0, npix]
         S = len(cuts_p) - 1
+        # A page-locked input map (LightconeShell(pinned=True), engine.pin / pinned_empty) goes up as asynchronous DMA slices that
+        # never block the host thread; its result then comes down by DMA as well -- measured on the single-shell path (tools/
+        # bary_timeline_probe.py, eight slices): 3.17 ms with both directions on the DMA engines, 3.40 ms with the download as a copy
+        # kernel (whose stores slow the upload's slices from 0.29 to 0.40 ms each).  A pageable map keeps the copy kernel.
+        h_src = torch.from_numpy(flat)
+        src_pinned = h_src.is_pinned()
+        down_by_kernel = not src_pinned
+        if os.environ.get("BFG_BARY_DOWN"):
+            down_by_kernel = os.environ["BFG_BARY_DOWN"] == "kernel"
         with torch.cuda.stream(up):
             d_orig = torch.empty(npix, dtype=torch.float64, device=dev)
         d_orig.record_stream(main)
@@ -639,7 +648,7 @@ def _baryonify_pipelined(runners, in_flight=2):
         def send(lo, hi):                                                 # d_out[lo:hi] -> h[lo:hi] on the download stream
             if hi <= lo:
                 return
-            if h.is_pinned() and (n > 1 or S > 1):
+            if h.is_pinned() and (n > 1 or S > 1) and down_by_kernel:
                 # a copy KERNEL, not the DMA engine: an upload is (or will be) running as a DMA copy, and two DMA copies in opposite
                 # directions take turns on this platform (tools/copy_probe.py: 3.7 ms for the pair, 2.3 ms with the kernel)
                 ctx.copy_to_pinned(h[lo:hi], d_out[lo:hi])
@@ -649,7 +658,7 @@ def _baryonify_pipelined(runners, in_flight=2):
         for sl in range(S):
             lo, hi = cuts_p[sl], cuts_p[sl + 1]
             with torch.cuda.stream(up):
-                d_orig[lo:hi].copy_(torch.from_numpy(flat[lo:hi]), non_blocking=True)
+                d_orig[lo:hi].copy_(h_src[lo:hi], non_blocking=True)
                 ev_up = torch.cuda.Event()
                 ev_up.record(up)
             main.wait_event(ev_up)

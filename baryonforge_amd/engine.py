@@ -563,6 +563,52 @@ def pinned_empty(n):
     return require_gpu().empty(int(n), dtype=_torch().float64, pin_memory=True).numpy()
 
 
+_registered = {}      # data address -> (bytes, the array: kept alive while its pages are locked)
+
+
+def pin(array):
+    """Page-lock the memory of a C-contiguous numpy array IN PLACE (hipHostRegister) and return it: host <-> device copies of it
+    then run asynchronously at PCIe speed instead of through the runtime's staging buffers, which is what lets
+    BaryonifyShell.process() send a shell's map up in slices behind the kernels.  Registering costs about as much as one copy of
+    the array, so it pays for maps that are used more than once (or allocate them with pinned_empty() / pinned_copy() in the first
+    place).  unpin(array) releases the pages; the registry keeps the array alive until then."""
+    torch = require_gpu()
+    a = array
+    if not (isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"] and a.nbytes > 0):
+        raise ValueError("pin() needs a non-empty C-contiguous numpy array")
+    ptr = a.ctypes.data
+    if ptr in _registered or torch.from_numpy(a.reshape(-1).view(np.uint8)).is_pinned():
+        return array
+    rc = torch.cuda.cudart().cudaHostRegister(ptr, a.nbytes, 0)
+    if int(rc) != 0:
+        raise _lib.BFGError(f"hipHostRegister of {a.nbytes} bytes failed (error {int(rc)})")
+    _registered[ptr] = (a.nbytes, a)
+    return array
+
+
+def unpin(array):
+    """release the pages pin() locked (no-op for arrays it did not register)"""
+    ent = _registered.pop(array.ctypes.data, None)
+    if ent is not None:
+        _torch().cuda.cudart().cudaHostUnregister(array.ctypes.data)
+
+
+def pinned_copy(array):
+    """a float64 copy of `array` (same shape) in page-locked host memory"""
+    a = np.asarray(array, dtype=np.float64)
+    out = pinned_empty(a.size).reshape(a.shape)
+    out[...] = a
+    return out
+
+
+def is_pinned(array):
+    """True if host <-> device copies of this numpy array can run asynchronously (page-locked memory)"""
+    try:
+        return bool(_torch().from_numpy(np.ascontiguousarray(array).reshape(-1)).is_pinned())
+    except Exception:
+        return False
+
+
 def get_context(device=None):
     """The process-wide Context of a GPU (default: torch's current device)."""
     torch = require_gpu()

@@ -1923,3 +1923,35 @@ def test_baryonify_list_on_one_gpu_overlaps_transfers_and_equals_the_plain_path(
         assert np.isclose(outs[k].sum(), runners[k].LightconeShell.map.sum(), rtol=1e-12)
     assert_maps_close(single, plain[2], 1e-9, floor=BFLOOR, what="single process()")
     assert runners[0].last_stats["pixel_updates"] > 0
+
+
+def test_page_locked_shell_maps_give_the_same_result(cosmo):
+    """LightconeShell(pinned=True) page-locks the map in place (engine.pin -> hipHostRegister), pinned="copy" replaces it by a
+    page-locked copy: BaryonifyShell.process() then moves the map asynchronously in slices -- same map as from
+    pageable memory (to the rounding of the regrid's atomics), mass conserved, and unpin() gives the pages back."""
+    from baryonforge_amd import engine
+    nside = 128
+    ra, dec, M, z = syn.catalog(3000, seed=12, logM=(13.0, 15.3))
+    zd, Md, rd, d = syn.displacement_table()
+    bm = bfg.Baryonification2D.from_arrays(zd, Md, rd, d, cosmo, epsilon_max=20)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
+    m_in = syn.mass_map(nside)
+    ref = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo), 10, bm, verbose=False).process()
+    for mode in (True, "copy"):
+        src = m_in.copy()
+        shell = bfg.LightconeShell(map=src, cosmo=cosmo, pinned=mode)
+        assert engine.is_pinned(shell.map) and (shell.map is src) == (mode is True)
+        got = bfg.BaryonifyShell(Cat, shell, 10, bm, verbose=False).process()
+        assert np.isclose(got.sum(), m_in.sum())
+        assert_maps_close(got, ref, 1e-9, floor=1e-12, what=f"pinned={mode!r} vs pageable")
+        assert np.array_equal(shell.map, m_in)                          # the input map is untouched
+        if mode is True:
+            engine.unpin(src)
+            assert not engine.is_pinned(src)
+    # paint into a caller's page-locked output
+    zax, Max, rax, T = syn.pressure_table()
+    Rp = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), 10, _paint_model(zax, Max, rax, T),
+                                verbose=False)
+    out = engine.pinned_empty(12 * nside * nside)
+    a, b = Rp.process(), Rp.process(out=out)
+    assert b.base is not None and np.shares_memory(b, out) and np.array_equal(a, b)
