@@ -254,7 +254,12 @@ __global__ __launch_bounds__(256) void snap_overlap_kernel(const SnapParams P, i
         lo[k] = a; cnt[k] = min(b - a + 1, n);                 // at most every cell once
     }
     const int64_t nbox = (int64_t)cnt[0] * cnt[1] * cnt[2];
-    if (nbox > kSnapBigCells) {
+    // A list entry carries the halo's IMAGE as the particles of that cell see it (centre shifted by a multiple of L, below), so the
+    // particle pass needs no periodic wrap per candidate.  That image is unique only while the sphere covers at most half the box
+    // along every axis; larger spheres go to the global list, whose test wraps (compute_distance / enforce_periodicity).
+    bool half_box = false;
+    for (int k = 0; k < NDIM; ++k) half_box = half_box || 2 * cnt[k] > n;
+    if (nbox > kSnapBigCells || half_box) {
         if (!fill) P.big[1 + atomicAdd(&P.big[0], 1)] = (int32_t)j;
         return;
     }
@@ -264,6 +269,7 @@ __global__ __launch_bounds__(256) void snap_overlap_kernel(const SnapParams P, i
         int ic[3];
         for (int k = NDIM - 1; k >= 0; --k) { ic[k] = lo[k] + (int)(rem % cnt[k]); rem /= cnt[k]; }
         double dmin2 = 0.0;
+        double shift[3] = {0.0, 0.0, 0.0};
         for (int k = 0; k < NDIM; ++k) {
             const double c0 = (double)ic[k] * cell, c1 = c0 + cell;
             double gap = 0.0;
@@ -273,6 +279,7 @@ __global__ __launch_bounds__(256) void snap_overlap_kernel(const SnapParams P, i
             dmin2 += gap * gap;
             int w = ic[k] % n; if (w < 0) w += n;
             cid = cid * n + w;
+            shift[k] = (double)((ic[k] - w) / n) * P.L;        // the unwrapped cell is the wrapped one + this many box lengths
         }
         if (dmin2 > rq2) continue;                             // the sphere cannot reach this cell
         if (!fill) atomicAdd(&P.cell_count[cid], 1);
@@ -280,7 +287,8 @@ __global__ __launch_bounds__(256) void snap_overlap_kernel(const SnapParams P, i
             const int64_t pos = (int64_t)P.cell_start[cid] + atomicAdd(&P.cell_count[cid], 1);
             if (pos < P.cand_cap) {
                 SnapCand e;
-                e.x = h.x; e.y = h.y; e.z = h.z; e.rq = h.rq; e.xcut = h.xcut; e.lnshift = h.lnshift;
+                e.x = h.x - shift[0]; e.y = h.y - shift[1]; e.z = h.z - shift[2];     // the image next to this cell
+                e.rq = h.rq; e.xcut = h.xcut; e.lnshift = h.lnshift;
                 e.halo = (int32_t)j; e.pad[0] = e.pad[1] = e.pad[2] = 0;
                 P.cand[pos] = e;
             }
@@ -379,6 +387,13 @@ __global__ __launch_bounds__(256) void snap_particle_kernel(const SnapParams P)
             }
             return d2 <= rq_ * rq_;
         };
+        // ... of a cell list: the entry is the halo's image next to this cell (snap_overlap_kernel), the separation needs no wrap
+        auto test_image = [&](double hx_, double hy_, double hz_, double rq_, double *dd, double &d2) -> bool {
+            const double hc[3] = {hx_, hy_, hz_};
+            d2 = 0.0;
+            for (int k = 0; k < NDIM; ++k) { const double dx = p[k] - hc[k]; dd[k] = dx; d2 += dx * dx; }
+            return d2 <= rq_ * rq_;
+        };
         const int c0 = P.cell_start[cid], c1 = (int)min((int64_t)P.cell_start[cid + 1], P.cand_cap);
         // two phases per batch of 64 candidates, so that the expensive read-out runs on the lanes' own hits only
         // (a lane hits ~2 of its ~8 candidates; done inline, every trip of the test loop would pay for the read-out
@@ -391,7 +406,7 @@ __global__ __launch_bounds__(256) void snap_particle_kernel(const SnapParams P)
                 for (int u = 0; u < 4; ++u) e[u] = *reinterpret_cast<const double4 *>(&P.cand[min(q + u, qe - 1)]);   // x, y, z, rq
                 for (int u = 0; u < 4; ++u) {
                     double dd[3], d2;
-                    if (test(e[u].x, e[u].y, e[u].z, e[u].w, dd, d2) && q + u < qe) mask |= 1ull << (q + u - qb);
+                    if (test_image(e[u].x, e[u].y, e[u].z, e[u].w, dd, d2) && q + u < qe) mask |= 1ull << (q + u - qb);
                 }
             }
             while (mask) {
@@ -399,7 +414,7 @@ __global__ __launch_bounds__(256) void snap_particle_kernel(const SnapParams P)
                 mask &= mask - 1;
                 const SnapCand e = P.cand[q];
                 double dd[3] = {0, 0, 0}, d2;
-                (void)test(e.x, e.y, e.z, e.rq, dd, d2);
+                (void)test_image(e.x, e.y, e.z, e.rq, dd, d2);
                 ++hits;
                 snap_hit(H, d2, dd, NDIM, e.halo, e.xcut, e.lnshift, off, n_oob);
             }
@@ -486,13 +501,15 @@ __global__ __launch_bounds__(256) void snap_cell_kernel(const SnapParams P)
             load_coords<NDIM>(P.part, ip, P.pstride, p);
             // one candidate against this lane's particle: periodic distance (compute_distance / enforce_periodicity,
             // :104-158; KDTree radius :225 / :240), then the read-out
-            auto visit = [&](double hx_, double hy_, double hz_, double rq_, double xcut_, double lnshift_, int j) {
+            auto visit = [&](double hx_, double hy_, double hz_, double rq_, double xcut_, double lnshift_, int j, bool wrap) {
                 const double hc[3] = {hx_, hy_, hz_};
                 double dd[3] = {0.0, 0.0, 0.0}, d2 = 0.0;
                 for (int k = 0; k < NDIM; ++k) {
                     double dx = p[k] - hc[k];
-                    dx = (dx > halfL) ? dx - L : dx;
-                    dx = (dx < -halfL) ? dx + L : dx;
+                    if (wrap) {                                // (list entries are images next to the cell: no wrap; uniform per call)
+                        dx = (dx > halfL) ? dx - L : dx;
+                        dx = (dx < -halfL) ? dx + L : dx;
+                    }
                     dd[k] = dx; d2 += dx * dx;
                 }
                 if (!valid || !(d2 <= rq_ * rq_)) return;
@@ -501,12 +518,12 @@ __global__ __launch_bounds__(256) void snap_cell_kernel(const SnapParams P)
             };
             for (int q = c0; q < c1; ++q) {                                                  // wave-uniform: scalar loads
                 const SnapCand &e = P.cand[q];
-                visit(e.x, e.y, e.z, e.rq, e.xcut, e.lnshift, e.halo);
+                visit(e.x, e.y, e.z, e.rq, e.xcut, e.lnshift, e.halo, false);
             }
             for (int q = 0; q < nbig; ++q) {
                 const int j = P.big[1 + q];
                 const SnapHalo &h = P.hs[j];
-                visit(h.x, h.y, h.z, h.rq, h.xcut, h.lnshift, j);
+                visit(h.x, h.y, h.z, h.rq, h.xcut, h.lnshift, j, true);
             }
             if (valid) {
                 double pn[3] = {0.0, 0.0, 0.0};
