@@ -48,7 +48,7 @@ SYMBOLS = [
     "bfg_ndtable_create", "bfg_ndtable_destroy", "bfg_ndtable_rows", "bfg_ndtable_read",
     "bfg_regrid_band_rings", "bfg_regrid_shell_bands",
 ]
-ABI_VERSION = 4
+ABI_VERSION = 5
 # bfg_slice_fn: int (*)(void *user, int slice, int n_slices, int64_t elem_begin, int64_t elem_end)
 SLICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64)
 BFG_COMM_ID_BYTES = 128

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BFG_ABI_VERSION 4
+#define BFG_ABI_VERSION 5
 
 typedef enum {
     BFG_OK = 0,
