@@ -188,3 +188,46 @@ def test_nd_table_on_the_tile_path_equals_the_3d_table_at_full_size(cosmo):
     assert RN.last_stats["fallback_halos"] == 0
     assert np.array_equal(got != 0, ref != 0)
     assert_maps_close(got, ref, 1e-11, what="4 degenerate p_keys axes vs the 3-D table")
+
+
+@pytest.mark.parametrize("batched", [False, True])
+def test_nd_table_sliced_calls_report_final_slices(cosmo, batched, monkeypatch):
+    """bfg_paint_shell_sliced / bfg_baryonify_offsets_sliced with a table of four p_keys axes: in one batch the slices are reported
+    as the tile kernel finishes them (each final when reported: it is copied out at once and must equal the unsliced result there); in
+    several batches of halos (rows capped by BFG_ND_ROW_BYTES) the same K ranges are reported after the last batch.  The slice
+    ranges are those of the 3-D call (a function of NSIDE and the slice count only), so ranks with different tables stay in step."""
+    import torch
+    nside, n, eps = 64, 500, 8.0
+    if batched:
+        monkeypatch.setenv("BFG_ND_ROW_BYTES", str(8 * 60 * 90))
+    ra, dec, M, z = syn.catalog(n, seed=21, logM=(13.0, 15.3))
+    rng = np.random.default_rng(3)
+    ax = [np.array([0.6, 1.0, 1.5]), np.array([-1.5, 0.0, 2.5]), np.array([5.0, 25.0]), np.array([-0.5, 0.5, 1.5])]
+    p = [rng.uniform(a[0], a[-1], n) for a in ax]
+    keys = ["pa", "pb", "pc", "pd"]
+    zax, Max, rax, T = syn.pressure_table(3, 8, 60)
+    fac = (1.0 + 0.3 * (ax[0] - 1.0))[:, None, None, None] * (1.0 + 0.05 * ax[1] ** 2)[None, :, None, None] * \
+        (ax[2] / 10.0)[None, None, :, None] * (1.0 + 0.2 * ax[3])[None, None, None, :]
+    TN = T[..., None, None, None, None] * fac[None, None, None]
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo, **dict(zip(keys, p)))
+    model = bfg.ParamTabulatedProfile.from_arrays(zax, Max, rax, TN, other_params=dict(zip(keys, ax)))
+    R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), eps, model, verbose=False)
+    whole = R.process_device().clone()
+    got, ranges = torch.full_like(whole, float("nan")), []
+
+    def on_slice(k, K, lo, hi):
+        ranges.append((k, K, lo, hi))
+        got[lo:hi] = d_map[lo:hi]                                         # enqueued behind the kernels of this slice
+    d_map = torch.full_like(whole, float("nan"))
+    R.process_device(d_map=d_map, overwrite=True, slices=4, on_slice=on_slice)
+    torch.cuda.synchronize()
+    assert [r[0] for r in ranges] == list(range(len(ranges))) and len(ranges) == ranges[0][1] == 4
+    assert ranges[0][2] == 0 and ranges[-1][3] == whole.numel() and all(a[3] == b[2] for a, b in zip(ranges, ranges[1:]))
+    assert torch.allclose(got, whole, rtol=1e-12, atol=0.0) and torch.equal(got != 0, whole != 0)
+    ref, ptot = oracle_paint_nd(cosmo, ra, dec, M, z, (zax, Max, rax, *ax), TN, nside, eps, np.stack(p, 1))
+    assert_maps_close(whole.cpu().numpy(), ref, 1e-9, what="4 extra axes, unsliced")
+
+
+def oracle_paint_nd(cosmo, ra, dec, M, z, axes, TN, nside, eps, extra):
+    from util import oracle_paint
+    return oracle_paint(cosmo, ra, dec, M, z, axes, TN, nside, eps, extra=extra)
