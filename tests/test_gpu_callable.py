@@ -231,3 +231,46 @@ def test_nd_table_sliced_calls_report_final_slices(cosmo, batched, monkeypatch):
 def oracle_paint_nd(cosmo, ra, dec, M, z, axes, TN, nside, eps, extra):
     from util import oracle_paint
     return oracle_paint(cosmo, ra, dec, M, z, axes, TN, nside, eps, extra=extra)
+
+
+@pytest.mark.parametrize("variant,nr", [("auto", 60), ("scatter_quarter", 60), ("scatter_wave", 60), ("auto", 700)])
+def test_nd_table_rows_through_every_kernel_variant(cosmo, variant, nr):
+    """the per-halo rows of a table with four p_keys axes (DevTable::hstride) are read by the tile kernel's window path, by the
+    scatter kernels (left-overs / scatter variants) and by the table-direct read-out of finely sampled radial axes (nr = 700: no row
+    windows, the pixel stage reads the halo's row itself): each against the oracle's N-linear loops, paint and offsets."""
+    nside, n, eps = 128, 400, 6.0
+    ra, dec, M, z = syn.catalog(n, seed=31, logM=(13.0, 15.3))
+    ra[:3], dec[:3] = [10.0, 200.0, 359.9], [89.7, -89.8, 0.0]           # both poles and the seam: left-overs of the tile variant
+    rng = np.random.default_rng(4)
+    ax = [np.array([0.6, 1.0, 1.5]), np.array([-1.5, 0.0, 2.5]), np.array([5.0, 25.0]), np.array([-0.5, 0.5, 1.5])]
+    p = [rng.uniform(a[0], a[-1], n) for a in ax]
+    p[2][:5] = 30.0                                                      # outside the third parameter axis: NaN rows
+    keys = ["pa", "pb", "pc", "pd"]
+    fac = (1.0 + 0.3 * (ax[0] - 1.0))[:, None, None, None] * (1.0 + 0.05 * ax[1] ** 2)[None, :, None, None] * \
+        (ax[2] / 10.0)[None, None, :, None] * (1.0 + 0.2 * ax[3])[None, None, None, :]
+    extra = np.stack(p, 1)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo, **dict(zip(keys, p)))
+    zax, Max, rax, T = syn.pressure_table(3, 8, nr)
+    TN = T[..., None, None, None, None] * fac[None, None, None]
+    ref, ptot = oracle_paint_nd(cosmo, ra, dec, M, z, (zax, Max, rax, *ax), TN, nside, eps, extra)
+    model = bfg.ParamTabulatedProfile.from_arrays(zax, Max, rax, TN, other_params=dict(zip(keys, ax)))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), eps, model, verbose=False,
+                                   variant=variant)
+        got = R.process()
+    assert R.last_stats["pixel_updates"] == ptot and np.array_equal(got != 0, ref != 0)
+    assert_maps_close(got, ref, 1e-9, what=f"paint, 4 extra axes, variant {variant}, nr {nr}")
+    if nr == 60:
+        from util import oracle_baryonify
+        zd, Md, rd, d = syn.displacement_table(3, 8, nr)
+        dN = d[..., None, None, None, None] * fac[None, None, None]
+        m_in = syn.mass_map(nside)
+        refb = oracle_baryonify(cosmo, ra, dec, M, z, (zd, Md, rd, *ax), dN, nside, eps, 20, m_in, extra=extra)
+        bm = bfg.Baryonification2D.from_arrays(zd, Md, rd, dN, cosmo, epsilon_max=20, other_params=dict(zip(keys, ax)))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            gotb = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo), eps, bm, verbose=False, variant=variant).process()
+        assert np.isclose(gotb.sum(), m_in.sum())
+        assert_maps_close(gotb, refb, 1e-5, floor=1e-9, what=f"baryonify, 4 extra axes, variant {variant}")
