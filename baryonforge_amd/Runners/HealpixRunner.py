@@ -685,6 +685,7 @@ def _baryonify_pipelined(runners, in_flight=2):
         pend.append((k, orig, h, h_small, ev, d_out))
     for item in pend:
         finish(item)
+    up.synchronize()                                                      # (idle by now) the runtime drops its page locks on the callers' maps
     if ran:
         stats = ran[0].collect_stats()                                    # one read-back for the whole list
         for R in ran[1:]:

@@ -579,6 +579,9 @@ def pin(array):
     ptr = a.ctypes.data
     if ptr in _registered or torch.from_numpy(a.reshape(-1).view(np.uint8)).is_pinned():
         return array
+    # drain the device first: the runtime page-locks the source of a large pageable copy in place and may still hold that lock (it
+    # lets go at the queue's next fence) -- a registration nested inside such a transient lock would share its GPU mapping
+    torch.cuda.synchronize()
     rc = torch.cuda.cudart().cudaHostRegister(ptr, a.nbytes, 0)
     if int(rc) != 0:
         raise _lib.BFGError(f"hipHostRegister of {a.nbytes} bytes failed (error {int(rc)})")
@@ -590,6 +593,7 @@ def unpin(array):
     """release the pages pin() locked (no-op for arrays it did not register)"""
     ent = _registered.pop(array.ctypes.data, None)
     if ent is not None:
+        _torch().cuda.synchronize()                  # no copy of ours may still be reading or writing these pages
         _torch().cuda.cudart().cudaHostUnregister(array.ctypes.data)
 
 
