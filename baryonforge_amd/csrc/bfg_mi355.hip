@@ -2561,7 +2561,7 @@ int bfg_baryonify_snapshot_strided(bfg_ctx *c, const bfg_snapshot_args *a, const
     HIP_TRY(hipMemsetAsync(P.big, 0, sizeof(int32_t), c->stream));
     HIP_TRY(hipMemsetAsync(P.cell_start, 0, (size_t)(P.ncell_tot + 1) * sizeof(int32_t), c->stream));
     if (a->n_halo > 0) {
-        const unsigned hgrid = (unsigned)((a->n_halo + 255) / 256);
+        const unsigned hgrid = (unsigned)((a->n_halo * kSnapOverlapLanes + 255) / 256);
         hipLaunchKernelGGL(snap_halo_kernel, dim3((unsigned)a->n_halo), dim3(64), 0, c->stream, P);
         if (a->ndim == 3) hipLaunchKernelGGL(snap_overlap_kernel<3>, dim3(hgrid), dim3(256), 0, c->stream, P, 0);
         else hipLaunchKernelGGL(snap_overlap_kernel<2>, dim3(hgrid), dim3(256), 0, c->stream, P, 0);

@@ -17,6 +17,7 @@
 namespace bfg {
 
 constexpr int kSnapBigCells = 4096;
+constexpr int kSnapOverlapLanes = 16;    // lanes that share one halo's bounding box in snap_overlap_kernel
 
 struct __align__(16) SnapHalo {      // per-halo constants (written by snap_halo_kernel)
     double x, y, z, rq;              // centre [comoving Mpc], query radius
@@ -240,7 +241,10 @@ __global__ __launch_bounds__(64) void snap_halo_kernel(const SnapParams P)
 template <int NDIM>
 __global__ __launch_bounds__(256) void snap_overlap_kernel(const SnapParams P, int fill)
 {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // kSnapOverlapLanes lanes per halo share the cells of its bounding box (one thread per halo: the lanes of a wavefront waited for
+    // the largest sphere among 64 -- 0.285 ms per pass at BASELINE configs[4], 250 cells per halo on average, up to 4096)
+    const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kSnapOverlapLanes;
+    const int sub = (int)(threadIdx.x % kSnapOverlapLanes);
     if (j >= P.n_halo) return;
     const SnapHalo h = P.hs[j];
     if ((h.flags & HF_OOB) || !(h.rq > 0.0)) return;           // NaN displacement everywhere -> 0 (:231 / :248)
@@ -260,11 +264,11 @@ __global__ __launch_bounds__(256) void snap_overlap_kernel(const SnapParams P, i
     bool half_box = false;
     for (int k = 0; k < NDIM; ++k) half_box = half_box || 2 * cnt[k] > n;
     if (nbox > kSnapBigCells || half_box) {
-        if (!fill) P.big[1 + atomicAdd(&P.big[0], 1)] = (int32_t)j;
+        if (!fill && sub == 0) P.big[1 + atomicAdd(&P.big[0], 1)] = (int32_t)j;
         return;
     }
     const double rq2 = h.rq * h.rq * (1.0 + 1e-12);
-    for (int64_t ci = 0; ci < nbox; ++ci) {
+    for (int64_t ci = sub; ci < nbox; ci += kSnapOverlapLanes) {
         int64_t rem = ci, cid = 0;
         int ic[3];
         for (int k = NDIM - 1; k >= 0; --k) { ic[k] = lo[k] + (int)(rem % cnt[k]); rem /= cnt[k]; }
@@ -401,10 +405,13 @@ __global__ __launch_bounds__(256) void snap_particle_kernel(const SnapParams P)
         for (int qb = c0; qb < c1; qb += 64) {
             const int qe = min(qb + 64, c1);
             unsigned long long mask = 0;
-            for (int q = qb; q < qe; q += 4) {                 // four independent record loads in flight per trip
-                double4 e[4];
-                for (int u = 0; u < 4; ++u) e[u] = *reinterpret_cast<const double4 *>(&P.cand[min(q + u, qe - 1)]);   // x, y, z, rq
-                for (int u = 0; u < 4; ++u) {
+            // three independent record loads in flight per trip (four: 87 VGPRs = five wavefronts per SIMD; three: 78 = six, and the
+            // sixth wavefront hides more than the fourth load did -- 5.05 -> 4.79 ms at BASELINE configs[4]; two: 4.87)
+            constexpr int U = 3;
+            for (int q = qb; q < qe; q += U) {
+                double4 e[U];
+                for (int u = 0; u < U; ++u) e[u] = *reinterpret_cast<const double4 *>(&P.cand[min(q + u, qe - 1)]);   // x, y, z, rq
+                for (int u = 0; u < U; ++u) {
                     double dd[3], d2;
                     if (test_image(e[u].x, e[u].y, e[u].z, e[u].w, dd, d2) && q + u < qe) mask |= 1ull << (q + u - qb);
                 }
