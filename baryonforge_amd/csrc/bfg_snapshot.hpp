@@ -756,7 +756,7 @@ __global__ __launch_bounds__(kDepThreads) void dep_tile_kernel(const DepSortPara
     for (int e = threadIdx.x; e < NE; e += kDepThreads) acc[e] = 0.0;
     __syncthreads();
     const double step = P.L / (double)P.N;
-    constexpr int U = 2;                                       // particles per thread and trip: independent gathers
+    constexpr int U = 2;                                       // particles per thread and trip: independent gathers (4: the same time)
     for (int64_t qb = q0 + threadIdx.x; qb < q1; qb += U * kDepThreads) {
         int64_t ip[U];
         double x[U][NDIM], m[U];
@@ -794,21 +794,36 @@ __global__ __launch_bounds__(kDepThreads) void dep_tile_kernel(const DepSortPara
         }
     }
     __syncthreads();
+    // Flush in two passes: (1) the cells no other tile writes (the interior of the block) by a plain read-add-write, (2) the shared
+    // faces by atomics that nothing waits for.  (In one loop over all cells every read-add-write waited -- s_waitcnt vmcnt(0) --
+    // for the acknowledgement of the atomic the wavefront had issued just before it: dep_tile_kernel 2.60 -> 1.5 ms at 512^3
+    // particles.  Reading several owned cells ahead adds nothing on top.)
+    auto cell_of = [&](int e, bool &own) -> int64_t {
+        int rem = e;
+        int64_t cc = 0, mul = 1;
+        own = true;
+        for (int k = NDIM - 1; k >= 0; --k) {
+            const int l = rem % E; rem /= E;
+            int gk = tc[k] * T + l;
+            own = own && (l >= 1) && (l <= T - 1) && (gk < P.N);
+            if (gk >= P.N) gk -= P.N;                          // only g == N carries weight (the periodic +1 neighbour)
+            cc += (int64_t)gk * mul; mul *= P.N;
+        }
+        return cc;
+    };
     for (int e = threadIdx.x; e < NE; e += kDepThreads) {
         const double v = acc[e];
         if (v == 0.0) continue;
-        int rem = e;
-        int64_t c = 0, mul = 1;
-        bool own = true;
-        for (int k = NDIM - 1; k >= 0; --k) {
-            const int l = rem % E; rem /= E;
-            int g = tc[k] * T + l;
-            own = own && (l >= 1) && (l <= T - 1) && (g < P.N);
-            if (g >= P.N) g -= P.N;                            // only g == N carries weight (the periodic +1 neighbour)
-            c += (int64_t)g * mul; mul *= P.N;
-        }
+        bool own;
+        const int64_t c = cell_of(e, own);
         if (own) P.grid[c] += v;                               // no other tile writes this cell
-        else unsafeAtomicAdd(P.grid + c, v);
+    }
+    for (int e = threadIdx.x; e < NE; e += kDepThreads) {
+        const double v = acc[e];
+        if (v == 0.0) continue;
+        bool own;
+        const int64_t c = cell_of(e, own);
+        if (!own) unsafeAtomicAdd(P.grid + c, v);
     }
 }
 
