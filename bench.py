@@ -1095,7 +1095,7 @@ def run_snapshot(args, torch, local_rank, n1=512, L=1000.0, ngrid=512, zs=0.25):
                 "step_algorithmic_GBps": (kernel_bytes + dep_bytes) / (dt / steps) / 1e9,
                 "step_frac": (kernel_bytes + dep_bytes) / (dt / steps) / HBM_PEAK}
     dep_frac = dep_bytes / dep_s / HBM_PEAK if dep_s > 0 else 0.0
-    deposit = {"bound": "hbm", "kernel": "dep_key_kernel + dep_tile_kernel + dep_overflow_kernel (the whole deposit)", "achieved": dep_bytes / dep_s / 1e9 if dep_s > 0 else 0.0,
+    deposit = {"bound": bound_of(dep_frac, None, dep_s), "kernel": "dep_key_kernel + dep_tile_kernel + dep_overflow_kernel (the whole deposit)", "achieved": dep_bytes / dep_s / 1e9 if dep_s > 0 else 0.0,
                "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": dep_frac, "kernel_ms": d_ms / max(d_n, 1), "kernel_launches": d_n,
                "algorithmic_bytes_per_launch": dep_bytes, "grid_mass": mass, "grid_mass_expected": float(npart),
                "valu_issue_frac": sq_dep.get("valu_issue_frac") if sq_dep else None,

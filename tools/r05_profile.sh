@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box, from the repo root: bash tools/r05_profile.sh <part> ...   (parts: bench stats pmc sq sqjson snap resources workloads api rehearsal)
+# GPU box, from the repo root: bash tools/r05_profile.sh <part> ...   (parts: bench benchall stats pmc sq sqjson snaponly workloads api rehearsal)
 # The evidence of one build.  Everything lands in gpurun_out/r05_*; what is kept is copied to profiles/ afterwards.
 tag=r05
 R=$GRAFT_REPO_ROOT
@@ -84,6 +84,9 @@ sqjson)
     "_regrid_n100000_nside1024=$O/${tag}_sq_counters_bary1e5.txt,regrid_tile_kernel" \
     "_regrid_n1250000_nside2048=$O/${tag}_sq_counters_bary2048.txt,regrid_tile_kernel" \
     "_prep_paint_n1000000=$O/${tag}_sq_counters_paint.txt,halo_prep_kernel" ;;
+snaponly)   # the snapshot workload alone (after a change to its kernels): stats, traffic, SQ counters, bench line
+  stats snapshot 50; pmc snapshot; sq snapshot
+  python3 bench.py $BARGS $(wl_args snapshot) > $O/${tag}_bench_snapshot.json 2>/dev/null; tail -c 300 $O/${tag}_bench_snapshot.json; echo ;;
 workloads)
   bash tools/workloads.sh > $O/${tag}_other_workloads.txt 2>&1; cat $O/${tag}_other_workloads.txt ;;
 api)
