@@ -594,7 +594,9 @@ def unpin(array):
     ent = _registered.pop(array.ctypes.data, None)
     if ent is not None:
         _torch().cuda.synchronize()                  # no copy of ours may still be reading or writing these pages
-        _torch().cuda.cudart().cudaHostUnregister(array.ctypes.data)
+        rc = _torch().cuda.cudart().cudaHostUnregister(array.ctypes.data)
+        if int(rc) != 0:                              # (the pages would stay mapped for the GPU behind the array's back)
+            raise _lib.BFGError(f"hipHostUnregister failed (error {int(rc)})")
 
 
 def pinned_copy(array):
