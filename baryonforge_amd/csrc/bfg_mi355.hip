@@ -149,6 +149,8 @@ struct bfg_ctx {
     int64_t hwin_cap;
     double *d_ndrows = nullptr;     // [ndrows_cap] the halos' radial rows of an N-dimensional table (run_shell_nd)
     int64_t ndrows_cap = 0;
+    void *d_ndsort = nullptr;       // run_shell_nd, halos grouped by table cell: cell ids, sorted indices, weights, counters (bytes)
+    size_t ndsort_cap = 0;
     bool tile_attr_set;             // MaxDynamicSharedMemorySize raised for the tile kernels on this device
     // timing: a growing pool of event pairs per kernel class, resolved lazily in bfg_timing_read
     bool timing;
@@ -1335,6 +1337,7 @@ static void ctx_free_all(bfg_ctx *c)
     if (c->d_ht) (void)hipFree(c->d_ht);
     if (c->d_hwin) (void)hipFree(c->d_hwin);
     if (c->d_ndrows) (void)hipFree(c->d_ndrows);
+    if (c->d_ndsort) (void)hipFree(c->d_ndsort);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_red) (void)hipFree(c->d_red);
     for (int m = 0; m < 3; ++m) {
@@ -3009,6 +3012,28 @@ static int run_shell_nd(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t,
         HIP_TRY(hipMalloc((void **)&c->d_ndrows, (size_t)(nb_max * N.nr) * sizeof(double)));
         c->ndrows_cap = nb_max * N.nr;
     }
+    // the rows of halos that share a table cell are blended together (BFG_ND_ROWS=plain: every halo by itself, the A/B; also the
+    // path of tables with more than kNdMaxCells cells)
+    int64_t ncell = 1;
+    for (int k = 0; k < N.nouter && ncell <= bfg::kNdMaxCells; ++k) ncell *= std::max(1, N.oshape[k] - 1);
+    bool blocked = ncell <= bfg::kNdMaxCells && nb_max < ((int64_t)1 << 31);
+    int rshift = 0;                                             // R = 2^rshift counters per cell (<= 32, cells x R <= kNdMaxCells)
+    while (blocked && rshift < 5 && (ncell << (rshift + 1)) <= bfg::kNdMaxCells) ++rshift;
+    if (blocked) ncell <<= rshift;                              // from here on: the number of sort keys
+    if (const char *e = std::getenv("BFG_ND_ROWS")) if (!std::strcmp(e, "plain")) blocked = false;
+    const int64_t nblk = (ncell + 1023) / 1024;
+    size_t y_off = 0;
+    if (blocked) {
+        y_off = ((size_t)(2 * nb_max + 2 * ncell + 1 + nblk + 1) * sizeof(int32_t) + 15) / 16 * 16;
+        const size_t want = y_off + (size_t)nb_max * N.nouter * sizeof(double);
+        if (want > c->ndsort_cap) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->d_ndsort) (void)hipFree(c->d_ndsort);
+            c->d_ndsort = nullptr; c->ndsort_cap = 0;
+            HIP_TRY(hipMalloc(&c->d_ndsort, want));
+            c->ndsort_cap = want;
+        }
+    }
     bfg_table tv;
     tv.dev = t->dev; tv.d_blob = nullptr; tv.nd = nullptr;
     tv.dev.ndim = 3; tv.dev.nouter = 0; tv.dev.values = c->d_ndrows; tv.dev.hstride = N.nr;
@@ -3021,7 +3046,25 @@ static int run_shell_nd(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t,
         ab.n_halo = std::max<int64_t>(nb, 0);
         ab.n_extra = 0;
         if (b > 0) ab.flags &= ~(uint32_t)(BFG_SHELL_OUT_OVERWRITE | BFG_SHELL_OUT_IS_ZERO);      // accumulate into the batches before
-        if (nb > 0) {
+        if (nb > 0 && blocked) {
+            // halos grouped by table cell, eight of a cell per wavefront (bfg_ndtable.hpp)
+            int32_t *const d_cell = (int32_t *)c->d_ndsort, *const d_perm = d_cell + nb_max, *const d_count = d_perm + nb_max;
+            int32_t *const d_start = d_count + ncell, *const d_bsum = d_start + ncell + 1, *const d_total = d_bsum + nblk;
+            double *const d_y = (double *)((char *)c->d_ndsort + y_off);
+            HIP_TRY(hipMemsetAsync(d_count, 0, (size_t)ncell * sizeof(int32_t), c->stream));
+            hipLaunchKernelGGL(bfg::nd_cell_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream, N, ab.d_catalog, nb,
+                               a->cat_stride, rshift, d_cell, d_y, d_count, c->d_ndrows, c->d_stats);
+            hipLaunchKernelGGL(bfg::snap_scan_block_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, ncell, d_count, d_start, d_bsum);
+            hipLaunchKernelGGL(bfg::snap_scan_sums_kernel, dim3(1), dim3(1024), 0, c->stream, (int)nblk, d_bsum, d_total);
+            hipLaunchKernelGGL(bfg::snap_scan_add_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, c->stream, ncell, d_start,
+                               d_bsum, d_count, d_total);
+            hipLaunchKernelGGL(bfg::group_fill_kernel, dim3((unsigned)std::min<int64_t>((nb + 255) / 256, 4096)), dim3(256), 0, c->stream,
+                               nb, d_cell, d_count, d_start, d_perm);
+            const unsigned grid = (unsigned)std::min<int64_t>((nb + 4 * bfg::kNdBlockHalos - 1) / (4 * bfg::kNdBlockHalos), (int64_t)c->n_cu * 16);
+            hipLaunchKernelGGL(bfg::nd_rows_blocked_kernel, dim3(grid), dim3(256), 0, c->stream, N, rshift, d_cell, d_perm, d_start + ncell,
+                               d_y, c->d_ndrows);
+            HIP_TRY(hipGetLastError());
+        } else if (nb > 0) {
             const unsigned grid = (unsigned)std::min<int64_t>((nb + 3) / 4, (int64_t)c->n_cu * 16);
             hipLaunchKernelGGL(bfg::nd_rows_kernel, dim3(grid), dim3(256), 0, c->stream, N, ab.d_catalog, nb, a->cat_stride, c->d_ndrows,
                                c->d_stats);

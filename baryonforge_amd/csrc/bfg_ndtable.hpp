@@ -101,6 +101,148 @@ __global__ __launch_bounds__(256) void nd_rows_kernel(const NdTable T, const dou
     }
 }
 
+// ---- the same rows, halos grouped by table cell ---------------------------------------------------------------------------------
+// nd_rows_kernel reads the 2^(n+2) corner rows of every halo by itself: 51 / 102 KB per halo at four / five extra axes, out of a
+// table that only fits the Infinity Cache -- 2.8 / 7.1 ms per 1e6 halos, three to seven times the painting.  But a table has few
+// cells (nodes per parameter axis: a handful) and a catalog many halos per cell, and the corner ROWS are the cell's, only the
+// weights are the halo's.  So: nd_cell_kernel finds every halo's cell (and its interpolation weights per axis), a counting sort
+// groups the halo indices by cell (the scan / fill kernels of bfg_snapshot.hpp), and nd_rows_blocked_kernel gives kNdBlockHalos
+// consecutive halos of the sorted list to one wavefront: every corner row is loaded ONCE (two nodes per lane, as above) and added
+// into the rows of all the unit's halos of that cell, whose weights come from LDS (products and order of additions as in
+// nd_rows_kernel: the same rows, bit for bit).  Tables with more than kNdMaxCells cells keep nd_rows_kernel.
+// The sort key is cell * R + (halo index mod R), R a power of two: R counters per cell, because a catalog crowds into a few
+// (z, M) cells and the counting atomics of one address serialise (one counter per cell: 0.38 + 0.30 ms for the count and fill
+// passes of 1e6 halos, the hottest cell holding 1e4 of them).
+constexpr int kNdBlockHalos = 8;
+constexpr int kNdBlockChunk = 128;           // corners per pass of the weight table in LDS (8 KB per wavefront)
+constexpr int64_t kNdMaxCells = 1 << 22;     // (cells x R counters)
+
+// per halo: key[j] = cell * R + j % R, cell = flattened cell index over the outer axes (-1: outside the hull of an axis -> a NaN row,
+// written here, and the counters / warnings of nd_rows_kernel), y[j][k] = interpolation weight on axis k, count[key] += 1
+__global__ __launch_bounds__(256) void nd_cell_kernel(const NdTable T, const double *__restrict__ cat, int64_t n_halo, int cat_stride,
+                                                      int rshift, int32_t *__restrict__ key, double *__restrict__ y,
+                                                      int32_t *__restrict__ count, double *__restrict__ rows, bfg_stats *stats)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_halo) return;
+    const double *c = cat + j * (int64_t)cat_stride;
+    const double a = 1.0 / (1.0 + c[1]);
+    int64_t id = 0;
+    bool oob = false;
+    unsigned warn = 0;
+    for (int k = 0; k < T.nouter; ++k) {
+        const double x = (k == 0) ? log(1.0 / a) : (k == 1) ? log(c[0]) : c[4 + (k - 2)];   // Tabulate.py:308, :312, :620
+        const double *g = T.oaxis[k];
+        const int n = T.oshape[k];
+        if (!(x >= g[0]) || !(x <= g[n - 1])) {
+            oob = true;
+            if (k == 0) warn |= BFG_WARN_Z_RANGE;
+            if (k == 1) warn |= BFG_WARN_M_RANGE;
+        }
+        const int i = find_interval(g, n, x);
+        y[j * T.nouter + k] = (x - g[i]) / (g[i + 1] - g[i]);
+        id = id * (n - 1) + i;
+    }
+    if (oob) {
+        key[j] = -1;
+        if (stats) {
+            atomicAdd((unsigned long long *)&stats->halos_out_of_table, 1ull);
+            if (warn) atomicOr(&stats->warn_mask, warn);
+        }
+        for (int ir = 0; ir < T.nr; ++ir) rows[j * (int64_t)T.nr + ir] = __builtin_nan("");
+    } else {
+        const int32_t kk = (int32_t)((id << rshift) | (j & ((1 << rshift) - 1)));
+        key[j] = kk;
+        atomicAdd(&count[kk], 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void nd_rows_blocked_kernel(const NdTable T, int rshift, const int32_t *__restrict__ key,
+                                                              const int32_t *__restrict__ perm, const int32_t *__restrict__ n_sorted_ptr,
+                                                              const double *__restrict__ y, double *__restrict__ rows)
+{
+    __shared__ double s_y[4][kNdBlockHalos][kNdMaxOuter];
+    __shared__ int32_t s_ci[4][kNdMaxOuter];
+    __shared__ int32_t s_j[4][kNdBlockHalos];
+    __shared__ int64_t s_off[4][kNdBlockChunk];
+    __shared__ __align__(16) double s_w[4][kNdBlockChunk][kNdBlockHalos];
+    typedef double nd_v2d __attribute__((ext_vector_type(2), aligned(8)));
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int n_sorted = *n_sorted_ptr;
+    const int ncorner = 1 << T.nouter;
+    for (int64_t u = (int64_t)blockIdx.x * 4 + grp; u * kNdBlockHalos < n_sorted; u += (int64_t)gridDim.x * 4) {
+        const int p0 = (int)(u * kNdBlockHalos), np = min(kNdBlockHalos, n_sorted - p0);
+        int mycell = -1;
+        if (lane < np) { const int jj = perm[p0 + lane]; s_j[grp][lane] = jj; mycell = key[jj] >> rshift; }
+        __builtin_amdgcn_wave_barrier();
+        for (int run0 = 0; run0 < np;) {                                   // runs of halos that share a cell (sorted: contiguous)
+            const int cid = __shfl(mycell, run0, 64);
+            const int m = __popcll(__ballot(lane >= run0 && lane < np && mycell == cid));
+            if (lane == 0) {
+                int rem = cid;
+                for (int k = T.nouter - 1; k >= 0; --k) { const int nk = T.oshape[k] - 1; s_ci[grp][k] = rem % nk; rem /= nk; }
+            }
+            for (int t = lane; t < m * T.nouter; t += 64) {
+                const int h = t / T.nouter, k = t - h * T.nouter;
+                s_y[grp][h][k] = y[(int64_t)s_j[grp][run0 + h] * T.nouter + k];
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int r0 = 0; r0 < T.nr; r0 += 128) {
+                const int ir = r0 + 2 * lane;
+                const bool two = ir + 1 < T.nr, one = ir < T.nr;
+                double acc0[kNdBlockHalos], acc1[kNdBlockHalos];
+#pragma unroll
+                for (int h = 0; h < kNdBlockHalos; ++h) { acc0[h] = 0.0; acc1[h] = 0.0; }
+                for (int c0 = 0; c0 < ncorner; c0 += kNdBlockChunk) {
+                    const int nc = min(kNdBlockChunk, ncorner - c0);
+                    for (int q = lane; q < nc; q += 64) {                  // the chunk's row offsets (the cell's) and weights (the halos')
+                        const int cc = c0 + q;
+                        int64_t off = 0;
+                        for (int k = 0; k < T.nouter; ++k) off += (int64_t)(s_ci[grp][k] + ((cc >> (T.nouter - 1 - k)) & 1)) * T.ostride[k];
+                        s_off[grp][q] = off;
+                        for (int h = 0; h < kNdBlockHalos; ++h) {
+                            double w = 0.0;
+                            if (h < m) {
+                                w = 1.0;
+                                for (int k = 0; k < T.nouter; ++k) {
+                                    const double yy = s_y[grp][h][k];
+                                    w = w * (((cc >> (T.nouter - 1 - k)) & 1) ? yy : 1.0 - yy);
+                                }
+                            }
+                            s_w[grp][q][h] = w;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (one) {
+                        for (int q = 0; q < nc; ++q) {
+                            nd_v2d v;
+                            if (two) v = *reinterpret_cast<const nd_v2d *>(T.values + s_off[grp][q] + ir);
+                            else { v.x = T.values[s_off[grp][q] + ir]; v.y = 0.0; }
+                            const double4 wa = *reinterpret_cast<const double4 *>(&s_w[grp][q][0]);
+                            const double4 wb = *reinterpret_cast<const double4 *>(&s_w[grp][q][4]);
+                            const double w[kNdBlockHalos] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+                            for (int h = 0; h < kNdBlockHalos; ++h) { acc0[h] = fma(v.x, w[h], acc0[h]); acc1[h] = fma(v.y, w[h], acc1[h]); }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+#pragma unroll
+                for (int h = 0; h < kNdBlockHalos; ++h) {
+                    if (h < m) {
+                        double *row = rows + (int64_t)s_j[grp][run0 + h] * T.nr + ir;
+                        if (two) { nd_v2d o; o.x = acc0[h]; o.y = acc1[h]; *reinterpret_cast<nd_v2d *>(row) = o; }
+                        else if (one) row[0] = acc0[h];
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            run0 += m;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // One (halo, pixel) entry: the halo's row at ln(r_com) [- shift_j: Rdelta_sampling tables, BaryonCorrection.py:406-408], NaN outside the
 // radial axis.  exp_values (paint, Tabulate.py:640-650 + HealpixRunner.py:473, :478): exp of it, non-finite -> 0, times scale_j
 // (pixarea D_j^2).  Otherwise (displacement, BaryonCorrection.py:410-411): the value itself, 0 where r_com >= rcut_j; NaN is

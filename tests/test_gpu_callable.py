@@ -274,3 +274,52 @@ def test_nd_table_rows_through_every_kernel_variant(cosmo, variant, nr):
             gotb = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo), eps, bm, verbose=False, variant=variant).process()
         assert np.isclose(gotb.sum(), m_in.sum())
         assert_maps_close(gotb, refb, 1e-5, floor=1e-9, what=f"baryonify, 4 extra axes, variant {variant}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["usual", "batched", "all_outside", "one_cell"])
+def test_nd_rows_grouped_by_cell_equal_the_rows_blended_per_halo(cosmo, case, monkeypatch):
+    """run_shell_nd groups the halos by table cell and blends eight halos of a cell per wavefront (nd_rows_blocked_kernel; the same
+    products in the same order as nd_rows_kernel): the painted map must be the map of BFG_ND_ROWS=plain -- every halo's rows blended by
+    itself -- up to the order of the tile kernel's additions, with the same P_tot, non-zero set and warnings; also in batches of
+    halos, with every halo outside the hull of a parameter axis (nothing to sort), and with all halos in ONE cell (one hot counter)."""
+    import warnings
+    nside, n, eps = 256, 20_000, 8.0
+    ra, dec, M, z = syn.catalog(n, seed=77, logM=(13.0, 15.3))
+    rng = np.random.default_rng(8)
+    ax = [np.array([0.6, 1.0, 1.5]), np.array([-1.5, 0.0, 2.5]), np.array([5.0, 25.0]), np.array([-0.5, 0.5, 1.5]), np.array([1.0, 2.0, 4.0])]
+    p = [rng.uniform(a[0], a[-1], n) for a in ax]
+    if case == "all_outside":
+        p[1][:] = 3.0
+    if case == "one_cell":
+        p = [rng.uniform(a[0], a[1], n) for a in ax]
+        M[:] = 10 ** rng.uniform(14.0, 14.01, n); z[:] = rng.uniform(0.30, 0.301, n)
+    if case == "batched":
+        monkeypatch.setenv("BFG_ND_ROW_BYTES", str(8 * 60 * 777))
+    keys = ["pa", "pb", "pc", "pd", "pe"]
+    fac = 1.0
+    for k, a in enumerate(ax):
+        sh = [1] * len(ax); sh[k] = a.size
+        fac = fac * (1.0 + 0.1 * (k + 1) * (a - a[0]) / (a[-1] - a[0])).reshape(sh)
+    zax, Max, rax, T = syn.pressure_table(3, 8, 60)
+    TN = T.reshape(T.shape + (1,) * len(ax)) * fac[None, None, None]
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo, **dict(zip(keys, p)))
+    model = bfg.ParamTabulatedProfile.from_arrays(zax, Max, rax, TN, other_params=dict(zip(keys, ax)))
+
+    def paint():
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), eps, model, verbose=False)
+            out = R.process()
+        return out, R.last_stats, sorted(str(x.message)[:40] for x in w)
+    got, st, wg = paint()
+    monkeypatch.setenv("BFG_ND_ROWS", "plain")
+    ref, st_ref, wr = paint()
+    assert st["pixel_updates"] == st_ref["pixel_updates"] and st["halos_out_of_table"] == st_ref["halos_out_of_table"]
+    assert wg == wr
+    assert np.array_equal(got != 0, ref != 0)
+    if case == "all_outside":
+        assert st["halos_out_of_table"] == n and not got.any()
+    else:
+        assert got.any()
+        assert_maps_close(got, ref, 1e-12, what=f"rows grouped by cell vs per halo ({case})")
