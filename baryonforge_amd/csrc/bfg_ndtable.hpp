@@ -157,19 +157,34 @@ __global__ __launch_bounds__(256) void nd_cell_kernel(const NdTable T, const dou
     }
 }
 
+__device__ inline double nd_uniform(double v)             // a wave-uniform value into scalar registers (an FMA takes one scalar operand)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// The weight of corner c of halo h is a product over the axes; with the LAST TWO axes split off, w[h][c] = whi[h][c >> 2] * wlo[h][c & 3]:
+// the four wlo of each halo sit in scalar registers, the 2^n whi go through LDS (a quarter of the corners), and four consecutive
+// corner rows -- one (c >> 2) -- are first combined with wlo, then added with whi: one LDS broadcast per sixteen FMAs instead of
+// one per four, which was what bound this kernel (1.5 -> see DESIGN.md section 8).  The sums are associated differently from
+// nd_rows_kernel's (rows equal to ~1e-16 relative, not bit for bit).
 __global__ __launch_bounds__(256) void nd_rows_blocked_kernel(const NdTable T, int rshift, const int32_t *__restrict__ key,
                                                               const int32_t *__restrict__ perm, const int32_t *__restrict__ n_sorted_ptr,
                                                               const double *__restrict__ y, double *__restrict__ rows)
 {
+    constexpr int kGroups = kNdBlockChunk / 4;                            // groups of four corners per pass
     __shared__ double s_y[4][kNdBlockHalos][kNdMaxOuter];
     __shared__ int32_t s_ci[4][kNdMaxOuter];
     __shared__ int32_t s_j[4][kNdBlockHalos];
-    __shared__ int64_t s_off[4][kNdBlockChunk];
-    __shared__ __align__(16) double s_w[4][kNdBlockChunk][kNdBlockHalos];
+    __shared__ int64_t s_off[4][kGroups];
+    __shared__ __align__(16) double s_w[4][kGroups][kNdBlockHalos];
     typedef double nd_v2d __attribute__((ext_vector_type(2), aligned(8)));
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int n_sorted = *n_sorted_ptr;
-    const int ncorner = 1 << T.nouter;
+    const int nhi = T.nouter - 2;                                         // axes whose weights go into whi
+    const int ngroup = 1 << nhi;
+    const int64_t st2 = T.ostride[T.nouter - 2], st1 = T.ostride[T.nouter - 1];
     for (int64_t u = (int64_t)blockIdx.x * 4 + grp; u * kNdBlockHalos < n_sorted; u += (int64_t)gridDim.x * 4) {
         const int p0 = (int)(u * kNdBlockHalos), np = min(kNdBlockHalos, n_sorted - p0);
         int mycell = -1;
@@ -187,26 +202,37 @@ __global__ __launch_bounds__(256) void nd_rows_blocked_kernel(const NdTable T, i
                 s_y[grp][h][k] = y[(int64_t)s_j[grp][run0 + h] * T.nouter + k];
             }
             __builtin_amdgcn_wave_barrier();
+            // the last two axes: the four row offsets (the cell's) and the halos' four weights each, wave-uniform
+            const int64_t base2 = (int64_t)s_ci[grp][T.nouter - 2] * st2 + (int64_t)s_ci[grp][T.nouter - 1] * st1;
+            double wlo[kNdBlockHalos][4];
+#pragma unroll
+            for (int h = 0; h < kNdBlockHalos; ++h) {
+                const bool on = h < m;
+                const double ya = on ? s_y[grp][h][T.nouter - 2] : 0.0, yb = on ? s_y[grp][h][T.nouter - 1] : 0.0;
+                const double a0 = on ? 1.0 - ya : 0.0, b0 = 1.0 - yb;
+                wlo[h][0] = nd_uniform(a0 * b0); wlo[h][1] = nd_uniform(a0 * yb);
+                wlo[h][2] = nd_uniform(ya * b0); wlo[h][3] = nd_uniform(ya * yb);
+            }
             for (int r0 = 0; r0 < T.nr; r0 += 128) {
                 const int ir = r0 + 2 * lane;
                 const bool two = ir + 1 < T.nr, one = ir < T.nr;
                 double acc0[kNdBlockHalos], acc1[kNdBlockHalos];
 #pragma unroll
                 for (int h = 0; h < kNdBlockHalos; ++h) { acc0[h] = 0.0; acc1[h] = 0.0; }
-                for (int c0 = 0; c0 < ncorner; c0 += kNdBlockChunk) {
-                    const int nc = min(kNdBlockChunk, ncorner - c0);
-                    for (int q = lane; q < nc; q += 64) {                  // the chunk's row offsets (the cell's) and weights (the halos')
-                        const int cc = c0 + q;
-                        int64_t off = 0;
-                        for (int k = 0; k < T.nouter; ++k) off += (int64_t)(s_ci[grp][k] + ((cc >> (T.nouter - 1 - k)) & 1)) * T.ostride[k];
+                for (int g0 = 0; g0 < ngroup; g0 += kGroups) {
+                    const int ng = min(kGroups, ngroup - g0);
+                    for (int q = lane; q < ng; q += 64) {                  // this pass's groups: row offset and whi of every halo
+                        const int gg = g0 + q;
+                        int64_t off = base2;
+                        for (int k = 0; k < nhi; ++k) off += (int64_t)(s_ci[grp][k] + ((gg >> (nhi - 1 - k)) & 1)) * T.ostride[k];
                         s_off[grp][q] = off;
                         for (int h = 0; h < kNdBlockHalos; ++h) {
                             double w = 0.0;
                             if (h < m) {
                                 w = 1.0;
-                                for (int k = 0; k < T.nouter; ++k) {
+                                for (int k = 0; k < nhi; ++k) {
                                     const double yy = s_y[grp][h][k];
-                                    w = w * (((cc >> (T.nouter - 1 - k)) & 1) ? yy : 1.0 - yy);
+                                    w = w * (((gg >> (nhi - 1 - k)) & 1) ? yy : 1.0 - yy);
                                 }
                             }
                             s_w[grp][q][h] = w;
@@ -214,15 +240,27 @@ __global__ __launch_bounds__(256) void nd_rows_blocked_kernel(const NdTable T, i
                     }
                     __builtin_amdgcn_wave_barrier();
                     if (one) {
-                        for (int q = 0; q < nc; ++q) {
-                            nd_v2d v;
-                            if (two) v = *reinterpret_cast<const nd_v2d *>(T.values + s_off[grp][q] + ir);
-                            else { v.x = T.values[s_off[grp][q] + ir]; v.y = 0.0; }
+                        for (int q = 0; q < ng; ++q) {
+                            const double *r00 = T.values + s_off[grp][q] + ir;
+                            nd_v2d v0, v1, v2, v3;
+                            if (two) {
+                                v0 = *reinterpret_cast<const nd_v2d *>(r00); v1 = *reinterpret_cast<const nd_v2d *>(r00 + st1);
+                                v2 = *reinterpret_cast<const nd_v2d *>(r00 + st2); v3 = *reinterpret_cast<const nd_v2d *>(r00 + st2 + st1);
+                            } else {
+                                v0.x = r00[0]; v1.x = r00[st1]; v2.x = r00[st2]; v3.x = r00[st2 + st1];
+                                v0.y = 0.0; v1.y = 0.0; v2.y = 0.0; v3.y = 0.0;
+                            }
                             const double4 wa = *reinterpret_cast<const double4 *>(&s_w[grp][q][0]);
                             const double4 wb = *reinterpret_cast<const double4 *>(&s_w[grp][q][4]);
-                            const double w[kNdBlockHalos] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+                            const double whi[kNdBlockHalos] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
 #pragma unroll
-                            for (int h = 0; h < kNdBlockHalos; ++h) { acc0[h] = fma(v.x, w[h], acc0[h]); acc1[h] = fma(v.y, w[h], acc1[h]); }
+                            for (int h = 0; h < kNdBlockHalos; ++h) {
+                                double px = v0.x * wlo[h][0], py = v0.y * wlo[h][0];
+                                px = fma(v1.x, wlo[h][1], px); py = fma(v1.y, wlo[h][1], py);
+                                px = fma(v2.x, wlo[h][2], px); py = fma(v2.y, wlo[h][2], py);
+                                px = fma(v3.x, wlo[h][3], px); py = fma(v3.y, wlo[h][3], py);
+                                acc0[h] = fma(px, whi[h], acc0[h]); acc1[h] = fma(py, whi[h], acc1[h]);
+                            }
                         }
                     }
                     __builtin_amdgcn_wave_barrier();

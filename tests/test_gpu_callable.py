@@ -280,7 +280,7 @@ def test_nd_table_rows_through_every_kernel_variant(cosmo, variant, nr):
 @pytest.mark.parametrize("case", ["usual", "batched", "all_outside", "one_cell"])
 def test_nd_rows_grouped_by_cell_equal_the_rows_blended_per_halo(cosmo, case, monkeypatch):
     """run_shell_nd groups the halos by table cell and blends eight halos of a cell per wavefront (nd_rows_blocked_kernel; the same
-    products in the same order as nd_rows_kernel): the painted map must be the map of BFG_ND_ROWS=plain -- every halo's rows blended by
+    corner rows and weights as nd_rows_kernel, summed in another order): the painted map must be the map of BFG_ND_ROWS=plain -- every halo's rows blended by
     itself -- up to the order of the tile kernel's additions, with the same P_tot, non-zero set and warnings; also in batches of
     halos, with every halo outside the hull of a parameter axis (nothing to sort), and with all halos in ONE cell (one hot counter)."""
     import warnings
