@@ -101,20 +101,20 @@ __global__ __launch_bounds__(256) void nd_rows_kernel(const NdTable T, const dou
     }
 }
 
-// ---- the same rows, halos grouped by table cell ---------------------------------------------------------------------------------
+// ---- the rows again, halos grouped by table cell ---------------------------------------------------------------------------------
 // nd_rows_kernel reads the 2^(n+2) corner rows of every halo by itself: 51 / 102 KB per halo at four / five extra axes, out of a
 // table that only fits the Infinity Cache -- 2.8 / 7.1 ms per 1e6 halos, three to seven times the painting.  But a table has few
 // cells (nodes per parameter axis: a handful) and a catalog many halos per cell, and the corner ROWS are the cell's, only the
 // weights are the halo's.  So: nd_cell_kernel finds every halo's cell (and its interpolation weights per axis), a counting sort
 // groups the halo indices by cell (the scan / fill kernels of bfg_snapshot.hpp), and nd_rows_blocked_kernel gives kNdBlockHalos
 // consecutive halos of the sorted list to one wavefront: every corner row is loaded ONCE (two nodes per lane, as above) and added
-// into the rows of all the unit's halos of that cell, whose weights come from LDS (products and order of additions as in
-// nd_rows_kernel: the same rows, bit for bit).  Tables with more than kNdMaxCells cells keep nd_rows_kernel.
+// into the rows of all the unit's halos of that cell (see the kernel for how the weights get there).  Tables with more than
+// kNdMaxCells cells keep nd_rows_kernel.
 // The sort key is cell * R + (halo index mod R), R a power of two: R counters per cell, because a catalog crowds into a few
 // (z, M) cells and the counting atomics of one address serialise (one counter per cell: 0.38 + 0.30 ms for the count and fill
 // passes of 1e6 halos, the hottest cell holding 1e4 of them).
 constexpr int kNdBlockHalos = 8;
-constexpr int kNdBlockChunk = 128;           // corners per pass of the weight table in LDS (8 KB per wavefront)
+constexpr int kNdBlockChunk = 128;           // corners per pass (32 groups of four: their offsets and high-axes weights in LDS)
 constexpr int64_t kNdMaxCells = 1 << 22;     // (cells x R counters)
 
 // per halo: key[j] = cell * R + j % R, cell = flattened cell index over the outer axes (-1: outside the hull of an axis -> a NaN row,
@@ -167,7 +167,7 @@ __device__ inline double nd_uniform(double v)             // a wave-uniform valu
 // The weight of corner c of halo h is a product over the axes; with the LAST TWO axes split off, w[h][c] = whi[h][c >> 2] * wlo[h][c & 3]:
 // the four wlo of each halo sit in scalar registers, the 2^n whi go through LDS (a quarter of the corners), and four consecutive
 // corner rows -- one (c >> 2) -- are first combined with wlo, then added with whi: one LDS broadcast per sixteen FMAs instead of
-// one per four, which was what bound this kernel (1.5 -> see DESIGN.md section 8).  The sums are associated differently from
+// one per four, which was what bound this kernel (five extra axes: 1.5 -> 0.9 ms per 1e6 halos).  The sums are associated differently from
 // nd_rows_kernel's (rows equal to ~1e-16 relative, not bit for bit).
 __global__ __launch_bounds__(256) void nd_rows_blocked_kernel(const NdTable T, int rshift, const int32_t *__restrict__ key,
                                                               const int32_t *__restrict__ perm, const int32_t *__restrict__ n_sorted_ptr,
