@@ -79,6 +79,7 @@ struct bfg_table {
 
 // (bfg_ndtable is defined with its C-ABI functions at the end of this file)
 static const double *ndtable_raxis(const bfg_ndtable *t);
+static bool nd_rows_pay(const bfg_table *t, const bfg_shell_args *a);
 static int run_shell_nd(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, const bfg_spline *s, double *d_out, int mode,
                         int n_slices, bfg_slice_fn slice_fn, void *slice_user);
 
@@ -1490,7 +1491,11 @@ int bfg_table_create(bfg_ctx *c, int ndim, const int64_t *shape, const double *c
     // (A displacement table with three p_keys axes takes the row path as well: measured at 1e6 halos, NSIDE 1024, 3-node axes --
     // tools/nd_probe.py, profiles/r05_nd_tables.txt -- offsets 8.07 ms with the kernels blending 32 corners per window node against
     // 3.64 ms on rows; paint tables and narrower displacement tables are faster read directly: 2.27 vs 2.86 ms, 2.95 vs 2.95 ms.)
-    bool nd = ndim > BFG_MAX_DIM || (ndim == BFG_MAX_DIM && !(flags & BFG_TABLE_LOG_VALUES));
+    // With the halos grouped by table cell (nd_rows_blocked_kernel) the rows also beat the kernels' own corner blend for a paint table
+    // with three extra axes (2.31 -> 1.78 ms) and for displacement tables with one or two (2.93 -> 2.53 ms) -- where a cell holds
+    // several halos.  Such tables keep BOTH forms and run_shell decides per call (nd_rows_pay); a paint table with one or two extra
+    // axes stays direct (1.30 vs 1.77 ms on rows).
+    bool nd = ndim > BFG_MAX_DIM || ndim == BFG_MAX_DIM || (!(flags & BFG_TABLE_LOG_VALUES) && ndim >= 4);
     if (const char *e = std::getenv("BFG_ND_FROM_DIM")) nd = ndim > BFG_MAX_DIM || ndim >= std::max(4, std::atoi(e));   // A/B switch
     if (nd && ndim - 1 > kNdMaxOuterHost) return BFG_ERR_UNSUPPORTED;
     int64_t total = 1;
@@ -1822,7 +1827,7 @@ static int check_args(const bfg_shell_args *a, const bfg_table *t, const bfg_spl
     if (a->cat_stride < 4) return BFG_ERR_INVALID;
     if (t->dev.hstride == 0 && a->cat_stride < 4 + a->n_extra) return BFG_ERR_INVALID;
     if (t->dev.ndim != 3 + a->n_extra) return BFG_ERR_INVALID;
-    if (t->nd) return BFG_ERR_INVALID;               // (run_shell_nd hands run_shell the per-halo rows, never the N-dimensional table)
+    if (t->nd && !t->d_blob) return BFG_ERR_INVALID; // (run_shell_nd hands run_shell the per-halo rows, never an N-dimensional table the kernels cannot read)
     if (!(a->epsilon_max >= 0)) return BFG_ERR_INVALID;
     return BFG_OK;
 }
@@ -1873,7 +1878,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     DeviceGuard dg_;
     int rc = ctx_enter(c, dg_);
     if (rc) return rc;
-    if (t && t->nd) return run_shell_nd(c, a, t, s, d_out, mode, n_slices, slice_fn, slice_user);
+    if (t && t->nd && nd_rows_pay(t, a)) return run_shell_nd(c, a, t, s, d_out, mode, n_slices, slice_fn, slice_user);
     rc = check_args(a, t, s, d_out);
     if (rc) return rc;
     if (mode == MODE_PAINT && !t->dev.log_values) return BFG_ERR_INVALID;
@@ -2994,6 +2999,24 @@ static const double *ndtable_raxis(const bfg_ndtable *t) { return t->dev.raxis; 
 // as a table without outer axes whose values start at j * hstride for halo j.  Rows are float64[n][nr]: catalogs whose rows pass
 // BFG_ND_ROW_BYTES (default 4 GiB) are painted in batches of halos, each batch accumulating into the output of the one before;
 // a sliced call in several batches reports its slices after the last batch (they are not final earlier).
+// Does a shell call with this table go through the per-halo rows?  A table the kernels cannot read themselves: always.  A 6-D
+// displacement table: always (32 corners per window node in the kernels: 8.07 ms against 3.64 on rows even with every halo
+// blending its own).  Other tables that keep both forms: where a table cell holds eight halos or more on average -- the grouped
+// blend then shares every corner row among the halos of a wavefront --, else the kernels' own corner blend.
+// BFG_ND_FROM_DIM (A/B): every table that has the N-dimensional form takes the rows.
+static bool nd_rows_pay(const bfg_table *t, const bfg_shell_args *a)
+{
+    if (!t->nd) return false;
+    if (!t->d_blob) return true;
+    if (std::getenv("BFG_ND_FROM_DIM")) return true;
+    if (t->dev.ndim == BFG_MAX_DIM && !t->dev.log_values) return true;
+    if (!a) return false;
+    const bfg::NdTable &N = t->nd->dev;
+    double cells = 1.0;
+    for (int k = 0; k < N.nouter; ++k) cells *= (double)std::max(1, N.oshape[k] - 1);
+    return (double)a->n_halo >= 8.0 * cells;
+}
+
 static int run_shell_nd(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, const bfg_spline *s, double *d_out, int mode,
                         int n_slices, bfg_slice_fn slice_fn, void *slice_user)
 {

@@ -323,3 +323,47 @@ def test_nd_rows_grouped_by_cell_equal_the_rows_blended_per_halo(cosmo, case, mo
     else:
         assert got.any()
         assert_maps_close(got, ref, 1e-12, what=f"rows grouped by cell vs per halo ({case})")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["paint3", "offsets1"])
+def test_tables_with_both_forms_give_the_same_map_on_rows_and_direct(cosmo, kind, monkeypatch):
+    """A paint table with three p_keys axes / a displacement table with one keeps both forms (bfg_table_create) and a shell call takes
+    the per-halo rows where a table cell holds eight halos or more on average (nd_rows_pay), else the kernels' own corner blend:
+    the same catalog through both (BFG_ND_FROM_DIM=7 at table creation: no N-dimensional form, so direct) must give the same map."""
+    import warnings
+    nside, n, eps = 128, 3000, 8.0
+    ra, dec, M, z = syn.catalog(n, seed=5, logM=(13.0, 15.3))
+    rng = np.random.default_rng(2)
+    if kind == "paint3":
+        ax = [np.array([0.6, 1.0, 1.5]), np.array([-1.5, 0.0, 2.5]), np.array([5.0, 25.0])]
+    else:
+        ax = [np.array([0.6, 1.0, 1.5])]
+    keys = ["pa", "pb", "pc"][: len(ax)]
+    p = [rng.uniform(a[0], a[-1], n) for a in ax]
+    fac = 1.0
+    for k, a in enumerate(ax):
+        sh = [1] * len(ax); sh[k] = a.size
+        fac = fac * (1.0 + 0.1 * (k + 1) * (a - a[0]) / (a[-1] - a[0])).reshape(sh)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo, **dict(zip(keys, p)))
+
+    def run():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if kind == "paint3":
+                zax, Max, rax, T = syn.pressure_table(3, 8, 60)
+                TN = T.reshape(T.shape + (1,) * len(ax)) * fac[None, None, None]
+                model = bfg.ParamTabulatedProfile.from_arrays(zax, Max, rax, TN, other_params=dict(zip(keys, ax)))
+                R = bfg.PaintProfilesShell(Cat, bfg.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo), eps, model, verbose=False)
+            else:
+                zd, Md, rd, d = syn.displacement_table(3, 8, 60)
+                dN = d.reshape(d.shape + (1,) * len(ax)) * fac[None, None, None]
+                bm = bfg.Baryonification2D.from_arrays(zd, Md, rd, dN, cosmo, epsilon_max=20, other_params=dict(zip(keys, ax)))
+                R = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=syn.mass_map(nside), cosmo=cosmo), eps, bm, verbose=False)
+            return R.process(), R.last_stats
+    got, st = run()                                   # 3000 halos over 2 * 7 * (2 * 2 * 1 | 2) cells: rows
+    monkeypatch.setenv("BFG_ND_FROM_DIM", "7")
+    ref, st_ref = run()                               # a new table object without the N-dimensional form: direct
+    assert st["pixel_updates"] == st_ref["pixel_updates"] > 0
+    assert np.array_equal(got != 0, ref != 0)
+    assert_maps_close(got, ref, 1e-11, what=f"{kind}: rows vs direct")
