@@ -1931,6 +1931,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     // row window of the tile path: ~3.5 e-folds of radius below the disc edge (r_max/33 .. r_max)
     int win_nodes = 0;
     bool blend = false;          // row windows blended per pair inside the tile kernel (set below)
+    bool blend_rows = false;     // ... from the halos' own rows (run_shell_nd)
     bool win_table = false;      // finely sampled radial axis: no row windows, the pixel stage reads the table (bfg_tile.hpp)
     if (tile) {
         win_nodes = (int)std::ceil(3.5 * t->dev.inv_dr) + 2;
@@ -1947,7 +1948,10 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         // L2-resident table (the BLEND instantiation of shell_tile_kernel; BFG_BLEND=0: the windows of round 2, built by the prep
         // kernel and fetched by LDS-DMA).  Measured (profiles/r03_blend_ab.txt): 1e6 halos step 1.27 -> 1.14 ms (prep 0.223 ->
         // 0.156, tile kernel 1.01 -> 0.95), 1e5 halos 0.242 -> 0.235, steep mass function 0.533 -> 0.446.
-        const bool can_blend = mode == MODE_PAINT && !win_table && win_nodes == kWinLds && t->dev.nouter == 2;
+        // (per-halo rows of an N-dimensional table -- no outer axes, hstride > 0 --: the same instantiation's ROWS variant copies the
+        // windows straight out of the rows)
+        blend_rows = t->dev.nouter == 0 && t->dev.hstride > 0;
+        const bool can_blend = mode == MODE_PAINT && !win_table && win_nodes == kWinLds && (t->dev.nouter == 2 || blend_rows);
         blend = can_blend;
         if (const char *e = std::getenv("BFG_BLEND")) blend = can_blend && std::atoi(e) != 0;
         const int64_t want = (win_table || blend) ? 0 : a->n_halo * (int64_t)win_nodes;
@@ -2144,6 +2148,8 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lp));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_tile_kernel<MODE_PAINT, true, 0, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lp));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_tile_kernel<MODE_PAINT, true, 2, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lp));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_tile_kernel<MODE_BARYONIFY, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lb));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(shell_tile_kernel<MODE_BARYONIFY, false>),
@@ -2178,7 +2184,9 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         if (light && wl) {
             constexpr int ntp = TileCfg<MODE_PAINT, 1>::NT, ntb = TileCfg<MODE_BARYONIFY, 1>::NT;
             constexpr size_t ldp = tile_lds_bytes<MODE_PAINT, 1>(), ldb = tile_lds_bytes<MODE_BARYONIFY, 1>();
-            if (mode == MODE_PAINT && blend)
+            if (mode == MODE_PAINT && blend && blend_rows)
+                hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, true, 3, true>), tgrid, dim3(ntp), ldp, c->stream, tp);
+            else if (mode == MODE_PAINT && blend)
                 hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, true, 1, true>), tgrid, dim3(ntp), ldp, c->stream, tp);
             else if (mode == MODE_PAINT)
                 hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, true, 1>), tgrid, dim3(ntp), ldp, c->stream, tp);
@@ -2186,7 +2194,8 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
                 hipLaunchKernelGGL((shell_tile_kernel<MODE_BARYONIFY, true, 1>), tgrid, dim3(ntb), ldb, c->stream, tp);
         } else if (mode == MODE_PAINT) {
             const size_t tlds = tile_lds_bytes<MODE_PAINT>() + (BFG_STAGE_TIMING == 4 ? 128 : 0);
-            if (wl && blend) hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, true, 0, true>), tgrid, tblock, tlds, c->stream, tp);
+            if (wl && blend && blend_rows) hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, true, 2, true>), tgrid, tblock, tlds, c->stream, tp);
+            else if (wl && blend) hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, true, 0, true>), tgrid, tblock, tlds, c->stream, tp);
             else if (wl) hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, true>), tgrid, tblock, tlds, c->stream, tp);
             else hipLaunchKernelGGL((shell_tile_kernel<MODE_PAINT, false>), tgrid, tblock, tlds, c->stream, tp);
         } else {

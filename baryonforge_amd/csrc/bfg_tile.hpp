@@ -1084,11 +1084,16 @@ __device__ __forceinline__ void lds_barrier()
 // flight) and wave 0 sends the record of item k + 2 straight into LDS by LDS-DMA (two lanes x 16 B; landed by the time the
 // barrier that ends stage b has drained wave 0's vmcnt; two alternating slots, so the next item's DMA cannot overtake a slow
 // reader); every wavefront picks both up from LDS after the end-of-item barrier.
+// LIGHT & 2 (with BLEND): the "table" is the halos' own radial rows (run_shell_nd: values + j * hstride, no outer axes) -- stage b copies
+// each pair's window straight out of its halo's row (+ ln(pixarea D^2)) instead of blending four corner rows: no row windows in HBM
+// and no row phase in the prep kernel for the N-dimensional tables either.
 template <int MODE, bool WIN_LDS, int LIGHT = 0, bool BLEND = false>
-__global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::WPS)) void shell_tile_kernel(const TileParams P)
+__global__ __launch_bounds__((TileCfg<MODE, (LIGHT & 1)>::NT), (TileCfg<MODE, (LIGHT & 1)>::WPS)) void shell_tile_kernel(const TileParams P)
 {
     static_assert(!BLEND || (MODE == MODE_PAINT && WIN_LDS), "the blend instantiation is paint with LDS windows");
-    using Cfg = TileCfg<MODE, LIGHT>;
+    constexpr bool ROWS = (LIGHT & 2) != 0;
+    static_assert(!ROWS || BLEND, "rows are a variant of the blend instantiation");
+    using Cfg = TileCfg<MODE, (LIGHT & 1)>;
     using Pair = typename Cfg::Pair;
     constexpr int TR = Cfg::TR, TW = Cfg::TW, NT = Cfg::NT, NACC = Cfg::NACC;
     static_assert(TR <= 64 && TW <= 128, "segment records pack the ring row in 6 bits; segment lengths in 8");
@@ -1126,7 +1131,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
     [[maybe_unused]] DeferredPixel *rq = reinterpret_cast<DeferredPixel *>(smem_raw + rq_off);
     int32_t *ctl = reinterpret_cast<int32_t *>(smem_raw + ctl_off);
     static_assert(sizeof(RingRow) % 16 == 0 && sizeof(Pair) % 16 == 0, "16-byte aligned LDS records");
-    static_assert(ctl_off + 24 * sizeof(int32_t) == tile_lds_bytes<MODE, LIGHT>(), "layout and tile_lds_bytes() must agree");
+    static_assert(ctl_off + 24 * sizeof(int32_t) == tile_lds_bytes<MODE, (LIGHT & 1)>(), "layout and tile_lds_bytes() must agree");
     static_assert(ctl_off % 16 == 0, "the work records parked in ctl[8 .. 23] are 16-byte accesses");
 
     // Persistent workgroups: the grid is a few workgroups per CU and every workgroup takes work items from a counter until
@@ -1324,7 +1329,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
         const int i = min(max((int)t, 0), NRm1 - 1);
         const double f = t - (double)i;
         double c0v, c1v;
-        halo_row_pair<BLEND>(T, P.ht, P.cidx, P.cw, P.cap, j, i, c0v, c1v);
+        halo_row_pair<(BLEND && !ROWS)>(T, P.ht, P.cidx, P.cw, P.cap, j, i, c0v, c1v);
         return fma(f, c1v - c0v, c0v);
     };
     auto direct_row = [&](int pidx, double t) -> double {
@@ -1604,6 +1609,19 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                 // fill the workgroup (sparse catalogs) the blend -- two dependent L2 round trips -- runs in wavefronts that have
                 // no slot, beside the slot work instead of in front of it
                 const int i = NT - 1 - tid;
+                if constexpr (ROWS) {
+                    if (i < n_take * (kWinLds / 4)) {
+                        const int p = i >> 3, q = i & 7;
+                        const Pair &pi = pinfo[p];
+                        const double *r0 = T.values + (int64_t)pi.halo * T.hstride + (pi.win_lo + 4 * q);
+                        const double2u a0 = *reinterpret_cast<const double2u *>(r0), b0 = *reinterpret_cast<const double2u *>(r0 + 2);
+                        const double add = pi.lnpf;                    // (what halo_row4_kernel adds to a one-corner "blend": fma(v, 1, 0) + add)
+                        double2 o0, o1;
+                        o0.x = a0.x + add; o0.y = a0.y + add; o1.x = b0.x + add; o1.y = b0.y + add;
+                        double2 *dst = reinterpret_cast<double2 *>(pwin + p * kWinLds + 4 * q);
+                        dst[0] = o0; dst[1] = o1;
+                    }
+                } else
                 if (i < n_take * (kWinLds / 4)) {
                     const int p = i >> 3, q = i & 7;
                     const Pair &pi = pinfo[p];
@@ -2065,7 +2083,7 @@ __global__ __launch_bounds__((TileCfg<MODE, LIGHT>::NT), (TileCfg<MODE, LIGHT>::
                 for (int i = tid; i < dfill; i += NT) {
                     DeferredOut e;
                     e.pix = slice[i].pix; e.t = slice[i].t; e.halo = slice[i].halo;
-                    deferred_add<BLEND>(P, e, exptab);
+                    deferred_add<(BLEND && !ROWS)>(P, e, exptab);
                 }
             } else if (tid == 0) P.defer_count[blockIdx.x] = dfill;
         }
