@@ -55,9 +55,12 @@ def run(kind, n_extra):
     return ms, d_out.clone(), st["pixel_updates"] // reps, st["fallback_halos"] // reps
 
 
+only = os.environ.get("ND_PROBE_ONLY")        # e.g. paint:4 -- one configuration (for a kernel profile)
 for kind in ("paint", "bary"):
     ref = None
     for n_extra in (0, 1, 3, 4, 5):
+        if only and only != f"{kind}:{n_extra}":
+            continue
         ms, out, ptot, fb = run(kind, n_extra)
         if ref is None:
             ref = out
