@@ -221,22 +221,26 @@ __global__ __launch_bounds__(256) void nd_rows_blocked_kernel(const NdTable T, i
                 for (int h = 0; h < kNdBlockHalos; ++h) { acc0[h] = 0.0; acc1[h] = 0.0; }
                 for (int g0 = 0; g0 < ngroup; g0 += kGroups) {
                     const int ng = min(kGroups, ngroup - g0);
-                    for (int q = lane; q < ng; q += 64) {                  // this pass's groups: row offset and whi of every halo
+                    // this pass's groups: the row offset of each and its whi for every halo -- one (group, halo) product per lane and trip
+                    // (one GROUP per lane left three quarters of the lanes idle at four extra axes: this set-up was as many VALU
+                    // instructions as the blend below)
+                    for (int q = lane; q < ng; q += 64) {
                         const int gg = g0 + q;
                         int64_t off = base2;
                         for (int k = 0; k < nhi; ++k) off += (int64_t)(s_ci[grp][k] + ((gg >> (nhi - 1 - k)) & 1)) * T.ostride[k];
                         s_off[grp][q] = off;
-                        for (int h = 0; h < kNdBlockHalos; ++h) {
-                            double w = 0.0;
-                            if (h < m) {
-                                w = 1.0;
-                                for (int k = 0; k < nhi; ++k) {
-                                    const double yy = s_y[grp][h][k];
-                                    w = w * (((gg >> (nhi - 1 - k)) & 1) ? yy : 1.0 - yy);
-                                }
+                    }
+                    for (int t = lane; t < ng * kNdBlockHalos; t += 64) {
+                        const int q = t / kNdBlockHalos, h = t - q * kNdBlockHalos, gg = g0 + q;
+                        double w = 0.0;
+                        if (h < m) {
+                            w = 1.0;
+                            for (int k = 0; k < nhi; ++k) {
+                                const double yy = s_y[grp][h][k];
+                                w = w * (((gg >> (nhi - 1 - k)) & 1) ? yy : 1.0 - yy);
                             }
-                            s_w[grp][q][h] = w;
                         }
+                        s_w[grp][q][h] = w;
                     }
                     __builtin_amdgcn_wave_barrier();
                     if (one) {
