@@ -6,7 +6,7 @@ halos/s + achieved HBM GB/s, NSIDE = 1024 shell, 1e6 halos, at 1/2/4/8 GPUs).
   python bench.py --gpus N --steps K --warmup W          # any N: for N > 1 the process spawns its own N ranks (below)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W [--scaling strong|weak] [--collective torch|bfg]
-         [--exchange allreduce|owner|auto] [--legs auto|none|weak,owner,configs3,configs1,configs2,steep,configs4]
+         [--exchange allreduce|owner|auto] [--legs auto|none|weak,owner,configs3,configs1,configs2,steep,configs4,nd4]
 
 Launch.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) every process is one rank.  Started as plain
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE, the process becomes a LAUNCHER: before anything touches the GPU (it
@@ -85,8 +85,10 @@ LEG_ARGS = {
     "configs2": dict(workload="baryonify", nside=1024, halos=100_000, table="default", steep=False, eps=10.0),    # BASELINE configs[2]
     "steep": dict(workload="paint", nside=1024, halos=1_000_000, table="default", steep=True, eps=10.0),
     "configs4": dict(workload="snapshot", halos=100_000),                                                        # BASELINE configs[4]
+    # the headline catalog painted from a table with four extra p_keys axes (ParamTabulatedProfile, Tabulate.py:497-650)
+    "nd4": dict(workload="paint", nside=1024, halos=1_000_000, table="nd4", steep=False, eps=10.0),
 }
-N1_ONLY_LEGS = ("configs1", "configs2", "steep", "configs4")
+N1_ONLY_LEGS = ("configs1", "configs2", "steep", "configs4", "nd4")
 
 
 def parse():
@@ -118,7 +120,9 @@ def parse():
                    help="paint (BASELINE's metric), baryonify (BaryonifyShell incl. regrid), snapshot (N = 1: BASELINE configs[4], "
                         "BaryonifySnapshot 512^3 particles + CIC deposit, --halos halos)")
     p.add_argument("--variant", default="auto")
-    p.add_argument("--table", choices=["default", "stress"], default="default")
+    p.add_argument("--table", choices=["default", "stress", "nd4", "nd5"], default="default",
+                   help="stress: the notebooks' 2x30x2000 shape; nd4 / nd5: the default table with four / five extra p_keys axes of three nodes "
+                        "(values independent of them: the map must be the default table's) -- the N-dimensional table path")
     p.add_argument("--steep", action="store_true", help="dn/dlnM ~ M^-0.9 catalog instead of uniform log M")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-e2e", action="store_true")
@@ -451,7 +455,7 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
     # ---- guarded extra legs: whatever happens from here on, the main line above is printed and the run exits 0 -----------
     if args.legs == "auto":
         default_paint = args.workload == "paint" and args.nside == 1024 and args.table == "default" and not args.steep
-        legs = (["weak", "owner", "configs3"] if world > 1 else ["configs1", "configs2", "steep", "configs4", "configs3"]) if default_paint else []
+        legs = (["weak", "owner", "configs3"] if world > 1 else ["configs1", "configs2", "steep", "configs4", "nd4", "configs3"]) if default_paint else []
     else:
         legs = [x for x in args.legs.split(",") if x and x != "none"]       # (names validated in parse())
     if world == 1:
@@ -580,7 +584,8 @@ def run_config(args, torch, dist, rank, local_rank, world, backend, main=True):
     nside, npix = args.nside, 12 * args.nside * args.nside
     n_total = args.halos * world if args.scaling == "weak" else args.halos
     ra, dec, M, z = syn.catalog(n_total, seed=42, steep=args.steep)
-    shape = (10, 30, 100) if args.table == "default" else (2, 30, 2000)
+    shape = (2, 30, 2000) if args.table == "stress" else (10, 30, 100)
+    n_pkeys = int(args.table[2:]) if args.table.startswith("nd") else 0      # extra p_keys axes (three nodes each, uniform halo values)
     ctx = get_context(local_rank)
     bg = Background(cosmo)
     use_bfg = dist is not None and args.collective == "bfg" and backend == "nccl"
@@ -601,7 +606,8 @@ def run_config(args, torch, dist, rank, local_rank, world, backend, main=True):
         idx = sharding.shard_by_sky_patch(ra, dec, w, world, layout=args.layout)[rank]   # default: NSIDE-64 patches dealt round-robin
     else:
         idx = np.arange(n_total)
-    recs = np.stack([M[idx], z[idx], ra[idx], dec[idx]], axis=1)
+    extra_cols = [np.random.default_rng(100 + k).uniform(0.0, 1.0, n_total) for k in range(n_pkeys)]
+    recs = np.stack([M[idx], z[idx], ra[idx], dec[idx]] + [c[idx] for c in extra_cols], axis=1)
     d_cat = ctx.to_device(recs)
     spline = ctx.da_spline(bg, float(np.max(z)))
     md = ctx.massdef_struct(bg, None)
@@ -699,9 +705,12 @@ def run_config(args, torch, dist, rank, local_rank, world, backend, main=True):
     elif args.workload == "paint":
         zax, Max, rax, T = syn.pressure_table(*shape)
         with np.errstate(all="ignore"):
-            table = ctx.table([zax, Max, rax], np.log(T), log_values=True)
+            lnT = np.log(T)
+        if n_pkeys:
+            lnT = np.ascontiguousarray(np.broadcast_to(lnT.reshape(lnT.shape + (1,) * n_pkeys), lnT.shape + (3,) * n_pkeys))
+        table = ctx.table([zax, Max, rax] + [np.array([0.0, 0.5, 1.0])] * n_pkeys, lnT, log_values=True)
         # BFG_SHELL_OUT_OVERWRITE: the map buffer is not cleared beforehand, the call defines every pixel of it
-        sargs = ctx.shell_args(nside, d_cat, idx.size, 4, 0, args.eps, md, variant=args.variant, out_overwrite=True)
+        sargs = ctx.shell_args(nside, d_cat, idx.size, 4 + n_pkeys, n_pkeys, args.eps, md, variant=args.variant, out_overwrite=True)
         # N > 1: consecutive shells go to alternating map buffers, so the all-reduce of shell k (async, on RCCL's own
         # stream) overlaps the painting of shell k+1; every collective is waited for before its buffer is reused and
         # before the timed region ends (finish()).
@@ -953,7 +962,8 @@ def run_config(args, torch, dist, rank, local_rank, world, backend, main=True):
         "config": {"workload": f"{'PaintProfilesShell' if args.workload == 'paint' else 'BaryonifyShell'}: "
                                f"{halo_txt}, NSIDE={nside}, epsilon_max={args.eps:g}, "
                                f"{'TabulatedProfile(Pressure)' if args.workload == 'paint' else 'Baryonification2D'} "
-                               f"table {shape[0]}x{shape[1]}x{shape[2]}, catalog "
+                               f"table {shape[0]}x{shape[1]}x{shape[2]}{' x 3' * n_pkeys}"
+                               f"{' (ParamTabulatedProfile: ' + str(n_pkeys) + ' extra p_keys axes)' if n_pkeys else ''}, catalog "
                                f"{'dn/dlnM~M^-0.9' if args.steep else 'log10M~U(12,15.5)'}, z~U(0.4,0.5), seed 42",
                    "variant": args.variant, "halos_per_gpu": n_total // world, "halos_total": n_total, "nside": nside,
                    "sharding": sharding_txt, "world_size": world,
