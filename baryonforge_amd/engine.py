@@ -571,7 +571,11 @@ def pin(array):
     then run asynchronously at PCIe speed instead of through the runtime's staging buffers, which is what lets
     BaryonifyShell.process() send a shell's map up in slices behind the kernels.  Registering costs about as much as one copy of
     the array, so it pays for maps that are used more than once (or allocate them with pinned_empty() / pinned_copy() in the first
-    place).  unpin(array) releases the pages; the registry keeps the array alive until then."""
+    place).  unpin(array) releases the pages; the registry keeps the array alive until then.
+    CAUTION: registered pageable memory reaches the GPU through the kernel's user-pointer mapping (at its host address); in this
+    project's soak two of ~5000 shells pinned this way ended in a GPU memory fault inside an asynchronous DMA copy from such an
+    array -- no kernel running, the faulting address in the process heap (profiles/r05_soak.txt) --, none of the ~25000 that used
+    page-locked memory from the host allocator (pinned_empty / pinned_copy) or pageable memory did.  Prefer those."""
     torch = require_gpu()
     a = array
     if not (isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"] and a.nbytes > 0):

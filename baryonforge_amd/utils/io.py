@@ -178,10 +178,13 @@ class LightconeShell(object):
     """
 
     def __init__(self, map=None, path=None, cosmo=None, redshift=None, pinned=False):
-        """pinned (not in the reference): True page-locks the map's memory in place (engine.pin: hipHostRegister), "copy" replaces
-        the map by a page-locked copy -- either way the runners' host <-> device transfers of this shell run asynchronously, in
-        slices behind the kernels (BaryonifyShell.process() at BASELINE configs[2]: 4.06 -> 3.23 ms, 2.95 -> 2.58 ms per shell of a list;
-        tools/pinned_probe.py); needs the GPU -- without one the map stays pageable and a UserWarning says so."""
+        """pinned (not in the reference): True (or "copy") replaces the map by a page-locked copy of it (torch's host allocator:
+        hipHostMalloc), so that the runners' host <-> device transfers of this shell run asynchronously, in slices behind the kernels
+        (BaryonifyShell.process() at BASELINE configs[2]: 4.06 -> 3.23 ms, 2.95 -> 2.58 ms per shell of a list; tools/pinned_probe.py).
+        "inplace" page-locks the caller's own array instead (engine.pin: hipHostRegister) -- same speed, no copy, but NOT the default:
+        registered pageable memory is mapped for the GPU through the kernel's user-pointer path, and on this platform two shells in
+        ~5000 handled that way ended in a GPU memory fault inside an asynchronous DMA copy (profiles/r05_soak.txt).  Needs the GPU --
+        without one the map stays pageable and a UserWarning says so."""
         if (path is None) & (map is None):
             raise ValueError("Need to provide either path to map, or provide map values in healpix ring configuration")
         elif isinstance(path, str):
@@ -198,10 +201,10 @@ class LightconeShell(object):
         if pinned:
             try:
                 from .. import engine
-                if pinned == "copy" or not (self.map.dtype == np.float64 and self.map.flags["C_CONTIGUOUS"]):
-                    self.map = engine.pinned_copy(self.map)
-                else:
+                if pinned == "inplace" and self.map.dtype == np.float64 and self.map.flags["C_CONTIGUOUS"]:
                     engine.pin(self.map)
+                else:
+                    self.map = engine.pinned_copy(self.map)
             except Exception as exc:                                     # no GPU / no page-locked memory: the map stays pageable
                 import warnings
                 warnings.warn(f"LightconeShell(pinned=...): the map stays in pageable memory ({exc})", UserWarning)

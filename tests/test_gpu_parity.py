@@ -1926,9 +1926,9 @@ def test_baryonify_list_on_one_gpu_overlaps_transfers_and_equals_the_plain_path(
 
 
 def test_page_locked_shell_maps_give_the_same_result(cosmo):
-    """LightconeShell(pinned=True) page-locks the map in place (engine.pin -> hipHostRegister), pinned="copy" replaces it by a
-    page-locked copy: BaryonifyShell.process() then moves the map asynchronously in slices -- same map as from
-    pageable memory (to the rounding of the regrid's atomics), mass conserved, and unpin() gives the pages back."""
+    """LightconeShell(pinned=True) (= "copy") replaces the map by a page-locked copy, pinned="inplace" page-locks the caller's array
+    itself (engine.pin -> hipHostRegister): BaryonifyShell.process() then moves the map asynchronously in slices
+    -- same map as from pageable memory (to the rounding of the regrid's atomics), mass conserved, and unpin() gives the pages back."""
     from baryonforge_amd import engine
     nside = 128
     ra, dec, M, z = syn.catalog(3000, seed=12, logM=(13.0, 15.3))
@@ -1937,15 +1937,15 @@ def test_page_locked_shell_maps_give_the_same_result(cosmo):
     Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
     m_in = syn.mass_map(nside)
     ref = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo), 10, bm, verbose=False).process()
-    for mode in (True, "copy"):
+    for mode in (True, "copy", "inplace"):
         src = m_in.copy()
         shell = bfg.LightconeShell(map=src, cosmo=cosmo, pinned=mode)
-        assert engine.is_pinned(shell.map) and (shell.map is src) == (mode is True)
+        assert engine.is_pinned(shell.map) and (shell.map is src) == (mode == "inplace")
         got = bfg.BaryonifyShell(Cat, shell, 10, bm, verbose=False).process()
         assert np.isclose(got.sum(), m_in.sum())
         assert_maps_close(got, ref, 1e-9, floor=1e-12, what=f"pinned={mode!r} vs pageable")
         assert np.array_equal(shell.map, m_in)                          # the input map is untouched
-        if mode is True:
+        if mode == "inplace":
             engine.unpin(src)
             assert not engine.is_pinned(src)
     # paint into a caller's page-locked output

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Python API with page-locked host maps: BaryonifyShell.process() at BASELINE configs[2] with the shell's map pageable / registered in
-place (LightconeShell(pinned=True)) / a page-locked copy (pinned="copy"), PaintProfilesShell.process() at the headline size with the
+place (LightconeShell(pinned="inplace")) / a page-locked copy (pinned=True), PaintProfilesShell.process() at the headline size with the
 default output and with out= a page-locked array; results must be bit-identical to the pageable run."""
 import os, sys, time, warnings
 import numpy as np
@@ -30,7 +30,7 @@ bm = bfg.Baryonification2D.from_arrays(zd, Md, rd, d, cosmo, epsilon_max=20)
 ref = None
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
-    for label, kw in (("pageable", {}), ("pinned=True (registered in place)", {"pinned": True}), ("pinned='copy'", {"pinned": "copy"})):
+    for label, kw in (("pageable", {}), ("pinned='inplace' (registered in place)", {"pinned": "inplace"}), ("pinned=True (page-locked copy)", {"pinned": True})):
         t0 = time.perf_counter()
         shell = bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo, **kw)
         t_make = (time.perf_counter() - t0) * 1e3
