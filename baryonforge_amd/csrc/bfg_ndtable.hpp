@@ -123,6 +123,21 @@ __global__ __launch_bounds__(256) void nd_cell_kernel(const NdTable T, const dou
                                                       int rshift, int32_t *__restrict__ key, double *__restrict__ y,
                                                       int32_t *__restrict__ count, double *__restrict__ rows, bfg_stats *stats)
 {
+    // the outer axes in LDS while they fit (the bisections are chains of dependent loads: as in halo_prep_kernel)
+    constexpr int kAxisLds = 1024;
+    __shared__ double s_axis[kAxisLds];
+    __shared__ int s_axis0[kNdMaxOuter + 1];
+    if (threadIdx.x == 0) {
+        int pos = 0;
+        for (int k = 0; k < T.nouter; ++k) { s_axis0[k] = pos; pos += T.oshape[k]; }
+        s_axis0[T.nouter] = pos;
+    }
+    __syncthreads();
+    const bool axes_lds = s_axis0[T.nouter] <= kAxisLds;
+    if (axes_lds)
+        for (int k = 0; k < T.nouter; ++k)
+            for (int i = threadIdx.x; i < T.oshape[k]; i += blockDim.x) s_axis[s_axis0[k] + i] = T.oaxis[k][i];
+    __syncthreads();
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_halo) return;
     const double *c = cat + j * (int64_t)cat_stride;
@@ -132,7 +147,7 @@ __global__ __launch_bounds__(256) void nd_cell_kernel(const NdTable T, const dou
     unsigned warn = 0;
     for (int k = 0; k < T.nouter; ++k) {
         const double x = (k == 0) ? log(1.0 / a) : (k == 1) ? log(c[0]) : c[4 + (k - 2)];   // Tabulate.py:308, :312, :620
-        const double *g = T.oaxis[k];
+        const double *g = axes_lds ? s_axis + s_axis0[k] : T.oaxis[k];
         const int n = T.oshape[k];
         if (!(x >= g[0]) || !(x <= g[n - 1])) {
             oob = true;
