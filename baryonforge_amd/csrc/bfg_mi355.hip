@@ -3090,8 +3090,8 @@ static int run_shell_nd(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t,
             hipLaunchKernelGGL(bfg::snap_scan_sums_kernel, dim3(1), dim3(1024), 0, c->stream, (int)nblk, d_bsum, d_total);
             hipLaunchKernelGGL(bfg::snap_scan_add_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, c->stream, ncell, d_start,
                                d_bsum, d_count, d_total);
-            hipLaunchKernelGGL(bfg::group_fill_kernel, dim3((unsigned)std::min<int64_t>((nb + 255) / 256, 4096)), dim3(256), 0, c->stream,
-                               nb, d_cell, d_count, d_start, d_perm);
+            hipLaunchKernelGGL(bfg::nd_fill_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream, nb, d_cell, d_count, d_start,
+                               d_perm);
             const unsigned grid = (unsigned)std::min<int64_t>((nb + 4 * bfg::kNdBlockHalos - 1) / (4 * bfg::kNdBlockHalos), (int64_t)c->n_cu * 16);
             hipLaunchKernelGGL(bfg::nd_rows_blocked_kernel, dim3(grid), dim3(256), 0, c->stream, N, rshift, d_cell, d_perm, d_start + ncell,
                                d_y, c->d_ndrows);

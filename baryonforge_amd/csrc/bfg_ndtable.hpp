@@ -172,6 +172,17 @@ __global__ __launch_bounds__(256) void nd_cell_kernel(const NdTable T, const dou
     }
 }
 
+// perm[start[key] + rank] = halo index, the rank from a plain counting atomic (the keys of neighbouring halos are unrelated: the
+// ballot grouping of group_fill_kernel finds nothing to merge here, and the R counters per cell keep the atomics apart)
+__global__ __launch_bounds__(256) void nd_fill_kernel(int64_t n, const int32_t *__restrict__ key, int32_t *__restrict__ count,
+                                                      const int32_t *__restrict__ start, int32_t *__restrict__ perm)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int k = key[j];
+    if (k >= 0) perm[start[k] + atomicAdd(&count[k], 1)] = (int32_t)j;
+}
+
 __device__ inline double nd_uniform(double v)             // a wave-uniform value into scalar registers (an FMA takes one scalar operand)
 {
     const long long b = __double_as_longlong(v);
