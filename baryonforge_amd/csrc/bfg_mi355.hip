@@ -3056,7 +3056,7 @@ static int run_shell_nd(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t,
     const int64_t nblk = (ncell + 1023) / 1024;
     size_t y_off = 0;
     if (blocked) {
-        y_off = ((size_t)(2 * nb_max + 2 * ncell + 1 + nblk + 1) * sizeof(int32_t) + 15) / 16 * 16;
+        y_off = ((size_t)(3 * nb_max + 2 * ncell + 1 + nblk + 1) * sizeof(int32_t) + 15) / 16 * 16;
         const size_t want = y_off + (size_t)nb_max * N.nouter * sizeof(double);
         if (want > c->ndsort_cap) {
             HIP_TRY(hipStreamSynchronize(c->stream));
@@ -3080,17 +3080,18 @@ static int run_shell_nd(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t,
         if (b > 0) ab.flags &= ~(uint32_t)(BFG_SHELL_OUT_OVERWRITE | BFG_SHELL_OUT_IS_ZERO);      // accumulate into the batches before
         if (nb > 0 && blocked) {
             // halos grouped by table cell, eight of a cell per wavefront (bfg_ndtable.hpp)
-            int32_t *const d_cell = (int32_t *)c->d_ndsort, *const d_perm = d_cell + nb_max, *const d_count = d_perm + nb_max;
+            int32_t *const d_cell = (int32_t *)c->d_ndsort, *const d_perm = d_cell + nb_max, *const d_rank = d_perm + nb_max;
+            int32_t *const d_count = d_rank + nb_max;
             int32_t *const d_start = d_count + ncell, *const d_bsum = d_start + ncell + 1, *const d_total = d_bsum + nblk;
             double *const d_y = (double *)((char *)c->d_ndsort + y_off);
             HIP_TRY(hipMemsetAsync(d_count, 0, (size_t)ncell * sizeof(int32_t), c->stream));
             hipLaunchKernelGGL(bfg::nd_cell_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream, N, ab.d_catalog, nb,
-                               a->cat_stride, rshift, d_cell, d_y, d_count, c->d_ndrows, c->d_stats);
+                               a->cat_stride, rshift, d_cell, d_rank, d_y, d_count, c->d_ndrows, c->d_stats);
             hipLaunchKernelGGL(bfg::snap_scan_block_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, ncell, d_count, d_start, d_bsum);
             hipLaunchKernelGGL(bfg::snap_scan_sums_kernel, dim3(1), dim3(1024), 0, c->stream, (int)nblk, d_bsum, d_total);
             hipLaunchKernelGGL(bfg::snap_scan_add_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, c->stream, ncell, d_start,
                                d_bsum, d_count, d_total);
-            hipLaunchKernelGGL(bfg::nd_fill_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream, nb, d_cell, d_count, d_start,
+            hipLaunchKernelGGL(bfg::nd_fill_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream, nb, d_cell, d_rank, d_start,
                                d_perm);
             const unsigned grid = (unsigned)std::min<int64_t>((nb + 4 * bfg::kNdBlockHalos - 1) / (4 * bfg::kNdBlockHalos), (int64_t)c->n_cu * 16);
             hipLaunchKernelGGL(bfg::nd_rows_blocked_kernel, dim3(grid), dim3(256), 0, c->stream, N, rshift, d_cell, d_perm, d_start + ncell,

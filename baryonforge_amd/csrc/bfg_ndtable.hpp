@@ -120,8 +120,9 @@ constexpr int64_t kNdMaxCells = 1 << 22;     // (cells x R counters)
 // per halo: key[j] = cell * R + j % R, cell = flattened cell index over the outer axes (-1: outside the hull of an axis -> a NaN row,
 // written here, and the counters / warnings of nd_rows_kernel), y[j][k] = interpolation weight on axis k, count[key] += 1
 __global__ __launch_bounds__(256) void nd_cell_kernel(const NdTable T, const double *__restrict__ cat, int64_t n_halo, int cat_stride,
-                                                      int rshift, int32_t *__restrict__ key, double *__restrict__ y,
-                                                      int32_t *__restrict__ count, double *__restrict__ rows, bfg_stats *stats)
+                                                      int rshift, int32_t *__restrict__ key, int32_t *__restrict__ rank,
+                                                      double *__restrict__ y, int32_t *__restrict__ count, double *__restrict__ rows,
+                                                      bfg_stats *stats)
 {
     // the outer axes in LDS while they fit (the bisections are chains of dependent loads: as in halo_prep_kernel)
     constexpr int kAxisLds = 1024;
@@ -168,19 +169,18 @@ __global__ __launch_bounds__(256) void nd_cell_kernel(const NdTable T, const dou
     } else {
         const int32_t kk = (int32_t)((id << rshift) | (j & ((1 << rshift) - 1)));
         key[j] = kk;
-        atomicAdd(&count[kk], 1);
+        rank[j] = atomicAdd(&count[kk], 1);             // the halo's place among those of its key: the fill pass needs no second atomic
     }
 }
 
-// perm[start[key] + rank] = halo index, the rank from a plain counting atomic (the keys of neighbouring halos are unrelated: the
-// ballot grouping of group_fill_kernel finds nothing to merge here, and the R counters per cell keep the atomics apart)
-__global__ __launch_bounds__(256) void nd_fill_kernel(int64_t n, const int32_t *__restrict__ key, int32_t *__restrict__ count,
+// perm[start[key] + rank] = halo index (the rank is the value nd_cell_kernel's counting atomic returned)
+__global__ __launch_bounds__(256) void nd_fill_kernel(int64_t n, const int32_t *__restrict__ key, const int32_t *__restrict__ rank,
                                                       const int32_t *__restrict__ start, int32_t *__restrict__ perm)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const int k = key[j];
-    if (k >= 0) perm[start[k] + atomicAdd(&count[k], 1)] = (int32_t)j;
+    if (k >= 0) perm[start[k] + rank[j]] = (int32_t)j;
 }
 
 __device__ inline double nd_uniform(double v)             // a wave-uniform value into scalar registers (an FMA takes one scalar operand)
