@@ -129,6 +129,8 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the single-thread baseline leg")
     a = p.parse_args()
     # (before anything touches the GPU or spawns a rank: a typo here must not cost the run its main line)
+    if a.table.startswith("nd") and a.gpus > 1:
+        p.error("--table nd4 / nd5 is a single-GPU workload (the N > 1 paint path drives the product API with the 3-D table)")
     if a.legs not in ("auto", "none"):
         unknown = [x for x in a.legs.split(",") if x and x != "none" and x not in LEG_ARGS]
         if unknown:
