@@ -180,7 +180,7 @@ class LightconeShell(object):
     def __init__(self, map=None, path=None, cosmo=None, redshift=None, pinned=False):
         """pinned (not in the reference): True (or "copy") replaces the map by a page-locked copy of it (torch's host allocator:
         hipHostMalloc), so that the runners' host <-> device transfers of this shell run asynchronously, in slices behind the kernels
-        (BaryonifyShell.process() at BASELINE configs[2]: 4.06 -> 3.23 ms, 2.95 -> 2.58 ms per shell of a list; tools/pinned_probe.py).
+        (BaryonifyShell.process() at BASELINE configs[2]: 4.06 -> 3.15 ms, 2.95 -> 2.46 ms per shell of a list; tools/pinned_probe.py).
         "inplace" page-locks the caller's own array instead (engine.pin: hipHostRegister) -- same speed, no copy, but NOT the default:
         registered pageable memory is mapped for the GPU through the kernel's user-pointer path, and on this platform two shells in
         ~5000 handled that way ended in a GPU memory fault inside an asynchronous DMA copy (profiles/r05_soak.txt).  Needs the GPU --
