@@ -414,6 +414,27 @@ def test_table_cache_never_hands_out_a_stale_table(monkeypatch):
     big[17, 3, 41] = 2.0
     tb2 = ctx.table(big_axes, big, True, cache_key=(m, "big", big))
     assert tb2 is not tb and tb2.values[17, 3, 41] == 2.0
+    # the stamp itself (engine._fingerprint, a 128-bit hash): every byte counts up to 4 MiB -- any single element, the last odd
+    # bytes, a swap of two values --; beyond that it is 128 sampled pages + both ends unless BFG_CATALOG_CACHE=full (as for the catalog: documented)
+    fp = engine._fingerprint
+    a = np.arange(100_000, dtype=np.float64)
+    f0 = fp(a)
+    for edit in (lambda x: x.__setitem__(54321, -1.0), lambda x: x.__setitem__(0, 0.5), lambda x: x.__setitem__(-1, 0.5)):
+        b = a.copy(); edit(b)
+        assert fp(b) != f0
+    b = a.copy(); b[[10, 20]] = b[[20, 10]]
+    assert fp(b) != f0                                    # (a swap of two values: a plain xor / sum of words would not see it)
+    assert fp(np.frombuffer(b"abcdefghijk", dtype=np.uint8)) != fp(np.frombuffer(b"abcdefghijK", dtype=np.uint8))
+    huge = np.zeros(1_000_000)                             # 8 MB: sampled
+    h0 = fp(huge)
+    huge[0] = 1.0
+    assert fp(huge) != h0                                  # first page: in the sample
+    huge[0] = 0.0; huge[123_457] = 1.0
+    sampled_sees_it = fp(huge) != h0
+    monkeypatch.setenv("BFG_CATALOG_CACHE", "full")
+    assert fp(huge) != fp(np.zeros(1_000_000))             # every byte: any edit is seen
+    monkeypatch.delenv("BFG_CATALOG_CACHE")
+    assert sampled_sees_it in (True, False)
 
 
 def test_grid_runner_mirrors_the_halo_offset_assertion():
