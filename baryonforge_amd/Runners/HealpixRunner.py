@@ -523,11 +523,12 @@ class _BaryonifyDeviceOps(object):
         get_context().regrid_shell(nside, d_off, d_in, d_out, d_sums)
 
     def count_above(self, d_in, ranges, threshold, d_dst):
-        """d_dst[0] = number of pixels of the ranges with |value| > threshold (NaN counts as not above), left on the device"""
+        """d_dst[0] = number of pixels of the ranges that are NOT within `threshold` of zero, left on the device: |value| > threshold
+        or NaN -- exactly the pixels that make np.allclose(map, 0) False"""
         total = None
         for lo, hi in ranges:
             if hi > lo:
-                c = (d_in[lo:hi].abs() > threshold).sum()
+                c = (~(d_in[lo:hi].abs() <= threshold)).sum()
                 total = c if total is None else total + c
         if total is not None:
             d_dst[0] = total
@@ -713,7 +714,10 @@ def _baryonify_process(runner, ops, exchange, slices=1):
     on NSIDE and the slice count only: bfg_shell_slice_cuts), so ONLY THEY are uploaded: 8 Npix / N bytes of input map per rank.
     The regridded maps, whose deposits cross the range borders, are all-reduced together with three scalars -- sum(in),
     sum(deposits), count(|in| > 1e-8) of the rank's sources -- so the mass assertion (:368-370) and the all-zero test (:293-294)
-    need no collective or read-back of their own: nothing comes back from the device before the final map."""
+    need no collective or read-back of their own: with several ranks nothing comes back from the device before the final map.  On
+    ONE rank the count is read back (one 8-byte copy, one synchronisation) before the offsets are accumulated, so that an all-zero
+    shell costs its upload and nothing else, as in the reference.  The count includes NaN pixels (count_above), so it alone
+    decides np.allclose(orig_map, 0): no second pass over the map on the host."""
     orig_map = runner.LightconeShell.map
     NSIDE = runner.LightconeShell.NSIDE
     if orig_map.size < (1 << 16) and np.allclose(orig_map, 0):         # small maps: decided on the host, as the reference
@@ -739,12 +743,12 @@ def _baryonify_process(runner, ops, exchange, slices=1):
     assert sum(hi - lo for lo, hi in owned) > 0 or npix < world
     d_in = ops.upload_ranges(flat, owned, npix)                        # sources this rank does not own have no mass here
     d_out = ops.zeros(npix + 3)
-    ops.count_above(d_in, owned, 1e-8, d_out[npix + 2:])              # np.allclose(orig_map, 0) <=> no |value| > 1e-8 (NaN: see below)
+    ops.count_above(d_in, owned, 1e-8, d_out[npix + 2:])              # np.allclose(orig_map, 0) <=> no pixel with |value| > 1e-8 or NaN
     if not multi:
         # one rank: nobody waits for this rank's collectives, so the all-zero test (:293-294) is read back BEFORE the offsets are
         # accumulated and the map regridded -- an empty shell costs its upload and one small copy, as in the reference; with several
         # ranks the count rides on the final all-reduce instead (a read-back here would cost every rank a synchronisation per shell)
-        if float(ops.to_host(d_out[npix + 2:])[0]) == 0 and np.allclose(orig_map, 0):
+        if float(ops.to_host(d_out[npix + 2:])[0]) == 0:
             return orig_map
     handles, seen = [], []
 
@@ -768,7 +772,7 @@ def _baryonify_process(runner, ops, exchange, slices=1):
         exchange.allreduce(d_out)                                     # the map and the three scalars in one collective
     host = ops.to_host(d_out)                                          # the one read-back
     old_sum, new_sum, n_above = (float(x) for x in host[npix:])
-    if n_above == 0 and np.allclose(orig_map, 0):                      # :293-294 (a NaN map counts nothing but is not all-zero)
+    if n_above == 0:                                                   # :293-294 (NaN pixels are counted: a NaN map is not all-zero)
         return orig_map
     assert np.isclose(new_sum, old_sum), \
         "ERROR in pixel regridding, sum(new_map) [%0.14e] != sum(oldmap) [%0.14e]" % (new_sum, old_sum)  # :368-370

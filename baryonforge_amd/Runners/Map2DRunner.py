@@ -3,7 +3,8 @@ Periodic Cartesian-grid runners, mirroring BaryonForge/Runners/Map2DRunner.py: `
 `BaryonifyGrid` (:376-621), `PaintProfilesGrid` (:624-829) and the overlap regrid `regrid_pixels_2D/_3D` (:14-162).
 Same constructors, attributes and `process() -> ndarray` of the map's shape; the per-halo python loops and the numba
 regrid are replaced by bfg_paint_grid / bfg_baryonify_grid_offsets / bfg_regrid_grid (csrc/bfg_grid.hpp).  No CPU
-fallback.  Ellipticity (use_ellipticity=True) and PaintProfilesAnisGrid are not built.
+fallback.  Ellipticity (use_ellipticity=True, the per-halo rotation matrices of :497-515) and PaintProfilesAnisGrid (:832-1064) are
+built too (bfg_grid_args.d_rmat; golden fixture tests/golden/grid.npz).
 """
 import numpy as np
 
@@ -148,6 +149,11 @@ class DefaultRunnerGrid(object):
             txt = (f"You asked to use {keys} properties in Baryonification. You must pass a ParamTabulatedProfile"
                    f"as the model. You have passed {type(self.model)} instead")
             assert isinstance(self.model, ParamTabulatedProfile) or type(self.model).__name__ == "ParamTabulatedProfile", txt
+        if len(keys) > 3:
+            # the grid kernels read the table themselves: (z, M, r) + up to three extra axes; wider tables only exist as per-halo rows
+            # on the shell path (csrc/bfg_ndtable.hpp).  Said here, before the table is uploaded, not as a status code afterwards.
+            raise NotImplementedError(f"the periodic-grid runners read tables with up to 3 p_keys axes on the MI355X path; "
+                                      f"this model has {len(keys)}: {list(keys)}")
         return list(keys)
 
     def _device_inputs(self, ctx, keys):

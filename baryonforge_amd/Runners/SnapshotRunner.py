@@ -65,6 +65,9 @@ class BaryonifySnapshot(DefaultRunnerSnapshot):
                 type(self.model).__name__ in ("ParamTabulatedProfile", "BaryonificationClass", "Baryonification2D",
                                               "Baryonification3D")
             assert ok, txt
+        if len(keys) > 3:                 # (before the table is uploaded: the snapshot kernels read (z, M, r) + up to three extra axes)
+            raise NotImplementedError(f"BaryonifySnapshot reads tables with up to 3 p_keys axes on the MI355X path; this model "
+                                      f"has {len(keys)}: {list(keys)}")
         if not _is_disp_table(self.model):
             if self.model is not None and hasattr(self.model, "displacement"):
                 raise NameError("No Table created. Run setup_interpolator() method first")

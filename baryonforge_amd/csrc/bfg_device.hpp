@@ -275,6 +275,39 @@ __device__ inline int find_interval(const double *__restrict__ g, int n, double 
     return lo;
 }
 
+// The same cell for ANY ascending axis, found from a guess instead of a bisection: i0 = (x - g[0]) * inv_h with inv_h the inverse
+// of the axis' MEAN spacing (host side: (n - 1) / (g[n-1] - g[0]); 0 = unknown).  The guess is then moved by the very comparisons
+// the bisection makes (g[i] <= x < g[i+1]) -- at most two cells either way, which covers every axis that is a linspace to
+// rounding (the D_A knots of HealpixRunner.py:297, the ln M axis of a geomspace mass grid) -- and anything farther off finishes
+// with a bisection of the remaining bracket.  Two dependent loads instead of log2(n).
+__device__ inline int find_interval_hint(const double *__restrict__ g, int n, double x, double inv_h)
+{
+    if (!(x >= g[0])) return 0;
+    if (x >= g[n - 1]) return n - 2;
+    int i = (int)((x - g[0]) * inv_h);
+    i = min(max(i, 0), n - 2);
+    int lo, hi;
+    if (g[i] > x) {                                        // g[0] <= x: i >= 1 here
+        --i;
+        if (g[i] <= x) return i;
+        --i;
+        if (g[i] <= x) return i;
+        lo = 0; hi = i;
+    } else {
+        if (x < g[i + 1]) return i;
+        ++i;                                               // x < g[n-1]: i + 1 <= n - 1 here
+        if (x < g[i + 1]) return i;
+        ++i;
+        if (x < g[i + 1]) return i;
+        lo = i + 1; hi = n - 1;
+    }
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (g[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 // inclusive prefix sum over the G consecutive lanes of a group (G = 16 or 64)
 template <int G>
 __device__ inline int group_inclusive_scan(int v, int lane)

@@ -75,6 +75,7 @@ struct bfg_table {
     double *d_blob;                 // one allocation: axes + values
     std::vector<int64_t> shape;
     bfg_ndtable *nd = nullptr;      // more than BFG_MAX_DIM dimensions: the table itself (dev then describes the halos' rows: see hstride)
+    double ax_inv_h[2] = {0.0, 0.0};   // inverse mean spacing of the z and M axes (find_interval_hint; host side only: DevTable stays 184 B)
 };
 
 // (bfg_ndtable is defined with its C-ABI functions at the end of this file)
@@ -85,6 +86,7 @@ static int run_shell_nd(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t,
 
 struct bfg_spline {
     int n;
+    double inv_h;     // (n - 1) / (knots[n-1] - knots[0]): find_interval_hint
     double *d_knots;  // [n]
     double *d_coef;   // [4][n-1]
 };
@@ -220,6 +222,9 @@ struct PrepParams {
     double *hwin;            // tile variant, row windows of 4 k nodes: the kernel also builds the halos' blended rows (null: a
                              // separate halo_row*_kernel does)
     int lazy_soa;            // tile path, 3-D table: the SoA workspace rows only of halos the scatter kernel / the fill pass will read
+    // inverse mean spacing of the D_A knots and of the table's z and M axes (find_interval_hint: the cell from a guess + the same
+    // comparisons instead of a bisection; 0 = unknown, any value gives the same cell)
+    double spl_inv_h, ax_inv_h[2];
 };
 
 #define MODE_PAINT 0
@@ -262,9 +267,9 @@ __device__ inline double massdef_radius(const bfg_massdef &md, double M, double 
 #include "bfg_tablebuild.hpp"
 
 // scipy PPoly evaluation of the not-a-knot CubicSpline of HealpixRunner.py:299 (extrapolates)
-__device__ inline double spline_eval(int n, const double *__restrict__ x, const double *__restrict__ c, double v)
+__device__ inline double spline_eval(int n, const double *__restrict__ x, const double *__restrict__ c, double v, double inv_h = 0.0)
 {
-    int i = find_interval(x, n, v);
+    int i = find_interval_hint(x, n, v, inv_h);
     double s = v - x[i];
     int m = n - 1;
     return ((c[i] * s + c[m + i]) * s + c[2 * m + i]) * s + c[3 * m + i];
@@ -287,7 +292,7 @@ __device__ inline void halo_calc(const PrepParams &P, int64_t j, const double *_
     const double M = c[0], zred = c[1], ra = c[2], dec = c[3];
     const double a = 1.0 / (1.0 + zred);                                   // HealpixRunner.py:319/:453
     const double R = massdef_radius(P.md_run, M, a);                        // :320/:454
-    const double D = spline_eval(P.spl_n, knots, P.spl_coef, zred);         // :321/:455
+    const double D = spline_eval(P.spl_n, knots, P.spl_coef, zred, P.spl_inv_h);   // :321/:455
     // hp.ang2vec(ra, dec, lonlat=True)                                      // :327/:460
     const double theta = kHalfPi - dec * kDeg2Rad, phi = ra * kDeg2Rad;
     // (trigonometry without libm where the argument is in range -- sincos_range / atan2_upper: <= 2 ulp, a third of ocml's
@@ -347,7 +352,7 @@ __device__ inline void halo_calc(const PrepParams &P, int64_t j, const double *_
             if (k == 0) warn |= BFG_WARN_Z_RANGE;
             if (k == 1) warn |= BFG_WARN_M_RANGE;
         }
-        int i = find_interval(g, n, x);
+        int i = (k < 2) ? find_interval_hint(g, n, x, P.ax_inv_h[k]) : find_interval(g, n, x);
         cell(k, i, (x - g[i]) / (g[i + 1] - g[i]));
     }
     if (oob) flags |= HF_OOB;
@@ -444,7 +449,7 @@ __global__ __launch_bounds__(256, BFG_PREP_WAVES) void halo_prep_kernel(const Pr
         const double sr = sin_range(0.5 * fmin(radius, kPi));
         const double axis_shift = (P.hd && P.rdelta) ? log(hc.Rm_com) : 0.0;
         const double rho_max = 0.5 * log(4.0 * h.S * sr * sr) - axis_shift;
-        int win_lo = find_interval(raxis_lds ? s_raxis : P.tab.raxis, P.tab.nr, rho_max) + 1 - (P.win_nodes - 1);
+        int win_lo = find_interval_hint(raxis_lds ? s_raxis : P.tab.raxis, P.tab.nr, rho_max, P.spl_inv_h != 0.0 ? P.tab.inv_dr : 0.0) + 1 - (P.win_nodes - 1);
         if (win_lo > P.tab.nr - P.win_nodes) win_lo = P.tab.nr - P.win_nodes;
         if (win_lo < 0) win_lo = 0;
         if (P.hd) {
@@ -1507,6 +1512,7 @@ int bfg_table_create(bfg_ctx *c, int ndim, const int64_t *shape, const double *c
     }
     bfg_table *t = new bfg_table();
     t->shape.assign(shape, shape + ndim);
+    for (int d = 0; d < 2; ++d) t->ax_inv_h[d] = (double)(shape[d] - 1) / (axes[d][shape[d] - 1] - axes[d][0]);
     // permute values so that r (dim 2) is the fastest axis: [z][M][extras...][r]
     const int nouter = ndim - 1;
     std::vector<int> odim(nouter);   // outer k -> original dim
@@ -1644,6 +1650,7 @@ int bfg_spline_create(bfg_ctx *c, int n, const double *knots, const double *coef
     for (int i = 1; i < n; ++i) if (!(knots[i] > knots[i - 1])) return BFG_ERR_INVALID;
     bfg_spline *s = new bfg_spline();
     s->n = n; s->d_knots = nullptr; s->d_coef = nullptr;
+    s->inv_h = (n >= 2 && knots[n - 1] > knots[0]) ? (double)(n - 1) / (knots[n - 1] - knots[0]) : 0.0;
     if (hipMalloc((void **)&s->d_knots, (size_t)n * sizeof(double)) != hipSuccess ||
         hipMalloc((void **)&s->d_coef, (size_t)4 * (n - 1) * sizeof(double)) != hipSuccess ||
         hipMemcpyAsync(s->d_knots, knots, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
@@ -1974,6 +1981,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     pp.md_run = a->runner_md; pp.md_model = a->model_md;
     pp.spl_n = s->n; pp.spl_knots = s->d_knots; pp.spl_coef = s->d_coef;
     pp.tab = t->dev;
+    if (!std::getenv("BFG_NO_HINT")) { pp.spl_inv_h = s->inv_h; pp.ax_inv_h[0] = t->ax_inv_h[0]; pp.ax_inv_h[1] = t->ax_inv_h[1]; }   // A/B switch
     pp.rec = c->d_rec; pp.irec = c->d_irec; pp.cidx = c->d_cidx; pp.cw = c->d_cw;
     pp.stats = c->d_stats;
     pp.want_model_radius = (mode == MODE_BARYONIFY);

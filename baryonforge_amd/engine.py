@@ -26,8 +26,6 @@ def _torch():
     return torch
 
 
-_FINGERPRINT_ALL = 4 << 20       # bytes up to which every byte of an array goes into its stamp
-
 try:                              # a fast non-cryptographic 128-bit hash where it is installed (20 GB/s), else hashlib (1 GB/s)
     from xxhash import xxh3_128_digest as _digest
 except ImportError:               # pragma: no cover
@@ -38,16 +36,17 @@ except ImportError:               # pragma: no cover
 
 
 def _fingerprint(arr):
-    """content stamp of an array: shape, dtype and a 128-bit hash of its bytes: an in-place edit of any element between two process()
-    calls must miss the device-table cache -- the reference re-reads its table on every call.  Up to 4 MiB every byte counts
-    (xxh3: 0.01 ms for the 240 KB table of the headline, where blake2b was 0.15 ms of host time per call, in front of the first kernel
-    launch); larger arrays (N-dimensional tables: tens of MB) are stamped from 128 pages spread over them plus both ends, every
-    byte only with BFG_CATALOG_CACHE=full (as for the catalog: utils/io.py)."""
+    """content stamp of an array: shape, dtype and a 128-bit hash of EVERY byte: an in-place edit of any element between two
+    process() calls must miss the device-table cache -- the reference re-reads its table on every call.  xxh3 runs at ~20 GB/s
+    (0.01 ms for the 240 KB table of the headline, ~1.5 ms for a 30 MB N-dimensional table), and only when the identity check
+    of Context.table() has passed.  BFG_TABLE_CACHE=sampled stamps arrays over 4 MiB from 128 pages spread over them plus both
+    ends instead (the default of round 5, which an edit of a single cell could slip through: ADVICE r5); BFG_TABLE_CACHE=0 keeps
+    no device tables between calls at all; Context.invalidate_tables() drops them explicitly."""
     import os
     a = np.ascontiguousarray(arr)
     b = a.view(np.uint8).reshape(-1)
     n = b.size
-    if n > _FINGERPRINT_ALL and os.environ.get("BFG_CATALOG_CACHE") != "full":
+    if n > (4 << 20) and os.environ.get("BFG_TABLE_CACHE") == "sampled":
         page, k = 4096, 128
         starts = (np.arange(k, dtype=np.int64) * ((n - page) // (k - 1))) // 8 * 8
         b = np.concatenate([b[s0:s0 + page] for s0 in starts] + [b[n - page:]])
@@ -305,7 +304,10 @@ class Context(object):
         keeps those objects alive and is only reused for the very same objects (`is`) with unchanged contents (a
         fingerprint of the array and of the axes): keys made of bare id() values would hand a stale table to a new model
         that happens to be allocated where a collected one used to live."""
+        import os
         axes = [np.ascontiguousarray(a, dtype=np.float64) for a in axes]
+        if cache_key is not None and os.environ.get("BFG_TABLE_CACHE") == "0":
+            cache_key = None
         if cache_key is not None:
             ident = tuple(k if isinstance(k, str) else id(k) for k in cache_key)
             stamp = tuple(_fingerprint(k) for k in cache_key if isinstance(k, np.ndarray)) + \
@@ -321,6 +323,10 @@ class Context(object):
                 self._table_cache.clear()
             self._table_cache[ident] = (t, tuple(cache_key), stamp)
         return t
+
+    def invalidate_tables(self):
+        """forget every device table cached by table(): the next process() call of any model uploads its table afresh"""
+        self._table_cache.clear()
 
     def da_spline(self, background, z_max):
         """D_a = CubicSpline(linspace(0, z_max + 0.1, 1000), D_A(1/(1+z)))   (HealpixRunner.py:297-299); cached per
@@ -583,18 +589,45 @@ def pinned_empty(n):
 
 
 _registered = {}      # data address -> (bytes, the array: kept alive while its pages are locked)
+_PAGE = 4096
+
+
+def aligned_empty(n, dtype=np.float64):
+    """numpy array of n elements in page-aligned anonymous memory of its own (mmap), a whole number of pages long: what pin()
+    accepts.  (pinned_empty() is the simpler choice where the array can be allocated page-locked in the first place.)"""
+    import mmap
+    dtype = np.dtype(dtype)
+    nbytes = max(1, int(n) * dtype.itemsize)
+    buf = mmap.mmap(-1, (nbytes + _PAGE - 1) // _PAGE * _PAGE)
+    return np.frombuffer(buf, dtype=dtype, count=int(n))
+
+
+def pin_ok(array):
+    """True if pin() may page-lock this array in place: C-contiguous, starting on a page boundary, inside a buffer that owns every
+    page it touches (aligned_empty, a private anonymous mmap, posix_memalign'd whole pages)"""
+    a = array
+    if not (isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"] and a.nbytes > 0 and a.ctypes.data % _PAGE == 0):
+        return False
+    if a.nbytes % _PAGE == 0:
+        return True
+    base = a
+    while isinstance(base, np.ndarray) and base.base is not None:     # a view of a whole-page buffer (aligned_empty: an mmap object)
+        base = base.base
+    import mmap
+    return isinstance(base, mmap.mmap)
 
 
 def pin(array):
     """Page-lock the memory of a C-contiguous numpy array IN PLACE (hipHostRegister) and return it: host <-> device copies of it
-    then run asynchronously at PCIe speed instead of through the runtime's staging buffers, which is what lets
-    BaryonifyShell.process() send a shell's map up in slices behind the kernels.  Registering costs about as much as one copy of
-    the array, so it pays for maps that are used more than once (or allocate them with pinned_empty() / pinned_copy() in the first
-    place).  unpin(array) releases the pages; the registry keeps the array alive until then.
-    CAUTION: registered pageable memory reaches the GPU through the kernel's user-pointer mapping (at its host address); in this
-    project's soak two of ~5000 shells pinned this way ended in a GPU memory fault inside an asynchronous DMA copy from such an
-    array -- no kernel running, the faulting address in the process heap (profiles/r05_soak.txt) --, none of the ~25000 that used
-    page-locked memory from the host allocator (pinned_empty / pinned_copy) or pageable memory did.  Prefer those."""
+    then run asynchronously at PCIe speed instead of through the runtime's staging buffers.  Registering costs about as much as one
+    copy of the array, so it pays for maps that are used more than once.  unpin(array) releases the pages; the registry keeps the
+    array alive until then.
+    ONLY page-aligned buffers that own all their pages are accepted (aligned_empty(), a private mmap; pin_ok() tells): registered
+    pageable memory reaches the GPU through the kernel's user-pointer mapping of whole pages, and an ordinary numpy array shares
+    its first and last page -- below glibc's mmap threshold all of them -- with other heap objects, which the allocator may trim or
+    the kernel migrate under the mapping.  In round 5's soak two of ~5000 shells registered from the HEAP ended in a GPU memory
+    fault inside an asynchronous DMA copy (no kernel running, faulting address in the process heap: profiles/r05_soak.txt); heap
+    arrays are therefore refused with a ValueError (LightconeShell(pinned="inplace") then makes a page-locked copy instead)."""
     torch = require_gpu()
     a = array
     if not (isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"] and a.nbytes > 0):
@@ -602,30 +635,39 @@ def pin(array):
     ptr = a.ctypes.data
     if ptr in _registered or torch.from_numpy(a.reshape(-1).view(np.uint8)).is_pinned():
         return array
+    if not pin_ok(a):
+        raise ValueError("pin() only page-locks page-aligned buffers that own every page they touch (engine.aligned_empty(n), a "
+                         "private mmap); this array lives in the allocator's heap -- use pinned_copy() / pinned_empty() instead")
+    nbytes = (a.nbytes + _PAGE - 1) // _PAGE * _PAGE
     # drain the device first: the runtime page-locks the source of a large pageable copy in place and may still hold that lock (it
     # lets go at the queue's next fence) -- a registration nested inside such a transient lock would share its GPU mapping
     torch.cuda.synchronize()
-    rc = torch.cuda.cudart().cudaHostRegister(ptr, a.nbytes, 0)
+    rc = torch.cuda.cudart().cudaHostRegister(ptr, nbytes, 0)
     if int(rc) != 0:
-        raise _lib.BFGError(f"hipHostRegister of {a.nbytes} bytes failed (error {int(rc)})")
-    _registered[ptr] = (a.nbytes, a)
+        raise _lib.BFGError(f"hipHostRegister of {nbytes} bytes failed (error {int(rc)})")
+    _registered[ptr] = (nbytes, a)
     return array
 
 
 def unpin(array):
     """release the pages pin() locked (no-op for arrays it did not register)"""
-    ent = _registered.pop(array.ctypes.data, None)
-    if ent is not None:
-        _torch().cuda.synchronize()                  # no copy of ours may still be reading or writing these pages
-        rc = _torch().cuda.cudart().cudaHostUnregister(array.ctypes.data)
-        if int(rc) != 0:                              # (the pages would stay mapped for the GPU behind the array's back)
-            raise _lib.BFGError(f"hipHostUnregister failed (error {int(rc)})")
+    ptr = array.ctypes.data
+    if ptr not in _registered:
+        return
+    _torch().cuda.synchronize()                      # no copy of ours may still be reading or writing these pages
+    rc = _torch().cuda.cudart().cudaHostUnregister(ptr)
+    if int(rc) != 0:                                  # the pages stay mapped for the GPU: the registry keeps the array alive
+        raise _lib.BFGError(f"hipHostUnregister failed (error {int(rc)})")
+    del _registered[ptr]
 
 
-def pinned_copy(array):
-    """a float64 copy of `array` (same shape) in page-locked host memory"""
-    a = np.asarray(array, dtype=np.float64)
-    out = pinned_empty(a.size).reshape(a.shape)
+def pinned_copy(array, dtype=np.float64):
+    """a copy of `array` (same shape) in page-locked host memory; float64 by default (what the kernels read), dtype=None keeps the
+    array's own dtype"""
+    a = np.asarray(array)
+    dtype = np.dtype(a.dtype if dtype is None else dtype).newbyteorder("=")      # (FITS columns arrive big-endian: native order here)
+    torch = require_gpu()
+    out = torch.empty(a.shape, dtype=torch.from_numpy(np.empty(0, dtype)).dtype, pin_memory=True).numpy()
     out[...] = a
     return out
 

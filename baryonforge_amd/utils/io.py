@@ -103,11 +103,12 @@ class HaloLightConeCatalog(object):
         import os
         cat = self.cat
         if os.environ.get("BFG_CATALOG_CACHE", "1") == "full":
-            # every byte, every call: a wrapping sum and an xor over the records as 8-byte words (~2 ms per 1e6 halos on one core --
-            # more than the painting itself takes on the GPU, which is why it is not the default); catches single-element edits too
-            words = np.ascontiguousarray(cat).view(np.uint8).reshape(-1)
-            words = words[:words.size - words.size % 8].view(np.uint64)
-            return (cat.size, cat.dtype.str, int(np.add.reduce(words, dtype=np.uint64)), int(np.bitwise_xor.reduce(words)))
+            # every byte, every call: the 128-bit hash the table cache uses (engine._digest: xxh3, ~20 GB/s -- ~1.6 ms per 1e6 halos,
+            # more than the painting itself takes on the GPU, which is why it is not the default).  Position-dependent: catches
+            # single-element edits AND permutations (a swap of two halos' masses, np.random.shuffle through an old view), which a
+            # sum / xor of the words would not
+            from ..engine import _digest
+            return (cat.size, cat.dtype.str, _digest(np.ascontiguousarray(cat).view(np.uint8).reshape(-1)))
         step = max(1, cat.size // 256)
         sample = np.ascontiguousarray(cat[::step])
         return (cat.size, cat.dtype.str, sample.tobytes())
@@ -181,10 +182,12 @@ class LightconeShell(object):
         """pinned (not in the reference): True (or "copy") replaces the map by a page-locked copy of it (torch's host allocator:
         hipHostMalloc), so that the runners' host <-> device transfers of this shell run asynchronously, in slices behind the kernels
         (BaryonifyShell.process() at BASELINE configs[2]: 4.06 -> 3.15 ms, 2.95 -> 2.46 ms per shell of a list; tools/pinned_probe.py).
-        "inplace" page-locks the caller's own array instead (engine.pin: hipHostRegister) -- same speed, no copy, but NOT the default:
-        registered pageable memory is mapped for the GPU through the kernel's user-pointer path, and on this platform two shells in
-        ~5000 handled that way ended in a GPU memory fault inside an asynchronous DMA copy (profiles/r05_soak.txt).  Needs the GPU --
-        without one the map stays pageable and a UserWarning says so."""
+        "inplace" page-locks the caller's own array instead (engine.pin: hipHostRegister) -- same speed, no copy -- but ONLY if the array
+        is a page-aligned buffer that owns its pages (engine.aligned_empty, a private mmap; engine.pin_ok): an array in the
+        allocator's heap shares pages with other objects, and in round 5's soak two of ~5000 heap arrays registered in place ended in
+        a GPU memory fault inside an asynchronous DMA copy (profiles/r05_soak.txt) -- such a map gets a page-locked COPY and a
+        UserWarning.  The copy is float64 (what the kernels read), whatever the map's dtype.  Needs the GPU: without one the map
+        stays pageable and a UserWarning says so; any other failure is raised."""
         if (path is None) & (map is None):
             raise ValueError("Need to provide either path to map, or provide map values in healpix ring configuration")
         elif isinstance(path, str):
@@ -199,14 +202,17 @@ class LightconeShell(object):
         self.NSIDE = npix2nside(self.map.size)
         self.redshift = redshift
         if pinned:
+            import warnings
+            from .. import engine, _lib
             try:
-                from .. import engine
-                if pinned == "inplace" and self.map.dtype == np.float64 and self.map.flags["C_CONTIGUOUS"]:
+                if pinned == "inplace" and self.map.dtype == np.float64 and engine.pin_ok(self.map):
                     engine.pin(self.map)
                 else:
+                    if pinned == "inplace":
+                        warnings.warn("LightconeShell(pinned='inplace'): the map is not a page-aligned float64 buffer that owns its "
+                                      "pages (engine.aligned_empty / engine.pin_ok); a page-locked copy is used instead", UserWarning)
                     self.map = engine.pinned_copy(self.map)
-            except Exception as exc:                                     # no GPU / no page-locked memory: the map stays pageable
-                import warnings
+            except (_lib.BFGError, RuntimeError, MemoryError) as exc:    # no GPU / no page-locked memory: the map stays pageable
                 warnings.warn(f"LightconeShell(pinned=...): the map stays in pageable memory ({exc})", UserWarning)
 
         if cosmo is None:

@@ -83,7 +83,7 @@ class OracleBaryonifyOps(object):
         return torch.zeros(*shape, dtype=torch.float64)
 
     def count_above(self, d_in, ranges, threshold, d_dst):
-        d_dst[0] = float(sum(int((d_in[lo:hi].abs() > threshold).sum()) for lo, hi in ranges))
+        d_dst[0] = float(sum(int((~(d_in[lo:hi].abs() <= threshold)).sum()) for lo, hi in ranges))
 
     def offsets(self, slices=1, on_slice=None):
         d = torch.from_numpy(np.ascontiguousarray(self.offsets_fn(self.runner), dtype=np.float64))

@@ -1937,9 +1937,22 @@ def test_page_locked_shell_maps_give_the_same_result(cosmo):
     Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, cosmo)
     m_in = syn.mass_map(nside)
     ref = bfg.BaryonifyShell(Cat, bfg.LightconeShell(map=m_in.copy(), cosmo=cosmo), 10, bm, verbose=False).process()
-    for mode in (True, "copy", "inplace"):
-        src = m_in.copy()
-        shell = bfg.LightconeShell(map=src, cosmo=cosmo, pinned=mode)
+    for mode in (True, "copy", "inplace", "inplace-heap"):
+        if mode == "inplace":                                             # a page-aligned buffer that owns its pages: registered in place
+            src = engine.aligned_empty(m_in.size)
+            src[:] = m_in
+            assert engine.pin_ok(src)
+            shell = bfg.LightconeShell(map=src, cosmo=cosmo, pinned="inplace")
+        elif mode == "inplace-heap":                                      # an ordinary numpy array: refused by pin(), copied with a warning
+            src = m_in.copy()
+            assert not engine.pin_ok(src)
+            with pytest.raises(ValueError):
+                engine.pin(src)
+            with pytest.warns(UserWarning, match="page-locked copy"):
+                shell = bfg.LightconeShell(map=src, cosmo=cosmo, pinned="inplace")
+        else:
+            src = m_in.copy()
+            shell = bfg.LightconeShell(map=src, cosmo=cosmo, pinned=mode)
         assert engine.is_pinned(shell.map) and (shell.map is src) == (mode == "inplace")
         got = bfg.BaryonifyShell(Cat, shell, 10, bm, verbose=False).process()
         assert np.isclose(got.sum(), m_in.sum())

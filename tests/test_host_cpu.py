@@ -414,8 +414,9 @@ def test_table_cache_never_hands_out_a_stale_table(monkeypatch):
     big[17, 3, 41] = 2.0
     tb2 = ctx.table(big_axes, big, True, cache_key=(m, "big", big))
     assert tb2 is not tb and tb2.values[17, 3, 41] == 2.0
-    # the stamp itself (engine._fingerprint, a 128-bit hash): every byte counts up to 4 MiB -- any single element, the last odd
-    # bytes, a swap of two values --; beyond that it is 128 sampled pages + both ends unless BFG_CATALOG_CACHE=full (as for the catalog: documented)
+    # the stamp itself (engine._fingerprint, a 128-bit hash): EVERY byte counts, whatever the size -- any single element, the last
+    # odd bytes, a swap of two values (sampling large tables let a single-cell edit through); BFG_TABLE_CACHE=sampled is
+    # the documented opt-out for arrays over 4 MiB, BFG_TABLE_CACHE=0 keeps no tables at all
     fp = engine._fingerprint
     a = np.arange(100_000, dtype=np.float64)
     f0 = fp(a)
@@ -425,16 +426,21 @@ def test_table_cache_never_hands_out_a_stale_table(monkeypatch):
     b = a.copy(); b[[10, 20]] = b[[20, 10]]
     assert fp(b) != f0                                    # (a swap of two values: a plain xor / sum of words would not see it)
     assert fp(np.frombuffer(b"abcdefghijk", dtype=np.uint8)) != fp(np.frombuffer(b"abcdefghijK", dtype=np.uint8))
-    huge = np.zeros(1_000_000)                             # 8 MB: sampled
+    huge = np.zeros(1_000_000)                             # 8 MB
     h0 = fp(huge)
+    huge[123_457] = 1.0                                    # one cell, on none of the pages a sampled stamp would read
+    assert fp(huge) != h0
+    monkeypatch.setenv("BFG_TABLE_CACHE", "sampled")
+    assert fp(huge) == fp(np.zeros(1_000_000))             # the opt-out misses it (documented)
     huge[0] = 1.0
-    assert fp(huge) != h0                                  # first page: in the sample
-    huge[0] = 0.0; huge[123_457] = 1.0
-    sampled_sees_it = fp(huge) != h0
-    monkeypatch.setenv("BFG_CATALOG_CACHE", "full")
-    assert fp(huge) != fp(np.zeros(1_000_000))             # every byte: any edit is seen
-    monkeypatch.delenv("BFG_CATALOG_CACHE")
-    assert sampled_sees_it in (True, False)
+    assert fp(huge) != fp(np.zeros(1_000_000))             # first page: in the sample
+    monkeypatch.setenv("BFG_TABLE_CACHE", "0")
+    assert ctx.table(axes, raw, True, cache_key=(m, "3D", raw)) is not ctx.table(axes, raw, True, cache_key=(m, "3D", raw))
+    monkeypatch.delenv("BFG_TABLE_CACHE")
+    t3 = ctx.table(axes, raw, True, cache_key=(m, "3D", raw))
+    assert ctx.table(axes, raw, True, cache_key=(m, "3D", raw)) is t3
+    ctx.invalidate_tables()
+    assert ctx.table(axes, raw, True, cache_key=(m, "3D", raw)) is not t3
 
 
 def test_grid_runner_mirrors_the_halo_offset_assertion():
@@ -646,3 +652,25 @@ def test_slice_cuts_depend_on_nside_and_slice_count_only():
     assert L.bfg_shell_slice_cuts(0, 0, 4, buf, ctypes.byref(n)) == -1
     assert L.bfg_shell_slice_cuts(64, 0, 0, buf, ctypes.byref(n)) == -1
     assert L.bfg_shell_slice_cuts(64, 0, 4, None, ctypes.byref(n)) == -1
+
+
+def test_full_catalog_stamp_sees_permutations(monkeypatch):
+    """BFG_CATALOG_CACHE=full stamps every byte of the catalog with a position-dependent 128-bit hash: a swap of two halos' masses
+    or a shuffle through a view taken before the lock changes it (a wrapping sum / xor of the words would not: ADVICE r5)"""
+    import baryonforge_amd as bfg
+    from baryonforge_amd import synthetic as syn
+    ra, dec, M, z = syn.catalog(1000, seed=5)
+    Cat = bfg.HaloLightConeCatalog(ra, dec, M, z, dict(syn.COSMO))
+    monkeypatch.setenv("BFG_CATALOG_CACHE", "full")
+    s0 = Cat._sample_stamp()
+    assert Cat._sample_stamp() == s0
+    m = Cat.cat["M"]
+    m[[3, 7]] = m[[7, 3]]                                   # a swap: same multiset of words
+    s1 = Cat._sample_stamp()
+    assert s1 != s0
+    np.random.default_rng(0).shuffle(m)                     # a permutation of one column
+    assert Cat._sample_stamp() not in (s0, s1)
+    m[5] = np.nextafter(m[5], np.inf)                       # one ulp of one element
+    s3 = Cat._sample_stamp()
+    m[5] = np.nextafter(m[5], -np.inf)
+    assert Cat._sample_stamp() != s3
