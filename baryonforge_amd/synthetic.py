@@ -35,10 +35,10 @@ def grids(nz=10, nM=30, nr=100, z_min=0.01, z_max=1.0):
     return np.geomspace(z_min, z_max, nz), np.geomspace(1e12, 1e16, nM), np.geomspace(1e-3, 1e2, nr)
 
 
-def pressure_table(nz=10, nM=30, nr=100, cosmo=COSMO, bad_block=False):
+def pressure_table(nz=10, nM=30, nr=100, cosmo=COSMO, bad_block=False, grid=None):
     """GNFW-like projected pressure T2D = A (M/1e14)^{5/3} (1+z)^{8/3} [1 + (r/r_c)^2]^{-1.5} * a, r_c = 0.2 R200c.
-    Returns (ln(1+z), ln M, ln r, T2D)."""
-    z, M, r = grids(nz, nM, nr)
+    Returns (ln(1+z), ln M, ln r, T2D).  grid = (z, M, r) arrays: on that grid instead of grids(nz, nM, nr)."""
+    z, M, r = grids(nz, nM, nr) if grid is None else grid
     Z, MM, RR = np.meshgrid(z, M, r, indexing="ij")
     rc = 0.2 * _r200c_com(MM, Z, cosmo)
     T = 1e-6 * (MM / 1e14) ** (5.0 / 3.0) * (1 + Z) ** (8.0 / 3.0) * (1 + (RR / rc) ** 2) ** -1.5 / (1 + Z)
@@ -50,10 +50,10 @@ def pressure_table(nz=10, nM=30, nr=100, cosmo=COSMO, bad_block=False):
     return np.log(1 + z), np.log(M), np.log(r), T
 
 
-def displacement_table(nz=10, nM=30, nr=100, cosmo=COSMO, rdelta=False):
+def displacement_table(nz=10, nM=30, nr=100, cosmo=COSMO, rdelta=False, grid=None):
     """d = 0.1 Mpc (M/1e14)^{1/3} x (1 - x/4) e^{-x},  x = r / R200c,com  (signed, -> 0 at large r).
-    Returns (ln(1+z), ln M, ln r  [or ln r/R_delta], d)."""
-    z, M, r = grids(nz, nM, nr)
+    Returns (ln(1+z), ln M, ln r  [or ln r/R_delta], d).  grid = (z, M, r) arrays: on that grid."""
+    z, M, r = grids(nz, nM, nr) if grid is None else grid
     if rdelta:
         r = np.geomspace(1e-3, 10.0, nr)
     Z, MM, RR = np.meshgrid(z, M, r, indexing="ij")

@@ -290,16 +290,20 @@ def _extra_ptr(extra, n):
 
 
 def paint_shell(nside, ra, dec, M, a, D, R, axes, values_log, eps_run,
-                include_pixel_size=False, extra=None, njobs=None):
+                include_pixel_size=False, extra=None, njobs=None, out=None):
     """PaintProfilesShell.process loop (HealpixRunner.py:449-481) on a zero map.
     values_log is the table the interpolator holds, i.e. np.log(raw_input_2D)
-    (Tabulate.py:271).  Returns (map, P_tot).  njobs: SplitJoinParallel analogue."""
+    (Tabulate.py:271).  Returns (map, P_tot).  njobs: SplitJoinParallel analogue.
+    out: a float64[npix] array to accumulate into instead of a fresh zero map (bench.py's timing loop: a fresh 101 MB
+    allocation per call is page faults, not painting)."""
     ra, dec, M, a, D, R = map(_f, (ra, dec, M, a, D, R))
     n = ra.size
     ndim, shape, axes_concat, values = _table_args(axes, values_log)
     eptr, n_extra, _keep = _extra_ptr(extra, n)
     assert ndim == 3 + n_extra
-    out = np.zeros(nside2npix(nside))
+    if out is None:
+        out = np.zeros(nside2npix(nside))
+    assert out.dtype == np.float64 and out.flags["C_CONTIGUOUS"] and out.size == nside2npix(nside)
     if njobs is None:
         ptot = lib().orc_paint_shell(nside, n, ra, dec, M, a, D, R, eptr, n_extra, float(eps_run),
                                      int(bool(include_pixel_size)), ndim, shape, axes_concat,
@@ -313,14 +317,16 @@ def paint_shell(nside, ra, dec, M, a, D, R, axes, values_log, eps_run,
 
 
 def baryonify_offsets(nside, ra, dec, M, a, D, R, R_model_com, axes, values, eps_run,
-                      eps_model, rdelta_sampling=False, extra=None):
-    """BaryonifyShell.process halo loop (HealpixRunner.py:315-355). Returns (offsets[npix,3], P_tot)."""
+                      eps_model, rdelta_sampling=False, extra=None, out=None):
+    """BaryonifyShell.process halo loop (HealpixRunner.py:315-355). Returns (offsets[npix,3], P_tot).
+    out: a float64[npix, 3] array to accumulate into instead of a fresh zero field."""
     ra, dec, M, a, D, R, R_model_com = map(_f, (ra, dec, M, a, D, R, R_model_com))
     n = ra.size
     ndim, shape, axes_concat, values = _table_args(axes, values)
     eptr, n_extra, _keep = _extra_ptr(extra, n)
     assert ndim == 3 + n_extra
-    off = np.zeros((nside2npix(nside), 3))
+    off = np.zeros((nside2npix(nside), 3)) if out is None else out
+    assert off.dtype == np.float64 and off.flags["C_CONTIGUOUS"] and off.shape == (nside2npix(nside), 3)
     ptot = lib().orc_baryonify_offsets(nside, n, ra, dec, M, a, D, R, R_model_com, eptr, n_extra,
                                        float(eps_run), float(eps_model), int(bool(rdelta_sampling)),
                                        ndim, shape, axes_concat, values, off)
