@@ -2613,9 +2613,17 @@ int bfg_baryonify_snapshot_strided(bfg_ctx *c, const bfg_snapshot_args *a, const
     if (const char *e = std::getenv("BFG_SNAPSHOT"))
         if (!std::strcmp(e, "cell")) grouped = a->n_part < (int64_t)0x7fffffff;
     if (!grouped) {
-        const unsigned pgrid = (unsigned)std::min<int64_t>((a->n_part + 255) / 256, 8192);       // grid-stride
+        const unsigned pgrid = (unsigned)std::min<int64_t>(((a->n_part + 255) / 256 + 7) / 8 * 8, 8192);       // grid-stride; a multiple of 8
+        P.xcd_map = 1;
+        if (const char *e = std::getenv("BFG_SNAP_XCD")) P.xcd_map = std::atoi(e) != 0;                 // A/B switch
+        // default: the hits of a wavefront spread over its lanes through an LDS queue (snap_particle_q_kernel); BFG_SNAPSHOT=plain: every
+        // lane works through its own hits (the kernel of rounds 1-5, the A/B)
+        bool queued = true;
+        if (const char *e = std::getenv("BFG_SNAPSHOT")) if (!std::strcmp(e, "plain")) queued = false;
         timing_begin(c, 6);
-        if (a->ndim == 3) hipLaunchKernelGGL(snap_particle_kernel<3>, dim3(pgrid), dim3(256), 0, c->stream, P);
+        if (queued && a->ndim == 3) hipLaunchKernelGGL(snap_particle_q_kernel<3>, dim3(pgrid), dim3(256), 0, c->stream, P);
+        else if (queued) hipLaunchKernelGGL(snap_particle_q_kernel<2>, dim3(pgrid), dim3(256), 0, c->stream, P);
+        else if (a->ndim == 3) hipLaunchKernelGGL(snap_particle_kernel<3>, dim3(pgrid), dim3(256), 0, c->stream, P);
         else hipLaunchKernelGGL(snap_particle_kernel<2>, dim3(pgrid), dim3(256), 0, c->stream, P);
         HIP_TRY(hipGetLastError());
         timing_end(c, 6);

@@ -459,7 +459,7 @@ def paint_anis_shell(cosmo, nside, orig_map, shell_redshift, ra, dec, M, z, axes
 
 
 def displacement_readout(cosmo, axes, values, r, M, a, eps_model, rdelta_sampling=False, Delta=200, rho_type="critical",
-                         lnM=None):
+                         lnM=None, extra=()):
     """BaryonificationClass._readout for scalar M, a (BaryonCorrection.py:331-419): linear table of comoving
     displacement on (ln(1+z), ln M, ln r [- ln R_com]), NaN outside the hull, 0 where r >= eps_model * R_com.
     lnM: the table coordinate if it is not ln(M) in float64 (a float32 catalog column gives a float32 logarithm, :397)."""
@@ -467,18 +467,21 @@ def displacement_readout(cosmo, axes, values, r, M, a, eps_model, rdelta_samplin
     R = float(get_radius(cosmo, M, a, Delta, rho_type)) / a                 # comoving Mpc (:399)
     with np.errstate(all="ignore"):
         r_in = np.log(r) - (np.log(R) if rdelta_sampling else 0.0)
-    pts = np.stack([np.full(r.size, np.log(1 / a)), np.full(r.size, np.log(M) if lnM is None else lnM), r_in], axis=1)
+    pts = np.stack([np.full(r.size, np.log(1 / a)), np.full(r.size, np.log(M) if lnM is None else lnM), r_in] +
+                   [np.full(r.size, float(e)) for e in extra], axis=1)       # **kwargs in p_keys order (BaryonCorrection.py:374, :404-408)
     d = interp_linear(axes, values, pts)
     return np.where(r < eps_model * R, d, 0.0)                              # :410-411
 
 
 def baryonify_snapshot(cosmo, L, redshift, px, py, pz, hM, hx, hy, hz, axes, values, eps_run, eps_model,
-                       rdelta_sampling=False, Delta=200, rho_type="critical"):
+                       rdelta_sampling=False, Delta=200, rho_type="critical", extra=None):
     """BaryonifySnapshot.process (SnapshotRunner.py:176-275) restated with scipy's periodic KDTree (:99).
     pz / hz = None: 2D snapshot.  The reference keeps the halo columns in float32 (io.py:204): positions and masses are
     widened exactly, but the table coordinate ln M is a float32 logarithm (BaryonCorrection.py:397 on a float32 M).
+    extra: [n_halo, n_extra] p_keys columns of the halo catalogue (float32 there, io.py:204; SnapshotRunner.py:223 o_j).
     Returns the displaced, box-wrapped particle coordinates [n, ndim]."""
     from scipy.spatial import KDTree
+    ex = None if extra is None else np.asarray(extra, dtype=np.float32).astype(np.float64).reshape(len(hM), -1)
     is2D = pz is None
     P = np.stack([_f(px), _f(py)] + ([] if is2D else [_f(pz)]), axis=1)
     H = np.stack([_f(np.asarray(c, dtype=np.float32)) for c in ([hx, hy] + ([] if is2D else [hz]))], axis=1)
@@ -500,7 +503,7 @@ def baryonify_snapshot(cosmo, L, redshift, px, py, pz, hM, hx, hy, hz, axes, val
         d = np.sqrt(np.sum(dd ** 2, axis=1))
         with np.errstate(all="ignore"):
             off = displacement_readout(cosmo, axes, values, d, M_j, a, eps_model, rdelta_sampling, Delta, rho_type,
-                                       lnM=lnM_j)
+                                       lnM=lnM_j, extra=() if ex is None else ex[j])
             off = np.where(np.isfinite(off), off, 0)                         # :231 / :248
             tot[inds] += off[:, None] * (dd / d[:, None])
     new = P + tot
@@ -599,7 +602,7 @@ def _grid_flat_and_r(x, inds, d, Npix):
 
 
 def paint_grid(cosmo, bins, shape, redshift, hpos, hM, axes, T, eps_run, include_pixel_size=True, Delta=200,
-               rho_type="critical", q_ell=None, A_ell=None):
+               rho_type="critical", q_ell=None, A_ell=None, extra=None):
     """PaintProfilesGrid.process (Map2DRunner.py:676-829) without ellipticity.  hpos [n, ndim], T = the raw table the model
     reads for this dimensionality (projected for 2D maps, real for 3D).  Halo columns are narrowed to float32 as in
     HaloNDCatalog (io.py:204); ln M is a float32 logarithm (Tabulate.py:316)."""
@@ -611,6 +614,7 @@ def paint_grid(cosmo, bins, shape, redshift, hpos, hM, axes, T, eps_run, include
     with np.errstate(all="ignore"):
         lnT = np.log(_f(T))
     hpos32 = np.asarray(hpos, dtype=np.float32).astype(np.float64)
+    ex = None if extra is None else np.asarray(extra, dtype=np.float32).astype(np.float64).reshape(hpos32.shape[0], -1)   # :731 o_j
     for j in range(hpos32.shape[0]):
         M32 = np.float32(hM[j])
         R_j = float(get_radius(cosmo, float(M32), a, Delta, rho_type)) / a                  # comoving (:708)
@@ -622,7 +626,8 @@ def paint_grid(cosmo, bins, shape, redshift, hpos, hM, axes, T, eps_run, include
             Rmat = build_Rmat(A / np.sqrt(np.sum(A ** 2)), np.float32(q_ell[j]))
         r = _grid_r(comps, Rmat)
         with np.errstate(all="ignore"):
-            pts = np.stack([np.full(r.size, np.log(1 / a)), np.full(r.size, float(np.log(M32))), np.log(r)], axis=1)
+            pts = np.stack([np.full(r.size, np.log(1 / a)), np.full(r.size, float(np.log(M32))), np.log(r)] +
+                           ([] if ex is None else [np.full(r.size, e) for e in ex[j]]), axis=1)
             P = np.exp(interp_linear(axes, lnT, pts))
         mask = np.isfinite(P) & (r < R_j * eps_run)                                         # :812-815
         if mask.sum() == 0:

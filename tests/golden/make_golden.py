@@ -309,6 +309,8 @@ def main(only=None):
         obj.Rdelta_sampling = rdelta
         return obj
 
+    if only == "pkeys":
+        return pkeys_section(ccl, tab, bc, io, run, cosmo_obj, mdef)
     if only == "anis":
         return anis_section(ccl, io, run, make_tabulated, mdef)
     if only == "snapshot":
@@ -456,6 +458,7 @@ def main(only=None):
     anis_section(ccl, io, run, make_tabulated, mdef)
     snapshot_section(io, make_disp, mdef)
     grid_section(io, make_tabulated, make_disp, mdef)
+    pkeys_section(ccl, tab, bc, io, run, cosmo_obj, mdef)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
@@ -645,6 +648,163 @@ def grid_section(io, make_tabulated, make_disp, mdef):
                e_global_tracer_fraction=np.array(0.35), e_paint_ell=e_paint, e_bary_ell=e_bary, e_anis=anis, e_anis_ell=anis_e)
     print("grid ellipticity / anis sums", e_paint.sum(), e_bary.sum(), anis.sum(), anis_e.sum())
     save("grid.npz", **out)
+
+
+PKEY_AXES = {"cdelta": np.array([2.0, 4.0, 7.0, 11.0]), "alpha": np.array([0.5, 1.0, 1.5]), "beta": np.array([-1.0, 0.0, 1.0]),
+             "gamma": np.array([0.1, 0.2])}
+
+
+def pkeys_factor(keys, mesh):
+    """a positive, non-separable dependence of a table on its extra (p_keys) coordinates; mesh: key -> broadcastable array"""
+    g = lambda k: mesh[k] if k in keys else 0.0
+    c, al, be, ga = g("cdelta"), g("alpha"), g("beta"), g("gamma")
+    return (1.0 + 0.003 * c * c) * (1.0 + 0.02 * al * c) * (1.0 + 0.1 * be + 0.05 * be * al) * (1.0 + ga)
+
+
+def pkeys_section(ccl, tab, bc, io, run, cosmo_obj, mdef):
+    """9. tables with SEVERAL extra (p_keys) axes through the reference's own glue (missing 2): ParamTabulatedProfile
+    ._readout with 2 and 4 keys (Tabulate.py:598-650) and PaintProfilesShell.process with the keys as catalog columns
+    (HealpixRunner.py:436, :456, :472: o_j in p_keys order); Baryonification2D tables with one and two keys, with and without
+    Rdelta_sampling, through BaryonifyShell.process (HealpixRunner.py:304, :322, :345; BaryonCorrection.py:211-227, :404-408);
+    one key through BaryonifySnapshot.process (SnapshotRunner.py:208-258) and PaintProfilesGrid.process (Map2DRunner.py:716-812).
+    BaryonifyGrid asserts isinstance(model, ParamTabulatedProfile) for a model with p_keys (Map2DRunner.py:477-480), which no
+    displacement model satisfies: the exception's type is recorded instead of a map."""
+    out = {}
+    rng = np.random.default_rng(21)
+    r_q = np.concatenate([np.geomspace(5e-4, 2e2, 40), [0.0]])
+
+    def extra_mesh(keys, lead):
+        return {k: PKEY_AXES[k].reshape((1,) * (lead + i) + (-1,) + (1,) * (len(keys) - 1 - i)) for i, k in enumerate(keys)}
+
+    def make_param(keys, nz=4, nM=5, nr=20):
+        zax, Max, rax, T = paint_table(nz=nz, nM=nM, nr=nr)
+        T = T.reshape(T.shape + (1,) * len(keys)) * pkeys_factor(keys, extra_mesh(keys, 3))
+        obj = tab.ParamTabulatedProfile.__new__(tab.ParamTabulatedProfile)
+        obj.p_keys = list(keys)
+        obj.raw_input_2D = obj.raw_input_3D = T
+        obj.raw_input_z_range, obj.raw_input_M_range, obj.raw_input_r_range = zax, Max, rax
+        for k in keys:
+            setattr(obj, "raw_input_%s_range" % k, PKEY_AXES[k])
+        obj.interp2D = rgi((zax, Max, rax) + tuple(PKEY_AXES[k] for k in keys), np.log(T))   # Tabulate.py:589-590
+        obj.interp3D = obj.interp2D
+        return obj, zax, Max, rax, T
+
+    def make_disp_keys(keys, rdelta, eps):
+        zd, Md, rd, d = disp_table(nz=4, nM=6, nr=30, rdelta=rdelta)
+        d = d.reshape(d.shape + (1,) * len(keys)) * pkeys_factor(keys, extra_mesh(keys, 3))
+        obj = bc.Baryonification2D.__new__(bc.Baryonification2D)
+        obj.cosmo, obj.mass_def, obj.epsilon_max = cosmo_obj, mdef, eps
+        obj.p_keys = list(keys)
+        obj.raw_input_d = d
+        obj.raw_input_z_range, obj.raw_input_M_range, obj.raw_input_r_range = zd, Md, rd
+        for k in keys:
+            setattr(obj, "raw_input_%s_range" % k, PKEY_AXES[k])
+        obj.interp_d = rgi((zd, Md, rd) + tuple(PKEY_AXES[k] for k in keys), d, fill_value=np.nan)   # BaryonCorrection.py:322
+        obj.Rdelta_sampling = rdelta
+        return obj, zd, Md, rd, d
+
+    def halo_extras(keys, n, seed, outside=()):
+        """per-halo values inside every axis, a few exactly on nodes; `outside`: (halo, key, value) beyond the hull"""
+        r = np.random.default_rng(seed)
+        cols = {k: r.uniform(PKEY_AXES[k][0], PKEY_AXES[k][-1], n) for k in keys}
+        for i, k in enumerate(keys):
+            cols[k][3 + i] = PKEY_AXES[k][0]
+            cols[k][7 + i] = PKEY_AXES[k][-1]
+            cols[k][11 + i] = PKEY_AXES[k][1]
+        for j, k, v in outside:
+            cols[k][j] = v
+        return cols
+
+    # ---- read-out and PaintProfilesShell.process: two and four keys
+    for tag, keys in (("k2", ("cdelta", "alpha")), ("k4", ("cdelta", "alpha", "beta", "gamma"))):
+        pprof, zax, Max, rax, T = make_param(keys)
+        nq = 9
+        qe = {k: rng.uniform(PKEY_AXES[k][0], PKEY_AXES[k][-1], nq) for k in keys}
+        qe[keys[0]][0] = PKEY_AXES[keys[0]][0]; qe[keys[-1]][1] = PKEY_AXES[keys[-1]][-1]      # on the hull
+        qe[keys[0]][2] = PKEY_AXES[keys[0]][-1] + 0.5; qe[keys[-1]][3] = PKEY_AXES[keys[-1]][0] - 0.05   # outside -> NaN
+        qM = 10 ** rng.uniform(12.2, 15.8, nq)
+        qa = 1 / (1 + rng.uniform(0.02, 0.9, nq))
+        ro = np.array([pprof.projected(None, r_q, qM[i], qa[i], **{k: qe[k][i] for k in keys}) for i in range(nq)])
+        out.update({f"{tag}_keys": np.array(keys), f"{tag}_zax": zax, f"{tag}_Max": Max, f"{tag}_rax": rax, f"{tag}_T2D": T,
+                    f"{tag}_ro_r": r_q, f"{tag}_ro_M": qM, f"{tag}_ro_a": qa, f"{tag}_ro_projected": ro})
+        out.update({f"{tag}_ax_{k}": PKEY_AXES[k] for k in keys})
+        out.update({f"{tag}_ro_{k}": qe[k] for k in keys})
+        nside, n, eps = 32, 70, 10
+        ra, dec, M, z = catalog(n, 140 + len(keys))
+        cols = halo_extras(keys, n, 150 + len(keys), outside=((20, keys[0], PKEY_AXES[keys[0]][-1] + 1.0), (21, keys[-1], PKEY_AXES[keys[-1]][0] - 0.01)))
+        Cat = io.HaloLightConeCatalog(ra, dec, M, z, COSMO, **cols)
+        Shell = io.LightconeShell(map=np.zeros(orc.nside2npix(nside)), cosmo=COSMO)
+        res = run.PaintProfilesShell(Cat, Shell, epsilon_max=eps, model=pprof, mass_def=mdef, verbose=False).process()
+        out.update({f"{tag}_nside": np.array(nside), f"{tag}_ra": ra, f"{tag}_dec": dec, f"{tag}_M": M, f"{tag}_z": z,
+                    f"{tag}_eps": np.array(eps), f"{tag}_map": res})
+        out.update({f"{tag}_cat_{k}": cols[k] for k in keys})
+        print("pkeys paint", tag, "sum", res.sum(), "nonzero", np.count_nonzero(res), "read-out NaN rows", int(np.isnan(ro).all(axis=1).sum()))
+
+    # ---- BaryonifyShell.process: one and two keys, with and without Rdelta_sampling
+    for tag, keys, rdelta, emod, nside, n, seed in (("b1", ("cdelta",), False, 20, 32, 90, 161), ("b1r", ("alpha",), True, 4, 32, 90, 162),
+                                                    ("b2", ("cdelta", "beta"), False, 6, 64, 110, 163), ("b2r", ("alpha", "gamma"), True, 4, 32, 90, 164)):
+        disp, zd, Md, rd, d = make_disp_keys(keys, rdelta, emod)
+        ra, dec, M, z = catalog(n, seed)
+        cols = halo_extras(keys, n, seed + 50, outside=((25, keys[0], PKEY_AXES[keys[0]][-1] + 0.5),))
+        m_in = np.random.default_rng(7).uniform(0, 10, orc.nside2npix(nside))
+        m_in[np.random.default_rng(8).uniform(size=m_in.size) < 0.15] = 0.0
+        Cat = io.HaloLightConeCatalog(ra, dec, M, z, COSMO, **cols)
+        Shell = io.LightconeShell(map=m_in, cosmo=COSMO)
+        res = run.BaryonifyShell(Cat, Shell, epsilon_max=10, model=disp, mass_def=mdef, verbose=False).process()
+        out.update({f"{tag}_keys": np.array(keys), f"{tag}_nside": np.array(nside), f"{tag}_ra": ra, f"{tag}_dec": dec, f"{tag}_M": M,
+                    f"{tag}_z": z, f"{tag}_eps": np.array(10), f"{tag}_eps_model": np.array(emod), f"{tag}_rdelta": np.array(rdelta),
+                    f"{tag}_zax": zd, f"{tag}_Max": Md, f"{tag}_rax": rd, f"{tag}_d": d, f"{tag}_map_in": m_in, f"{tag}_map_out": res})
+        out.update({f"{tag}_ax_{k}": PKEY_AXES[k] for k in keys})
+        out.update({f"{tag}_cat_{k}": cols[k] for k in keys})
+        print("pkeys baryonify", tag, "sum in/out", m_in.sum(), res.sum(), "changed px", np.count_nonzero(~np.isclose(res, m_in)))
+
+    # ---- BaryonifySnapshot.process with one key
+    snap = load("BaryonForge.Runners.SnapshotRunner", "Runners/SnapshotRunner.py")
+    keys, L, npart, nhalo = ("cdelta",), 100.0, 9000, 40
+    r7 = np.random.default_rng(171)
+    disp, zd, Md, rd, d = make_disp_keys(keys, False, 20)
+    P = r7.uniform(0, L, (npart, 3))
+    H = r7.uniform(0, L, (nhalo, 3))
+    hM = 10 ** r7.uniform(13.0, 15.3, nhalo)
+    P[:150] = H[r7.integers(0, nhalo, 150)] + r7.normal(0, 0.3, (150, 3))
+    P %= L
+    cd = r7.uniform(2.0, 11.0, nhalo)
+    cd[4], cd[5], cd[6] = 2.0, 11.0, 12.5                          # on the hull / outside it (float32-exact values)
+    Cat = io.HaloNDCatalog(H[:, 0], H[:, 1], hM, 0.25, COSMO, z=H[:, 2], cdelta=cd)
+    Part = io.ParticleSnapshot(x=P[:, 0], y=P[:, 1], z=P[:, 2], M=np.ones(npart), L=L, redshift=0.25, cosmo=COSMO)
+    res = snap.BaryonifySnapshot(Cat, Part, epsilon_max=10, model=disp, mass_def=mdef, verbose=False).process()
+    new = np.stack([res["x"], res["y"], res["z"]], axis=1)
+    out.update(s1_keys=np.array(keys), s1_L=np.array(L), s1_redshift=np.array(0.25), s1_P=P, s1_H=H, s1_hM=hM, s1_cat_cdelta=cd,
+               s1_eps=np.array(10), s1_eps_model=np.array(20), s1_zax=zd, s1_Max=Md, s1_rax=rd, s1_d=d, s1_ax_cdelta=PKEY_AXES["cdelta"],
+               s1_P_new=new)
+    moved = np.abs(new - P); moved = np.minimum(moved, L - moved)
+    print("pkeys snapshot moved particles", np.count_nonzero(moved.max(axis=1) > 0), "max shift", moved.max())
+
+    # ---- PaintProfilesGrid.process with one key; BaryonifyGrid with a p_keys displacement model: the reference's assertion
+    m2d = load("BaryonForge.Runners.Map2DRunner", "Runners/Map2DRunner.py")
+    Npix, L, nhalo = 72, 50.0, 30
+    r8 = np.random.default_rng(181)
+    bins = (np.arange(Npix) + 0.5) * (L / Npix)
+    H = r8.uniform(0, L, (nhalo, 2))
+    hM = 10 ** r8.uniform(13.0, 15.0, nhalo)
+    cd = r8.uniform(2.0, 11.0, nhalo)
+    cd[2], cd[3] = 11.0, 1.5
+    pprof, zax, Max, rax, T = make_param(("cdelta",), nz=6, nM=9, nr=40)
+    Cat = io.HaloNDCatalog(H[:, 0], H[:, 1], hM, 0.3, COSMO, cdelta=cd)
+    Map = io.GriddedMap(map=np.zeros((Npix, Npix)), redshift=0.3, bins=bins, cosmo=COSMO)
+    gmap = m2d.PaintProfilesGrid(Cat, Map, epsilon_max=4, model=pprof, mass_def=mdef, include_pixel_size=True, verbose=False).process()
+    disp, zd, Md, rd, d = make_disp_keys(("cdelta",), False, 20)
+    try:
+        m2d.BaryonifyGrid(Cat, io.GriddedMap(map=np.ones((Npix, Npix)), redshift=0.3, bins=bins, cosmo=COSMO), epsilon_max=4,
+                          model=disp, mass_def=mdef, verbose=False).process()
+        raised = "none"
+    except Exception as exc:
+        raised = type(exc).__name__
+    out.update(g1_keys=np.array(("cdelta",)), g1_Npix=np.array(Npix), g1_bins=bins, g1_H=H, g1_hM=hM, g1_cat_cdelta=cd,
+               g1_redshift=np.array(0.3), g1_eps=np.array(4), g1_zax=zax, g1_Max=Max, g1_rax=rax, g1_T2D=T,
+               g1_ax_cdelta=PKEY_AXES["cdelta"], g1_map=gmap, g1_baryonify_grid_with_pkeys_raises=np.array(raised))
+    print("pkeys grid paint sum", gmap.sum(), "nonzero", np.count_nonzero(gmap), "; BaryonifyGrid with a p_keys displacement model raises", raised)
+    save("pkeys.npz", **out)
 
 
 def notebook_outputs():

@@ -466,12 +466,14 @@ def _periodic_close(got, ref, L, atol):
     assert d.max() <= atol, f"max periodic deviation {d.max():.3e} > {atol:.1e}"
 
 
-@pytest.mark.parametrize("path", ["direct", "cell"])
+@pytest.mark.parametrize("path", ["direct", "plain", "cell"])
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_baryonify_snapshot_golden(golden, cosmo, tag, path, monkeypatch):
     """BaryonifySnapshot (SnapshotRunner.py:162-275) against the reference's own run; displacements are ~0.1 Mpc, so
     1e-9 Mpc absolute is 1e-8 relative on the shift (tolerance of the path: 1e-5)"""
-    monkeypatch.setenv("BFG_SNAPSHOT", path)      # one thread per particle / particle indices grouped by cell
+    # one thread per particle, a wavefront's hits spread over its lanes (the default) / every lane its own hits / particle indices
+    # grouped by cell
+    monkeypatch.setenv("BFG_SNAPSHOT", path)
     import warnings
     g = golden("snapshot.npz")
     Cat, Part, model, is2D, L = _snapshot_inputs(g, tag, cosmo)
@@ -488,7 +490,7 @@ def test_baryonify_snapshot_golden(golden, cosmo, tag, path, monkeypatch):
     assert np.array_equal(moved_ref, moved_got)       # exactly the same particles are displaced
 
 
-@pytest.mark.parametrize("path", ["direct", "cell"])
+@pytest.mark.parametrize("path", ["direct", "plain", "cell"])
 @pytest.mark.parametrize("is2D", [False, True])
 def test_baryonify_snapshot_vs_oracle(cosmo, is2D, path, monkeypatch):
     """larger box than the golden cases, vs the oracle (KDTree restatement): many cells, halos on the box faces"""

@@ -222,6 +222,65 @@ def _notebook_cases():
         return json.load(f)["cases"]
 
 
+def _pk_axes(g, tag):
+    keys = [str(k) for k in g[f"{tag}_keys"]]
+    return keys, (g[f"{tag}_zax"], g[f"{tag}_Max"], g[f"{tag}_rax"]) + tuple(g[f"{tag}_ax_{k}"] for k in keys)
+
+
+@pytest.mark.parametrize("tag", ["k2", "k4"])
+def test_oracle_multi_pkeys_readout_and_paint_match_reference(golden, cosmo, tag):
+    """ParamTabulatedProfile with two and four p_keys axes, as the reference's own _readout and PaintProfilesShell.process ran them
+    (make_golden.py pkeys; Tabulate.py:598-650, HealpixRunner.py:436-472): the oracle's N-linear read-out and paint loop with the
+    keys as per-halo coordinates in p_keys order"""
+    g = golden("pkeys.npz")
+    keys, axes = _pk_axes(g, tag)
+    with np.errstate(all="ignore"):
+        lnT = np.log(g[f"{tag}_T2D"])
+        for i in range(g[f"{tag}_ro_M"].size):
+            r = g[f"{tag}_ro_r"]
+            cols = [np.full(r.size, np.log(1 / g[f"{tag}_ro_a"][i])), np.full(r.size, np.log(g[f"{tag}_ro_M"][i])), np.log(r)] + \
+                   [np.full(r.size, g[f"{tag}_ro_{k}"][i]) for k in keys]
+            _eq(np.exp(o.interp_linear(axes, lnT, np.stack(cols, 1))), g[f"{tag}_ro_projected"][i])
+    a, R, D = o.halo_scalars(cosmo, g[f"{tag}_M"], g[f"{tag}_z"])
+    extra = np.stack([g[f"{tag}_cat_{k}"] for k in keys], axis=1)
+    with np.errstate(all="ignore"):
+        m, _ = o.paint_shell(int(g[f"{tag}_nside"]), g[f"{tag}_ra"], g[f"{tag}_dec"], g[f"{tag}_M"], a, D, R, axes, lnT,
+                             float(g[f"{tag}_eps"]), extra=extra)
+    assert np.array_equal(m != 0, g[f"{tag}_map"] != 0)
+    np.testing.assert_allclose(m, g[f"{tag}_map"], rtol=RT, atol=0)
+
+
+@pytest.mark.parametrize("tag", ["b1", "b1r", "b2", "b2r"])
+def test_oracle_baryonify_shell_with_pkeys_matches_reference(golden, cosmo, tag):
+    """Baryonification2D tables with one and two p_keys axes, with and without Rdelta_sampling, through the reference's
+    BaryonifyShell.process (HealpixRunner.py:304-355 with **o_j; BaryonCorrection.py:374, :404-408)"""
+    g = golden("pkeys.npz")
+    keys, axes = _pk_axes(g, tag)
+    a, R, D = o.halo_scalars(cosmo, g[f"{tag}_M"], g[f"{tag}_z"])
+    extra = np.stack([g[f"{tag}_cat_{k}"] for k in keys], axis=1)
+    with np.errstate(all="ignore"):
+        got = o.baryonify_shell(int(g[f"{tag}_nside"]), g[f"{tag}_map_in"], g[f"{tag}_ra"], g[f"{tag}_dec"], g[f"{tag}_M"], a, D, R, R / a,
+                                axes, g[f"{tag}_d"], float(g[f"{tag}_eps"]), float(g[f"{tag}_eps_model"]), bool(g[f"{tag}_rdelta"]), extra)
+    np.testing.assert_allclose(got, g[f"{tag}_map_out"], rtol=1e-10, atol=1e-10)
+
+
+def test_oracle_snapshot_and_grid_with_one_pkey_match_reference(golden, cosmo):
+    """one p_keys axis through BaryonifySnapshot.process (SnapshotRunner.py:223-258) and PaintProfilesGrid.process (Map2DRunner.py:731-812)"""
+    g = golden("pkeys.npz")
+    _, axes = _pk_axes(g, "s1")
+    P, H = g["s1_P"], g["s1_H"]
+    got = o.baryonify_snapshot(cosmo, float(g["s1_L"]), float(g["s1_redshift"]), P[:, 0], P[:, 1], P[:, 2], g["s1_hM"], H[:, 0], H[:, 1],
+                               H[:, 2], axes, g["s1_d"], float(g["s1_eps"]), float(g["s1_eps_model"]), False, extra=g["s1_cat_cdelta"])
+    np.testing.assert_allclose(got, g["s1_P_new"], rtol=0, atol=1e-11)
+    _, axes = _pk_axes(g, "g1")
+    N = int(g["g1_Npix"])
+    got = o.paint_grid(cosmo, g["g1_bins"], (N, N), float(g["g1_redshift"]), g["g1_H"], g["g1_hM"], axes, g["g1_T2D"], float(g["g1_eps"]),
+                       True, extra=g["g1_cat_cdelta"])
+    assert np.array_equal(got != 0, g["g1_map"] != 0)
+    np.testing.assert_allclose(got, g["g1_map"], rtol=1e-11, atol=1e-300)
+    assert str(g["g1_baryonify_grid_with_pkeys_raises"]) == "AssertionError"
+
+
 @pytest.mark.parametrize("case", _notebook_cases(), ids=lambda c: c["source"].split(".ipynb")[0].split("/")[-1])
 def test_background_reproduces_what_live_pyccl_printed_in_the_reference_notebooks(case):
     """a9 against the REAL libccl: the reference's example notebooks store the output of
