@@ -172,9 +172,43 @@ def test_eight_ranks_rehearsal_on_cpu_prints_the_strong_scaling_line_with_all_le
     assert sum(x["shard_halos"] for x in r["ranks"]) == 480
     assert r["vs_n1"] is not None and r["n1"]["halos"] == 480
     assert r["rccl_ranks"] == 0 and r["backend"] == "gloo"            # a rehearsal: RCCL took no part
-    assert set(r["legs"]) == {"weak", "owner", "configs3"}
+    # the owner-computes join is either the guarded leg or -- if the all-reduce run was exchange-bound and the join passed its
+    # self-check and was faster -- the main line, with the all-reduce's measurement kept as the leg `allreduce` (promote_owner)
+    choice = r["exchange_choice"]
+    assert choice["picked"] in ("owner", "allreduce") and choice["owner_selfcheck"] == "passed"
+    other = "allreduce" if choice["picked"] == "owner" else "owner"
+    assert set(r["legs"]) == {"weak", other, "configs3"}
     for name, leg in r["legs"].items():
         assert "error" not in leg and leg["value"] > 0 and len(leg["ranks"]) == 8, (name, leg)
     assert r["legs"]["weak"]["scaling"] == "weak" and r["legs"]["weak"]["halos_total"] == 8 * 480
-    assert "owner-computes" in r["legs"]["owner"]["exchange"]["mode"]
+    owner_rec = r if choice["picked"] == "owner" else r["legs"]["owner"]
+    assert "owner-computes" in owner_rec["exchange"]["mode"]
+    assert ("stripes" in r["config"]["sharding"]) == (choice["picked"] == "owner")
     assert r["legs"]["configs3"]["workload"].startswith("BaryonifyShell")
+
+
+def test_owner_join_is_promoted_only_when_the_run_is_exchange_bound_and_the_join_checked_out():
+    """bench.promote_owner on stand-in records: promotion needs (i) all-reduce alone slower than painting alone, (ii) the owner leg's
+    self-check passed, (iii) the owner leg faster; the all-reduce measurement is then kept as the leg `allreduce`"""
+    import argparse
+    import bench
+
+    def rec(value, exch, selfcheck=None, a_ms=2.0, c_ms=1.0):
+        return {"value": value, "unit": "halos/s", "ms_per_step": 1.0, "scaling": "strong", "steps": 2, "ramp_steps": 0, "dtype": "f64",
+                "n_gpus": 8, "warmup": 1, "config": {"workload": "w", "halos_total": 10, "sharding": exch}, "roofline": {"frac": 0.5},
+                "ranks": [{"rank": r, "shard_halos": 1, "compute_ms": c_ms, "allreduce_ms": a_ms} for r in range(2)],
+                "exchange": {"mode": exch, "selfcheck": selfcheck}, "rccl_ranks": 8, "n1": {"value": 5.0}, "vs_n1": value / 5.0}
+    args = argparse.Namespace(exchange="allreduce", workload="paint")
+    # exchange-bound, checked, faster: promoted
+    out, done = rec(10.0, "all-reduce"), {"owner": {"value": 20.0}}
+    bench.promote_owner(out, rec(20.0, "owner-computes stripes", "passed"), done, args)
+    assert out["value"] == 20.0 and out["exchange_choice"]["picked"] == "owner" and out["vs_n1"] == 4.0 and out["rccl_ranks"] == 8
+    assert set(done) == {"allreduce"} and done["allreduce"]["value"] == 10.0 and "stripes" in out["config"]["sharding"]
+    # compute-bound / self-check not passed / slower / forced exchange: the all-reduce stays
+    for main, leg, a in ((rec(10.0, "all-reduce", a_ms=0.5), rec(20.0, "owner", "passed"), args),
+                         (rec(10.0, "all-reduce"), rec(20.0, "owner", "failed (maps differ)"), args),
+                         (rec(10.0, "all-reduce"), rec(9.0, "owner", "passed"), args),
+                         (rec(10.0, "all-reduce"), rec(20.0, "owner", "passed"), argparse.Namespace(exchange="owner", workload="paint"))):
+        done = {"owner": {"value": leg["value"]}}
+        bench.promote_owner(main, leg, done, a)
+        assert main["value"] == 10.0 and main["exchange_choice"]["picked"] == "allreduce" and set(done) == {"owner"}
