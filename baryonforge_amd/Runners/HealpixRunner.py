@@ -233,7 +233,11 @@ class PaintProfilesShell(DefaultRunner):
             d_map = ctx.empty(12 * NSIDE * NSIDE)                         # :424 -- the zeros come from the kernels (OUT_OVERWRITE)
         args = ctx.shell_args(NSIDE, d_cat, d_cat.shape[0], stride, len(keys), self.epsilon_max,
                               ctx.massdef_struct(bg, self.mass_def), include_pixel_size=self.include_pixel_size,
-                              variant=self.variant, out_overwrite=fresh if overwrite is None else bool(overwrite))
+                              variant=self.variant, out_overwrite=fresh if overwrite is None else bool(overwrite),
+                              # one plan, K models: if the context's previous shell call was given this very catalog tensor, its
+                              # per-halo records and pair lists serve this model too where everything but the table's values agrees
+                              # (the library checks that much: BFG_SHELL_REUSE_PLAN) -- examples/05_Paint_tSZ_shell.ipynb:303-324
+                              reuse_plan=ctx.same_catalog(d_cat))
         if sync_stats:
             ctx.stats_reset()
         ctx.paint_shell(args, table, spline, d_map, slices=slices, on_slice=on_slice)
@@ -373,7 +377,7 @@ class PaintProfilesAnisShell(DefaultRunner):
         d_sum = ctx.zeros(npix)
         args = ctx.shell_args(NSIDE, d_cat, d_cat.shape[0], stride, len(keys), self.epsilon_max,
                               ctx.massdef_struct(bgc, self.mass_def), include_pixel_size=self.include_pixel_size,
-                              variant=self.variant)
+                              variant=self.variant, reuse_plan=ctx.same_catalog(d_cat))
         ctx.stats_reset()
         ctx.paint_shell(args, table, spline, d_sum)
         self.last_stats = ctx.stats()
@@ -450,7 +454,7 @@ class BaryonifyShell(DefaultRunner):
                               ctx.massdef_struct(bg, self.mass_def), model_md=model_md,
                               model_epsilon_max=model.epsilon_max,
                               rdelta_sampling=getattr(model, "Rdelta_sampling", False), variant=self.variant,
-                              out_overwrite=True)
+                              out_overwrite=True, reuse_plan=ctx.same_catalog(d_cat))
         d_off = ctx.empty(12 * NSIDE * NSIDE, 3)                          # :313 -- the zeros come from the kernels
         if sync_stats:
             ctx.stats_reset()

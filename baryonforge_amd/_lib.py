@@ -27,7 +27,7 @@ VARIANTS = {"auto": VARIANT_AUTO, "scatter_wave": VARIANT_SCATTER_WAVE,
             "scatter_quarter": VARIANT_SCATTER_QUARTER, "tile_lds": VARIANT_TILE_LDS}
 
 WARN_Z_RANGE, WARN_M_RANGE, WARN_R_RANGE = 1, 2, 4
-SHELL_OUT_IS_ZERO, SHELL_OUT_OVERWRITE = 1, 2
+SHELL_OUT_IS_ZERO, SHELL_OUT_OVERWRITE, SHELL_REUSE_PLAN = 1, 2, 4
 
 # every symbol include/bfg_mi355.h declares (tests check the .so exports all of them)
 SYMBOLS = [
@@ -46,9 +46,9 @@ SYMBOLS = [
     "bfg_disc_enumerate_count", "bfg_disc_enumerate", "bfg_map_add_values", "bfg_offsets_add_displacements",
     "bfg_copy_to_mapped_host", "bfg_shell_slice_cuts",
     "bfg_ndtable_create", "bfg_ndtable_destroy", "bfg_ndtable_rows", "bfg_ndtable_read",
-    "bfg_regrid_band_rings", "bfg_regrid_shell_bands",
+    "bfg_regrid_band_rings", "bfg_regrid_shell_bands", "bfg_plan_reuses",
 ]
-ABI_VERSION = 5
+ABI_VERSION = 6
 # bfg_slice_fn: int (*)(void *user, int slice, int n_slices, int64_t elem_begin, int64_t elem_end)
 SLICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64)
 BFG_COMM_ID_BYTES = 128
@@ -181,6 +181,7 @@ def load(build_if_missing=True):
     L.bfg_map_add_values.argtypes = [_vp, _vp, _vp, _vp, _i64]
     L.bfg_offsets_add_displacements.argtypes = [_vp, C.POINTER(ShellArgs), _vp, _vp, _vp, _vp, _i64, _vp]
     L.bfg_reduce_absmax_sum.argtypes = [_vp, _i64, _vp, C.POINTER(_dbl), C.POINTER(_dbl)]
+    L.bfg_plan_reuses.argtypes = [_vp, C.POINTER(_i64)]
     L.bfg_stats_reset.argtypes = [_vp]
     L.bfg_stats_read.argtypes = [_vp, C.POINTER(Stats)]
     L.bfg_timing_enable.argtypes = [_vp, C.c_int]

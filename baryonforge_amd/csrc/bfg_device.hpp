@@ -340,6 +340,10 @@ struct TileGeom {
 
 
 // what the halo -> tile binning needs (count pass inside halo_prep_kernel, fill pass in tile_fill_kernel)
+// counters behind the ntiles tile counts of a set: [0] left-over halos, [1] needs_scan, then what the planning call added to the
+// statistics (bfg_tile.hpp: plan_reinit_kernel adds them again for a call that reuses the plan)
+constexpr int kTileTail = 8, kPlanOob = 2, kPlanWarn = 3, kPlanFallback = 4;
+
 struct BinCtx {
     TileGeom geo;
     int32_t *tile_count;          // [ntiles] counts, then fill cursors

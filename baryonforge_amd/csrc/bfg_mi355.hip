@@ -76,6 +76,7 @@ struct bfg_table {
     std::vector<int64_t> shape;
     bfg_ndtable *nd = nullptr;      // more than BFG_MAX_DIM dimensions: the table itself (dev then describes the halos' rows: see hstride)
     double ax_inv_h[2] = {0.0, 0.0};   // inverse mean spacing of the z and M axes (find_interval_hint; host side only: DevTable stays 184 B)
+    uint64_t axes_hash = 0;            // FNV-1a over the shape and every axis value: two tables on the same grid share it (plan reuse)
 };
 
 // (bfg_ndtable is defined with its C-ABI functions at the end of this file)
@@ -118,7 +119,7 @@ struct bfg_ctx {
         int64_t nside;
         TileGeom geo;
         int32_t *d_geo;             // band_ns | band_tile0 | band_nrmin | tile_band
-        int32_t *d_tile_count, *d_tile_start;   // d_tile_count: two sets of ntiles + 2 counters; a call uses set `flip` and its scan
+        int32_t *d_tile_count, *d_tile_start;   // d_tile_count: two sets of ntiles + kTileTail counters; a call uses set `flip` and its scan
                                                 // kernel clears the other one for the next call (no memset launch per call)
         int flip;
         bool counting;                          // a call counted into set `flip` and its scan kernel was never launched (an error in between)
@@ -162,6 +163,19 @@ struct bfg_ctx {
     size_t ev_used[kTimingSlots];
     double t_ms[kTimingSlots];
     int64_t t_n[kTimingSlots];
+    // The records and pair lists the last tile-path shell call left behind, and what they were built from (BFG_SHELL_REUSE_PLAN)
+    struct ShellPlanKey {
+        const double *cat; const void *spline; int64_t n_halo, nside; uint64_t axes_hash;
+        double eps, eps_model, pixfac_area; bfg_massdef md_run, md_model;
+        int cat_stride, n_extra, rdelta, mode, win_nodes, win_table, blend, blend_rows, overwrite, out_zero, slice_K, hstride, n_knots;
+        int cap_direct, direct_limit; long long pair_cap;      // (test hooks BFG_TILE_CAP / BFG_PAIR_CAP / BFG_DIRECT_LIMIT change them)
+    };
+    struct ShellPlan {
+        bool valid;
+        ShellPlanKey key;
+        int32_t *tail;              // the planning call's counter set behind its tile counts (left_n, needs_scan, plan statistics)
+    } plan;
+    unsigned long long plan_reuses; // calls that ran on a reused plan (bfg_plan_reuses: tests, bench)
     hipEvent_t ev_switch;           // orders the context's work across a change of stream (bfg_ctx_set_stream)
     struct bfg_comm_state *comm;    // RCCL communicator of bfg_comm_init (multi-GPU), or null
 };
@@ -428,6 +442,7 @@ __global__ __launch_bounds__(256, BFG_PREP_WAVES) void halo_prep_kernel(const Pr
     if (hc.oob) {
         atomicAdd((unsigned long long *)&P.stats->halos_out_of_table, 1ull);
         atomicOr(&P.stats->warn_mask, hc.warn);
+        if (P.left_n) { atomicAdd(&P.left_n[kPlanOob], 1); atomicOr(&P.left_n[kPlanWarn], (int32_t)hc.warn); }   // (for a call that reuses this plan)
     }
     int32_t flags = hc.flags;
     const int32_t rfirst = hc.rfirst, rlast = hc.rlast, irmin = hc.irmin, irmax = hc.irmax;
@@ -526,7 +541,10 @@ __global__ __launch_bounds__(256, BFG_PREP_WAVES) void halo_prep_kernel(const Pr
         write_soa(again, flags);
     }
     if (P.left && (flags & HF_SCATTER) && !(flags & HF_SKIP)) P.left[1 + atomicAdd(P.left_n, 1)] = (int32_t)j;
-    if ((flags & HF_SLOW) && !(flags & (HF_SKIP | HF_OOB))) atomicAdd(&P.stats->halos_scatter_fallback, 1u);
+    if ((flags & HF_SLOW) && !(flags & (HF_SKIP | HF_OOB))) {
+        atomicAdd(&P.stats->halos_scatter_fallback, 1u);
+        if (P.left_n) atomicAdd(&P.left_n[kPlanFallback], 1);
+    }
     }   // j < n_halo
     // ---- row phase (what halo_row4_kernel does, same arithmetic): hwin[j][e] = sum over the corners of the halo's outer cell of
     // w_c T[c][win_lo + e] (+ ln(pixfac) for ln tables), four nodes per thread.  Done here the rows cost neither a second
@@ -1513,6 +1531,13 @@ int bfg_table_create(bfg_ctx *c, int ndim, const int64_t *shape, const double *c
     bfg_table *t = new bfg_table();
     t->shape.assign(shape, shape + ndim);
     for (int d = 0; d < 2; ++d) t->ax_inv_h[d] = (double)(shape[d] - 1) / (axes[d][shape[d] - 1] - axes[d][0]);
+    {
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&](const void *p_, size_t n_) { const unsigned char *b = (const unsigned char *)p_; for (size_t i = 0; i < n_; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
+        mix(&ndim, sizeof(ndim)); mix(&flags, sizeof(flags));
+        for (int d = 0; d < ndim; ++d) { mix(&shape[d], sizeof(shape[d])); mix(axes[d], (size_t)shape[d] * sizeof(double)); }
+        t->axes_hash = h;
+    }
     // permute values so that r (dim 2) is the fastest axis: [z][M][extras...][r]
     const int nouter = ndim - 1;
     std::vector<int> odim(nouter);   // outer k -> original dim
@@ -1779,8 +1804,8 @@ static int ensure_tiles(bfg_ctx *c, int mode, int tr, int tw, int64_t nside, int
         HIP_TRY(hipMalloc((void **)&ts.d_geo, blob.size() * sizeof(int32_t)));
         HIP_TRY(hipMemcpyAsync(ts.d_geo, blob.data(), blob.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipMalloc((void **)&ts.d_tile_count, (size_t)2 * (ntiles + 2) * sizeof(int32_t)));   // per set: + the left-over list's length, + needs_scan
-        HIP_TRY(hipMemsetAsync(ts.d_tile_count, 0, (size_t)2 * (ntiles + 2) * sizeof(int32_t), c->stream));
+        HIP_TRY(hipMalloc((void **)&ts.d_tile_count, (size_t)2 * (ntiles + kTileTail) * sizeof(int32_t)));   // per set: + the left-over list's length, needs_scan, plan statistics
+        HIP_TRY(hipMemsetAsync(ts.d_tile_count, 0, (size_t)2 * (ntiles + kTileTail) * sizeof(int32_t), c->stream));
         ts.flip = 0; ts.counting = false;
         HIP_TRY(hipMalloc((void **)&ts.d_tile_start, (size_t)(ntiles + 1) * sizeof(int32_t)));
         HIP_TRY(hipMalloc((void **)&ts.d_work, (size_t)(2 * ntiles + kWorkExtra) * 2 * sizeof(int4)));
@@ -1972,6 +1997,60 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     }
     const double pixfac_area = a->include_pixel_size ? 4.0 * kPi / (double)(12 * a->nside * a->nside) : 0.0;
 
+    // launch geometry of the tile kernel (host arithmetic only; decided here because a reused plan must have been built for the same one)
+    bool light = false;
+    int items_max = 0, persist = 0, tile_grid = 0, n_counters = 1;
+    if (tile) {
+        const bfg_ctx::TileSet &ts = c->tiles[mode];
+        // grid of the tile kernel: persistent (a few workgroups per CU looping over the work list) unless BFG_TILE_PERSIST=0
+        const bool win_lds_path = win_nodes <= kWinLds;
+        // Sparse catalogs take the 256-thread instantiation with four (paint) / three (offsets) workgroups per CU (TileCfg<., 1>):
+        // below ~6 (paint) / ~10 (offsets) halos per sky tile an item is a chain of latencies, and more items in flight beat larger
+        // chunks (profiles/r03_light_ab.txt: paint 1e4 halos at NSIDE 1024 0.072 -> 0.057 ms, offsets 1e4 halos 0.170 -> 0.115,
+        // offsets 1e5 halos 0.292 -> 0.283; paint 1e5 halos 0.140 -> 0.160, so not there).  BFG_TILE_LIGHT=0 / 1 forces either.
+        const double halos_per_tile = (double)a->n_halo / (double)std::max(1, ts.geo.ntiles);
+        light = win_lds_path && halos_per_tile < (mode == MODE_PAINT ? 6.0 : 10.0);
+        if (const char *e = std::getenv("BFG_TILE_LIGHT")) light = win_lds_path && std::atoi(e) != 0;
+        items_max = 2 * ts.geo.ntiles + kWorkExtra;
+        persist = c->n_cu * (light ? (mode == MODE_PAINT ? 4 : 3) : 2);
+        if (const char *e = std::getenv("BFG_TILE_PERSIST")) persist = std::atoi(e) > 1 ? std::atoi(e) : (std::atoi(e) ? persist : 0);
+        tile_grid = persist > 0 ? std::min(persist, items_max) : items_max;
+        // item counters of the persistent grid (bfg_tile.hpp: one address serialises the hand-out); BFG_ITEM_COUNTERS=1: the A/B
+        n_counters = 8;
+        if (const char *e = std::getenv("BFG_ITEM_COUNTERS")) n_counters = std::atoi(e);
+        n_counters = std::max(1, std::min(std::min(n_counters, kMaxCounters), tile_grid));
+    }
+    // ---- BFG_SHELL_REUSE_PLAN: the per-halo records (HaloTile / HaloDisp / SoA rows), the halo -> tile pair lists and the work list
+    // are functions of the catalog, the geometry (nside, epsilon, mass definitions, D_A spline) and the table's AXES -- not of its
+    // values.  A call that carries the flag and finds the context's last tile-path call built from exactly these runs neither
+    // halo_prep_kernel nor the binning kernels: one small launch (plan_reinit_kernel) re-arms the item counters, and -- where windows
+    // are pre-blended (offsets, tables with extra axes) -- halo_row4_kernel blends them from THIS table.  What the library cannot
+    // check is that the catalog buffer still holds the same records: that is what the caller vouches for with the flag.
+    bfg_ctx::ShellPlanKey key;
+    std::memset(&key, 0, sizeof(key));
+    key.cat = a->d_catalog; key.spline = s; key.n_knots = s->n; key.n_halo = a->n_halo; key.nside = a->nside; key.axes_hash = t->axes_hash;
+    key.eps = a->epsilon_max; key.eps_model = (mode == MODE_BARYONIFY) ? a->model_epsilon_max : 0.0; key.pixfac_area = pixfac_area;
+    key.md_run = a->runner_md; key.md_run.reserved = 0;
+    if (mode == MODE_BARYONIFY) { key.md_model = a->model_md; key.md_model.reserved = 0; }
+    key.cat_stride = a->cat_stride; key.n_extra = a->n_extra; key.rdelta = (mode == MODE_BARYONIFY) ? a->rdelta_sampling : 0; key.mode = mode;
+    key.win_nodes = win_nodes; key.win_table = win_table; key.blend = blend; key.blend_rows = blend_rows;
+    key.overwrite = overwrite; key.out_zero = out_zero; key.slice_K = slice_fn ? slice_K : 0; key.hstride = t->dev.hstride;
+    key.n_knots = s->n + 1000 * (light ? 1 : 0) + 10000 * n_counters;          // (launch geometry folded in: a changed A/B switch misses)
+    int direct_limit = 0;
+    if (tile) {
+        // tiles of up to 512 pairs are one work item each and need no scan (256: the 1e6-halo headline, ~115 pairs per tile with
+        // a tail beyond 256, paid the 0.02 ms single-workgroup scan -- 0.043 ms on the offsets tiles -- for items no better balanced)
+        direct_limit = std::min(c->tiles[mode].cap_direct, 512);
+        if (const char *e = std::getenv("BFG_DIRECT_LIMIT")) direct_limit = std::min(c->tiles[mode].cap_direct, std::atoi(e));
+        if (std::getenv("BFG_TILE_SCAN")) direct_limit = 0;                   // A/B: always the scan kernel
+        key.cap_direct = c->tiles[mode].cap_direct; key.direct_limit = direct_limit; key.pair_cap = c->pair_cap;
+    }
+    bool reuse = tile && (a->flags & BFG_SHELL_REUSE_PLAN) && c->plan.valid && t->dev.hstride == 0 &&
+                 std::memcmp(&key, &c->plan.key, sizeof(key)) == 0;
+    if (const char *e = std::getenv("BFG_PLAN_REUSE")) if (!std::atoi(e)) reuse = false;               // A/B switch
+    int32_t *const plan_tail = reuse ? c->plan.tail : nullptr;
+    c->plan.valid = false;           // (set again at the end of a tile-path call that ran to its end)
+
     PrepParams pp;
     std::memset(&pp, 0, sizeof(pp));
     pp.hpx = make_hpx(a->nside);
@@ -1988,12 +2067,15 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     pp.ht = tile ? c->d_ht : nullptr; pp.win_nodes = win_nodes; pp.pixfac_area = pixfac_area;
     if (tile) {
         bfg_ctx::TileSet &tsw = c->tiles[mode];
-        if (tsw.counting) {                     // left dirty by a call that failed half-way: start from clean counters
-            HIP_TRY(hipMemsetAsync(tsw.d_tile_count, 0, (size_t)2 * (tsw.geo.ntiles + 2) * sizeof(int32_t), c->stream));
+        if (!reuse && tsw.counting) {           // left dirty by a call that failed half-way: start from clean counters
+            HIP_TRY(hipMemsetAsync(tsw.d_tile_count, 0, (size_t)2 * (tsw.geo.ntiles + kTileTail) * sizeof(int32_t), c->stream));
             tsw.flip = 0;
         }
-        tsw.counting = true;
-        int32_t *const tile_count = tsw.d_tile_count + (size_t)tsw.flip * (tsw.geo.ntiles + 2);   // this call's counters (all zero)
+        if (!reuse) tsw.counting = true;
+        // this call's counters (all zero) -- or, on a reused plan, the planning call's set: its tile counts are spent, the entries
+        // behind them (left-over halos, needs_scan, plan statistics) stay valid until the next planning call's scan clears the set
+        int32_t *const tile_count = reuse ? plan_tail - tsw.geo.ntiles
+                                          : tsw.d_tile_count + (size_t)tsw.flip * (tsw.geo.ntiles + kTileTail);
         pp.bin.geo = c->tiles[mode].geo; pp.bin.tile_count = tile_count;
         pp.bin.tile_start = c->tiles[mode].d_tile_start;
         pp.bin.pairs = c->d_pairs; pp.bin.pair_total = c->d_pair_total; pp.bin.pair_cap = c->pair_cap;
@@ -2003,26 +2085,25 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         pp.eps_model = a->model_epsilon_max; pp.rdelta = a->rdelta_sampling;
         // the tile counters and, right behind them, the length of the left-over list and the needs_scan flag
         pp.bin.needs_scan = tile_count + c->tiles[mode].geo.ntiles + 1;
-        // tiles of up to 512 pairs are one work item each and need no scan (256: the 1e6-halo headline, ~115 pairs per tile with
-        // a tail beyond 256, paid the 0.02 ms single-workgroup scan -- 0.043 ms on the offsets tiles -- for items no better balanced)
-        pp.bin.direct_limit = std::min(c->tiles[mode].cap_direct, 512);
-        if (const char *e = std::getenv("BFG_DIRECT_LIMIT")) pp.bin.direct_limit = std::min(c->tiles[mode].cap_direct, std::atoi(e));
-        if (std::getenv("BFG_TILE_SCAN")) pp.bin.direct_limit = 0;                   // A/B: always the scan kernel
+        pp.bin.direct_limit = direct_limit;
         pp.left = c->d_left; pp.left_n = tile_count + c->tiles[mode].geo.ntiles;
     }
     // row windows of 4 k nodes are built by the prep kernel itself (BFG_ROWS=separate: by halo_row4_kernel, the A/B)
     bool fuse_rows = tile && !win_table && !blend && win_nodes % 4 == 0 && win_nodes >= 8;
     if (const char *e = std::getenv("BFG_ROWS")) if (!std::strcmp(e, "separate")) fuse_rows = false;
+    if (reuse) fuse_rows = false;                // no prep kernel: the windows of THIS table come from halo_row4_kernel
     // the row phase needs 64 x 2^nouter x 16 B of dynamic LDS on top of the kernel's 34 KB of static LDS: tables with three extra
     // axes would pass 64 KB -- those take the separate row kernel
     if (fuse_rows && 15360 + kPrepRowLds + (size_t)64 * ((size_t)1 << t->dev.nouter) * 16 > std::min<size_t>(c->max_dyn_lds, 65536)) fuse_rows = false;
     pp.hwin = fuse_rows ? c->d_hwin : nullptr;
     pp.lazy_soa = (tile && t->dev.nouter == 2 && !std::getenv("BFG_EAGER_SOA")) ? 1 : 0;
     const size_t prep_lds = fuse_rows ? kPrepRowLds + (size_t)64 * ((size_t)1 << t->dev.nouter) * 16 : (t->dev.nouter > 2 ? kPrepRowLds : 0);
-    timing_begin(c, 0);
-    hipLaunchKernelGGL(halo_prep_kernel, dim3((unsigned)((a->n_halo + 255) / 256)), dim3(256), prep_lds, c->stream, pp);
-    HIP_TRY(hipGetLastError());
-    timing_end(c, 0);
+    if (!reuse) {
+        timing_begin(c, 0);
+        hipLaunchKernelGGL(halo_prep_kernel, dim3((unsigned)((a->n_halo + 255) / 256)), dim3(256), prep_lds, c->stream, pp);
+        HIP_TRY(hipGetLastError());
+        timing_end(c, 0);
+    }
 
     ShellParams sp;
     std::memset(&sp, 0, sizeof(sp));
@@ -2064,23 +2145,6 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     if (tile) {
         timing_begin(c, 3);
         const bfg_ctx::TileSet &ts = c->tiles[mode];
-        // grid of the tile kernel: persistent (a few workgroups per CU looping over the work list) unless BFG_TILE_PERSIST=0
-        const bool win_lds_path = win_nodes <= kWinLds;
-        // Sparse catalogs take the 256-thread instantiation with four (paint) / three (offsets) workgroups per CU (TileCfg<., 1>):
-        // below ~6 (paint) / ~10 (offsets) halos per sky tile an item is a chain of latencies, and more items in flight beat larger
-        // chunks (profiles/r03_light_ab.txt: paint 1e4 halos at NSIDE 1024 0.072 -> 0.057 ms, offsets 1e4 halos 0.170 -> 0.115,
-        // offsets 1e5 halos 0.292 -> 0.283; paint 1e5 halos 0.140 -> 0.160, so not there).  BFG_TILE_LIGHT=0 / 1 forces either.
-        const double halos_per_tile = (double)a->n_halo / (double)std::max(1, ts.geo.ntiles);
-        bool light = win_lds_path && halos_per_tile < (mode == MODE_PAINT ? 6.0 : 10.0);
-        if (const char *e = std::getenv("BFG_TILE_LIGHT")) light = win_lds_path && std::atoi(e) != 0;
-        const int items_max = 2 * ts.geo.ntiles + kWorkExtra;
-        int persist = c->n_cu * (light ? (mode == MODE_PAINT ? 4 : 3) : 2);
-        if (const char *e = std::getenv("BFG_TILE_PERSIST")) persist = std::atoi(e) > 1 ? std::atoi(e) : (std::atoi(e) ? persist : 0);
-        const int tile_grid = persist > 0 ? std::min(persist, items_max) : items_max;
-        // item counters of the persistent grid (bfg_tile.hpp: one address serialises the hand-out); BFG_ITEM_COUNTERS=1: the A/B
-        int n_counters = 8;
-        if (const char *e = std::getenv("BFG_ITEM_COUNTERS")) n_counters = std::atoi(e);
-        n_counters = std::max(1, std::min(std::min(n_counters, kMaxCounters), tile_grid));
         // sliced call: cut the tiles into n_slices runs of whole bands (contiguous ring ranges = contiguous RING pixel ranges)
         SliceCuts cuts;
         std::memset(&cuts, 0, sizeof(cuts));
@@ -2096,10 +2160,19 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
             if (cuts.tile[K] != ts.geo.ntiles) { g_last_error = "slice cuts do not cover the tiles"; return BFG_ERR_INVALID; }
             cuts.n = K; cuts.range = ts.d_slices;
         }
+        if (reuse) {
+            ReinitParams rq;
+            std::memset(&rq, 0, sizeof(rq));
+            rq.geo = ts.geo; rq.hpx = pp.hpx; rq.counters = ts.d_counters; rq.n_counters = n_counters; rq.first_dynamic = 3 * tile_grid;
+            rq.n_slices = cuts.n; rq.stats = c->d_stats; rq.tail = plan_tail; rq.overwrite = overwrite ? 1 : 0;
+            rq.nacc = (mode == MODE_PAINT) ? 1 : 3; rq.shared_flag = ts.d_shared; rq.out = d_out;
+            hipLaunchKernelGGL(plan_reinit_kernel, dim3((unsigned)std::min(std::max(ts.geo.ntiles / 8, 8), 1024)), dim3(256), 0, c->stream, rq);
+            ++c->plan_reuses;
+        } else {
         hipLaunchKernelGGL(tile_scan_kernel, dim3((unsigned)(1 + (ts.geo.ntiles + 1023) / 1024)), dim3(1024), 0, c->stream, ts.geo,
                            ts.cap_direct, pp.bin.tile_count, ts.d_tile_start, ts.d_work, ts.d_nwork, ts.d_counters, n_counters, 3 * tile_grid,
                            overwrite ? 1 : 0, ts.d_shared, pp.bin.tile_count + ts.geo.ntiles + 1,
-                           ts.d_tile_count + (size_t)(1 - ts.flip) * (ts.geo.ntiles + 2), cuts);
+                           ts.d_tile_count + (size_t)(1 - ts.flip) * (ts.geo.ntiles + kTileTail), cuts);
         c->tiles[mode].flip = 1 - ts.flip;             // the next call counts in the set this scan kernel clears
         c->tiles[mode].counting = false;
         FillParams fp;
@@ -2108,6 +2181,7 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         fp.hpx = pp.hpx;
         fp.stats = c->d_stats; fp.n_halo = a->n_halo; fp.cap = c->cap_halo; fp.rec = c->d_rec; fp.irec = c->d_irec; fp.ht = c->d_ht; fp.bin = pp.bin; fp.prep = pp;
         hipLaunchKernelGGL(tile_fill_kernel, dim3((unsigned)((a->n_halo + 255) / 256)), dim3(256), 0, c->stream, fp);
+        }
         RowParams rp;
         std::memset(&rp, 0, sizeof(rp));
         rp.n_halo = a->n_halo; rp.cap = c->cap_halo; rp.ht = c->d_ht; rp.cidx = c->d_cidx; rp.cw = c->d_cw;
@@ -2224,10 +2298,12 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
             return BFG_ERR_INVALID;
         }
         }   // slices
+        // what this call leaves behind is a plan (its own, or the one it ran on)
+        c->plan.key = key; c->plan.tail = const_cast<int32_t *>(pp.left_n); c->plan.valid = (t->dev.hstride == 0);
         if (cuts.n > 0) return BFG_OK;
     }
     rc = launch_scatter();
-    if (rc) return rc;
+    if (rc) { c->plan.valid = false; return rc; }
     return whole_output();
 }
 
@@ -2929,6 +3005,13 @@ int bfg_build_displacement_table(bfg_ctx *c, int geometry, int n_rows, int n_int
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d_blob); (void)hipFree(d_status);
     if (e != hipSuccess) { g_last_error = std::string("bfg_build_displacement_table: ") + hipGetErrorString(e); return BFG_ERR_HIP; }
+    return BFG_OK;
+}
+
+int bfg_plan_reuses(bfg_ctx *c, int64_t *count)
+{
+    if (!c || !count) return BFG_ERR_INVALID;
+    *count = (int64_t)c->plan_reuses;
     return BFG_OK;
 }
 

@@ -453,45 +453,47 @@ struct FillParams {
     PrepParams prep;                 // lazy_soa: what halo_calc needs to rebuild a halo's SoA row
 };
 
+// Clear the tiles the tile kernel will add to with atomics (those cut into several work items: crowded catalogs, compact
+// multi-GPU shards) -- overwrite mode only.  Tile t belongs to workgroup t mod gridDim, so the clearing is spread over the whole
+// grid; a workgroup reads the flags of up to 256 of its tiles in one go, one per thread (a small grid walking its flags one by
+// one took 78 us at 1e4 halos; 25 workgroups clearing 256 tiles each took 1 ms on a half-sky shard).  256 threads per workgroup.
+__device__ inline void clear_shared_tiles(const TileGeom &G, const Hpx &hpx, const int32_t *shared_flag, double *out, int nacc)
+{
+    __shared__ unsigned long long s_mask[4];
+    for (int base = 0; base < G.ntiles; base += 256 * (int)gridDim.x) {
+        const int tt = base + (int)threadIdx.x * (int)gridDim.x + (int)blockIdx.x;
+        const int f = (tt < G.ntiles) ? shared_flag[tt] : 0;
+        const unsigned long long m = __ballot(f != 0);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) s_mask[threadIdx.x >> 6] = m;
+        __syncthreads();
+        for (int w = 0; w < 4; ++w) {
+          unsigned long long todo = s_mask[w];               // workgroup-uniform; zero for a catalog spread over the sky
+          while (todo) {
+            const int i = 64 * w + __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int t = base + i * (int)gridDim.x + (int)blockIdx.x;
+            const int band = G.tile_band[t], sector = t - G.band_tile0[band], NS = G.band_ns[band];
+            const int ring_lo = 1 + band * G.tr;
+            for (int e = threadIdx.x; e < G.tr * G.tw; e += blockDim.x) {
+                const int row = e / G.tw, col = e % G.tw;
+                const int64_t ring = ring_lo + row;
+                if (ring > 4 * hpx.nside - 1) continue;
+                int64_t start, nr; bool shifted;
+                ring_info_small(hpx, ring, start, nr, shifted);
+                const int k0 = (int)(((int64_t)sector * nr) / NS), k1 = (int)(((int64_t)(sector + 1) * nr) / NS);
+                if (k0 + col < k1) for (int c = 0; c < nacc; ++c) out[nacc * (start + k0 + col) + c] = 0.0;
+            }
+          }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void tile_fill_kernel(const FillParams P)
 {
     // no tile beyond its fixed slots (the count pass says so): no overflow lists to fill, no tile cut into shared items
     if (!*P.bin.needs_scan) return;
-    if (P.overwrite) {
-        // Clear the tiles the tile kernel will add to with atomics (those cut into several work items: crowded catalogs,
-        // compact multi-GPU shards).  Tile t belongs to workgroup t mod gridDim, so the clearing is spread over the whole
-        // grid; a workgroup reads the flags of up to 256 of its tiles in one go, one per thread (a small grid walking its
-        // flags one by one took 78 us at 1e4 halos; 25 workgroups clearing 256 tiles each took 1 ms on a half-sky shard).
-        const TileGeom &G = P.bin.geo;
-        __shared__ unsigned long long s_mask[4];
-        for (int base = 0; base < G.ntiles; base += 256 * (int)gridDim.x) {
-            const int tt = base + (int)threadIdx.x * (int)gridDim.x + (int)blockIdx.x;
-            const int f = (tt < G.ntiles) ? P.shared_flag[tt] : 0;
-            const unsigned long long m = __ballot(f != 0);
-            __syncthreads();
-            if ((threadIdx.x & 63) == 0) s_mask[threadIdx.x >> 6] = m;
-            __syncthreads();
-            for (int w = 0; w < 4; ++w) {
-              unsigned long long todo = s_mask[w];               // workgroup-uniform; zero for a catalog spread over the sky
-              while (todo) {
-                const int i = 64 * w + __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const int t = base + i * (int)gridDim.x + (int)blockIdx.x;
-                const int band = G.tile_band[t], sector = t - G.band_tile0[band], NS = G.band_ns[band];
-                const int ring_lo = 1 + band * G.tr;
-                for (int e = threadIdx.x; e < G.tr * G.tw; e += blockDim.x) {
-                    const int row = e / G.tw, col = e % G.tw;
-                    const int64_t ring = ring_lo + row;
-                    if (ring > 4 * P.hpx.nside - 1) continue;
-                    int64_t start, nr; bool shifted;
-                    ring_info_small(P.hpx, ring, start, nr, shifted);
-                    const int k0 = (int)(((int64_t)sector * nr) / NS), k1 = (int)(((int64_t)(sector + 1) * nr) / NS);
-                    if (k0 + col < k1) for (int c = 0; c < P.nacc; ++c) P.out[P.nacc * (start + k0 + col) + c] = 0.0;
-                }
-              }
-            }
-        }
-    }
+    if (P.overwrite) clear_shared_tiles(P.bin.geo, P.hpx, P.shared_flag, P.out, P.nacc);
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= P.n_halo) return;
     const int64_t cap = P.cap;
@@ -505,7 +507,7 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const FillParams P)
             halo_write_soa(P.prep, j, hc, f);
         } else P.irec[I_FLAGS * cap + j] = f;
         P.ht[j].flags = f;
-        if (!(f0 & (HF_SCATTER | HF_SKIP))) atomicAdd(&P.stats->halos_scatter_fallback, 1u);
+        if (!(f0 & (HF_SCATTER | HF_SKIP))) { atomicAdd(&P.stats->halos_scatter_fallback, 1u); atomicAdd(&P.prep.left_n[kPlanFallback], 1); }
         return;
     }
     unsigned long long mask = P.bin.ovf_mask[j];
@@ -525,6 +527,7 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const FillParams P)
 // that crowds into part of the sky (an octant light cone, a compact multi-GPU shard: 1/8 of the tiles with 8x the pairs)
 // still yields a few thousand items of similar size instead of 784 heavy ones on 512 workgroup slots.
 constexpr int kWorkExtra = 4096;
+
 // Sliced calls: the work list is cut at tile boundaries slices.tile[0] = 0 < tile[1] < ... < tile[n] = ntiles (whole bands); the scan
 // kernel writes the item range of slice k to slices.range[2 k .. 2 k + 1], which the k-th launch of the tile kernel reads.
 constexpr int kMaxSlices = 16;
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const TileGeom geo, int
     if (blockIdx.x != 0) {
         const int t = ((int)blockIdx.x - 1) * 1024 + (int)threadIdx.x;
         if (t < geo.ntiles) next_count[t] = 0;
-        if (t == 0) { next_count[geo.ntiles] = 0; next_count[geo.ntiles + 1] = 0; }
+        if (t < kTileTail) next_count[geo.ntiles + t] = 0;
     }
     // overwrite: the tile kernel initialises the map itself, so tiles without a single pair get an (empty) work item too,
     // and tiles cut into several items -- which add to the map with atomics -- are listed for tile_fill_kernel to clear first
@@ -664,6 +667,34 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const TileGeom geo, int
         *n_work = carry;                                         // (the first items of a workgroup are static)
         if (slices.n > 0) slices.range[2 * slices.n - 1] = carry;
     }
+}
+
+// What a later call needs to run the tile kernels AGAIN on the records and pair lists of this one (bfg_shell_args.flags &
+// BFG_SHELL_REUSE_PLAN: another model tabulated on the same grid, painted over the same catalog): the item counters of the
+// persistent tile kernel (consumed by every launch), the planning call's contributions to the statistics, and -- overwrite mode,
+// crowded catalogs -- the tiles that several work items add to with atomics, cleared again.  One launch instead of halo_prep_kernel,
+// tile_scan_kernel and tile_fill_kernel.
+struct ReinitParams {
+    TileGeom geo;
+    Hpx hpx;
+    int32_t *counters;
+    int n_counters, first_dynamic, n_slices;
+    bfg_stats *stats;
+    const int32_t *tail;             // the planning call's counter set behind its tile counts: left_n, needs_scan, plan statistics
+    int overwrite, nacc;
+    const int32_t *shared_flag;
+    double *out;
+};
+__global__ __launch_bounds__(256) void plan_reinit_kernel(const ReinitParams P)
+{
+    const int t = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (t < (1 + P.n_slices) * P.n_counters) init_item_counter(P.counters, t, P.first_dynamic, P.n_counters);
+    if (t == 0) {
+        if (P.tail[kPlanOob]) atomicAdd((unsigned long long *)&P.stats->halos_out_of_table, (unsigned long long)P.tail[kPlanOob]);
+        if (P.tail[kPlanWarn]) atomicOr(&P.stats->warn_mask, (uint32_t)P.tail[kPlanWarn]);
+        if (P.tail[kPlanFallback]) atomicAdd(&P.stats->halos_scatter_fallback, (uint32_t)P.tail[kPlanFallback]);
+    }
+    if (P.overwrite && P.tail[1]) clear_shared_tiles(P.geo, P.hpx, P.shared_flag, P.out, P.nacc);     // tail[1] = needs_scan
 }
 
 // Per-halo blended radial row: hwin[j][e] = B_i, i = win_lo_j + e, where

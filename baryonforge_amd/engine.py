@@ -356,7 +356,7 @@ class Context(object):
 
     def shell_args(self, nside, d_catalog, n_halo, cat_stride, n_extra, epsilon_max, runner_md, model_md=None,
                    model_epsilon_max=0.0, rdelta_sampling=False, include_pixel_size=False, variant="auto",
-                   out_is_zero=False, out_overwrite=False):
+                   out_is_zero=False, out_overwrite=False, reuse_plan=False):
         a = _lib.ShellArgs()
         a.nside, a.n_halo = int(nside), int(n_halo)
         a.d_catalog = d_catalog.data_ptr() if n_halo else None
@@ -370,8 +370,26 @@ class Context(object):
         a.variant = _lib.VARIANTS[variant]
         # out_is_zero: the caller cleared the output (tiles are stored, not added); out_overwrite: the output is uninitialised
         # memory and the call defines all of it (no clearing pass at all on the tile path)
-        a.flags = (_lib.SHELL_OUT_IS_ZERO if out_is_zero else 0) | (_lib.SHELL_OUT_OVERWRITE if out_overwrite else 0)
+        # reuse_plan: the caller vouches that d_catalog holds the records of this context's previous shell call (BFG_SHELL_REUSE_PLAN:
+        # another model on the same grid over the same catalog runs the tile kernels only); same_catalog() is how the runners know
+        a.flags = (_lib.SHELL_OUT_IS_ZERO if out_is_zero else 0) | (_lib.SHELL_OUT_OVERWRITE if out_overwrite else 0) | \
+            (_lib.SHELL_REUSE_PLAN if reuse_plan else 0)
         return a
+
+    def same_catalog(self, d_catalog):
+        """True if `d_catalog` is the very tensor object the previous shell call of this context was given (and so, the containers
+        never writing to their device copies, the same records): what entitles a runner to set reuse_plan.  The tensor is kept
+        referenced, so its address cannot be recycled for other data in between.  BFG_PLAN_REUSE=0 switches the short cut off."""
+        import os
+        same = getattr(self, "_plan_cat", None) is d_catalog and os.environ.get("BFG_PLAN_REUSE", "1") != "0"
+        self._plan_cat = d_catalog
+        return same
+
+    def plan_reuses(self):
+        """shell calls of this context that ran on a reused plan (bfg_plan_reuses)"""
+        n = C.c_int64(0)
+        _lib.check(self.lib.bfg_plan_reuses(self.handle, C.byref(n)), "bfg_plan_reuses")
+        return n.value
 
     def _sliced(self, fn_name, args, table, spline, d_out, slices, on_slice):
         """bfg_*_sliced: on_slice(k, n, elem_begin, elem_end) is called on this thread after the k-th slice of the output has

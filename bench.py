@@ -90,8 +90,10 @@ LEG_ARGS = {
     "nd4": dict(workload="paint", nside=1024, halos=1_000_000, table="nd4", steep=False, eps=10.0),
     # the reference's own published workload (18 512 halos, 2 x 30 x 2000 tables) through process(), host to host: run_published
     "published": dict(workload="paint", nside=1024, halos=18_512, table="stress", steep=False, eps=10.0),
+    # five models over one catalog on one plan (BFG_SHELL_REUSE_PLAN): run_multi_model
+    "multi_model": dict(workload="paint", nside=1024, halos=1_000_000, table="default", steep=False, eps=10.0),
 }
-N1_ONLY_LEGS = ("configs1", "configs2", "steep", "configs4", "nd4", "published")
+N1_ONLY_LEGS = ("configs1", "configs2", "steep", "configs4", "nd4", "published", "multi_model")
 
 
 def parse():
@@ -457,6 +459,9 @@ WATCHDOG = Watchdog()
 
 def main():
     args = parse()
+    # every timed step of this file does ALL of its work: the K steps of a run paint the SAME catalog, which would entitle steps 2..K
+    # to the plan of step 1 (BFG_SHELL_REUSE_PLAN through the runners).  Off, except inside the leg that measures it (multi_model).
+    os.environ["BFG_PLAN_REUSE"] = "0"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher (no GPU call has happened or will happen in this process)
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
@@ -550,7 +555,7 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
     # ---- guarded extra legs: whatever happens from here on, the main line above is printed and the run exits 0 -----------
     if args.legs == "auto":
         default_paint = args.workload == "paint" and args.nside == 1024 and args.table == "default" and not args.steep
-        legs = (["weak", "owner", "configs3"] if world > 1 else ["configs1", "configs2", "steep", "configs4", "nd4", "configs3", "published"]) if default_paint else []
+        legs = (["weak", "owner", "configs3"] if world > 1 else ["configs1", "configs2", "steep", "configs4", "nd4", "configs3", "published", "multi_model"]) if default_paint else []
     else:
         legs = [x for x in args.legs.split(",") if x and x != "none"]       # (names validated in parse())
     if world == 1:
@@ -595,6 +600,8 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
             try:
                 if name == "published":
                     res = run_published(largs, torch, local_rank)
+                elif name == "multi_model":
+                    res = run_multi_model(largs, torch, local_rank)
                 elif largs.workload == "snapshot":
                     res = run_snapshot(largs, torch, local_rank)
                 else:
@@ -677,7 +684,7 @@ def leg_summary(res, wall_s):
     o["roofline"] = dict(res["roofline"])
     for k in ("other_kernels_timed_in", "lds_atomic_ceiling_per_s"):
         o["roofline"].pop(k, None)
-    for k in ("paint", "baryonify"):             # the `published` leg's two API measurements
+    for k in ("paint", "baryonify", "multi_model"):             # the `published` leg's two API measurements, the shared-plan leg's
         if res.get(k):
             o[k] = res[k]
     if res.get("deposit_roofline"):
@@ -1352,6 +1359,88 @@ def run_snapshot(args, torch, local_rank, n1=512, L=1000.0, ngrid=512, zs=0.25, 
                                    f"epsilon_max 10, Baryonification3D table 10x30x100, + CIC deposit on a {ngrid}^3 mesh",
                        "halos_total": nhalo, "sharding": "none"},
             "roofline": roofline, "deposit_roofline": deposit, "cpu_baseline": cpu}
+
+
+def run_multi_model(args, torch, local_rank, n_models=5):
+    """One plan, K models (include/bfg_mi355.h BFG_SHELL_REUSE_PLAN): the reference's workflow paints five models
+    over ONE catalog (examples/05_Paint_tSZ_shell.ipynb:303-324, utils/Parallelize.py:92-113).  The headline catalog (--halos halos,
+    NSIDE 1024, eps 10) and five tables on the default grid whose values differ; a step = the five maps, inputs resident in HBM:
+    the first call plans (halo_prep_kernel + binning), the other four carry the flag and run the tile kernels only.  Timed beside it:
+    the same five calls without the flag.  value = halos x models / step time (never the headline value)."""
+    from baryonforge_amd import synthetic as syn
+    from baryonforge_amd.background import Background
+    from baryonforge_amd.engine import get_context
+    ctx = get_context(local_rank)
+    cosmo = dict(syn.COSMO)
+    nside, npix, n = args.nside, 12 * args.nside ** 2, args.halos
+    ra, dec, M, z = syn.catalog(n, seed=42, steep=args.steep)
+    d_cat = ctx.to_device(np.stack([M, z, ra, dec], axis=1))
+    bg = Background(cosmo)
+    spline, md = ctx.da_spline(bg, float(np.max(z))), ctx.massdef_struct(bg, None)
+    zax, Max, rax, T = syn.pressure_table()
+    with np.errstate(all="ignore"):
+        tables = [ctx.table([zax, Max, rax], np.log(T * (1.0 + 0.5 * k)), log_values=True) for k in range(n_models)]
+    first = ctx.shell_args(nside, d_cat, n, 4, 0, args.eps, md, variant=args.variant, out_overwrite=True)
+    again = ctx.shell_args(nside, d_cat, n, 4, 0, args.eps, md, variant=args.variant, out_overwrite=True, reuse_plan=True)
+    d_maps = [ctx.empty(npix) for _ in range(n_models)]
+
+    def step(share):
+        for k in range(n_models):
+            ctx.paint_shell(again if (share and k) else first, tables[k], spline, d_maps[k])
+
+    def timed(nsteps, share):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step(share)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / nsteps
+    old = os.environ.get("BFG_PLAN_REUSE")
+    os.environ["BFG_PLAN_REUSE"] = "1"
+    try:
+        steps = max(5, min(args.steps, 20))
+        step(False)
+        ref = [m.clone() for m in d_maps]
+        r0 = ctx.plan_reuses()
+        step(True)
+        torch.cuda.synchronize()
+        reused = ctx.plan_reuses() - r0
+        same = all(bool(torch.allclose(a_, b_, rtol=1e-11, atol=0.0)) and bool(torch.equal(a_ != 0, b_ != 0)) for a_, b_ in zip(d_maps, ref))
+        del ref
+        for _ in range(max(1, int(0.25 / max(timed(2, True), 1e-4) / 2))):
+            step(True)
+        t_sep = timed(steps, False)
+        ctx.stats_reset()
+        ctx.timing_enable(True, which=[1])
+        t_one = timed(steps, True)
+        k_ms, k_n = ctx.timing_read(1)
+        ptot = ctx.stats()["pixel_updates"] / (steps * n_models)
+        ctx.timing_enable(False)
+    finally:
+        if old is None:
+            os.environ.pop("BFG_PLAN_REUSE", None)
+        else:
+            os.environ["BFG_PLAN_REUSE"] = old
+    kernel_s = k_ms / max(k_n, 1) * 1e-3
+    kernel_bytes = 32.0 * n + 16.0 * ptot
+    key = f"paint_{args.variant}_n{n}_nside{nside}"
+    traffic, traffic_source, sq = stored_counters(key)
+    roofline = {"bound": "hbm", "kernel": "shell_tile_kernel", "achieved": kernel_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0,
+                "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": kernel_bytes / kernel_s / HBM_PEAK if kernel_s > 0 else 0.0,
+                "traffic": traffic, "traffic_source": traffic_source, "counters": sq, "counters_key": key,
+                "kernel_ms": k_ms / max(k_n, 1), "kernel_launches": k_n, "algorithmic_bytes_per_launch": kernel_bytes,
+                "pixel_updates_per_launch": ptot}
+    finish_roofline(roofline, sq, kernel_s, traffic)
+    return {"metric": "halos_per_s", "value": n * n_models / t_one, "unit": "halos/s", "ms_per_step": t_one * 1e3, "scaling": "weak",
+            "steps": steps, "ramp_steps": 0, "dtype": "f64",
+            "config": {"workload": f"{n_models} TabulatedProfile models (table 10x30x100, same grid) painted over ONE catalog of {n} halos, "
+                                   f"NSIDE={nside}, epsilon_max={args.eps:g}: one plan (halo records + pair lists), {n_models} tile-kernel passes",
+                       "halos_total": n, "sharding": "none"},
+            "roofline": roofline, "cpu_baseline": None,
+            "multi_model": {"models": n_models, "ms_one_plan": t_one * 1e3, "ms_separate_calls": t_sep * 1e3,
+                            "ms_per_extra_model": (t_one * 1e3 - t_sep * 1e3 / n_models) / (n_models - 1),
+                            "ms_single_call": t_sep * 1e3 / n_models, "calls_on_a_reused_plan_per_step": reused,
+                            "maps_equal_separate_calls": same}}
 
 
 PUBLISHED = {   # the only first-party throughput numbers of this path (BASELINE.md): tqdm rates of the example notebooks, author's laptop

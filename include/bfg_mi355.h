@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BFG_ABI_VERSION 5
+#define BFG_ABI_VERSION 6
 
 typedef enum {
     BFG_OK = 0,
@@ -160,6 +160,15 @@ typedef struct {
  * On the tile path the kernels write each sky tile exactly once, so no separate clearing pass over the 101 MB map (302 MB
  * of offsets) is needed; on every other path the library clears the buffer itself first.                        */
 #define BFG_SHELL_OUT_OVERWRITE 2
+/* One plan, K models (ABI 6).  The reference's workflow paints several models over ONE catalog (examples/05_Paint_tSZ_shell.ipynb
+ * :303-324, utils/Parallelize.py:92-113: a list of runners that differ in `model` only).  The per-halo records and the halo -> sky
+ * tile pair lists a shell call builds depend on the catalog, NSIDE, epsilon, the mass definitions, the D_A spline and the table's
+ * AXES -- not on its values.  With this flag the caller vouches that d_catalog holds the same records as in the context's previous
+ * shell call; if that call (same kind: paint / offsets) was built from the same everything-else -- the library compares pointers,
+ * sizes, scalars and a hash of the table axes -- the call reuses its records and pair lists and runs only the tile kernels (one
+ * small launch re-arms their work counters).  Otherwise the flag is ignored and the call does all of its work.  Results are those
+ * of a call without the flag (the same kernels on the same records); bfg_plan_reuses() counts the calls that took the short cut. */
+#define BFG_SHELL_REUSE_PLAN 4
 
 #define BFG_VARIANT_AUTO 0
 #define BFG_VARIANT_SCATTER_WAVE 1     /* one 64-lane wavefront per halo, global f64 atomics   */
@@ -430,6 +439,7 @@ int bfg_ndtable_read(bfg_ctx *ctx, const bfg_ndtable *table, const double *d_row
 /* max |x| over a device array (np.allclose(orig_map, 0) early return, :293-294) and sum. */
 int bfg_reduce_absmax_sum(bfg_ctx *ctx, int64_t n, const double *d_x, double *absmax, double *sum);
 
+int bfg_plan_reuses(bfg_ctx *ctx, int64_t *count);   /* shell calls of this context that ran on a reused plan (BFG_SHELL_REUSE_PLAN) */
 int bfg_stats_reset(bfg_ctx *ctx);
 int bfg_stats_read(bfg_ctx *ctx, bfg_stats *out);   /* synchronises the stream */
 

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.bfg_abi_version() == _lib.ABI_VERSION == 5
+    assert L.bfg_abi_version() == _lib.ABI_VERSION == 6
     assert L.bfg_status_string(0) == b"ok" and b"invalid" in L.bfg_status_string(-1)
 
 
