@@ -2633,7 +2633,9 @@ int bfg_baryonify_snapshot_strided(bfg_ctx *c, const bfg_snapshot_args *a, const
     P.logtab = reinterpret_cast<const double2 *>(c->d_mathtab);
     // coarse cell grid for the halo-overlap lists: a few candidate halos per cell
     const int nmax = (a->ndim == 3) ? 128 : 2048;
-    int ncell = (int)std::floor(std::pow(4.0 * (double)std::max<int64_t>(a->n_halo, 1), 1.0 / a->ndim));
+    double cell_factor = 4.0;
+    if (const char *e = std::getenv("BFG_SNAP_CELL_FACTOR")) cell_factor = std::max(0.25, std::atof(e));      // A/B switch
+    int ncell = (int)std::floor(std::pow(cell_factor * (double)std::max<int64_t>(a->n_halo, 1), 1.0 / a->ndim));
     ncell = std::max(4, std::min(ncell, nmax));
     P.ncell = ncell;
     P.ncell_tot = (a->ndim == 3) ? (int64_t)ncell * ncell * ncell : (int64_t)ncell * ncell;
@@ -2692,12 +2694,17 @@ int bfg_baryonify_snapshot_strided(bfg_ctx *c, const bfg_snapshot_args *a, const
         const unsigned pgrid = (unsigned)std::min<int64_t>(((a->n_part + 255) / 256 + 7) / 8 * 8, 8192);       // grid-stride; a multiple of 8
         P.xcd_map = 1;
         if (const char *e = std::getenv("BFG_SNAP_XCD")) P.xcd_map = std::atoi(e) != 0;                 // A/B switch
-        // default: the hits of a wavefront spread over its lanes through an LDS queue (snap_particle_q_kernel); BFG_SNAPSHOT=plain: every
-        // lane works through its own hits (the kernel of rounds 1-5, the A/B)
-        bool queued = true;
-        if (const char *e = std::getenv("BFG_SNAPSHOT")) if (!std::strcmp(e, "plain")) queued = false;
+        // default: candidate lists staged in LDS run by run (snap_particle_s_kernel); BFG_SNAPSHOT=plain: every lane gathers its own
+        // records (the kernel of rounds 1-5); BFG_SNAPSHOT=queue: that, with the hits of a wavefront spread over its lanes
+        bool queued = false, staged = true;
+        if (const char *e = std::getenv("BFG_SNAPSHOT")) {
+            if (!std::strcmp(e, "plain")) staged = false;
+            if (!std::strcmp(e, "queue")) { staged = false; queued = true; }
+        }
         timing_begin(c, 6);
-        if (queued && a->ndim == 3) hipLaunchKernelGGL(snap_particle_q_kernel<3>, dim3(pgrid), dim3(256), 0, c->stream, P);
+        if (staged && a->ndim == 3) hipLaunchKernelGGL(snap_particle_s_kernel<3>, dim3(pgrid), dim3(256), 0, c->stream, P);
+        else if (staged) hipLaunchKernelGGL(snap_particle_s_kernel<2>, dim3(pgrid), dim3(256), 0, c->stream, P);
+        else if (queued && a->ndim == 3) hipLaunchKernelGGL(snap_particle_q_kernel<3>, dim3(pgrid), dim3(256), 0, c->stream, P);
         else if (queued) hipLaunchKernelGGL(snap_particle_q_kernel<2>, dim3(pgrid), dim3(256), 0, c->stream, P);
         else if (a->ndim == 3) hipLaunchKernelGGL(snap_particle_kernel<3>, dim3(pgrid), dim3(256), 0, c->stream, P);
         else hipLaunchKernelGGL(snap_particle_kernel<2>, dim3(pgrid), dim3(256), 0, c->stream, P);
