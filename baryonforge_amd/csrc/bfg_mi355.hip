@@ -2633,7 +2633,10 @@ int bfg_baryonify_snapshot_strided(bfg_ctx *c, const bfg_snapshot_args *a, const
     P.logtab = reinterpret_cast<const double2 *>(c->d_mathtab);
     // coarse cell grid for the halo-overlap lists: a few candidate halos per cell
     const int nmax = (a->ndim == 3) ? 128 : 2048;
-    double cell_factor = 4.0;
+    // ~8 cells per halo (4 until round 6: 2.1 of a particle's ~8 candidates were hits; with cells of 11 instead of 14 Mpc at BASELINE
+    // configs[4] it tests ~6: particle kernel 4.70 -> 4.53 ms, 21.8 -> 20.2 ms with the particles in random order; 16: 4.47 ms, but the
+    // overlap lists then cost what the kernel gains -- profiles/r06_snapshot_ab.txt)
+    double cell_factor = 8.0;
     if (const char *e = std::getenv("BFG_SNAP_CELL_FACTOR")) cell_factor = std::max(0.25, std::atof(e));      // A/B switch
     int ncell = (int)std::floor(std::pow(cell_factor * (double)std::max<int64_t>(a->n_halo, 1), 1.0 / a->ndim));
     ncell = std::max(4, std::min(ncell, nmax));
@@ -2694,19 +2697,10 @@ int bfg_baryonify_snapshot_strided(bfg_ctx *c, const bfg_snapshot_args *a, const
         const unsigned pgrid = (unsigned)std::min<int64_t>(((a->n_part + 255) / 256 + 7) / 8 * 8, 8192);       // grid-stride; a multiple of 8
         P.xcd_map = 1;
         if (const char *e = std::getenv("BFG_SNAP_XCD")) P.xcd_map = std::atoi(e) != 0;                 // A/B switch
-        // default: candidate lists staged in LDS run by run (snap_particle_s_kernel); BFG_SNAPSHOT=plain: every lane gathers its own
-        // records (the kernel of rounds 1-5); BFG_SNAPSHOT=queue: that, with the hits of a wavefront spread over its lanes
-        bool queued = false, staged = true;
-        if (const char *e = std::getenv("BFG_SNAPSHOT")) {
-            if (!std::strcmp(e, "plain")) staged = false;
-            if (!std::strcmp(e, "queue")) { staged = false; queued = true; }
-        }
+        // (round 6, measured and not kept -- profiles/r06_snapshot_ab.txt, commits aa966fe / d66acd4: the hits of a wavefront spread
+        // over its lanes through an LDS queue, 4.80 -> 4.73 ms; the candidate lists staged in LDS run by run, 4.75 -> 5.70 ms)
         timing_begin(c, 6);
-        if (staged && a->ndim == 3) hipLaunchKernelGGL(snap_particle_s_kernel<3>, dim3(pgrid), dim3(256), 0, c->stream, P);
-        else if (staged) hipLaunchKernelGGL(snap_particle_s_kernel<2>, dim3(pgrid), dim3(256), 0, c->stream, P);
-        else if (queued && a->ndim == 3) hipLaunchKernelGGL(snap_particle_q_kernel<3>, dim3(pgrid), dim3(256), 0, c->stream, P);
-        else if (queued) hipLaunchKernelGGL(snap_particle_q_kernel<2>, dim3(pgrid), dim3(256), 0, c->stream, P);
-        else if (a->ndim == 3) hipLaunchKernelGGL(snap_particle_kernel<3>, dim3(pgrid), dim3(256), 0, c->stream, P);
+        if (a->ndim == 3) hipLaunchKernelGGL(snap_particle_kernel<3>, dim3(pgrid), dim3(256), 0, c->stream, P);
         else hipLaunchKernelGGL(snap_particle_kernel<2>, dim3(pgrid), dim3(256), 0, c->stream, P);
         HIP_TRY(hipGetLastError());
         timing_end(c, 6);

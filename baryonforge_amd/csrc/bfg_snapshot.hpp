@@ -467,285 +467,6 @@ __global__ __launch_bounds__(256) void snap_particle_kernel(const SnapParams P)
     }
 }
 
-// ---- the same pass with the HITS of a wavefront spread evenly over its lanes ------------------------------------------------
-// In snap_particle_kernel every lane works through its own hits: a lane has 2.1 of them on average at BASELINE configs[4], the
-// wavefront runs the read-out (~80 VALU instructions) as often as its BUSIEST lane has hits -- 6-8 times.  Here the lanes only test;
-// every hit becomes an entry (owner lane, candidate) of a per-wavefront queue in LDS, and the queue is worked through 64 entries at
-// a time: entry i goes to lane i mod 64, which reads the owner's position from LDS, repeats the separation, reads the displacement
-// and adds the offset to the owner's accumulator with ds_add_f64.  ceil(134 / 64) = 3 trips of the read-out instead of 6-8.  Any
-// particle order (nothing is sorted); the order in which a particle's offsets are added is no longer the list's (they are
-// LDS atomics), so results agree with the plain kernel to rounding, not bit for bit.
-constexpr int kSnapQueue = 256;      // queue entries per wavefront and round (a batch of 64 candidates x 64 lanes can yield 4096 hits)
-struct SnapWaveLds {
-    double p[3][64];                 // the lanes' particle positions
-    double o[3][64];                 // ... and offset accumulators
-    uint32_t q_cand[kSnapQueue];     // queue: candidate index
-    uint8_t q_owner[kSnapQueue];     // ... and owner lane
-};
-
-template <int NDIM>
-__global__ __launch_bounds__(256) void snap_particle_q_kernel(const SnapParams P)
-{
-    __shared__ double2 s_logtab[kLogTab];
-    __shared__ SnapWaveLds s_wave[4];
-    if (threadIdx.x < kLogTab) s_logtab[threadIdx.x] = P.logtab[threadIdx.x];
-    __syncthreads();
-    const SnapHit H = {&P.tab, P.hrow, s_logtab, P.tab.raxis[0], P.tab.raxis[P.tab.nr - 1]};
-    SnapWaveLds &W = s_wave[threadIdx.x >> 6];
-    const int lane = threadIdx.x & 63;
-    unsigned long long hits = 0, n_oob = 0;
-    const double L = P.L, halfL = 0.5 * P.L;
-    const int n = P.ncell;
-    const double inv_cell = (double)n / L;
-    const int64_t nchunk = (P.n_part + blockDim.x - 1) / blockDim.x, per_xcd = (nchunk + 7) / 8;
-    for (int64_t it = blockIdx.x; it < (P.xcd_map ? 8 * per_xcd : nchunk); it += gridDim.x) {      // (see snap_particle_kernel)
-        const int64_t chunk = P.xcd_map ? (it & 7) * per_xcd + (it >> 3) : it;
-        if (chunk >= nchunk) continue;                                                             // workgroup-uniform
-        const int64_t ip = chunk * blockDim.x + threadIdx.x;
-        const bool valid = ip < P.n_part;
-        double p[3] = {0.0, 0.0, 0.0};
-        int c0 = 0, c1 = 0;
-        if (valid) {
-            int64_t cid = 0;
-            load_coords<NDIM>(P.part, ip, P.pstride, p);
-            for (int k = 0; k < NDIM; ++k) cid = cid * n + snap_cell_of(p[k], inv_cell, n);
-            c0 = P.cell_start[cid]; c1 = (int)min((int64_t)P.cell_start[cid + 1], P.cand_cap);
-        }
-        for (int k = 0; k < 3; ++k) { W.p[k][lane] = p[k]; W.o[k][lane] = 0.0; }
-        // batches of 64 candidates per lane: (1) distance tests -> the lane's hit mask, (2) the wavefront's hits through the queue
-        for (int qb = c0; __any(qb < c1); qb += 64) {
-            const int qe = min(qb + 64, c1);
-            unsigned long long mask = 0;
-            constexpr int U = 3;
-            for (int q = qb; q < qe; q += U) {
-                double4 e[U];
-                for (int u = 0; u < U; ++u) e[u] = *reinterpret_cast<const double4 *>(&P.cand[min(q + u, qe - 1)]);   // x, y, z, rq
-                for (int u = 0; u < U; ++u) {
-                    const double hc[3] = {e[u].x, e[u].y, e[u].z};
-                    double d2 = 0.0;
-                    for (int k = 0; k < NDIM; ++k) { const double dx = p[k] - hc[k]; d2 += dx * dx; }
-                    if (d2 <= e[u].w * e[u].w && q + u < qe) mask |= 1ull << (q + u - qb);
-                }
-            }
-            const int h = __popcll(mask);
-            const int incl = wave_scan_incl(h), excl = incl - h;
-            const int total = __builtin_amdgcn_readlane(incl, 63);
-            hits += (lane == 0) ? (unsigned long long)total : 0ull;
-            for (int base = 0; base < total; base += kSnapQueue) {                                  // wave-uniform
-                // (the previous round's entries have been consumed: one wavefront, program order; LDS operations of a wavefront
-                // complete in order)
-                unsigned long long m = mask;
-                for (int pos = excl - base; m && pos < kSnapQueue; ++pos) {
-                    const int bit = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    if (pos >= 0) { W.q_cand[pos] = (uint32_t)(qb + bit); W.q_owner[pos] = (uint8_t)lane; }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int nq = min(kSnapQueue, total - base);
-                for (int i = lane; i < nq; i += 64) {
-                    const int q = (int)W.q_cand[i], owner = (int)W.q_owner[i];
-                    const SnapCand e = P.cand[q];
-                    const double hc[3] = {e.x, e.y, e.z};
-                    double dd[3] = {0.0, 0.0, 0.0}, d2 = 0.0, off[3] = {0.0, 0.0, 0.0};
-                    for (int k = 0; k < NDIM; ++k) { const double dx = W.p[k][owner] - hc[k]; dd[k] = dx; d2 += dx * dx; }
-                    snap_hit(H, d2, dd, NDIM, e.halo, e.xcut, e.lnshift, off, n_oob);
-                    for (int k = 0; k < NDIM; ++k)
-                        if (off[k] != 0.0) atomicAdd(&W.o[k][owner], off[k]);                       // (NaN != 0: a particle on a halo centre)
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-        }
-        double off[3] = {W.o[0][lane], W.o[1][lane], W.o[2][lane]};
-        if (valid) {
-            const int nbig = P.big[0];
-            for (int q = 0; q < nbig; ++q) {
-                const int j = P.big[1 + q];
-                const SnapHalo h = P.hs[j];
-                const double hc[3] = {h.x, h.y, h.z};
-                double dd[3] = {0, 0, 0}, d2 = 0.0;
-                for (int k = 0; k < NDIM; ++k) {
-                    double dx = p[k] - hc[k];
-                    dx = (dx > halfL) ? dx - L : dx;
-                    dx = (dx < -halfL) ? dx + L : dx;
-                    dd[k] = dx; d2 += dx * dx;
-                }
-                if (d2 <= h.rq * h.rq) { ++hits; snap_hit(H, d2, dd, NDIM, j, h.xcut, h.lnshift, off, n_oob); }
-            }
-            double pn[3] = {0.0, 0.0, 0.0};
-            for (int k = 0; k < NDIM; ++k) {
-                double v = p[k] + off[k];                          // :262-265
-                v = (v > L) ? v - L : v;                           // :268-273
-                v = (v < 0.0) ? v + L : v;
-                pn[k] = v;
-            }
-            store_coords<NDIM>(P.out, ip, P.ostride, pn);
-        }
-    }
-    __shared__ unsigned long long s_red[2][4];
-    for (int o = 32; o > 0; o >>= 1) { hits += __shfl_down(hits, o, 64); n_oob += __shfl_down(n_oob, o, 64); }
-    if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = hits; s_red[1][threadIdx.x >> 6] = n_oob; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        hits = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
-        n_oob = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
-        if (hits) atomicAdd((unsigned long long *)&P.stats->pixel_updates, hits);
-        if (n_oob) {
-            atomicAdd((unsigned long long *)&P.stats->pixels_out_of_table, n_oob);
-            if (!P.rdelta) atomicOr(&P.stats->warn_mask, BFG_WARN_R_RANGE);       // BaryonCorrection.py:391-394
-        }
-    }
-}
-
-// ---- the same pass with every RUN's candidate list staged in LDS -----------------------------------------------------------------
-// What bounds snap_particle_kernel is neither arithmetic nor latency but the number of divergent vector memory instructions: 52 per
-// wavefront of 64 particles (SQ_INSTS_VMEM 1.09e8 per launch at BASELINE configs[4]), most of them 16-byte gathers of candidate
-// records that a handful of lanes share -- the texture path looks up one cache line per distinct address.  (Spreading the hits over
-// the lanes, an XCD-contiguous chunk order and finer cells moved the kernel by 1 %, 1 % and 4 %: profiles/r06_snapshot_ab.txt.)
-// In a snapshot stored in any spatially coherent order (lattice, ID, Morton: what N-body codes write) consecutive particles sit in
-// the same cell: the lanes of a wavefront form RUNS of equal cell id (7 lanes on average at configs[4]).  Here the lanes of a run
-// copy their cell's list into the wavefront's LDS region ONCE, 16 contiguous bytes per lane and trip (coalesced inside the run),
-// and tests and read-outs take the records from LDS (same-address reads of a run are one broadcast).  A wavefront with more than
-// kStageRuns runs, or more records than its region holds -- particles in random order -- takes the gathers of snap_particle_kernel.
-constexpr int kStageRecs = 96, kStageRuns = 20;
-
-template <int NDIM>
-__global__ __launch_bounds__(256) void snap_particle_s_kernel(const SnapParams P)
-{
-    __shared__ double2 s_logtab[kLogTab];
-    __shared__ SnapCand s_stage[4][kStageRecs];
-    if (threadIdx.x < kLogTab) s_logtab[threadIdx.x] = P.logtab[threadIdx.x];
-    __syncthreads();
-    const SnapHit H = {&P.tab, P.hrow, s_logtab, P.tab.raxis[0], P.tab.raxis[P.tab.nr - 1]};
-    SnapCand *const stage = s_stage[threadIdx.x >> 6];
-    const int lane = threadIdx.x & 63;
-    unsigned long long hits = 0, n_oob = 0;
-    const double L = P.L, halfL = 0.5 * P.L;
-    const int n = P.ncell;
-    const double inv_cell = (double)n / L;
-    const int64_t nchunk = (P.n_part + blockDim.x - 1) / blockDim.x, per_xcd = (nchunk + 7) / 8;
-    for (int64_t it = blockIdx.x; it < (P.xcd_map ? 8 * per_xcd : nchunk); it += gridDim.x) {      // (see snap_particle_kernel)
-        const int64_t chunk = P.xcd_map ? (it & 7) * per_xcd + (it >> 3) : it;
-        if (chunk >= nchunk) continue;                                                             // workgroup-uniform
-        const int64_t ip = chunk * blockDim.x + threadIdx.x;
-        const bool valid = ip < P.n_part;
-        double p[3] = {0.0, 0.0, 0.0}, off[3] = {0.0, 0.0, 0.0};
-        int c0 = 0, c1 = 0, cid = -1;
-        if (valid) {
-            int64_t c = 0;
-            load_coords<NDIM>(P.part, ip, P.pstride, p);
-            for (int k = 0; k < NDIM; ++k) c = c * n + snap_cell_of(p[k], inv_cell, n);
-            cid = (int)c;
-            c0 = P.cell_start[cid]; c1 = (int)min((int64_t)P.cell_start[cid + 1], P.cand_cap);
-        }
-        // runs of equal cell id among consecutive lanes
-        const int prev = __shfl_up(cid, 1, 64);
-        const bool head = lane == 0 || cid != prev;
-        const unsigned long long hmask = __ballot(head);
-        const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-        const int head_lane = 63 - __clzll((long long)(hmask & upto));
-        const unsigned long long above = (head_lane == 63) ? 0ull : (hmask >> (head_lane + 1));
-        const int run_len = above ? (__ffsll((long long)above)) : (64 - head_lane);
-        const int rank = lane - head_lane;
-        const int nrec = c1 - c0;
-        const int incl = wave_scan_incl(head ? nrec : 0);
-        const int total = __builtin_amdgcn_readlane(incl, 63);
-        const int lbase = __shfl(incl - nrec, head_lane, 64);                  // first slot of my run's list (the head's exclusive sum)
-        const bool staged = __popcll(hmask) <= kStageRuns && total <= kStageRecs;                   // wave-uniform
-        if (staged) {
-            // the lanes of a run copy its list: 16-byte piece k of the run goes to lane rank = k mod run_len
-            const double2 *src = reinterpret_cast<const double2 *>(P.cand + c0);
-            double2 *dst = reinterpret_cast<double2 *>(stage + lbase);
-            const int npieces = 4 * nrec;
-            for (int k = rank; __any(k < npieces); k += run_len)
-                if (k < npieces) dst[k] = src[k];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-        for (int qb = 0; qb < nrec; qb += 64) {
-            const int qe = min(qb + 64, nrec);
-            unsigned long long mask = 0;
-            if (staged) {
-                for (int q = qb; q < qe; ++q) {
-                    const double4 e = *reinterpret_cast<const double4 *>(&stage[lbase + q]);
-                    const double hc[3] = {e.x, e.y, e.z};
-                    double d2 = 0.0;
-                    for (int k = 0; k < NDIM; ++k) { const double dx = p[k] - hc[k]; d2 += dx * dx; }
-                    if (d2 <= e.w * e.w) mask |= 1ull << (q - qb);
-                }
-            } else {
-                constexpr int U = 3;
-                for (int q = qb; q < qe; q += U) {
-                    double4 e[U];
-                    for (int u = 0; u < U; ++u) e[u] = *reinterpret_cast<const double4 *>(&P.cand[c0 + min(q + u, qe - 1)]);
-                    for (int u = 0; u < U; ++u) {
-                        const double hc[3] = {e[u].x, e[u].y, e[u].z};
-                        double d2 = 0.0;
-                        for (int k = 0; k < NDIM; ++k) { const double dx = p[k] - hc[k]; d2 += dx * dx; }
-                        if (d2 <= e[u].w * e[u].w && q + u < qe) mask |= 1ull << (q + u - qb);
-                    }
-                }
-            }
-            while (mask) {
-                const int q = qb + __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                SnapCand e;
-                if (staged) e = stage[lbase + q]; else e = P.cand[c0 + q];
-                const double hc[3] = {e.x, e.y, e.z};
-                double dd[3] = {0, 0, 0}, d2 = 0.0;
-                for (int k = 0; k < NDIM; ++k) { const double dx = p[k] - hc[k]; dd[k] = dx; d2 += dx * dx; }
-                ++hits;
-                snap_hit(H, d2, dd, NDIM, e.halo, e.xcut, e.lnshift, off, n_oob);
-            }
-        }
-        if (staged) {                                      // the region is rewritten by the next chunk: every lane is done reading it
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (valid) {
-            const int nbig = P.big[0];
-            for (int q = 0; q < nbig; ++q) {
-                const int j = P.big[1 + q];
-                const SnapHalo h = P.hs[j];
-                const double hc[3] = {h.x, h.y, h.z};
-                double dd[3] = {0, 0, 0}, d2 = 0.0;
-                for (int k = 0; k < NDIM; ++k) {
-                    double dx = p[k] - hc[k];
-                    dx = (dx > halfL) ? dx - L : dx;
-                    dx = (dx < -halfL) ? dx + L : dx;
-                    dd[k] = dx; d2 += dx * dx;
-                }
-                if (d2 <= h.rq * h.rq) { ++hits; snap_hit(H, d2, dd, NDIM, j, h.xcut, h.lnshift, off, n_oob); }
-            }
-            double pn[3] = {0.0, 0.0, 0.0};
-            for (int k = 0; k < NDIM; ++k) {
-                double v = p[k] + off[k];                          // :262-265
-                v = (v > L) ? v - L : v;                           // :268-273
-                v = (v < 0.0) ? v + L : v;
-                pn[k] = v;
-            }
-            store_coords<NDIM>(P.out, ip, P.ostride, pn);
-        }
-    }
-    __shared__ unsigned long long s_red[2][4];
-    for (int o = 32; o > 0; o >>= 1) { hits += __shfl_down(hits, o, 64); n_oob += __shfl_down(n_oob, o, 64); }
-    if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = hits; s_red[1][threadIdx.x >> 6] = n_oob; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        hits = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
-        n_oob = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
-        if (hits) atomicAdd((unsigned long long *)&P.stats->pixel_updates, hits);
-        if (n_oob) {
-            atomicAdd((unsigned long long *)&P.stats->pixels_out_of_table, n_oob);
-            if (!P.rdelta) atomicOr(&P.stats->warn_mask, BFG_WARN_R_RANGE);       // BaryonCorrection.py:391-394
-        }
-    }
-}
-
 // ---- cell-grouped pass ----------------------------------------------------------------------------------------------
 // The one-thread-per-particle kernel above reads its candidate records lane by lane: a wavefront of 64 consecutive
 // particles straddles several cells, so every trip of the candidate loop is a divergent 64-byte gather (8 tests per

@@ -101,7 +101,7 @@ def test_baryonify_shell_with_pkeys_matches_reference(golden, cosmo, tag, route,
     assert_maps_close(got, g[f"{tag}_map_out"], RTOL, floor=BFLOOR, what=f"baryonify {tag} ({route[0]})")
 
 
-@pytest.mark.parametrize("path", ["direct", "plain", "queue", "cell"])
+@pytest.mark.parametrize("path", ["direct", "cell"])
 def test_baryonify_snapshot_with_one_pkey_matches_reference(golden, cosmo, path, monkeypatch):
     monkeypatch.setenv("BFG_SNAPSHOT", path)
     g = golden("pkeys.npz")
