@@ -628,10 +628,13 @@ def pin_ok(array):
         return False
     if a.nbytes % _PAGE == 0:
         return True
-    base = a
-    while isinstance(base, np.ndarray) and base.base is not None:     # a view of a whole-page buffer (aligned_empty: an mmap object)
-        base = base.base
     import mmap
+    base = a                                          # a view of a whole-page buffer (aligned_empty: ndarray -> memoryview -> mmap)
+    while True:
+        nxt = base.base if isinstance(base, np.ndarray) else base.obj if isinstance(base, memoryview) else None
+        if nxt is None:
+            break
+        base = nxt
     return isinstance(base, mmap.mmap)
 
 
