@@ -761,6 +761,8 @@ def finish_roofline(r, sq, kernel_s, traffic):
     b = bound_of(alg, traffic, kernel_s)
     if b == "hbm":
         r["bound"] = "hbm"
+        if traffic is None:
+            r["bound_basis"] = "algorithmic bytes only: no PMC traffic or SQ counters are stored for this workload"
         return r
     if valu is None and lds is None:             # no stored counters for this workload: no ceiling to price against
         r["bound"] = "valu+lds (no stored counters for this workload: frac withheld)"
@@ -1320,7 +1322,7 @@ def run_snapshot(args, torch, local_rank, n1=512, L=1000.0, ngrid=512, zs=0.25, 
     dep_s = d_ms / max(d_n, 1) * 1e-3
     key = f"snapshot_n{nhalo}_part{n1}"
     traffic, traffic_source, sq = stored_counters(key)
-    _, _, sq_dep = stored_counters(key + "_deposit")
+    dep_traffic, _, sq_dep = stored_counters(key + "_deposit")
     frac = kernel_bytes / kernel_s / HBM_PEAK if kernel_s > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": "snap_particle_kernel",
                 "achieved": kernel_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": frac,
@@ -1342,9 +1344,8 @@ def run_snapshot(args, torch, local_rank, n1=512, L=1000.0, ngrid=512, zs=0.25, 
                "algorithmic_bytes_per_launch": dep_bytes, "grid_mass": mass, "grid_mass_expected": float(npart),
                "valu_issue_frac": sq_dep.get("valu_issue_frac") if sq_dep else None,
                "lds_pipe_frac": sq_dep.get("lds_pipe_frac") if sq_dep else None, "counters": sq_dep}
-    finish_roofline(deposit, sq_dep, dep_s, None)
-    if deposit["frac"] is not None and dep_frac > 1.0 and deposit["bound"] == "hbm":
-        deposit["bound"] = "valu+lds"
+    deposit["traffic"] = dep_traffic             # dep_key_kernel + dep_tile_kernel (the overflow kernel is empty for a lattice)
+    finish_roofline(deposit, sq_dep, dep_s, dep_traffic)
     del P, d_out, keep
     cpu = None
     if not args.no_cpu_baseline:

@@ -566,3 +566,78 @@ def test_device_distances_reproduce_what_live_pyccl_printed_in_the_reference_not
             b.free()
         _lib.check(L.bfg_spline_destroy(ctx, spl))
     _lib.check(L.bfg_ctx_destroy(ctx))
+
+
+def test_cabi_reuse_plan_flag_against_the_oracle(cosmo):
+    """BFG_SHELL_REUSE_PLAN at the boundary itself (ABI 6): three tables on one grid painted over one catalog -- the first call plans,
+    the two that carry the flag run the tile kernels only (bfg_plan_reuses) -- each map and each counter against the oracle's run of
+    THAT table; then a table on another grid with the flag set: ignored, full call, still the oracle's map.  Offsets likewise."""
+    from scipy import interpolate
+    L = _lib.load()
+    ctx = C.c_void_p()
+    _lib.check(L.bfg_ctx_create(0, C.c_void_p(-1), C.byref(ctx)), "ctx")
+    nside, npix, eps, n = 256, 12 * 256 * 256, 10.0, 6000
+    ra, dec, M, z = syn.catalog(n, seed=33, z=(0.1, 0.4))
+    M[3] = 7e16                                                     # outside the hull: counted by the planning call AND by the reusing ones
+    bg = Background(cosmo)
+    z_t = np.linspace(0, z.max() + 0.1, 1000)
+    cs = interpolate.CubicSpline(z_t, bg.angular_diameter_distance(1 / (1 + z_t)))
+    spl = C.c_void_p()
+    knots, coef = np.ascontiguousarray(cs.x), np.ascontiguousarray(cs.c)
+    _lib.check(L.bfg_spline_create(ctx, knots.size, _dp(knots), _dp(coef), C.byref(spl)), "spline")
+    d_cat = Dev(L, ctx, n * 32).up(np.stack([M, z, ra, dec], 1))
+    a, R, D = orc.halo_scalars(cosmo, M, z)
+    args = _lib.ShellArgs()
+    args.nside, args.n_halo, args.d_catalog, args.cat_stride, args.n_extra = nside, n, d_cat.p.value, 4, 0
+    args.epsilon_max, args.runner_md, args.model_md = eps, _massdef(bg), _massdef(bg)
+    args.model_epsilon_max, args.variant = 20.0, 0
+
+    def reuses():
+        k = C.c_int64()
+        _lib.check(L.bfg_plan_reuses(ctx, C.byref(k)))
+        return k.value
+    zax, Max, rax, T = syn.pressure_table()
+    d_map = Dev(L, ctx, npix * 8)
+    st = _lib.Stats()
+    with np.errstate(all="ignore"):
+        for k, scale in enumerate((1.0, 2.5, 0.3)):
+            Tk = T * scale * (1.0 + 0.2 * k * np.tanh(np.exp(rax)))[None, None, :]
+            tab = _table(L, ctx, (zax, Max, rax), np.log(Tk), _lib.BFG_TABLE_LOG_VALUES)
+            args.flags = _lib.SHELL_OUT_OVERWRITE | (_lib.SHELL_REUSE_PLAN if k else 0)
+            r0 = reuses()
+            _lib.check(L.bfg_stats_reset(ctx))
+            _lib.check(L.bfg_paint_shell(ctx, C.byref(args), tab, spl, d_map.p), "paint")
+            _lib.check(L.bfg_stats_read(ctx, C.byref(st)))
+            assert reuses() - r0 == (1 if k else 0)
+            ref, ptot = orc.paint_shell(nside, ra, dec, M, a, D, R, (zax, Max, rax), np.log(Tk), eps)
+            assert st.pixel_updates == ptot and st.halos_out_of_table == 1 and (st.warn_mask & 2)
+            got = d_map.down(npix)
+            assert np.array_equal(got != 0, ref != 0)
+            assert_maps_close(got, ref, 1e-5, what=f"C-ABI paint on a reused plan, table {k}")
+            _lib.check(L.bfg_table_destroy(ctx, tab))
+        # another grid (nine redshift nodes), flag set: the library notices and does the whole call
+        z9, M9, r9, T9 = syn.pressure_table(9, 30, 100)
+        tab = _table(L, ctx, (z9, M9, r9), np.log(T9), _lib.BFG_TABLE_LOG_VALUES)
+        r0 = reuses()
+        _lib.check(L.bfg_paint_shell(ctx, C.byref(args), tab, spl, d_map.p), "paint")
+        assert reuses() == r0
+        ref, _ = orc.paint_shell(nside, ra, dec, M, a, D, R, (z9, M9, r9), np.log(T9), eps)
+        assert_maps_close(d_map.down(npix), ref, 1e-5, what="C-ABI paint, flag ignored for another grid")
+        _lib.check(L.bfg_table_destroy(ctx, tab))
+    # offsets: the pre-blended row windows are rebuilt from the table the call is given
+    zd, Md, rd, d = syn.displacement_table()
+    d_off = Dev(L, ctx, npix * 24)
+    for k, scale in enumerate((1.0, 1.7)):
+        dtab = _table(L, ctx, (zd, Md, rd), d * scale, 0)
+        args.flags = _lib.SHELL_OUT_OVERWRITE | (_lib.SHELL_REUSE_PLAN if k else 0)
+        r0 = reuses()
+        _lib.check(L.bfg_baryonify_offsets(ctx, C.byref(args), dtab, spl, d_off.p), "offsets")
+        assert reuses() - r0 == (1 if k else 0)
+        ref, _ = orc.baryonify_offsets(nside, ra, dec, M, a, D, R, R / a, (zd, Md, rd), d * scale, eps, 20.0)
+        got = d_off.down((npix, 3))
+        assert np.max(np.abs(got - ref)) <= 1e-5 * np.max(np.abs(ref)) * 1e-3 + 1e-15, f"offsets on a reused plan, table {k}"
+        _lib.check(L.bfg_table_destroy(ctx, dtab))
+    for dv in (d_cat, d_map, d_off):
+        dv.free()
+    _lib.check(L.bfg_spline_destroy(ctx, spl))
+    _lib.check(L.bfg_ctx_destroy(ctx))

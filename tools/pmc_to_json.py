@@ -29,8 +29,12 @@ for spec in sys.argv[3:]:
     key, files = spec.split("=")
     parts = files.split(",")
     kernel = parts[2] if len(parts) > 2 else "shell_tile_kernel"
-    fetch, nf = mean_of(parts[0], kernel, "FETCH_SIZE")
-    write, nw = mean_of(parts[1], kernel, "WRITE_SIZE")
+    fetch = write = 0.0
+    nf = nw = 0
+    for kern in kernel.split("+"):                             # "a+b+c": the sum over several kernels of one step (the tiled deposit)
+        f_, nf = mean_of(parts[0], kern, "FETCH_SIZE")
+        w_, nw = mean_of(parts[1], kern, "WRITE_SIZE")
+        fetch, write = fetch + f_, write + w_
     if key.startswith("_"):                                    # not a bench key: kept under _raw only (e.g. the prep kernel)
         j["_raw"][key] = {"kernel": kernel, "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "launches_averaged": [nf, nw]}
         continue

@@ -25,7 +25,7 @@ def counters_of(path, kernel):
 
 tag, out = sys.argv[1], sys.argv[2]
 j = {"_source": f"rocprofv3 --pmc SQ_* (separate passes, --kernel-trace only) of `bench.py --steps 3 --warmup 1` on the {tag} build; "
-                f"summaries profiles/{tag}_sq_counters_<workload>.txt (tools/r05_profile.sh sq)",
+                f"summaries profiles/{tag}_sq_counters_<workload>.txt (tools/r06_profile.sh sq)",
      "_note": "per launch of the named kernel; valu_issue_frac = SQ_ACTIVE_INST_VALU*4/1024/(SQ_BUSY_CYCLES/32), "
               "lds_pipe_frac = SQ_LDS_IDX_ACTIVE/256/(SQ_BUSY_CYCLES/32)"}
 for spec in sys.argv[3:]:
