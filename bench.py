@@ -35,8 +35,8 @@ BASELINE configurations that fit one GPU -- configs1 (PaintProfilesShell, 1e5 ha
 included), configs4 (BaryonifySnapshot, 512^3 particles, 1e5 halos, CIC deposit), configs3's per-GPU share, and `steep` (the
 dn/dlnM ~ M^-0.9 catalog) -- each guarded: a leg that fails, or hangs past
 BFG_BENCH_LEGS_DEADLINE_S (default 600 s), is recorded as an error and the main line is printed all the same, exit 0.
-Before the W warm-up steps the run executes BFG_BENCH_RAMP_S (default 0.25 s) of the very same steps (`ramp_steps` in the line):
-an idle MI355X needs ~50 ms of load to reach its sustained clocks, W = 5 steps are 6 ms of it.
+Before the W warm-up steps the run executes BFG_BENCH_RAMP_S (default 1 s for the main line, 0.4 s for a leg) of the very same steps
+(`ramp_steps` in the line): an idle MI355X needs load for a while to reach its sustained clocks, W = 5 steps are 6 ms of it.
 The run exits non-zero with a one-line reason -- it never hangs -- when fewer than N GPUs are visible, when RCCL cannot be
 loaded, when a rank fails (collective timeout BFG_BENCH_TIMEOUT_S, default 180 s) or when the whole run exceeds
 BFG_BENCH_DEADLINE_S (default 1500 s; a watchdog THREAD, so it also fires while the main thread sits in a HIP / RCCL call).
@@ -1014,7 +1014,9 @@ def run_config(args, torch, dist, rank, local_rank, world, backend, main=True):
     # headline size (1 ms at 1e5 halos): timed straight after, the same 20 steps are 2 % (1e6 halos) to 7 % (1e5) slower than in
     # steady state (tools/warm_ab.sh, profiles/r03_warmup_ab.txt).  So the untimed part of the run is BFG_BENCH_RAMP_S (default
     # 0.25 s) of the very same steps, THEN the W warm-up steps, then the K timed steps; `ramp_steps` in the line says how many.
-    ramp_s = float(os.environ.get("BFG_BENCH_RAMP_S", "0.25"))
+    # (round 6: 1 s for the main line -- on one box of the pool the K steps timed after 0.25 s ran 8 % below the rate the same
+    # process held in its later legs: kernel 0.999 vs 0.921 ms, profiles/r06_bench_b.json vs r06_bench_paint.json)
+    ramp_s = float(os.environ.get("BFG_BENCH_RAMP_S", "1.0" if main else "0.4"))
     ramp_steps = 0
     if ramp_s > 0:
         batch = max(args.steps, 1)
@@ -1024,7 +1026,7 @@ def run_config(args, torch, dist, rank, local_rank, world, backend, main=True):
             tb = torch.tensor([t_batch], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(tb, op=dist.ReduceOp.MAX)
             t_batch = float(tb.item())
-        for _ in range(min(200, int(ramp_s / max(t_batch, 1e-4)))):
+        for _ in range(min(400, int(ramp_s / max(t_batch, 1e-4)))):
             run_steps(batch)
             ramp_steps += batch
     if args.warmup > 0 or api is not None:
