@@ -34,7 +34,7 @@ owner-computes join (half the bytes) and BASELINE configs[3] (BaryonifyShell, NS
 BASELINE configurations that fit one GPU -- configs1 (PaintProfilesShell, 1e5 halos), configs2 (BaryonifyShell, 1e5 halos, regrid
 included), configs4 (BaryonifySnapshot, 512^3 particles, 1e5 halos, CIC deposit), configs3's per-GPU share, and `steep` (the
 dn/dlnM ~ M^-0.9 catalog) -- each guarded: a leg that fails, or hangs past
-BFG_BENCH_LEGS_DEADLINE_S (default 600 s), is recorded as an error and the main line is printed all the same, exit 0.
+BFG_BENCH_LEGS_DEADLINE_S (default 600 s at N = 1, where every leg times its own CPU baseline; 300 s at N > 1), is recorded as an error and the main line is printed all the same, exit 0.
 Before the W warm-up steps the run executes BFG_BENCH_RAMP_S (default 1 s for the main line, 0.4 s for a leg) of the very same steps
 (`ramp_steps` in the line): an idle MI355X needs load for a while to reach its sustained clocks, W = 5 steps are 6 ms of it.
 The run exits non-zero with a one-line reason -- it never hangs -- when fewer than N GPUs are visible, when RCCL cannot be
@@ -555,7 +555,9 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
     # ---- guarded extra legs: whatever happens from here on, the main line above is printed and the run exits 0 -----------
     if args.legs == "auto":
         default_paint = args.workload == "paint" and args.nside == 1024 and args.table == "default" and not args.steep
-        legs = (["weak", "owner", "configs3"] if world > 1 else ["configs1", "configs2", "steep", "configs4", "nd4", "configs3", "published", "multi_model"]) if default_paint else []
+        # (N > 1: the owner-computes join LAST -- it is the one leg whose collectives no RCCL installation has run for us yet: if it
+        # fails or hangs, the legs before it are already in the line)
+        legs = (["weak", "configs3", "owner"] if world > 1 else ["configs1", "configs2", "steep", "configs4", "nd4", "configs3", "published", "multi_model"]) if default_paint else []
     else:
         legs = [x for x in args.legs.split(",") if x and x != "none"]       # (names validated in parse())
     if world == 1:
@@ -582,7 +584,7 @@ def _main(args, torch, dist, rank, local_rank, world, backend):
     def legs_overdue():
         emit(f"the extra legs exceeded BFG_BENCH_LEGS_DEADLINE_S = {legs_deadline:g} s; the main measurement above is complete")
         return 0
-    legs_deadline = float(os.environ.get("BFG_BENCH_LEGS_DEADLINE_S", "600"))
+    legs_deadline = float(os.environ.get("BFG_BENCH_LEGS_DEADLINE_S", "600" if world == 1 else "300"))
     if legs:
         WATCHDOG.arm(legs_deadline, legs_overdue)
     try:
