@@ -374,10 +374,10 @@ class PaintProfilesAnisShell(DefaultRunner):
         prod = _ProductTable(self.model, self.Tracer_model, keys)
         bgc, spline, d_cat, stride = self._device_inputs(ctx, keys)
         table = ctx.table(_table_axes(prod, keys), prod.ln_product, log_values=True)
-        d_sum = ctx.zeros(npix)
-        args = ctx.shell_args(NSIDE, d_cat, d_cat.shape[0], stride, len(keys), self.epsilon_max,
-                              ctx.massdef_struct(bgc, self.mass_def), include_pixel_size=self.include_pixel_size,
-                              variant=self.variant, reuse_plan=ctx.same_catalog(d_cat))
+        d_sum = ctx.empty(npix)                                          # defined by the call (the zeros come from the kernels), as the
+        args = ctx.shell_args(NSIDE, d_cat, d_cat.shape[0], stride, len(keys), self.epsilon_max,   # Mtot paint above: the same plan where
+                              ctx.massdef_struct(bgc, self.mass_def), include_pixel_size=self.include_pixel_size,   # include_pixel_size agrees
+                              variant=self.variant, out_overwrite=True, reuse_plan=ctx.same_catalog(d_cat))
         ctx.stats_reset()
         ctx.paint_shell(args, table, spline, d_sum)
         self.last_stats = ctx.stats()

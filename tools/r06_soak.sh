@@ -11,6 +11,14 @@ if [ "${SOAK_PART:-all}" != 2 ]; then
 echo "== in-place page-locked shells (soak_inplace.py ${INPLACE_CASES:-20000} cases)" >> $O
 timeout -k 10 ${INPLACE_TIMEOUT:-900} python3 tests/soak/soak_inplace.py ${INPLACE_CASES:-20000} 6001 2>&1 | grep -v "amdgpu.ids" | tail -4 >> $O
 fi
+if [ "${SOAK_PART:-all}" = 3 ]; then      # after the soak learnt to paint a second model on the first one's plan: default + forced slow binning path
+run "BFG_X=0" 150 6201
+run "BFG_TILE_CAP=3 BFG_TILE_SCAN=1" 90 6202
+run "BFG_TILE_CAP=2 BFG_PAIR_CAP=100" 45 6203
+run "BFG_D2H_SLICES=1 BFG_EAGER_SOA=1" 45 6204
+run "BFG_TILE_LIGHT=1" 45 6205
+cat $O; if grep -q "Memory access fault\|Error\|error\|dumped core" $O; then exit 1; fi; exit 0
+fi
 if [ "${SOAK_PART:-all}" != 1 ]; then
 run "BFG_X=0" 200 6101
 run "BFG_SOAK_INPLACE=all" 90 6102
