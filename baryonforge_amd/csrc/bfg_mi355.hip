@@ -1828,6 +1828,8 @@ static int ensure_tiles(bfg_ctx *c, int mode, int tr, int tw, int64_t nside, int
         ts.geo.tile_band = ts.d_geo + 3 * nbands + 1;
         ts.nside = nside;
     }
+    // (the regrid kernel bins nothing: it must not resize -- or re-cap -- the pair buffer a shell call's plan lives in)
+    if (mode == kRegridSet) return BFG_OK;
     // pair buffer: cap_direct fixed slots per tile (filled by the count pass) followed by the overflow lists.  Slots for
     // ~8x the mean number of halos per tile hold every pair of a catalog spread over the sky (4-5 pairs per halo).
     int64_t cap_direct = 32;
