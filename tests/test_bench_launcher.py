@@ -212,3 +212,33 @@ def test_owner_join_is_promoted_only_when_the_run_is_exchange_bound_and_the_join
         done = {"owner": {"value": leg["value"]}}
         bench.promote_owner(main, leg, done, a)
         assert main["value"] == 10.0 and main["exchange_choice"]["picked"] == "allreduce" and set(done) == {"owner"}
+
+
+def test_roofline_block_cannot_pass_one_and_keeps_the_algorithmic_figure():
+    """bench.finish_roofline: `algorithmic_frac` is always SURVEY 8(d) bytes / time / 8 TB/s; `frac` is that only
+    where the bytes travel, otherwise a counted issue fraction (<= 1 by construction) in the unit of the resource that bounds the kernel"""
+    import bench
+
+    def block(alg_bytes, kernel_s):
+        a = alg_bytes / kernel_s
+        return {"bound": "hbm", "achieved": a / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": a / 8e12, "algorithmic_bytes_per_launch": alg_bytes}
+    sq = {"raw": {"SQ_INSTS_VALU": 3.7756e8, "SQ_LDS_IDX_ACTIVE": 3.2365e8}, "valu_issue_frac": 0.70, "lds_pipe_frac": 0.59}
+    # the headline tile kernel: 4.469 GB algorithmic in 0.92 ms, 0.32 GB measured -> the bytes do not travel: VALU-counted
+    r = bench.finish_roofline(block(4.469e9, 0.92e-3), sq, 0.92e-3, 0.32e9)
+    assert r["bound"] == "valu" and abs(r["algorithmic_frac"] - 4.469e9 / 0.92e-3 / 8e12) < 1e-12
+    assert abs(r["frac"] - 3.7756e8 * 64 / 0.92e-3 / (256 * 4 * 16 * 2.4e9)) < 1e-12 and r["frac"] <= 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["unit"] == "Tlane-op/s"
+    assert r["hbm"]["frac"] == r["algorithmic_frac"] and r["hbm"]["traffic"] == 0.32e9 and r["lds_counted_frac"] < r["valu_counted_frac"]
+    # the offsets kernel at NSIDE 2048: algorithmic fraction 1.25 -> never reported as `frac`
+    sq3 = {"raw": {"SQ_INSTS_VALU": 2.8626e9, "SQ_LDS_IDX_ACTIVE": 2.4086e9}}
+    r = bench.finish_roofline(block(66.5e9, 6.65e-3), sq3, 6.65e-3, 3.9e9)
+    assert r["algorithmic_frac"] > 1.0 and r["bound"] == "valu" and 0.0 < r["frac"] <= 1.0
+    # no stored counters and an algorithmic fraction above 1: withheld, not invented
+    r = bench.finish_roofline(block(66.5e9, 6.65e-3), None, 6.65e-3, None)
+    assert r["frac"] is None and r["algorithmic_frac"] > 1.0 and "no stored counters" in r["bound"]
+    # a kernel whose bytes do travel (the deposit: 11.3 GB measured in 2.6 ms) stays on the HBM yardstick
+    r = bench.finish_roofline(block(20.4e9, 2.6e-3), sq, 2.6e-3, 11.3e9)
+    assert r["bound"] == "hbm" and r["frac"] == r["algorithmic_frac"] <= 1.0 and r["unit"] == "GB/s"
+    # LDS-bound when the LDS pipe is the fuller one
+    r = bench.finish_roofline(block(4.0e9, 1e-3), {"raw": {"SQ_INSTS_VALU": 1e8, "SQ_LDS_IDX_ACTIVE": 5e8}}, 1e-3, 0.1e9)
+    assert r["bound"] == "lds" and abs(r["frac"] - 5e8 / 256 / (1e-3 * 2.4e9)) < 1e-12
