@@ -1915,6 +1915,10 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
     if (t && t->nd && nd_rows_pay(t, a)) return run_shell_nd(c, a, t, s, d_out, mode, n_slices, slice_fn, slice_user);
     rc = check_args(a, t, s, d_out);
     if (rc) return rc;
+    // whatever plan the context holds is void from here on (workspaces may be resized below, a failure may leave them half-built);
+    // it is reinstated at the end of a tile-path call that ran to its end.  A call without halos touches nothing and keeps it.
+    const bool had_plan = c->plan.valid && a->n_halo > 0;
+    if (a->n_halo > 0) c->plan.valid = false;
     if (mode == MODE_PAINT && !t->dev.log_values) return BFG_ERR_INVALID;
     if (mode == MODE_BARYONIFY && t->dev.log_values) return BFG_ERR_INVALID;
     // BFG_SHELL_OUT_OVERWRITE: the output is uninitialised.  The tile kernels write every pixel themselves; every other route
@@ -2047,11 +2051,10 @@ static int run_shell(bfg_ctx *c, const bfg_shell_args *a, const bfg_table *t, co
         if (std::getenv("BFG_TILE_SCAN")) direct_limit = 0;                   // A/B: always the scan kernel
         key.cap_direct = c->tiles[mode].cap_direct; key.direct_limit = direct_limit; key.pair_cap = c->pair_cap;
     }
-    bool reuse = tile && (a->flags & BFG_SHELL_REUSE_PLAN) && c->plan.valid && t->dev.hstride == 0 &&
+    bool reuse = tile && (a->flags & BFG_SHELL_REUSE_PLAN) && had_plan && t->dev.hstride == 0 &&
                  std::memcmp(&key, &c->plan.key, sizeof(key)) == 0;
     if (const char *e = std::getenv("BFG_PLAN_REUSE")) if (!std::atoi(e)) reuse = false;               // A/B switch
     int32_t *const plan_tail = reuse ? c->plan.tail : nullptr;
-    c->plan.valid = false;           // (set again at the end of a tile-path call that ran to its end)
 
     PrepParams pp;
     std::memset(&pp, 0, sizeof(pp));
