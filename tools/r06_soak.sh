@@ -6,7 +6,7 @@ cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out/r06
 O=gpurun_out/r06/soak_${SOAK_PART:-all}.txt
 : > $O
-run() { d=$2; sd=$3; echo "== $1 ($d s, seed $sd)" >> $O; env $1 BFG_SOAK_TRACE=gpurun_out/r06/soak_trace_$sd.txt timeout -k 10 $(( d + 120 )) python3 tests/soak/soak.py $d $sd 2>&1 | grep -v "^ok\|amdgpu.ids" | tail -3 >> $O; }
+run() { d=$(( $2 * ${SOAK_SCALE:-1} )); sd=$(( $3 + ${SOAK_SEED:-0} )); echo "== $1 ($d s, seed $sd)" >> $O; env $1 BFG_SOAK_TRACE=gpurun_out/r06/soak_trace_$sd.txt timeout -k 10 $(( d + 120 )) python3 tests/soak/soak.py $d $sd 2>&1 | grep -v "^ok\|amdgpu.ids" | tail -3 >> $O; }
 if [ "${SOAK_PART:-all}" != 2 ]; then
 echo "== in-place page-locked shells (soak_inplace.py ${INPLACE_CASES:-20000} cases)" >> $O
 timeout -k 10 ${INPLACE_TIMEOUT:-900} python3 tests/soak/soak_inplace.py ${INPLACE_CASES:-20000} 6001 2>&1 | grep -v "amdgpu.ids" | tail -4 >> $O
