@@ -139,6 +139,9 @@ class StubOps(OraclePaintOps):
 Parallelize._DeviceOps = StubOps
 # the legs at rehearsal size (BASELINE configs[3] is 1.25e6 halos per GPU at NSIDE 2048: hours for the serial oracle)
 bench.LEG_ARGS["configs3"] = dict(bench.LEG_ARGS["configs3"], nside=32, halos=60)
+if os.environ.get("BFG_STUB_SMALL_LEGS"):                      # the N = 1 legs at rehearsal size (tests/test_bench_launcher.py)
+    for name in ("configs1", "configs2", "steep"):
+        bench.LEG_ARGS[name] = dict(bench.LEG_ARGS[name], nside=32, halos=150, min_steps=2)
 
 if __name__ == "__main__":
     bench.main()

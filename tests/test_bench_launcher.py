@@ -242,3 +242,30 @@ def test_roofline_block_cannot_pass_one_and_keeps_the_algorithmic_figure():
     # LDS-bound when the LDS pipe is the fuller one
     r = bench.finish_roofline(block(4.0e9, 1e-3), {"raw": {"SQ_INSTS_VALU": 1e8, "SQ_LDS_IDX_ACTIVE": 5e8}}, 1e-3, 0.1e9)
     assert r["bound"] == "lds" and abs(r["frac"] - 5e8 / 256 / (1e-3 * 2.4e9)) < 1e-12
+
+
+def test_single_gpu_legs_rehearsal_on_cpu_every_leg_has_a_cpu_baseline_and_no_frac_above_one():
+    """`bench.py` at N = 1 with its paint / baryonify legs, rehearsed without a GPU (tests/bench_host_stub.py: bench.py unchanged, the
+    device side replaced by the oracle, timings meaningless): ONE line; the main line and every leg carry a non-null `cpu_baseline`
+    with value / unit / cores / kind / sample; every roofline block keeps `algorithmic_frac` and never reports a `frac` above 1
+    ("BENCH_r06 legs all carry non-null cpu_baseline, no frac > 1")"""
+    env = dict(os.environ, BFG_BENCH_RAMP_S="0", BFG_STUB_SMALL_LEGS="1", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    pr = subprocess.run([sys.executable, os.path.join(REPO, "tests", "bench_host_stub.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                         "--halos", "300", "--nside", "32", "--no-e2e", "--cpu-seconds", "0.2", "--cpu-seconds-leg", "0.2",
+                         "--legs", "configs1,configs2,steep"], env=env, capture_output=True, text=True, timeout=600)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, pr.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and r["metric"] == "halos_per_s" and r["vs_baseline"] is None and r["dtype"] == "f64"
+    assert set(r["legs"]) == {"configs1", "configs2", "steep"}
+    for name, rec in [("main", r)] + list(r["legs"].items()):
+        assert "error" not in rec, (name, rec)
+        cb = rec["cpu_baseline"]
+        assert cb and cb["value"] > 0 and cb["unit"] == "halos/s" and cb["cores"] >= 1 and cb["kind"] == "port" and cb["sample"], (name, cb)
+        rf = rec["roofline"]
+        assert rf["algorithmic_frac"] > 0 and (rf["frac"] is None or 0 < rf["frac"] <= 1.0), (name, rf["frac"], rf["algorithmic_frac"])
+        assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(rf)
+    assert r["legs"]["configs2"]["workload"].startswith("BaryonifyShell") and r["legs"]["configs2"]["cpu_baseline"]["cores"] == 1
